@@ -1,0 +1,108 @@
+"""Pins the CPU oracle (oracle/urnn_oracle.c) against fixtures produced by the REFERENCE itself
+(tests/golden/make_golden.py).  CPU-only; this is what makes the oracle trustworthy as the
+checker for the HIP path."""
+import numpy as np
+import pytest
+
+from conftest import assert_close, masked_parity
+from oracle import oracle as orc
+import urnn_amd.weights as uw
+
+TOL = 1e-4  # the north-star bar, metric of conftest.rel_err
+
+
+@pytest.fixture(scope="module")
+def kern(golden):
+    g = golden("kernels_16x16.npz")
+    sd = uw.make_state_dict(int(g["H"]), int(g["W"]), int(g["C"]), seed=int(g["weights_seed"]))
+    return g, sd, orc.OracleNet(sd)
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_stage_convs(kern, B):
+    g, sd, net = kern
+    t = f"B{B}"
+    for i, pool in ((1, False), (2, True), (3, True)):
+        y = orc.stage_conv(g[f"s{i}_in_{t}"], sd[f"encoder.stage{i}.conv{i}_leaky_1.weight"],
+                           sd[f"encoder.stage{i}.conv{i}_leaky_1.bias"], pool)
+        assert_close(y, g[f"s{i}_out_{t}"], TOL, f"stage{i}")
+    y = orc.stage_conv(g[f"dc1_in_{t}"], sd["decoder.stage1.conv3_leaky_1.weight"], sd["decoder.stage1.conv3_leaky_1.bias"], False)
+    assert_close(y, g[f"dc1_out_{t}"], TOL, "dec stage1 conv")
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_gru_cells(kern, B):
+    g, sd, net = kern
+    t = f"B{B}"
+    for i in (1, 2, 3):
+        y = orc.gru_cell(g[f"enc{i}_x_{t}"], None, g[f"enc{i}_h_{t}"], net.enc[i - 1])
+        assert_close(y, g[f"enc{i}_out_{t}"], TOL, f"enc cell {i}")
+    for i in (3, 2, 1):
+        x = None if i == 3 else g[f"dec{i}_x_{t}"]
+        y = orc.gru_cell(x, g[f"dec{i}_e_{t}"], g[f"dec{i}_d_{t}"], net.dec[i])
+        assert_close(y, g[f"dec{i}_out_{t}"], TOL, f"dec cell {i}")
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_deconvs(kern, B):
+    g, sd, net = kern
+    t = f"B{B}"
+    y = orc.deconv2x2(g[f"dc3_in_{t}"], sd["decoder.stage3.deconv1_leaky_1.weight"], sd["decoder.stage3.deconv1_leaky_1.bias"])
+    assert_close(y, g[f"dc3_out_{t}"], TOL, "deconv stage3")
+    y = orc.deconv2x2(g[f"dc2_in_{t}"], sd["decoder.stage2.deconv2_leaky_1.weight"], sd["decoder.stage2.deconv2_leaky_1.bias"])
+    assert_close(y, g[f"dc2_out_{t}"], TOL, "deconv stage2")
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_head(kern, B):
+    g, sd, net = kern
+    t = f"B{B}"
+    masked, cls, raw = orc.head(g[f"head_in_{t}"], net.hp)
+    assert_close(cls, g[f"head_cls_{t}"], TOL, "cls")
+    assert_close(raw, g[f"head_raw_{t}"], TOL, "raw reg")
+    masked_parity(masked, g[f"head_masked_{t}"], g[f"head_cls_{t}"], g[f"head_raw_{t}"], TOL)
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_full_step(kern, B):
+    g, sd, net = kern
+    t = f"B{B}"
+    st = [g[f"step_state{k}_{t}"] for k in range(6)]
+    out, new, _ = net.step(g[f"step_x_{t}"][:, 0], st)
+    for k in range(6):
+        assert_close(new[k], g[f"step_newstate{k}_{t}"], TOL, f"state {k}")
+    # masked output: compare away from the threshold only
+    ref = g[f"step_reg_{t}"][:, 0]
+    diff = np.abs(out - ref)
+    assert (diff > 1e-4 * max(1e-3, np.abs(ref).max())).mean() < 0.01
+
+
+def test_preprocess(golden):
+    g = golden("preprocess.npz")
+    H, W, nums, T = int(g["H"]), int(g["W"]), int(g["nums"]), int(g["T"])
+    for spatial in (0, 1):
+        for B in (1, 2):
+            ev = uw.make_event(T, H, W, float(g["rain_max"]), seed=int(g["event_seed"]), spatial_rain=bool(spatial), batch=B)
+            for t in (0, nums - 1, nums, T - 1):
+                y = orc.preprocess_inputs(t, ev, nums, float(g["rain_max"]), float(g["cumsum_max"]))
+                assert_close(y, g[f"pre_sp{spatial}_B{B}_t{t}"], 1e-6, f"preprocess sp={spatial} B={B} t={t}")
+
+
+@pytest.mark.parametrize("name", ["rollout_64x64_T30.npz", "rollout_24x40_T8_spatial.npz"])
+def test_rollout(golden, name):
+    g = golden(name)
+    H, W, nums, T = int(g["H"]), int(g["W"]), int(g["nums"]), int(g["T"])
+    sd = uw.make_state_dict(H, W, 2 * nums + 3, seed=int(g["weights_seed"]))
+    ev = uw.make_event(T, H, W, float(g["rain_max"]), seed=int(g["event_seed"]), spatial_rain=bool(int(g["spatial"])))
+    net = orc.OracleNet(sd)
+    frames, states, aux = orc.rollout(net, ev, T, nums, float(g["rain_max"]), float(g["cumsum_max"]), want_aux=True)
+    every = int(g["every"])
+    cls = np.stack([a["cls"][0] for a in aux])[::every]
+    raw = np.stack([a["reg_raw"][0] for a in aux])[::every]
+    tol = 1e-4  # recurrent accumulation over T steps
+    assert_close(cls, g["cls"], tol, "cls over rollout")
+    assert_close(raw, g["raw"], tol, "pre-mask reg over rollout")
+    for k in range(6):
+        assert_close(states[k], g[f"final_state{k}"], tol, f"final state {k}")
+    nflip = masked_parity(frames[::every, 0], g["reg"], g["cls"], g["raw"], tol)
+    assert nflip < 0.001 * g["reg"].size
