@@ -1,0 +1,112 @@
+/*
+ * urnn_hip.h -- C ABI of liburnn_hip.so, the MI355X (gfx950) kernels under the U-RNN rollout path.
+ *
+ * The reference has no FFI/operator interface: its hot path sits behind plain nn.Module calls
+ * (SURVEY 8b).  Each entry point below replaces the torch.nn / ATen ops of one reference module
+ * forward, cited as file:line relative to /root/reference/code/.  INTEGRATION.md shows the ctypes
+ * binding a reference maintainer would add at each of those sites.
+ *
+ * Conventions (all entry points):
+ *   - tensors are float32, NCHW, contiguous, device pointers (hipMalloc / torch storage);
+ *   - `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream on ROCm); calls only
+ *     ENQUEUE on it, never synchronise, allocate or retain pointers => safe under hipGraph capture;
+ *   - scratch memory is caller-owned: size it with the matching *_workspace_bytes();
+ *   - return 0 on success, a negative URNN_E* code on argument errors, or a positive hipError_t;
+ *     urnn_last_error() gives the message of the calling thread's last failure;
+ *   - weights cross the ABI in a PACKED layout produced once by urnn_pack_*() from the
+ *     reference's nn.Conv2d / nn.ConvTranspose2d parameter layout.
+ */
+#ifndef URNN_HIP_H
+#define URNN_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define URNN_ABI_VERSION 1
+
+#define URNN_OK 0
+#define URNN_EINVAL (-1)   /* bad dimension / unsupported shape                     */
+#define URNN_ENULL (-2)    /* required pointer is NULL                              */
+#define URNN_EWORKSPACE (-3) /* workspace too small                                 */
+#define URNN_EALIGN (-4)   /* pointer not 16-byte aligned                           */
+
+int urnn_abi_version(void);
+const char *urnn_last_error(void);
+
+/* ---- weight packing (one-off, at checkpoint-load time) ------------------------------------------ */
+
+/* Packed 1x1-conv weights: transposed, K padded to 8, N padded to 32, bias appended.
+ * Source: nn.Conv2d.weight (Cout, Cin, 1, 1) + bias (Cout) -- utils.py:109-115 (make_layers 'conv'). */
+size_t urnn_packed_conv_floats(int Cin, int Cout);
+int urnn_pack_conv_f32(const float *weight, const float *bias, float *packed, int Cin, int Cout, void *stream);
+
+/* Packed ConvGRU / Skip-ConvGRU weights: conv1 (2F x K) and conv2 (F x K) fused column-wise as
+ * [z_i | r_i | c_i] per 32-channel block, split row-wise into the x | e | h segments; conv2's h part
+ * (F x F) is stored separately (it multiplies r*h).  K = I + F (encoder, skip=0) or I + 2F (decoder).
+ * Source: CGRU_cell.conv1[0] / conv2[0] weight+bias -- ConvRNN.py:94-104. */
+size_t urnn_packed_gru_floats(int I, int F, int skip);
+int urnn_pack_gru_f32(const float *W1, const float *b1, const float *W2, const float *b2, float *packed, int I, int F,
+                      int skip, void *stream);
+
+/* Packed ConvTranspose2d(k=2,s=2) weights.  Source: nn.ConvTranspose2d.weight (Cin, Cout, 2, 2) + bias
+ * -- utils.py:95-101 (make_layers 'deconv'). */
+size_t urnn_packed_deconv_floats(int Cin, int Cout);
+int urnn_pack_deconv_f32(const float *weight, const float *bias, float *packed, int Cin, int Cout, void *stream);
+
+/* ---- per-module forwards -------------------------------------------------------------------------- */
+
+/* Encoder/decoder stage conv: out = [AvgPool2d(2,2)](LeakyReLU_slope(W.in + b)).
+ * Replaces Encoder.stage{1,2,3}(inputs) -- encoder.py:140-151 with specs net_params.py:80-88 -- and
+ * Decoder.stage1 (plain conv) -- decoder.py:150-164 / net_params.py:117-120.
+ * in (B,Cin,H,W) -> out (B,Cout,H,W) or (B,Cout,H/2,W/2) when pool != 0. */
+int urnn_stage_conv_f32(const float *in, const float *packed, float *out, int B, int Cin, int Cout, int H, int W, int pool,
+                        float slope, void *stream);
+
+/* ConvGRU (e == NULL) / Skip-ConvGRU cell, one timestep.
+ * Replaces CGRU_cell.forward(inputs, hidden_state, seq_len=1) -- ConvRNN.py:111-194 -- including the
+ * torch.cat of decoder.py:130-135.  x (B,I,H,W) may be NULL: x == 0 (decoder stage 3, ConvRNN.py:143-146).
+ * h_out may alias h (in-place state update).  gn*_w / gn*_b are the GroupNorm affines of conv1[1]/conv2[1]. */
+size_t urnn_gru_cell_workspace_bytes(int B, int F, int H, int W);
+int urnn_gru_cell_f32(const float *x, const float *e, const float *h, const float *packed, const float *gn1_w,
+                      const float *gn1_b, const float *gn2_w, const float *gn2_b, float *h_out, void *workspace,
+                      size_t workspace_bytes, int B, int I, int F, int H, int W, float eps, void *stream);
+
+/* Decoder up-sampling: out = LeakyReLU_slope(ConvTranspose2d(k=2,s=2,p=0)(in)).
+ * Replaces Decoder.stage{3,2}(inputs) -- decoder.py:150-164 with specs net_params.py:106-116.
+ * in (B,Cin,H,W) -> out (B,Cout,2H,2W). */
+int urnn_deconv2x2_f32(const float *in, const float *packed, float *out, int B, int Cin, int Cout, int H, int W, float slope,
+                       void *stream);
+
+/* Dual head + wet/dry mask.  Replaces YOLOXHead.forward + correction_depth -- flood_head.py:131-202 --
+ * with BaseConv = Conv1x1(no bias) -> LayerNorm([C,H,W]) -> SiLU (network_blocks.py:74-101) and
+ * finalConv (network_blocks.py:129-171).
+ *   feat (B,C,H,W); conv_w 5 x (C x C) row-major in the order stems, cls_convs.0, cls_convs.1,
+ *   reg_convs.0, reg_convs.1; ln_w / ln_b 5 x (C,H,W) same order; cls_w/reg_w (C), cls_b/reg_b (1).
+ *   out_masked = reg * [cls >= cls_thred], out_cls = cls, out_raw (nullable) = reg before the mask;
+ *   each written at  base + frame * B*H*W  where frame = *frame_index (device int, NULL => 0): a rollout
+ *   graph replays the same node while the device-side frame counter advances. */
+size_t urnn_head_workspace_bytes(int B, int C, int H, int W);
+int urnn_head_f32(const float *feat, const float *conv_w, const float *ln_w, const float *ln_b, const float *cls_w,
+                  const float *cls_b, const float *reg_w, const float *reg_b, float *out_masked, float *out_cls,
+                  float *out_raw, const int *frame_index, void *workspace, size_t workspace_bytes, int B, int C, int H,
+                  int W, float cls_thred, float eps, float slope, void *stream);
+
+/* Per-frame input assembly.  Replaces preprocess_inputs / get_past_rainfall / MinMaxScaler --
+ * Dynamic2DFlood.py:265-376.  out (B, 2*nums+3, H, W) = [rain(t-n+1..t)/rain_max, cumsum(..)/cumsum_max,
+ * (DEM-min)/(max-min), (imp-0.05)/0.9, manhole], history left-zero-padded.
+ *   rain / cumsum: (B,T) if spatial == 0 else (B,T,H,W); dem / imperv / manhole: (B,H,W);
+ *   t is read from *t_dev when t_dev != NULL (device int), else from the host argument t. */
+int urnn_preprocess_f32(const float *rain, const float *cumsum, const float *dem, const float *imperv,
+                        const float *manhole, float dem_min, float dem_max, float *out, int t, const int *t_dev, int B,
+                        int T, int nums, int H, int W, int spatial, float rain_max, float cumsum_max, void *stream);
+
+/* Device-side frame counter helper for graph-captured rollouts: *counter += delta. */
+int urnn_advance_counter(int *counter, int delta, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* URNN_HIP_H */

@@ -1,0 +1,153 @@
+"""GPU parity tests of the HIP kernels (through the C ABI) against the reference-generated goldens and
+against the CPU oracle on fresh seeded inputs.  Run on the MI355X box: pytest -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close, masked_parity
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def gnet(golden, dev):
+    import urnn_amd.weights as uw
+    from urnn_amd.net_config import load_net_config
+    from urnn_amd.networks import ED, get_network_params
+    g = golden("kernels_16x16.npz")
+    H, W, C = int(g["H"]), int(g["W"]), int(g["C"])
+    sd = uw.make_state_dict(H, W, C, seed=int(g["weights_seed"]))
+    ep, dp = get_network_params(False, H, W, C, load_net_config())
+    net = ED(False, ep, dp, 0.5, False, H, W)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return g, net.to(dev).eval(), sd
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_stage_convs_vs_reference(gnet, dev, B):
+    g, net, _ = gnet
+    t = f"B{B}"
+    for i in (1, 2, 3):
+        y = getattr(net.encoder, f"stage{i}")(T(g[f"s{i}_in_{t}"], dev))
+        assert_close(y.cpu().numpy(), g[f"s{i}_out_{t}"], TOL, f"encoder stage{i}")
+    y = net.decoder.stage1(T(g[f"dc1_in_{t}"], dev))
+    assert_close(y.cpu().numpy(), g[f"dc1_out_{t}"], TOL, "decoder stage1 conv")
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_deconvs_vs_reference(gnet, dev, B):
+    g, net, _ = gnet
+    t = f"B{B}"
+    assert_close(net.decoder.stage3(T(g[f"dc3_in_{t}"], dev)).cpu().numpy(), g[f"dc3_out_{t}"], TOL, "deconv stage3")
+    assert_close(net.decoder.stage2(T(g[f"dc2_in_{t}"], dev)).cpu().numpy(), g[f"dc2_out_{t}"], TOL, "deconv stage2")
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_gru_cells_vs_reference(gnet, dev, B):
+    g, net, _ = gnet
+    t = f"B{B}"
+    for i in (1, 2, 3):
+        rnn = getattr(net.encoder, f"rnn{i}")
+        y = rnn(T(g[f"enc{i}_x_{t}"], dev)[None], T(g[f"enc{i}_h_{t}"], dev))[0]
+        assert_close(y.cpu().numpy(), g[f"enc{i}_out_{t}"], TOL, f"encoder cell {i}")
+    for i in (3, 2, 1):
+        rnn = getattr(net.decoder, f"rnn{i}")
+        st = torch.cat((T(g[f"dec{i}_e_{t}"], dev), T(g[f"dec{i}_d_{t}"], dev)), 1)
+        x = None if i == 3 else T(g[f"dec{i}_x_{t}"], dev)[None]
+        y = rnn(x, st)[0]
+        assert_close(y.cpu().numpy(), g[f"dec{i}_out_{t}"], TOL, f"decoder cell {i}")
+
+
+def test_gru_cell_in_place(gnet, dev):
+    g, net, _ = gnet
+    x, h = T(g["enc1_x_B1"], dev), T(g["enc1_h_B1"], dev)
+    ref = net.encoder.rnn1.step(x, None, h)
+    hh = h.clone()
+    net.encoder.rnn1.step(x, None, hh, out=hh)
+    assert torch.equal(ref, hh)
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_head_vs_reference(gnet, dev, B):
+    g, net, _ = gnet
+    t = f"B{B}"
+    masked, cls, raw = net.head.run(T(g[f"head_in_{t}"], dev), want_raw=True)
+    assert_close(cls.cpu().numpy(), g[f"head_cls_{t}"], TOL, "cls")
+    assert_close(raw.cpu().numpy(), g[f"head_raw_{t}"], TOL, "raw reg")
+    masked_parity(masked.cpu().numpy(), g[f"head_masked_{t}"], g[f"head_cls_{t}"], g[f"head_raw_{t}"], TOL)
+    out = net.head(T(g[f"head_in_{t}"], dev)[None])
+    assert out.shape == (1, B, 2, 16, 16)
+    assert torch.equal(out[0, :, 1], cls)
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_full_step_vs_reference(gnet, dev, B):
+    g, net, _ = gnet
+    t = f"B{B}"
+    res = net(T(g[f"step_x_{t}"], dev), *[T(g[f"step_state{k}_{t}"], dev) for k in range(6)])
+    assert res[0].shape == g[f"step_reg_{t}"].shape
+    for k in range(6):
+        assert_close(res[1 + k].cpu().numpy(), g[f"step_newstate{k}_{t}"], TOL, f"new state {k}")
+    diff = np.abs(res[0].cpu().numpy() - g[f"step_reg_{t}"])
+    assert (diff > 1e-4 * max(1e-3, np.abs(g[f"step_reg_{t}"]).max())).mean() < 0.01   # threshold flips only
+
+
+def test_preprocess_vs_reference(golden, dev):
+    import urnn_amd.weights as uw
+    from urnn_amd.dataset import preprocess_inputs
+    g = golden("preprocess.npz")
+    H, W, nums, Tn = int(g["H"]), int(g["W"]), int(g["nums"]), int(g["T"])
+    for spatial in (0, 1):
+        for B in (1, 2):
+            ev = uw.make_event(Tn, H, W, float(g["rain_max"]), seed=int(g["event_seed"]), spatial_rain=bool(spatial), batch=B)
+            for t in (0, nums - 1, nums, Tn - 1):
+                y = preprocess_inputs(t, ev, dev, nums=nums, rain_max=float(g["rain_max"]), cumsum_rain_max=float(g["cumsum_max"]))
+                ref = g[f"pre_sp{spatial}_B{B}_t{t}"]
+                assert y.shape == ref.shape
+                assert_close(y.cpu().numpy(), ref, 1e-6, f"preprocess sp={spatial} B={B} t={t}")
+
+
+# ---- ragged / odd shapes against the oracle --------------------------------------------------------------
+@pytest.mark.parametrize("H,W,B", [(20, 12, 1), (36, 52, 2), (100, 60, 1), (8, 8, 3), (4, 4, 1)])
+def test_full_step_vs_oracle_shapes(dev, H, W, B):
+    import urnn_amd.weights as uw
+    from oracle import oracle as orc
+    from urnn_amd.net_config import load_net_config
+    from urnn_amd.networks import ED, get_network_params
+    C = 15
+    sd = uw.make_state_dict(H, W, C, seed=H * 100 + W)
+    ep, dp = get_network_params(False, H, W, C, load_net_config())
+    net = ED(False, ep, dp, 0.5, False, H, W)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net = net.to(dev).eval()
+    rs = np.random.RandomState(5)
+    x = (0.5 * rs.standard_normal((B, 1, C, H, W))).astype(np.float32)
+    st = [(0.5 * rs.standard_normal(s.shape)).astype(np.float32) for s in orc.zero_states(B, H, W)]
+    res = net(T(x, dev), *[T(s, dev) for s in st])
+    ref_out, ref_st, aux = orc.OracleNet(sd).step(x[:, 0], st, want_aux=True)
+    for k in range(6):
+        assert_close(res[1 + k].cpu().numpy(), ref_st[k], TOL, f"state {k} at {H}x{W} B={B}")
+    masked_parity(res[0].cpu().numpy()[:, 0], ref_out, aux["cls"], aux["reg_raw"], TOL)
+
+
+def test_argument_errors(dev):
+    from urnn_amd import ops
+    from urnn_amd._lib import UrnnError
+    x = torch.zeros(1, 8, 4, 4, device=dev)
+    with pytest.raises(RuntimeError):
+        ops.stage_conv(torch.zeros(1, 8, 4, 4), torch.zeros(10), 16, False)       # CPU tensor: no fallback
+    packed = ops.pack_conv(torch.zeros(16, 8, 1, 1, device=dev), torch.zeros(16, device=dev))
+    with pytest.raises(UrnnError):
+        ops.stage_conv(x, packed, 16, True, out=torch.zeros(1, 16, 2, 2, device=dev)[:, :, :, 1:].contiguous()[..., :0].new_zeros(3)[1:])

@@ -1,0 +1,64 @@
+"""ctypes binding of ``liburnn_hip.so`` (the C ABI in include/urnn_hip.h).
+
+There is NO fallback: if the shared library is missing or fails to load, importing any op raises.
+The product path never touches ``oracle/``.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liburnn_hip.so")
+
+_lib = None
+
+c_float_p = ctypes.c_void_p  # raw device pointers (tensor.data_ptr())
+_i, _f, _p, _sz = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/urnn_hip.h exactly
+SIGNATURES = {
+    "urnn_abi_version": (_i, []),
+    "urnn_last_error": (ctypes.c_char_p, []),
+    "urnn_packed_conv_floats": (_sz, [_i, _i]),
+    "urnn_pack_conv_f32": (_i, [_p, _p, _p, _i, _i, _p]),
+    "urnn_packed_gru_floats": (_sz, [_i, _i, _i]),
+    "urnn_pack_gru_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    "urnn_packed_deconv_floats": (_sz, [_i, _i]),
+    "urnn_pack_deconv_f32": (_i, [_p, _p, _p, _i, _i, _p]),
+    "urnn_stage_conv_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "urnn_gru_cell_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "urnn_gru_cell_f32": (_i, [_p] * 10 + [_sz, _i, _i, _i, _i, _i, _f, _p]),
+    "urnn_deconv2x2_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
+    "urnn_head_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "urnn_head_f32": (_i, [_p] * 13 + [_sz, _i, _i, _i, _i, _f, _f, _f, _p]),
+    "urnn_preprocess_f32": (_i, [_p] * 5 + [_f, _f, _p, _i, _p, _i, _i, _i, _i, _i, _i, _f, _f, _p]),
+    "urnn_advance_counter": (_i, [_p, _i, _p]),
+}
+
+
+class UrnnError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises loudly when the HIP extension is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise UrnnError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU/PyTorch fallback for the U-RNN hot path.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if handle.urnn_abi_version() != 1:
+            raise UrnnError("liburnn_hip.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().urnn_last_error()
+        raise UrnnError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

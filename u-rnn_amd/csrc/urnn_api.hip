@@ -1,0 +1,355 @@
+// urnn_api.hip -- the C ABI of liburnn_hip.so (declared in include/urnn_hip.h): argument checking, workspace carving and
+// kernel sequencing.  Enqueue-only: nothing here synchronises, allocates or keeps state besides the thread-local error text.
+#include "urnn_common.h"
+#include "urnn_kernels.h"
+#include "../../include/urnn_hip.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static int hip_fail(hipError_t e, const char *what)
+{
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+}
+
+#define CHECK_HIP(expr, what)                      \
+    do {                                           \
+        hipError_t e_ = (expr);                    \
+        if (e_ != hipSuccess) return hip_fail(e_, what); \
+    } while (0)
+
+static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+extern "C" int urnn_abi_version(void) { return URNN_ABI_VERSION; }
+extern "C" const char *urnn_last_error(void) { return g_err; }
+
+// Pixel-block count per wave tile: big planes use 128-pixel tiles; small planes shrink the tile so that the launch still
+// covers the chip (1024 SIMDs) -- the deep stages are 15 625 pixels at 500x500.
+static int pick_pb(long pixels_total, int waves_per_tile, bool vec_ok4, bool vec_ok2, bool *vec)
+{
+    int pb = 4;
+    while (pb > 1 && (pixels_total / (32 * pb)) * waves_per_tile < 2048) pb >>= 1;
+    if (pb == 4 && !vec_ok4) pb = 2;   // scalar-load tiles of 128 pixels cost too many address registers
+    *vec = (pb == 4 && vec_ok4) || (pb == 2 && vec_ok2);
+    return pb;
+}
+
+// ---- packing ---------------------------------------------------------------------------------------------------------
+extern "C" size_t urnn_packed_conv_floats(int Cin, int Cout)
+{
+    const size_t Kpad = urnn_round_up(Cin, URNN_KPAD), Npad = urnn_round_up(Cout, 32);
+    return Kpad * Npad + Npad;
+}
+
+extern "C" int urnn_pack_conv_f32(const float *weight, const float *bias, float *packed, int Cin, int Cout, void *stream)
+{
+    if (!weight || !packed) return fail(URNN_ENULL, "urnn_pack_conv_f32: weight/packed is NULL");
+    if (Cin < 1 || Cout < 1) return fail(URNN_EINVAL, "urnn_pack_conv_f32: Cin=%d Cout=%d", Cin, Cout);
+    CHECK_HIP(urnn_launch_pack_conv(weight, bias, packed, Cin, Cout, (hipStream_t)stream), "pack_conv");
+    return URNN_OK;
+}
+
+extern "C" size_t urnn_packed_gru_floats(int I, int F, int skip)
+{
+    const size_t Kp = (size_t)urnn_round_up(I, URNN_KPAD) + (skip ? F : 0) + F;
+    return Kp * 3 * F + 3 * F + (size_t)F * F;
+}
+
+extern "C" int urnn_pack_gru_f32(const float *W1, const float *b1, const float *W2, const float *b2, float *packed, int I, int F,
+                                 int skip, void *stream)
+{
+    if (!W1 || !b1 || !W2 || !b2 || !packed) return fail(URNN_ENULL, "urnn_pack_gru_f32: NULL argument");
+    if (I < 1 || F < 32 || F % 32 != 0 || F > 128)
+        return fail(URNN_EINVAL, "urnn_pack_gru_f32: need I>=1 and F in {32,64,96,128} (got I=%d F=%d)", I, F);
+    CHECK_HIP(urnn_launch_pack_gru(W1, b1, W2, b2, packed, I, F, skip ? 1 : 0, (hipStream_t)stream), "pack_gru");
+    return URNN_OK;
+}
+
+extern "C" size_t urnn_packed_deconv_floats(int Cin, int Cout)
+{
+    const size_t Kpad = urnn_round_up(Cin, URNN_KPAD), Npad = 4 * (size_t)((Cout + 31) / 32) * 32;
+    return Kpad * Npad + Npad;
+}
+
+extern "C" int urnn_pack_deconv_f32(const float *weight, const float *bias, float *packed, int Cin, int Cout, void *stream)
+{
+    if (!weight || !packed) return fail(URNN_ENULL, "urnn_pack_deconv_f32: weight/packed is NULL");
+    if (Cin < 1 || Cout < 1 || Cout > 96) return fail(URNN_EINVAL, "urnn_pack_deconv_f32: need 1<=Cout<=96 (got Cin=%d Cout=%d)", Cin, Cout);
+    CHECK_HIP(urnn_launch_pack_deconv(weight, bias, packed, Cin, Cout, (hipStream_t)stream), "pack_deconv");
+    return URNN_OK;
+}
+
+// ---- stage conv ------------------------------------------------------------------------------------------------------
+extern "C" int urnn_stage_conv_f32(const float *in, const float *packed, float *out, int B, int Cin, int Cout, int H, int W,
+                                   int pool, float slope, void *stream)
+{
+    if (!in || !packed || !out) return fail(URNN_ENULL, "urnn_stage_conv_f32: NULL argument");
+    if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return fail(URNN_EINVAL, "urnn_stage_conv_f32: bad dims");
+    if ((Cout + 31) / 32 > 12) return fail(URNN_EINVAL, "urnn_stage_conv_f32: Cout=%d > 384 unsupported", Cout);
+    if (pool && (H < 2 || W < 2)) return fail(URNN_EINVAL, "urnn_stage_conv_f32: pool needs H,W >= 2");
+    if (!aligned16(in) || !aligned16(out) || !aligned16(packed)) return fail(URNN_EALIGN, "urnn_stage_conv_f32: pointers must be 16-byte aligned");
+    const long P = (long)H * W;
+    ConvGemmParams p = {};
+    p.seg[0] = in;
+    p.segC[0] = Cin;
+    p.hseg = -1;
+    p.wt = packed;
+    p.ldw = urnn_round_up(Cout, 32);
+    p.Kpad = urnn_round_up(Cin, URNN_KPAD);
+    p.P = (int)P;
+    p.W = W;
+    p.Cout = Cout;
+    p.slope = slope;
+    p.out0 = out;
+    hipStream_t st = (hipStream_t)stream;
+    if (pool) {
+        p.W2 = W / 2;
+        p.P2 = (H / 2) * (W / 2);
+        const bool vec = (W % 2) == 0;
+        CHECK_HIP(urnn_launch_conv_pool(p, B, vec, st), "stage_conv(pool)");
+    } else {
+        bool vec;
+        const int nblk = (Cout + 31) / 32;
+        const int nw = nblk <= 3 ? 1 : nblk / (nblk % 3 == 0 ? 3 : (nblk % 2 == 0 ? 2 : 1));
+        if (nw > 4) return fail(URNN_EINVAL, "urnn_stage_conv_f32: Cout=%d needs more than 4 waves per tile", Cout);
+        const int pb = pick_pb((long)B * P, nw, P % 4 == 0, P % 2 == 0, &vec);
+        CHECK_HIP(urnn_launch_conv_flat(p, B, pb, vec, st), "stage_conv");
+    }
+    return URNN_OK;
+}
+
+// ---- GRU cell --------------------------------------------------------------------------------------------------------
+struct GruWs {
+    float *g1, *cx, *part1, *part2, *ss1, *ss2;
+    size_t bytes;
+};
+
+static GruWs carve_gru(void *base, int B, int F, long P)
+{
+    // partial buffers are sized for the smallest tile (32 pixels) so any PB choice fits
+    const size_t tiles = (size_t)((P + 31) / 32);
+    size_t off = 0;
+    auto take = [&](size_t nfloats) {
+        float *p = base ? reinterpret_cast<float *>(reinterpret_cast<char *>(base) + off) : nullptr;
+        off += align_up(nfloats * sizeof(float), 256);
+        return p;
+    };
+    GruWs w;
+    w.g1 = take((size_t)B * 2 * F * P);
+    w.cx = take((size_t)B * F * P);
+    w.part1 = take((size_t)B * (2 * F / 32) * tiles * 2);
+    w.part2 = take((size_t)B * (F / 32) * tiles * 2);
+    w.ss1 = take((size_t)B * 2 * F * 2);
+    w.ss2 = take((size_t)B * F * 2);
+    w.bytes = off;
+    return w;
+}
+
+extern "C" size_t urnn_gru_cell_workspace_bytes(int B, int F, int H, int W)
+{
+    if (B < 1 || F < 1 || H < 1 || W < 1) return 0;
+    return carve_gru(nullptr, B, F, (long)H * W).bytes;
+}
+
+extern "C" int urnn_gru_cell_f32(const float *x, const float *e, const float *h, const float *packed, const float *gn1_w,
+                                 const float *gn1_b, const float *gn2_w, const float *gn2_b, float *h_out, void *workspace,
+                                 size_t workspace_bytes, int B, int I, int F, int H, int W, float eps, void *stream)
+{
+    if (!h || !packed || !gn1_w || !gn1_b || !gn2_w || !gn2_b || !h_out || !workspace)
+        return fail(URNN_ENULL, "urnn_gru_cell_f32: NULL argument");
+    if (B < 1 || I < 1 || H < 1 || W < 1) return fail(URNN_EINVAL, "urnn_gru_cell_f32: bad dims");
+    if (F < 32 || F % 32 != 0 || F > 128)
+        return fail(URNN_EINVAL, "urnn_gru_cell_f32: hidden channels F=%d must be a multiple of 32 in [32,128]", F);
+    if (!aligned16(h) || !aligned16(h_out) || !aligned16(packed) || !aligned16(workspace) || (x && !aligned16(x)) || (e && !aligned16(e)))
+        return fail(URNN_EALIGN, "urnn_gru_cell_f32: pointers must be 16-byte aligned");
+    const long P = (long)H * W;
+    const GruWs ws = carve_gru(workspace, B, F, P);
+    if (workspace_bytes < ws.bytes)
+        return fail(URNN_EWORKSPACE, "urnn_gru_cell_f32: workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
+    hipStream_t st = (hipStream_t)stream;
+    const int skip = e != nullptr;
+    const int Ip = urnn_round_up(I, URNN_KPAD);
+    const int Kp = Ip + (skip ? F : 0) + F;
+    const int N = 3 * F;
+
+    // K1: gates (raw) + candidate x/e part, GroupNorm partials of the gates
+    ConvGemmParams p = {};
+    p.seg[0] = x;  // may be nullptr: x == 0
+    p.segC[0] = I;
+    if (skip) {
+        p.seg[1] = e; p.segC[1] = F;
+        p.seg[2] = h; p.segC[2] = F;
+        p.hseg = 2;
+    } else {
+        p.seg[1] = h; p.segC[1] = F;
+        p.hseg = 1;
+    }
+    p.wt = packed;
+    p.ldw = N;
+    p.Kpad = Kp;
+    p.P = (int)P;
+    p.W = W;
+    p.F = F;
+    p.Cout = N;
+    p.out0 = ws.g1;
+    p.out1 = ws.cx;
+    p.partial = ws.part1;
+    bool vec1;
+    const int pb1 = pick_pb((long)B * P, F / 32, P % 4 == 0, P % 2 == 0, &vec1);
+    const int tiles1 = (int)((P + 32 * pb1 - 1) / (32 * pb1));
+    CHECK_HIP(urnn_launch_gru1(p, B, pb1, vec1, st), "gru gates");
+    CHECK_HIP(urnn_launch_gn_finalize(ws.part1, tiles1, 32.0 * (double)P, gn1_w, gn1_b, eps, ws.ss1, B, 2 * F, st), "gn finalize 1");
+
+    // K2: candidate = cx + W2h . (sigmoid(GN(r)) * h), GroupNorm partials of the candidate
+    GruCandParams c = {};
+    c.g1 = ws.g1;
+    c.h = h;
+    c.ss1 = ws.ss1;
+    c.w2h = packed + (size_t)Kp * N + N;
+    c.cx = ws.cx;
+    c.partial = ws.part2;
+    c.P = (int)P;
+    bool vec2;
+    const int pb2 = pick_pb((long)B * P, 1, P % 4 == 0, P % 2 == 0, &vec2);
+    const int tiles2 = (int)((P + 32 * pb2 - 1) / (32 * pb2));
+    CHECK_HIP(urnn_launch_cand(c, B, F, pb2, vec2, st), "gru candidate");
+    CHECK_HIP(urnn_launch_gn_finalize(ws.part2, tiles2, 32.0 * (double)P, gn2_w, gn2_b, eps, ws.ss2, B, F, st), "gn finalize 2");
+
+    // K3: blend
+    CHECK_HIP(urnn_launch_blend(ws.g1, ws.cx, h, ws.ss1, ws.ss2, h_out, B, F, (int)P, st), "gru blend");
+    return URNN_OK;
+}
+
+// ---- deconv ----------------------------------------------------------------------------------------------------------
+extern "C" int urnn_deconv2x2_f32(const float *in, const float *packed, float *out, int B, int Cin, int Cout, int H, int W,
+                                  float slope, void *stream)
+{
+    if (!in || !packed || !out) return fail(URNN_ENULL, "urnn_deconv2x2_f32: NULL argument");
+    if (B < 1 || Cin < 1 || Cout < 1 || Cout > 96 || H < 1 || W < 1)
+        return fail(URNN_EINVAL, "urnn_deconv2x2_f32: bad dims (Cout must be <= 96, got %d)", Cout);
+    if (!aligned16(in) || !aligned16(out) || !aligned16(packed)) return fail(URNN_EALIGN, "urnn_deconv2x2_f32: pointers must be 16-byte aligned");
+    const long P = (long)H * W;
+    ConvGemmParams p = {};
+    p.seg[0] = in;
+    p.segC[0] = Cin;
+    p.hseg = -1;
+    p.wt = packed;
+    p.ldw = 4 * ((Cout + 31) / 32) * 32;
+    p.Kpad = urnn_round_up(Cin, URNN_KPAD);
+    p.P = (int)P;
+    p.W = W;
+    p.Cout = Cout;
+    p.slope = slope;
+    p.out0 = out;
+    const bool big = ((long)B * P / 64) * 2 >= 1024;
+    const int pb = big ? 2 : 1;
+    const bool vec = pb == 2 && (W % 2) == 0;
+    CHECK_HIP(urnn_launch_deconv(p, B, pb, vec, (hipStream_t)stream), "deconv2x2");
+    return URNN_OK;
+}
+
+// ---- head ------------------------------------------------------------------------------------------------------------
+struct HeadWs {
+    float *u1, *u2, *partial, *stats;
+    size_t bytes;
+};
+
+static HeadWs carve_head(void *base, int B, int C, long P)
+{
+    size_t off = 0;
+    auto take = [&](size_t nfloats) {
+        float *p = base ? reinterpret_cast<float *>(reinterpret_cast<char *>(base) + off) : nullptr;
+        off += align_up(nfloats * sizeof(float), 256);
+        return p;
+    };
+    HeadWs w;
+    w.u1 = take((size_t)B * C * P);
+    w.u2 = take((size_t)B * C * P);
+    w.partial = take((size_t)5 * B * urnn_head_nblk((int)P) * 2);
+    w.stats = take((size_t)5 * B * 2);
+    w.bytes = off;
+    return w;
+}
+
+extern "C" size_t urnn_head_workspace_bytes(int B, int C, int H, int W)
+{
+    if (B < 1 || C < 1 || H < 1 || W < 1) return 0;
+    return carve_head(nullptr, B, C, (long)H * W).bytes;
+}
+
+extern "C" int urnn_head_f32(const float *feat, const float *conv_w, const float *ln_w, const float *ln_b, const float *cls_w,
+                             const float *cls_b, const float *reg_w, const float *reg_b, float *out_masked, float *out_cls,
+                             float *out_raw, const int *frame_index, void *workspace, size_t workspace_bytes, int B, int C,
+                             int H, int W, float cls_thred, float eps, float slope, void *stream)
+{
+    if (!feat || !conv_w || !ln_w || !ln_b || !cls_w || !cls_b || !reg_w || !reg_b || !out_masked || !out_cls || !workspace)
+        return fail(URNN_ENULL, "urnn_head_f32: NULL argument");
+    if (C != 16) return fail(URNN_EINVAL, "urnn_head_f32: head width C=%d unsupported (kernels are built for 16)", C);
+    if (B < 1 || H < 1 || W < 1) return fail(URNN_EINVAL, "urnn_head_f32: bad dims");
+    if (!aligned16(feat) || !aligned16(ln_w) || !aligned16(ln_b) || !aligned16(workspace))
+        return fail(URNN_EALIGN, "urnn_head_f32: pointers must be 16-byte aligned");
+    const long P = (long)H * W;
+    const HeadWs ws = carve_head(workspace, B, C, P);
+    if (workspace_bytes < ws.bytes) return fail(URNN_EWORKSPACE, "urnn_head_f32: workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
+    HeadParams p = {};
+    p.feat = feat;
+    p.conv_w = conv_w;
+    p.ln_w = ln_w;
+    p.ln_b = ln_b;
+    p.cls_w = cls_w;
+    p.cls_b = cls_b;
+    p.reg_w = reg_w;
+    p.reg_b = reg_b;
+    p.out_masked = out_masked;
+    p.out_cls = out_cls;
+    p.out_raw = out_raw;
+    p.frame_index = frame_index;
+    p.u1 = ws.u1;
+    p.u2 = ws.u2;
+    p.partial = ws.partial;
+    p.stats = ws.stats;
+    p.B = B;
+    p.C = C;
+    p.P = (int)P;
+    p.nblk = urnn_head_nblk((int)P);
+    p.cls_thred = cls_thred;
+    p.eps = eps;
+    p.slope = slope;
+    CHECK_HIP(urnn_launch_head(p, (hipStream_t)stream), "head");
+    return URNN_OK;
+}
+
+// ---- input assembly --------------------------------------------------------------------------------------------------
+extern "C" int urnn_preprocess_f32(const float *rain, const float *cumsum, const float *dem, const float *imperv,
+                                   const float *manhole, float dem_min, float dem_max, float *out, int t, const int *t_dev,
+                                   int B, int T, int nums, int H, int W, int spatial, float rain_max, float cumsum_max,
+                                   void *stream)
+{
+    if (!rain || !cumsum || !dem || !imperv || !manhole || !out) return fail(URNN_ENULL, "urnn_preprocess_f32: NULL argument");
+    if (B < 1 || T < 1 || nums < 1 || H < 1 || W < 1) return fail(URNN_EINVAL, "urnn_preprocess_f32: bad dims");
+    if (!t_dev && t < 0) return fail(URNN_EINVAL, "urnn_preprocess_f32: t=%d", t);
+    CHECK_HIP(urnn_launch_preprocess(rain, cumsum, dem, imperv, manhole, dem_min, dem_max, out, t, t_dev, B, T, nums, H * W,
+                                     spatial ? 1 : 0, rain_max, cumsum_max, (hipStream_t)stream),
+              "preprocess");
+    return URNN_OK;
+}
+
+extern "C" int urnn_advance_counter(int *counter, int delta, void *stream)
+{
+    if (!counter) return fail(URNN_ENULL, "urnn_advance_counter: NULL counter");
+    CHECK_HIP(urnn_launch_advance(counter, delta, (hipStream_t)stream), "advance_counter");
+    return URNN_OK;
+}

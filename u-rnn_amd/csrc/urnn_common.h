@@ -1,0 +1,40 @@
+// urnn_common.h -- shared device helpers for the gfx950 U-RNN kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// k-pairs (one v_mfma_f32_32x32x2_f32 consumes a k-pair) per software-pipeline chunk.  Every K segment of a
+// packed weight matrix is padded to a multiple of 2*KU rows.
+#define URNN_KU 4
+#define URNN_KPAD (2 * URNN_KU)
+
+static inline int urnn_round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// Row of the 32x32 MFMA C/D tile held in accumulator register r by a lane of the given half-wave:
+// row = (r & 3) + 8 * (r >> 2) + 4 * half  (cdna_hip_programming.md section 3; col = lane & 31).
+__device__ __forceinline__ int mfma_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+__device__ __forceinline__ float sigmoidf_fast(float v) { return __frcp_rn(1.0f + __expf(-v)); }
+
+__device__ __forceinline__ float tanhf_fast(float v)
+{
+    // tanh(v) = sign(v) * (1 - t) / (1 + t), t = exp(-2|v|)  (absolute error ~1e-7)
+    const float t = __expf(-2.0f * fabsf(v));
+    const float r = (1.0f - t) * __frcp_rn(1.0f + t);
+    return copysignf(r, v);
+}
+
+__device__ __forceinline__ float lrelu(float v, float slope) { return v >= 0.f ? v : v * slope; }
+__device__ __forceinline__ float siluf_fast(float v) { return v * sigmoidf_fast(v); }

@@ -1,0 +1,536 @@
+// urnn_elem.hip -- HBM-bound streaming kernels of the U-RNN timestep: GroupNorm/LayerNorm statistics finalisation,
+// the GRU blend, the LayerNorm head, per-frame input assembly and the one-off weight packers.
+#include "urnn_common.h"
+#include "urnn_kernels.h"
+
+// ------------------------------------------------------------------------------------------------------------------
+// GroupNorm finalise: partial (sum, sumsq) per tile -> per-channel (scale, shift) with
+//   y = (v - mean) * rstd * gamma + beta = v * scale + shift.   One block per (sample, 32-channel group).
+// Partials are fp32 sums over <= 4096 values; they are combined in double in a fixed order (deterministic).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restrict__ partial, int ntiles, double count,
+                                                          const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                          float eps, float *__restrict__ ss, int C)
+{
+    __shared__ double sh1[256], sh2[256];
+    const int G = C / 32;
+    const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+    const float *pp = partial + ((size_t)b * G + g) * ntiles * 2;
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = threadIdx.x; t < ntiles; t += 256) {
+        s1 += (double)pp[2 * t];
+        s2 += (double)pp[2 * t + 1];
+    }
+    sh1[threadIdx.x] = s1;
+    sh2[threadIdx.x] = s2;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if ((int)threadIdx.x < m) {
+            sh1[threadIdx.x] += sh1[threadIdx.x + m];
+            sh2[threadIdx.x] += sh2[threadIdx.x + m];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 32) {
+        const double mean = sh1[0] / count;
+        double var = sh2[0] / count - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        const int c = g * 32 + threadIdx.x;
+        const double sc = (double)gamma[c] * rstd;
+        ss[((size_t)b * C + c) * 2] = (float)sc;
+        ss[((size_t)b * C + c) * 2 + 1] = (float)((double)beta[c] - mean * sc);
+    }
+}
+
+hipError_t urnn_launch_gn_finalize(const float *partial, int ntiles, double count, const float *gamma, const float *beta,
+                                   float eps, float *ss, int B, int C, hipStream_t st)
+{
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * (C / 32)), dim3(256), 0, st, partial, ntiles, count, gamma, beta, eps, ss, C);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// GRU blend: z = sigmoid(GN(g_z)); n = tanh(GN(c)); h' = (1 - z) * h + z * n          (ConvRNN.py:183-189)
+// grid = (chunks, B*F): one (sample, channel) plane per blockIdx.y so scale/shift are block-uniform.
+// ------------------------------------------------------------------------------------------------------------------
+template <int V>
+__global__ __launch_bounds__(256) void gru_blend_kernel(const float *__restrict__ g1, const float *__restrict__ c,
+                                                        const float *h, const float *__restrict__ ss1,
+                                                        const float *__restrict__ ss2, float *out, int F, int P)
+{
+    const int bc = blockIdx.y;
+    const int b = bc / F, f = bc - b * F;
+    const float s1 = ss1[((size_t)b * 2 * F + f) * 2], t1 = ss1[((size_t)b * 2 * F + f) * 2 + 1];
+    const float s2 = ss2[((size_t)b * F + f) * 2], t2 = ss2[((size_t)b * F + f) * 2 + 1];
+    const float *gz = g1 + ((size_t)b * 2 * F + f) * P;
+    const float *cc = c + ((size_t)bc) * P;
+    const float *hh = h + ((size_t)bc) * P;
+    float *oo = out + ((size_t)bc) * P;
+    constexpr int ITER = 4;
+    const int base = blockIdx.x * (256 * V * ITER);
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int p = base + (it * 256 + threadIdx.x) * V;
+        if (p >= P) break;
+        if constexpr (V == 4) {
+            const f32x4 g = *reinterpret_cast<const f32x4 *>(gz + p);
+            const f32x4 cv = *reinterpret_cast<const f32x4 *>(cc + p);
+            const f32x4 hv = *reinterpret_cast<const f32x4 *>(hh + p);
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float z = sigmoidf_fast(g[k] * s1 + t1);
+                const float n = tanhf_fast(cv[k] * s2 + t2);
+                o[k] = (1.f - z) * hv[k] + z * n;
+            }
+            *reinterpret_cast<f32x4 *>(oo + p) = o;
+        } else {
+            const float z = sigmoidf_fast(gz[p] * s1 + t1);
+            const float n = tanhf_fast(cc[p] * s2 + t2);
+            oo[p] = (1.f - z) * hh[p] + z * n;
+        }
+    }
+}
+
+hipError_t urnn_launch_blend(const float *g1, const float *c, const float *h, const float *ss1, const float *ss2, float *out,
+                             int B, int F, int P, hipStream_t st)
+{
+    const bool v4 = (P % 4) == 0;
+    const int per_block = 256 * (v4 ? 4 : 1) * 4;
+    dim3 grid((P + per_block - 1) / per_block, B * F);
+    if (v4) hipLaunchKernelGGL(gru_blend_kernel<4>, grid, dim3(256), 0, st, g1, c, h, ss1, ss2, out, F, P);
+    else hipLaunchKernelGGL(gru_blend_kernel<1>, grid, dim3(256), 0, st, g1, c, h, ss1, ss2, out, F, P);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Head (flood_head.py:131-202).  C = 16 channels; each thread owns V consecutive pixels x 16 channels in registers.
+// LayerNorm([16,H,W]) statistics are whole-sample reductions => four passes separated by finalise kernels:
+//   k1: stats(u0 = Ws.f)                                   k2: t = SiLU(LN0(u0)); u1 = Wc1.t, u2 = Wq1.t (+stats)
+//   k3: u1 <- Wc2.SiLU(LN1(u1)), u2 <- Wq2.SiLU(LN3(u2)) (+stats)      k4: cls / reg predictions + wet/dry mask
+// The element-wise LayerNorm affine (16,H,W) per block is the dominant HBM stream.
+// ------------------------------------------------------------------------------------------------------------------
+#define HEAD_C 16
+
+template <int V>
+__device__ __forceinline__ void head_load(const float *__restrict__ src, int P, int p, float (&v)[HEAD_C][V])
+{
+#pragma unroll
+    for (int c = 0; c < HEAD_C; ++c) {
+        if constexpr (V == 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(src + (size_t)c * P + p);
+            v[c][0] = t.x; v[c][1] = t.y; v[c][2] = t.z; v[c][3] = t.w;
+        } else if constexpr (V == 2) {
+            const f32x2 t = *reinterpret_cast<const f32x2 *>(src + (size_t)c * P + p);
+            v[c][0] = t.x; v[c][1] = t.y;
+        } else {
+            v[c][0] = src[(size_t)c * P + p];
+        }
+    }
+}
+
+template <int V>
+__device__ __forceinline__ void head_store(float *dst, int P, int p, const float (&v)[HEAD_C][V])
+{
+#pragma unroll
+    for (int c = 0; c < HEAD_C; ++c) {
+        if constexpr (V == 4) *reinterpret_cast<f32x4 *>(dst + (size_t)c * P + p) = f32x4{v[c][0], v[c][1], v[c][2], v[c][3]};
+        else if constexpr (V == 2) *reinterpret_cast<f32x2 *>(dst + (size_t)c * P + p) = f32x2{v[c][0], v[c][1]};
+        else dst[(size_t)c * P + p] = v[c][0];
+    }
+}
+
+// u[n] = sum_c w[n][c] * x[c]    (w is block-uniform -> scalar loads)
+template <int V>
+__device__ __forceinline__ void head_conv(const float *__restrict__ w, const float (&x)[HEAD_C][V], float (&u)[HEAD_C][V])
+{
+#pragma unroll
+    for (int n = 0; n < HEAD_C; ++n) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) u[n][k] = 0.f;
+#pragma unroll
+        for (int c = 0; c < HEAD_C; ++c) {
+            const float wv = w[n * HEAD_C + c];
+#pragma unroll
+            for (int k = 0; k < V; ++k) u[n][k] = fmaf(wv, x[c][k], u[n][k]);
+        }
+    }
+}
+
+// x <- SiLU((x - mean) * rstd * gamma[c][p] + beta[c][p])
+template <int V>
+__device__ __forceinline__ void head_ln_silu(float (&x)[HEAD_C][V], const float *__restrict__ gamma, const float *__restrict__ beta,
+                                             int P, int p, float mean, float rstd)
+{
+    float g[HEAD_C][V], bt[HEAD_C][V];
+    head_load<V>(gamma, P, p, g);
+    head_load<V>(beta, P, p, bt);
+#pragma unroll
+    for (int c = 0; c < HEAD_C; ++c)
+#pragma unroll
+        for (int k = 0; k < V; ++k) x[c][k] = siluf_fast((x[c][k] - mean) * rstd * g[c][k] + bt[c][k]);
+}
+
+template <int V>
+__device__ __forceinline__ void head_sums(const float (&u)[HEAD_C][V], float &s1, float &s2)
+{
+#pragma unroll
+    for (int c = 0; c < HEAD_C; ++c)
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            s1 += u[c][k];
+            s2 += u[c][k] * u[c][k];
+        }
+}
+
+__device__ __forceinline__ void head_block_partial(float s1, float s2, float *dst)
+{
+    __shared__ float sh[2][4];
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) {
+        sh[0][wave] = s1;
+        sh[1][wave] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        dst[0] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+        dst[1] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+    }
+}
+
+// partial layout: [which(5)][B][nblk][2];  stats layout: [which(5)][B][2]
+__device__ __forceinline__ float *head_partial(const HeadParams &p, int which, int b, int blk)
+{
+    return p.partial + ((((size_t)which * p.B + b) * p.nblk) + blk) * 2;
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void head_k1(const HeadParams prm)
+{
+    const int b = blockIdx.y;
+    const int p = (blockIdx.x * 256 + threadIdx.x) * V;
+    float s1 = 0.f, s2 = 0.f;
+    if (p < prm.P) {
+        float f[HEAD_C][V], u[HEAD_C][V];
+        head_load<V>(prm.feat + (size_t)b * HEAD_C * prm.P, prm.P, p, f);
+        head_conv<V>(prm.conv_w, f, u);
+        head_sums<V>(u, s1, s2);
+    }
+    head_block_partial(s1, s2, head_partial(prm, 0, b, blockIdx.x));
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void head_k2(const HeadParams prm)
+{
+    const int b = blockIdx.y;
+    const int p = (blockIdx.x * 256 + threadIdx.x) * V;
+    float c1 = 0.f, c2 = 0.f, q1 = 0.f, q2 = 0.f;
+    if (p < prm.P) {
+        const size_t CP = (size_t)HEAD_C * prm.P;
+        float f[HEAD_C][V], t[HEAD_C][V];
+        head_load<V>(prm.feat + b * CP, prm.P, p, f);
+        head_conv<V>(prm.conv_w, f, t);
+        head_ln_silu<V>(t, prm.ln_w, prm.ln_b, prm.P, p, prm.stats[(0 * prm.B + b) * 2], prm.stats[(0 * prm.B + b) * 2 + 1]);
+        head_conv<V>(prm.conv_w + 1 * HEAD_C * HEAD_C, t, f);
+        head_sums<V>(f, c1, c2);
+        head_store<V>(prm.u1 + b * CP, prm.P, p, f);
+        head_conv<V>(prm.conv_w + 3 * HEAD_C * HEAD_C, t, f);
+        head_sums<V>(f, q1, q2);
+        head_store<V>(prm.u2 + b * CP, prm.P, p, f);
+    }
+    head_block_partial(c1, c2, head_partial(prm, 1, b, blockIdx.x));
+    head_block_partial(q1, q2, head_partial(prm, 3, b, blockIdx.x));
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void head_k3(const HeadParams prm)
+{
+    const int b = blockIdx.y;
+    const int p = (blockIdx.x * 256 + threadIdx.x) * V;
+    float c1 = 0.f, c2 = 0.f, q1 = 0.f, q2 = 0.f;
+    if (p < prm.P) {
+        const size_t CP = (size_t)HEAD_C * prm.P;
+        float x[HEAD_C][V], u[HEAD_C][V];
+        head_load<V>(prm.u1 + b * CP, prm.P, p, x);
+        head_ln_silu<V>(x, prm.ln_w + 1 * CP, prm.ln_b + 1 * CP, prm.P, p, prm.stats[(1 * prm.B + b) * 2], prm.stats[(1 * prm.B + b) * 2 + 1]);
+        head_conv<V>(prm.conv_w + 2 * HEAD_C * HEAD_C, x, u);
+        head_sums<V>(u, c1, c2);
+        head_store<V>(prm.u1 + b * CP, prm.P, p, u);
+        head_load<V>(prm.u2 + b * CP, prm.P, p, x);
+        head_ln_silu<V>(x, prm.ln_w + 3 * CP, prm.ln_b + 3 * CP, prm.P, p, prm.stats[(3 * prm.B + b) * 2], prm.stats[(3 * prm.B + b) * 2 + 1]);
+        head_conv<V>(prm.conv_w + 4 * HEAD_C * HEAD_C, x, u);
+        head_sums<V>(u, q1, q2);
+        head_store<V>(prm.u2 + b * CP, prm.P, p, u);
+    }
+    head_block_partial(c1, c2, head_partial(prm, 2, b, blockIdx.x));
+    head_block_partial(q1, q2, head_partial(prm, 4, b, blockIdx.x));
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void head_k4(const HeadParams prm)
+{
+    const int b = blockIdx.y;
+    const int p = (blockIdx.x * 256 + threadIdx.x) * V;
+    if (p >= prm.P) return;
+    const size_t CP = (size_t)HEAD_C * prm.P;
+    const int frame = prm.frame_index ? *prm.frame_index : 0;
+    const size_t obase = ((size_t)frame * prm.B + b) * prm.P + p;
+    float x[HEAD_C][V];
+    float cls[V], reg[V];
+    head_load<V>(prm.u1 + b * CP, prm.P, p, x);
+    head_ln_silu<V>(x, prm.ln_w + 2 * CP, prm.ln_b + 2 * CP, prm.P, p, prm.stats[(2 * prm.B + b) * 2], prm.stats[(2 * prm.B + b) * 2 + 1]);
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        float a = prm.cls_b[0];
+#pragma unroll
+        for (int c = 0; c < HEAD_C; ++c) a = fmaf(prm.cls_w[c], x[c][k], a);
+        cls[k] = sigmoidf_fast(a);
+    }
+    head_load<V>(prm.u2 + b * CP, prm.P, p, x);
+    head_ln_silu<V>(x, prm.ln_w + 4 * CP, prm.ln_b + 4 * CP, prm.P, p, prm.stats[(4 * prm.B + b) * 2], prm.stats[(4 * prm.B + b) * 2 + 1]);
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        float a = prm.reg_b[0];
+#pragma unroll
+        for (int c = 0; c < HEAD_C; ++c) a = fmaf(prm.reg_w[c], x[c][k], a);
+        reg[k] = lrelu(a, prm.slope);
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        prm.out_masked[obase + k] = reg[k] * (cls[k] >= prm.cls_thred ? 1.f : 0.f);
+        prm.out_cls[obase + k] = cls[k];
+        if (prm.out_raw) prm.out_raw[obase + k] = reg[k];
+    }
+}
+
+// LayerNorm finalise: one block per (which, sample); which = first + i * stride for i < n (blockIdx.y).
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const HeadParams prm, int first, int stride, int nblk_used)
+{
+    __shared__ double sh1[256], sh2[256];
+    const int which = first + blockIdx.y * stride;
+    const int b = blockIdx.x;
+    const float *pp = prm.partial + (((size_t)which * prm.B + b) * prm.nblk) * 2;
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = threadIdx.x; t < nblk_used; t += 256) {
+        s1 += (double)pp[2 * t];
+        s2 += (double)pp[2 * t + 1];
+    }
+    sh1[threadIdx.x] = s1;
+    sh2[threadIdx.x] = s2;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if ((int)threadIdx.x < m) {
+            sh1[threadIdx.x] += sh1[threadIdx.x + m];
+            sh2[threadIdx.x] += sh2[threadIdx.x + m];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double count = (double)HEAD_C * (double)prm.P;
+        const double mean = sh1[0] / count;
+        double var = sh2[0] / count - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        prm.stats[((size_t)which * prm.B + b) * 2] = (float)mean;
+        prm.stats[((size_t)which * prm.B + b) * 2 + 1] = (float)(1.0 / sqrt(var + (double)prm.eps));
+    }
+}
+
+int urnn_head_nblk(int P) { return (P + 255) / 256; }
+
+template <int V>
+static hipError_t launch_head_v(const HeadParams &p, hipStream_t st)
+{
+    const int nb = (p.P + 256 * V - 1) / (256 * V);
+    dim3 grid(nb, p.B), blk(256);
+    hipLaunchKernelGGL(head_k1<V>, grid, blk, 0, st, p);
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3(p.B, 1), blk, 0, st, p, 0, 1, nb);
+    hipLaunchKernelGGL(head_k2<V>, grid, blk, 0, st, p);
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3(p.B, 2), blk, 0, st, p, 1, 2, nb);
+    hipLaunchKernelGGL(head_k3<V>, grid, blk, 0, st, p);
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3(p.B, 2), blk, 0, st, p, 2, 2, nb);
+    hipLaunchKernelGGL(head_k4<V>, grid, blk, 0, st, p);
+    return hipGetLastError();
+}
+
+hipError_t urnn_launch_head(const HeadParams &p, hipStream_t st)
+{
+    if (p.P % 2 == 0) return launch_head_v<2>(p, st);
+    return launch_head_v<1>(p, st);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Per-frame input assembly (Dynamic2DFlood.py:265-376).  grid = (chunks, B*C); one output plane per blockIdx.y.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void preprocess_kernel(const float *__restrict__ rain, const float *__restrict__ cumsum,
+                                                         const float *__restrict__ dem, const float *__restrict__ imperv,
+                                                         const float *__restrict__ manhole, float dem_min, float dem_max,
+                                                         float *__restrict__ out, int t_host, const int *__restrict__ t_dev,
+                                                         int T, int nums, int P, int spatial, float rain_max, float cumsum_max)
+{
+    const int C = 2 * nums + 3;
+    const int bc = blockIdx.y;
+    const int b = bc / C, c = bc - b * C;
+    const int t = t_dev ? *t_dev : t_host;
+    float *dst = out + (size_t)bc * P;
+    const int p0 = blockIdx.x * 1024;
+    const int pend = min(P, p0 + 1024);
+    if (c < 2 * nums) {
+        const int which = c / nums, slot = c - which * nums;
+        const int start = max(0, t - nums + 1), end = min(t + 1, T);
+        const int nsteps = end - start;
+        const int k = slot - (nums - nsteps);
+        const float *src = which ? cumsum : rain;
+        const float mx = which ? cumsum_max : rain_max;
+        if (k < 0) {
+            for (int p = p0 + threadIdx.x; p < pend; p += 256) dst[p] = 0.f;
+        } else if (!spatial) {
+            const float v = (src[(size_t)b * T + start + k] - 0.f) / (mx - 0.f);
+            for (int p = p0 + threadIdx.x; p < pend; p += 256) dst[p] = v;
+        } else {
+            const float *plane = src + ((size_t)b * T + start + k) * P;
+            for (int p = p0 + threadIdx.x; p < pend; p += 256) dst[p] = (plane[p] - 0.f) / (mx - 0.f);
+        }
+    } else if (c == 2 * nums) {
+        const float *plane = dem + (size_t)b * P;
+        const float span = dem_max - dem_min;
+        for (int p = p0 + threadIdx.x; p < pend; p += 256) dst[p] = (plane[p] - dem_min) / span;
+    } else if (c == 2 * nums + 1) {
+        const float *plane = imperv + (size_t)b * P;
+        const float lo = 0.05f, span = 0.9f;   // python-double 0.95 - 0.05 rounded once to fp32, as torch does
+        for (int p = p0 + threadIdx.x; p < pend; p += 256) dst[p] = (plane[p] - lo) / span;
+    } else {
+        const float *plane = manhole + (size_t)b * P;
+        for (int p = p0 + threadIdx.x; p < pend; p += 256) dst[p] = plane[p];
+    }
+}
+
+hipError_t urnn_launch_preprocess(const float *rain, const float *cumsum, const float *dem, const float *imperv,
+                                  const float *manhole, float dem_min, float dem_max, float *out, int t, const int *t_dev,
+                                  int B, int T, int nums, int P, int spatial, float rain_max, float cumsum_max,
+                                  hipStream_t st)
+{
+    const int C = 2 * nums + 3;
+    dim3 grid((P + 1023) / 1024, B * C);
+    hipLaunchKernelGGL(preprocess_kernel, grid, dim3(256), 0, st, rain, cumsum, dem, imperv, manhole, dem_min, dem_max, out, t,
+                       t_dev, T, nums, P, spatial, rain_max, cumsum_max);
+    return hipGetLastError();
+}
+
+__global__ void advance_kernel(int *counter, int delta) { *counter += delta; }
+
+hipError_t urnn_launch_advance(int *counter, int delta, hipStream_t st)
+{
+    hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, st, counter, delta);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight packers (one-off).  See include/urnn_hip.h for the packed layouts.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void pack_conv_kernel(const float *__restrict__ w, const float *__restrict__ bias, float *__restrict__ packed, int Cin,
+                                 int Cout, int Kpad, int Npad)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = Kpad * Npad + Npad;
+    if (idx >= total) return;
+    if (idx < Kpad * Npad) {
+        const int k = idx / Npad, n = idx - k * Npad;
+        packed[idx] = (k < Cin && n < Cout) ? w[(size_t)n * Cin + k] : 0.f;
+    } else {
+        const int n = idx - Kpad * Npad;
+        packed[idx] = (bias && n < Cout) ? bias[n] : 0.f;
+    }
+}
+
+hipError_t urnn_launch_pack_conv(const float *w, const float *bias, float *packed, int Cin, int Cout, hipStream_t st)
+{
+    const int Kpad = urnn_round_up(Cin, URNN_KPAD), Npad = urnn_round_up(Cout, 32);
+    const int total = Kpad * Npad + Npad;
+    hipLaunchKernelGGL(pack_conv_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, bias, packed, Cin, Cout, Kpad, Npad);
+    return hipGetLastError();
+}
+
+// rows: x (Ip = I padded to 8) | e (F, decoder only) | h (F); columns: for i < F/32: [z_i | r_i | c_i]; then bias[3F];
+// then W2h[F][F] (k-major).  Source K index order of W1 / W2 is cat(x, [e,] h) (ConvRNN.py:153,165-168).
+__global__ void pack_gru_kernel(const float *__restrict__ W1, const float *__restrict__ b1, const float *__restrict__ W2,
+                                const float *__restrict__ b2, float *__restrict__ packed, int I, int F, int skip)
+{
+    const int Ip = (I + URNN_KPAD - 1) / URNN_KPAD * URNN_KPAD;
+    const int Fe = skip ? F : 0;
+    const int Kp = Ip + Fe + F, N = 3 * F, Ksrc = I + Fe + F;
+    const int total = Kp * N + N + F * F;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    if (idx < Kp * N + N) {
+        const bool is_bias = idx >= Kp * N;
+        const int k = is_bias ? 0 : idx / N;
+        const int n = is_bias ? idx - Kp * N : idx - k * N;
+        const int i = n / 96, which = (n - i * 96) / 32, j = n & 31;   // which: 0 z, 1 r, 2 c
+        const int ch = i * 32 + j;
+        if (is_bias) {
+            packed[idx] = which == 0 ? b1[ch] : (which == 1 ? b1[F + ch] : b2[ch]);
+            return;
+        }
+        int ks;            // source column, -1: padding
+        bool hrow = false;
+        if (k < Ip) ks = k < I ? k : -1;
+        else if (k < Ip + Fe) ks = I + (k - Ip);
+        else { ks = I + Fe + (k - Ip - Fe); hrow = true; }
+        float v = 0.f;
+        if (ks >= 0) {
+            if (which == 0) v = W1[(size_t)ch * Ksrc + ks];
+            else if (which == 1) v = W1[(size_t)(F + ch) * Ksrc + ks];
+            else v = hrow ? 0.f : W2[(size_t)ch * Ksrc + ks];
+        }
+        packed[idx] = v;
+    } else {
+        const int r = idx - (Kp * N + N);
+        const int k = r / F, n = r - k * F;
+        packed[idx] = W2[(size_t)n * Ksrc + I + Fe + k];
+    }
+}
+
+hipError_t urnn_launch_pack_gru(const float *W1, const float *b1, const float *W2, const float *b2, float *packed, int I,
+                                int F, int skip, hipStream_t st)
+{
+    const int Ip = urnn_round_up(I, URNN_KPAD);
+    const int Kp = Ip + (skip ? F : 0) + F, N = 3 * F;
+    const int total = Kp * N + N + F * F;
+    hipLaunchKernelGGL(pack_gru_kernel, dim3((total + 255) / 256), dim3(256), 0, st, W1, b1, W2, b2, packed, I, F, skip);
+    return hipGetLastError();
+}
+
+// columns: a (2) x [bb (2) x co-block (NBC) x 32]; Wt[ci][n] = w[ci][co][a][bb]; bias replicated per column.
+__global__ void pack_deconv_kernel(const float *__restrict__ w, const float *__restrict__ bias, float *__restrict__ packed, int Cin,
+                                   int Cout, int Kpad, int NBC)
+{
+    const int Npad = 4 * NBC * 32;
+    const int total = Kpad * Npad + Npad;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const bool is_bias = idx >= Kpad * Npad;
+    const int k = is_bias ? 0 : idx / Npad;
+    const int n = is_bias ? idx - Kpad * Npad : idx - k * Npad;
+    const int a = n / (2 * NBC * 32);
+    const int rem = n - a * (2 * NBC * 32);
+    const int bb = rem / (NBC * 32);
+    const int co = rem - bb * (NBC * 32);
+    float v = 0.f;
+    if (co < Cout) {
+        if (is_bias) v = bias ? bias[co] : 0.f;
+        else if (k < Cin) v = w[(((size_t)k * Cout + co) * 2 + a) * 2 + bb];
+    }
+    packed[idx] = v;
+}
+
+hipError_t urnn_launch_pack_deconv(const float *w, const float *bias, float *packed, int Cin, int Cout, hipStream_t st)
+{
+    const int Kpad = urnn_round_up(Cin, URNN_KPAD), NBC = (Cout + 31) / 32;
+    const int total = Kpad * 4 * NBC * 32 + 4 * NBC * 32;
+    hipLaunchKernelGGL(pack_deconv_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, bias, packed, Cin, Cout, Kpad, NBC);
+    return hipGetLastError();
+}

@@ -1,0 +1,69 @@
+// urnn_kernels.h -- kernel parameter blocks and internal launchers shared between the .hip translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+enum { MODE_FLAT = 0, MODE_POOL = 1, MODE_DECONV = 2, MODE_GRU1 = 3 };
+
+struct ConvGemmParams {
+    const float *seg[3];  // up to three channel-concatenated inputs (x | e | h); nullptr with segC > 0 == all-zero input
+    int segC[3];
+    int hseg;             // MODE_GRU1: index of the hidden-state segment
+    const float *wt;      // packed Wt[Kpad][ldw] followed by bias[ldw]
+    int ldw, Kpad;
+    int P, W, P2, W2;     // input plane size / width; pooled plane size / width (MODE_POOL)
+    int tilesPerSample;
+    int Cout, F;
+    float slope;
+    float *out0, *out1;
+    float *partial;       // MODE_GRU1: [B][2F/32][tiles][2]
+};
+
+struct GruCandParams {
+    const float *g1;   // raw gates (B,2F,P)
+    const float *h;    // (B,F,P)
+    const float *ss1;  // gate GroupNorm folded to per-channel (scale, shift): [B][2F][2]
+    const float *w2h;  // packed W2 h-part, [F][F] (k-major)
+    float *cx;         // in: candidate x/e part + bias; out: full pre-norm candidate (B,F,P)
+    float *partial;    // [B][F/32][tiles][2]
+    int P, tilesPerSample, blocksPerSample;
+};
+
+hipError_t urnn_launch_conv_flat(ConvGemmParams p, int B, int PB, bool vec, hipStream_t st);
+hipError_t urnn_launch_conv_pool(ConvGemmParams p, int B, bool vec, hipStream_t st);
+hipError_t urnn_launch_deconv(ConvGemmParams p, int B, int PB, bool vec, hipStream_t st);
+hipError_t urnn_launch_gru1(ConvGemmParams p, int B, int PB, bool vec, hipStream_t st);
+hipError_t urnn_launch_cand(GruCandParams p, int B, int F, int PB, bool vec, hipStream_t st);
+
+// ---- elementwise / reduction kernels (urnn_elem.hip) ----
+hipError_t urnn_launch_gn_finalize(const float *partial, int ntiles, double count, const float *gamma, const float *beta,
+                                   float eps, float *ss, int B, int C, hipStream_t st);
+hipError_t urnn_launch_blend(const float *g1, const float *c, const float *h, const float *ss1, const float *ss2, float *out,
+                             int B, int F, int P, hipStream_t st);
+
+struct HeadParams {
+    const float *feat;
+    const float *conv_w;        // 5 x C x C
+    const float *ln_w, *ln_b;   // 5 x C x P
+    const float *cls_w, *cls_b, *reg_w, *reg_b;
+    float *out_masked, *out_cls, *out_raw;
+    const int *frame_index;
+    float *u1, *u2;             // workspace activations (B,C,P) each: cls / reg branch pre-norm values
+    float *partial;             // [5][B][nblk][2]
+    float *stats;               // [5][B][2] mean, rstd
+    int B, C, P, nblk;
+    float cls_thred, eps, slope;
+};
+hipError_t urnn_launch_head(const HeadParams &p, hipStream_t st);
+int urnn_head_nblk(int P);
+
+hipError_t urnn_launch_preprocess(const float *rain, const float *cumsum, const float *dem, const float *imperv,
+                                  const float *manhole, float dem_min, float dem_max, float *out, int t, const int *t_dev,
+                                  int B, int T, int nums, int P, int spatial, float rain_max, float cumsum_max,
+                                  hipStream_t st);
+hipError_t urnn_launch_advance(int *counter, int delta, hipStream_t st);
+
+hipError_t urnn_launch_pack_conv(const float *w, const float *bias, float *packed, int Cin, int Cout, hipStream_t st);
+hipError_t urnn_launch_pack_gru(const float *W1, const float *b1, const float *W2, const float *b2, float *packed, int I,
+                                int F, int skip, hipStream_t st);
+hipError_t urnn_launch_pack_deconv(const float *w, const float *bias, float *packed, int Cin, int Cout, hipStream_t st);

@@ -1,0 +1,166 @@
+"""Tensor-level wrappers over the C ABI: torch owns memory and streams, HIP kernels do the arithmetic.
+
+Every function takes contiguous float32 CUDA(=HIP) tensors, passes ``data_ptr()`` + dims + the current
+stream across the ABI and returns torch tensors.  No op has a PyTorch fallback.
+"""
+import torch
+
+from ._lib import check, lib
+
+LRELU_SLOPE = 0.2   # get_activation("lrelu"), utils.py:63
+NORM_EPS = 1e-5     # nn.GroupNorm / nn.LayerNorm default eps
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev_check(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("urnn_amd ops need tensors on the GPU (cuda:N / HIP device); there is no CPU path")
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"urnn_amd ops are float32 only (got {t.dtype})")
+        if not t.is_contiguous():
+            raise RuntimeError("urnn_amd ops need contiguous tensors")
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+class Workspace:
+    """Grow-only scratch buffer per device (GroupNorm/LayerNorm partials, gate pre-activations)."""
+
+    def __init__(self):
+        self._buf = {}
+
+    def get(self, nbytes, device):
+        key = (device.type, device.index)
+        buf = self._buf.get(key)
+        if buf is None or buf.numel() < nbytes:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("workspace must be pre-sized before graph capture (call reserve())")
+            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            self._buf[key] = buf
+        return buf
+
+    def reserve(self, nbytes, device):
+        return self.get(nbytes, device)
+
+
+WORKSPACE = Workspace()
+
+
+# ---- weight packing ----------------------------------------------------------------------------------
+def pack_conv(weight, bias):
+    """nn.Conv2d (Cout,Cin,1,1) [+ bias] -> packed buffer for stage_conv."""
+    _dev_check(weight, bias)
+    Cout, Cin = weight.shape[0], weight.shape[1]
+    L = lib()
+    out = torch.empty(L.urnn_packed_conv_floats(Cin, Cout), dtype=torch.float32, device=weight.device)
+    check(L.urnn_pack_conv_f32(_ptr(weight), _ptr(bias), _ptr(out), Cin, Cout, _stream()), "urnn_pack_conv_f32")
+    return out
+
+
+def pack_gru(W1, b1, W2, b2, I, F, skip):
+    _dev_check(W1, b1, W2, b2)
+    L = lib()
+    out = torch.empty(L.urnn_packed_gru_floats(I, F, int(skip)), dtype=torch.float32, device=W1.device)
+    check(L.urnn_pack_gru_f32(_ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(out), I, F, int(skip), _stream()),
+          "urnn_pack_gru_f32")
+    return out
+
+
+def pack_deconv(weight, bias):
+    """nn.ConvTranspose2d (Cin,Cout,2,2) + bias -> packed buffer for deconv2x2."""
+    _dev_check(weight, bias)
+    Cin, Cout = weight.shape[0], weight.shape[1]
+    L = lib()
+    out = torch.empty(L.urnn_packed_deconv_floats(Cin, Cout), dtype=torch.float32, device=weight.device)
+    check(L.urnn_pack_deconv_f32(_ptr(weight), _ptr(bias), _ptr(out), Cin, Cout, _stream()), "urnn_pack_deconv_f32")
+    return out
+
+
+# ---- forwards ----------------------------------------------------------------------------------------
+def stage_conv(x, packed, Cout, pool, out=None, slope=LRELU_SLOPE):
+    """[AvgPool2](LeakyReLU(conv1x1(x))): x (B,Cin,H,W) -> (B,Cout,H[/2],W[/2])."""
+    _dev_check(x, packed, out)
+    B, Cin, H, W = x.shape
+    if out is None:
+        out = torch.empty((B, Cout, H // 2, W // 2) if pool else (B, Cout, H, W), dtype=torch.float32, device=x.device)
+    check(lib().urnn_stage_conv_f32(_ptr(x), _ptr(packed), _ptr(out), B, Cin, Cout, H, W, 1 if pool else 0, slope,
+                                    _stream()), "urnn_stage_conv_f32")
+    return out
+
+
+def gru_cell(x, e, h, packed, gn1_w, gn1_b, gn2_w, gn2_b, I, out=None, eps=NORM_EPS):
+    """ConvGRU (e None) / Skip-ConvGRU step.  x may be None (zeros, I channels).  out may be h (in place)."""
+    _dev_check(x, e, h, packed, gn1_w, gn1_b, gn2_w, gn2_b, out)
+    B, F, H, W = h.shape
+    if x is not None and tuple(x.shape) != (B, I, H, W):
+        raise RuntimeError(f"gru_cell: x has shape {tuple(x.shape)}, expected {(B, I, H, W)}")
+    if e is not None and tuple(e.shape) != (B, F, H, W):
+        raise RuntimeError(f"gru_cell: e has shape {tuple(e.shape)}, expected {(B, F, H, W)}")
+    L = lib()
+    nbytes = L.urnn_gru_cell_workspace_bytes(B, F, H, W)
+    ws = WORKSPACE.get(nbytes, h.device)
+    if out is None:
+        out = torch.empty_like(h)
+    check(L.urnn_gru_cell_f32(_ptr(x), _ptr(e), _ptr(h), _ptr(packed), _ptr(gn1_w), _ptr(gn1_b), _ptr(gn2_w), _ptr(gn2_b),
+                              _ptr(out), _ptr(ws), ws.numel(), B, I, F, H, W, eps, _stream()), "urnn_gru_cell_f32")
+    return out
+
+
+def deconv2x2(x, packed, Cout, out=None, slope=LRELU_SLOPE):
+    """LeakyReLU(ConvTranspose2d(k=2,s=2)(x)): (B,Cin,H,W) -> (B,Cout,2H,2W)."""
+    _dev_check(x, packed, out)
+    B, Cin, H, W = x.shape
+    if out is None:
+        out = torch.empty((B, Cout, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+    check(lib().urnn_deconv2x2_f32(_ptr(x), _ptr(packed), _ptr(out), B, Cin, Cout, H, W, slope, _stream()),
+          "urnn_deconv2x2_f32")
+    return out
+
+
+def head(feat, conv_w, ln_w, ln_b, cls_w, cls_b, reg_w, reg_b, cls_thred, out_masked=None, out_cls=None, out_raw=None,
+         frame_index=None, want_raw=False, eps=NORM_EPS, slope=LRELU_SLOPE):
+    """Dual head + mask.  Returns (masked, cls, raw|None), each (B,H,W) unless preallocated (T,B,H,W) buffers
+    plus a device ``frame_index`` are given."""
+    _dev_check(feat, conv_w, ln_w, ln_b, cls_w, cls_b, reg_w, reg_b, out_masked, out_cls, out_raw)
+    B, C, H, W = feat.shape
+    L = lib()
+    nbytes = L.urnn_head_workspace_bytes(B, C, H, W)
+    ws = WORKSPACE.get(nbytes, feat.device)
+    if out_masked is None:
+        out_masked = torch.empty((B, H, W), dtype=torch.float32, device=feat.device)
+    if out_cls is None:
+        out_cls = torch.empty((B, H, W), dtype=torch.float32, device=feat.device)
+    if out_raw is None and want_raw:
+        out_raw = torch.empty((B, H, W), dtype=torch.float32, device=feat.device)
+    check(L.urnn_head_f32(_ptr(feat), _ptr(conv_w), _ptr(ln_w), _ptr(ln_b), _ptr(cls_w), _ptr(cls_b), _ptr(reg_w),
+                          _ptr(reg_b), _ptr(out_masked), _ptr(out_cls), _ptr(out_raw), _ptr(frame_index), _ptr(ws),
+                          ws.numel(), B, C, H, W, float(cls_thred), eps, slope, _stream()), "urnn_head_f32")
+    return out_masked, out_cls, out_raw
+
+
+def preprocess(rain, cumsum, dem, imperv, manhole, dem_min, dem_max, t, nums, rain_max, cumsum_max, out=None, t_dev=None):
+    """Per-frame input assembly: returns (B, 2*nums+3, H, W).  rain/cumsum (B,T) scalar or (B,T,H,W) spatial;
+    dem/imperv/manhole (B,H,W).  ``t_dev`` (int32 device scalar) overrides ``t`` for graph replay."""
+    _dev_check(rain, cumsum, dem, imperv, manhole, out)
+    B, H, W = dem.shape
+    T = rain.shape[1]
+    spatial = 1 if rain.dim() == 4 else 0
+    C = 2 * nums + 3
+    if out is None:
+        out = torch.empty((B, C, H, W), dtype=torch.float32, device=dem.device)
+    check(lib().urnn_preprocess_f32(_ptr(rain), _ptr(cumsum), _ptr(dem), _ptr(imperv), _ptr(manhole), float(dem_min),
+                                    float(dem_max), _ptr(out), int(t), _ptr(t_dev), B, T, nums, H, W, spatial,
+                                    float(rain_max), float(cumsum_max), _stream()), "urnn_preprocess_f32")
+    return out
+
+
+def advance_counter(counter, delta=1):
+    check(lib().urnn_advance_counter(_ptr(counter), int(delta), _stream()), "urnn_advance_counter")
