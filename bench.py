@@ -1,0 +1,246 @@
+#!/usr/bin/env python
+"""bench.py -- flood-map frames/s of the U-RNN rollout hot path on MI355X.
+
+A "step" is one timestep of the rollout = one H x W water-depth frame per event in the batch: per-frame input
+assembly + encoder + decoder + head (`ED.forward`, reference model.py:65-121, inside the `Inference` loop of
+test.py:326-377), replayed as a captured hipGraph with the six hidden states resident in HBM.
+
+Workload at N=1: BASELINE.json configs[1] -- location1 inference, 500x500 @ 2 m, historical_nums=30 (C=63),
+T=360, one event per GPU, fp32, synthetic event + seeded random weights (no datasets/checkpoints offline).
+N>1: one process per GPU (torchrun), one independent event per rank, no data-path collective (events are
+independent: test.py:741-746) -> weak scaling; value = total frames of all ranks / max-over-ranks time.
+
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel = the fp32-MFMA gate GEMM of the
+full-resolution ConvGRU cells, timed live with events on the launch stream) and "cpu_baseline" (the C oracle
+on the host cores, bounded sample, rank 0 at N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+CONFIGS = {
+    # name: (H, W, historical_nums, T, rain_max, cumsum_max, spatial_rain)
+    "location1": (500, 500, 30, 360, 6.0, 250.0, False),   # BASELINE configs[1]
+    "lite64": (64, 64, 3, 30, 60.0, 250.0, False),         # BASELINE configs[0] (plumbing size)
+    "lite128": (128, 128, 3, 36, 60.0, 250.0, False),
+    "futian": (400, 560, 6, 72, 5.0, 100.0, True),
+    "ukea": (52, 120, 6, 36, 10.0, 150.0, True),
+}
+
+PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X fp32 matrix peak (MI355X_MICROARCH.md)
+PEAK_HBM_TBS = 8.0
+
+
+def algorithmic_work(H, W, C):
+    """GFLOP and A_stage MB per frame (SURVEY 8d formulas: GEMM MAC = P*K*N per row of 8a; bytes = 4*P*channels)."""
+    P1, P2, P4 = H * W, (H // 2) * (W // 2), (H // 4) * (W // 4)
+    mac = 0
+    mac += P1 * C * 16 + P1 * 64 * 64 + P2 * 96 * 96                          # encoder stage convs
+    mac += P1 * 80 * 192 + P2 * 160 * 288 + P4 * 192 * 288                    # encoder cells
+    mac += P4 * 288 * 288 + P2 * 288 * 288 + P1 * 224 * 192                   # decoder cells
+    mac += P4 * 96 * 96 * 4 + P2 * 96 * 96 * 4 + P1 * 64 * 16                 # deconvs + final conv
+    mac += P1 * (5 * 16 * 16 + 2 * 16)                                        # head
+    return 2.0 * mac / 1e9
+
+
+def gate_gemm_flops(P):
+    """Algorithmic FLOP of the two launches per frame of conv_gemm_kernel<3,4,MODE_GRU1,vec> at full resolution:
+    enc1 (I=16,F=64): gates 128 x 80 + candidate-x 64 x 16; dec1 (I=96,F=64): gates 128 x 224 + candidate-xe 64 x 160."""
+    enc1 = P * (128 * 80 + 64 * 16) * 2.0
+    dec1 = P * (128 * 224 + 64 * 160) * 2.0
+    return enc1, dec1
+
+
+def build_net(H, W, C, dev, seed=0):
+    import urnn_amd.weights as uw
+    from urnn_amd.net_config import load_net_config
+    from urnn_amd.networks import ED, get_network_params
+    cfg = load_net_config()
+    sd = uw.make_state_dict(H, W, C, seed=seed)
+    ep, dp = get_network_params(False, H, W, C, cfg)
+    net = ED(False, ep, dp, 0.5, False, H, W)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return net.to(dev).eval(), sd, cfg
+
+
+def time_gate_gemm(net, eng, iters=20):
+    """Average duration (s) of the gate-GEMM kernel alone, for the enc1 and dec1 call sites, measured with
+    events on the stream the kernel is launched on (torch's current stream == the stream handed to the C ABI)."""
+    from urnn_amd import ops
+    e1, _, _, _, _, d3 = eng.states
+    sites = [("enc1", lambda: net.encoder.rnn1.step(eng.a1, None, e1, out=e1, phases=ops.PHASE_GATES)),
+             ("dec1", lambda: net.decoder.rnn1.step(eng.u2, e1, d3, out=d3, phases=ops.PHASE_GATES))]
+    out = {}
+    for name, fn in sites:
+        for _ in range(3):
+            fn()
+        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        for _ in range(iters):
+            fn()
+        stop.record()
+        stop.synchronize()
+        out[name] = start.elapsed_time(stop) / 1e3 / iters
+    return out
+
+
+def cpu_baseline(sd, cfgname, budget_s=15.0, max_frames=8):
+    """The C oracle (oracle/urnn_oracle.c, OpenMP) on the host cores: same synthetic event, first frames of the
+    rollout, input assembly included -- frames/s like the reference's Inference timer."""
+    from oracle import oracle as orc
+    import urnn_amd.weights as uw
+    H, W, nums, T, rain_max, cum_max, spatial = CONFIGS[cfgname]
+    net = orc.OracleNet(sd)
+    ev = uw.make_event(min(T, max_frames + 1), H, W, rain_max, seed=42, spatial_rain=spatial)
+    states = orc.zero_states(1, H, W)
+    # one untimed warm-up frame (page faults, thread pool)
+    x = orc.preprocess_inputs(0, ev, nums, rain_max, cum_max)[:, 0]
+    _, states, _ = net.step(x, states)
+    n, t0 = 0, time.time()
+    while n < max_frames and (time.time() - t0) < budget_s:
+        x = orc.preprocess_inputs(n + 1, ev, nums, rain_max, cum_max)[:, 0]
+        _, states, _ = net.step(x, states)
+        n += 1
+    dt = time.time() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": orc.num_threads(), "kind": "port",
+            "sample": f"{n} frames of the {H}x{W} C={2*nums+3} rollout after 1 warm-up frame ({dt:.1f} s), "
+                      f"C oracle with OpenMP on {orc.num_threads()} threads of {os.cpu_count()} logical CPUs"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=360)
+    ap.add_argument("--warmup", type=int, default=36)
+    ap.add_argument("--config", default="location1", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=1, help="events per GPU (the reference entry points use 1)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of the captured hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI; used for the barrier + max-reduce only
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+
+    import urnn_amd.weights as uw
+    from urnn_amd.rollout import RolloutEngine
+
+    H, W, nums, T, rain_max, cum_max, spatial = CONFIGS[args.config]
+    C = 2 * nums + 3
+    B = args.batch
+    net, sd, cfg = build_net(H, W, C, dev)
+    eng = RolloutEngine(net, H, W, nums, rain_max, cum_max, batch=B, max_frames=T, spatial_rain=spatial, net_cfg=cfg,
+                        use_graph=not args.no_graph, device=dev)
+    event = uw.make_event(T, H, W, rain_max, seed=42 + rank, spatial_rain=spatial, batch=B)
+    eng.load_event(event)
+    eng.reset()
+
+    def run_steps(k):
+        """k timesteps; a new event starts (states zeroed, frame counter reset) whenever T frames are done."""
+        done = 0
+        while done < k:
+            n = min(k - done, T - run_steps.t)
+            eng.run(n)
+            run_steps.t += n
+            done += n
+            if run_steps.t == T:
+                eng.reset()
+                run_steps.t = 0
+    run_steps.t = 0
+
+    run_steps(args.warmup)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    frames = args.steps * B * world
+    fps = frames / elapsed
+    gflop = algorithmic_work(H, W, C)
+
+    result = {
+        "metric": "flood-map frames/s (HxW water-depth grids), whole job",
+        "value": fps,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{args.config}: {H}x{W} grid, historical_nums={nums} (C={C}), T={T}, "
+                               f"{B} event(s) per GPU, inference rollout incl. per-frame input assembly",
+                   "events_per_gpu": B, "parallelism": f"event-parallel x{world} (no collective)",
+                   "graph": not args.no_graph},
+        "gflop_per_frame": gflop,
+        "step_mfma_frac": fps / world * gflop / 1e3 / PEAK_MFMA_F32_TFLOPS,
+    }
+
+    if rank == 0:
+        # dominant kernel: fp32-MFMA gate GEMM at full resolution (2 launches per frame: enc1, dec1)
+        try:
+            dur = time_gate_gemm(net, eng)
+            f_enc1, f_dec1 = gate_gemm_flops(H * W * B)
+            flops_per_launch = 0.5 * (f_enc1 + f_dec1)
+            avg = 0.5 * (dur["enc1"] + dur["dec1"])
+            achieved = flops_per_launch / avg / 1e12
+            traffic = None
+            pmc = os.path.join(REPO, "profiles", "pmc_gate_gemm.json")
+            if os.path.isfile(pmc) and args.config == "location1" and B == 1:
+                with open(pmc) as fh:
+                    traffic = json.load(fh).get("hbm_bytes_per_launch")
+            result["roofline"] = {
+                "bound": "mfma", "kernel": "conv_gemm_kernel<NB=3,PB=4,MODE_GRU1,VEC> (ConvGRU gate GEMM, fp32 MFMA 32x32x2)",
+                "achieved": achieved, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_F32_TFLOPS,
+                "traffic": traffic,
+                "avg_launch_us": avg * 1e6, "launch_us": {k: v * 1e6 for k, v in dur.items()},
+                "flops_per_launch": flops_per_launch,
+            }
+        except Exception as exc:  # keep the headline number even if the side measurement fails
+            result["roofline"] = {"error": repr(exc)}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline(sd, args.config)
+            except Exception as exc:
+                result["cpu_baseline"] = {"error": repr(exc)}
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

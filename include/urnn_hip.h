@@ -74,6 +74,19 @@ int urnn_gru_cell_f32(const float *x, const float *e, const float *h, const floa
                       const float *gn1_b, const float *gn2_w, const float *gn2_b, float *h_out, void *workspace,
                       size_t workspace_bytes, int B, int I, int F, int H, int W, float eps, void *stream);
 
+/* The same cell with a subset of its five kernels enqueued (profiling / roofline measurement: bench.py times the
+ * gate GEMM alone with this).  phase_mask is an OR of URNN_PHASE_*; URNN_PHASE_ALL == urnn_gru_cell_f32. */
+#define URNN_PHASE_GATES 1  /* gate GEMM: raw z|r gates, candidate x/e part, GroupNorm partial sums */
+#define URNN_PHASE_GN1 2    /* GroupNorm finalise of the gates                                       */
+#define URNN_PHASE_CAND 4   /* candidate GEMM on sigmoid(GN(r)) * h, GroupNorm partial sums          */
+#define URNN_PHASE_GN2 8    /* GroupNorm finalise of the candidate                                   */
+#define URNN_PHASE_BLEND 16 /* h' = (1 - z) * h + z * tanh(GN(c))                                    */
+#define URNN_PHASE_ALL 31
+int urnn_gru_cell_phases_f32(const float *x, const float *e, const float *h, const float *packed, const float *gn1_w,
+                             const float *gn1_b, const float *gn2_w, const float *gn2_b, float *h_out, void *workspace,
+                             size_t workspace_bytes, int B, int I, int F, int H, int W, float eps, int phase_mask,
+                             void *stream);
+
 /* Decoder up-sampling: out = LeakyReLU_slope(ConvTranspose2d(k=2,s=2,p=0)(in)).
  * Replaces Decoder.stage{3,2}(inputs) -- decoder.py:150-164 with specs net_params.py:106-116.
  * in (B,Cin,H,W) -> out (B,Cout,2H,2W). */

@@ -161,51 +161,90 @@ void orc_deconv2x2(const float *in, const float *w, const float *bias, float *ou
 }
 
 /* nn.GroupNorm(groups, C), eps, biased variance over (C/groups channels x P) per sample, per-channel
- * affine (ConvRNN.py:97,103).  In place. */
+ * affine (ConvRNN.py:97,103).  In place.  Two-pass (mean, then centred squares) in double; parallel over
+ * channels with a fixed-order combine per group. */
 void orc_group_norm(float *x, const float *gamma, const float *beta, int B, int C, long P, int groups, float eps)
 {
     const int cg = C / groups;
-#pragma omp parallel for collapse(2) schedule(static)
-    for (int b = 0; b < B; ++b) {
-        for (int g = 0; g < groups; ++g) {
-            float *base = x + ((size_t)b * C + (size_t)g * cg) * P;
-            const long n = (long)cg * P;
-            double s = 0.0;
-            for (long i = 0; i < n; ++i) s += base[i];
-            const double mean = s / (double)n;
-            double v = 0.0;
-            for (long i = 0; i < n; ++i) {
-                const double d = base[i] - mean;
-                v += d * d;
-            }
-            const double rstd = 1.0 / sqrt(v / (double)n + (double)eps);
-            for (int c = 0; c < cg; ++c) {
-                const double ga = gamma[g * cg + c], be = beta[g * cg + c];
-                float *row = base + (size_t)c * P;
-                for (long i = 0; i < P; ++i) row[i] = (float)(((double)row[i] - mean) * rstd * ga + be);
-            }
-        }
+    double *part = (double *)malloc(sizeof(double) * (size_t)B * C);
+    double *mean = (double *)malloc(sizeof(double) * (size_t)B * groups);
+    double *rstd = (double *)malloc(sizeof(double) * (size_t)B * groups);
+#pragma omp parallel for schedule(static)
+    for (int bc = 0; bc < B * C; ++bc) {
+        const float *row = x + (size_t)bc * P;
+        double s = 0.0;
+        for (long i = 0; i < P; ++i) s += row[i];
+        part[bc] = s;
     }
+    for (int bg = 0; bg < B * groups; ++bg) {
+        double s = 0.0;
+        for (int c = 0; c < cg; ++c) s += part[(size_t)bg * cg + c];
+        mean[bg] = s / ((double)cg * (double)P);
+    }
+#pragma omp parallel for schedule(static)
+    for (int bc = 0; bc < B * C; ++bc) {
+        const float *row = x + (size_t)bc * P;
+        const double m = mean[bc / cg];
+        double v = 0.0;
+        for (long i = 0; i < P; ++i) {
+            const double d = row[i] - m;
+            v += d * d;
+        }
+        part[bc] = v;
+    }
+    for (int bg = 0; bg < B * groups; ++bg) {
+        double v = 0.0;
+        for (int c = 0; c < cg; ++c) v += part[(size_t)bg * cg + c];
+        rstd[bg] = 1.0 / sqrt(v / ((double)cg * (double)P) + (double)eps);
+    }
+#pragma omp parallel for schedule(static)
+    for (int bc = 0; bc < B * C; ++bc) {
+        float *row = x + (size_t)bc * P;
+        const int c = bc % C;
+        const double m = mean[bc / cg], r = rstd[bc / cg], ga = gamma[c], be = beta[c];
+        for (long i = 0; i < P; ++i) row[i] = (float)(((double)row[i] - m) * r * ga + be);
+    }
+    free(part);
+    free(mean);
+    free(rstd);
 }
 
 /* nn.LayerNorm([C, H, W]): statistics over all N = C*H*W elements of a sample, element-wise affine of
- * shape (C, H, W) (network_blocks.py:90-91).  In place. */
+ * shape (C, H, W) (network_blocks.py:90-91).  In place.  Same two-pass scheme over 4096-element chunks. */
 void orc_layer_norm(float *x, const float *gamma, const float *beta, int B, long N, float eps)
 {
-#pragma omp parallel for schedule(static)
+    const long CH = 4096;
+    const long nch = (N + CH - 1) / CH;
+    double *part = (double *)malloc(sizeof(double) * (size_t)nch);
     for (int b = 0; b < B; ++b) {
         float *base = x + (size_t)b * N;
-        double s = 0.0;
-        for (long i = 0; i < N; ++i) s += base[i];
-        const double mean = s / (double)N;
-        double v = 0.0;
-        for (long i = 0; i < N; ++i) {
-            const double d = base[i] - mean;
-            v += d * d;
+#pragma omp parallel for schedule(static)
+        for (long c = 0; c < nch; ++c) {
+            const long lo = c * CH, hi = (lo + CH) < N ? (lo + CH) : N;
+            double s = 0.0;
+            for (long i = lo; i < hi; ++i) s += base[i];
+            part[c] = s;
         }
+        double s = 0.0;
+        for (long c = 0; c < nch; ++c) s += part[c];
+        const double mean = s / (double)N;
+#pragma omp parallel for schedule(static)
+        for (long c = 0; c < nch; ++c) {
+            const long lo = c * CH, hi = (lo + CH) < N ? (lo + CH) : N;
+            double v = 0.0;
+            for (long i = lo; i < hi; ++i) {
+                const double d = base[i] - mean;
+                v += d * d;
+            }
+            part[c] = v;
+        }
+        double v = 0.0;
+        for (long c = 0; c < nch; ++c) v += part[c];
         const double rstd = 1.0 / sqrt(v / (double)N + (double)eps);
+#pragma omp parallel for schedule(static)
         for (long i = 0; i < N; ++i) base[i] = (float)(((double)base[i] - mean) * rstd * gamma[i] + beta[i]);
     }
+    free(part);
 }
 
 static inline float orc_sigmoidf(float v) { return (float)(1.0 / (1.0 + exp(-(double)v))); }

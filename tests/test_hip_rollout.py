@@ -1,0 +1,144 @@
+"""GPU rollout parity: the on-device engine (hipGraph-captured timestep, in-place states, device frame counter)
+against the reference-generated rollout goldens, the float64 reference, and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close, masked_parity, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def make_net(H, W, C, seed, dev):
+    import urnn_amd.weights as uw
+    from urnn_amd.net_config import load_net_config
+    from urnn_amd.networks import ED, get_network_params
+    sd = uw.make_state_dict(H, W, C, seed=seed)
+    ep, dp = get_network_params(False, H, W, C, load_net_config())
+    net = ED(False, ep, dp, 0.5, False, H, W)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return net.to(dev).eval(), sd
+
+
+@pytest.mark.parametrize("name", ["rollout_64x64_T30.npz", "rollout_24x40_T8_spatial.npz"])
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_rollout_vs_reference(golden, dev, name, use_graph):
+    import urnn_amd.weights as uw
+    from urnn_amd.rollout import RolloutEngine
+    g = golden(name)
+    H, W, nums, T = int(g["H"]), int(g["W"]), int(g["nums"]), int(g["T"])
+    spatial = bool(int(g["spatial"]))
+    net, _ = make_net(H, W, 2 * nums + 3, int(g["weights_seed"]), dev)
+    ev = uw.make_event(T, H, W, float(g["rain_max"]), seed=int(g["event_seed"]), spatial_rain=spatial)
+    eng = RolloutEngine(net, H, W, nums, float(g["rain_max"]), float(g["cumsum_max"]), max_frames=T, spatial_rain=spatial,
+                        use_graph=use_graph, keep_raw=True)
+    frames = eng.rollout(ev)
+    torch.cuda.synchronize()
+    every = int(g["every"])
+    got = frames[::every, 0].cpu().numpy()
+    cls = eng.out_cls[:T:every, 0].cpu().numpy()
+    raw = eng.out_raw[:T:every, 0].cpu().numpy()
+    tol = 1e-4
+    assert_close(cls, g["cls"], tol, "cls over rollout")
+    assert_close(raw, g["raw"], tol, "pre-mask reg over rollout")
+    for k in range(6):
+        assert_close(eng.states[k].cpu().numpy(), g[f"final_state{k}"], tol, f"final state {k}")
+    nflip = masked_parity(got, g["reg"], g["cls"], g["raw"], tol)
+    assert nflip < 0.001 * got.size
+    # no further from the exact (float64) rollout than the fp32 reference itself is (x3 slack), strict floor
+    for k in range(6):
+        truth = g[f"final_state64_{k}"]
+        e_hip = rel_err(eng.states[k].cpu().numpy(), truth, 1e-3)
+        e_ref = rel_err(g[f"final_state{k}"], truth, 1e-3)
+        assert e_hip <= max(1e-4, 3.0 * e_ref), f"state {k}: HIP {e_hip:.2e} vs reference-fp32 {e_ref:.2e} (vs fp64 truth)"
+
+
+def test_inference_entry_matches_reference(golden, dev):
+    """Inference() mirror: same (T,H,W) float32 contract and values as the reference's test.Inference."""
+    import urnn_amd.weights as uw
+    from urnn_amd.inference import Inference
+    g = golden("inference_entry_16x16_T6.npz")
+    H, W, nums, T = int(g["H"]), int(g["W"]), int(g["nums"]), int(g["T"])
+    net, _ = make_net(H, W, 2 * nums + 3, int(g["weights_seed"]), dev)
+    ev = uw.make_event(T, H, W, float(g["rain_max"]), seed=int(g["event_seed"]))
+    out = Inference(net, {k: torch.from_numpy(np.asarray(v)) for k, v in ev.items()}, dev, historical_nums=nums,
+                    rain_max=float(g["rain_max"]), cumsum_rain_max=float(g["cumsum_max"]), input_height=H, input_width=W)
+    assert out.shape == g["out"].shape and out.dtype == np.float32
+    diff = np.abs(out - g["out"])
+    assert (diff > 1e-4 * max(1e-3, np.abs(g["out"]).max())).mean() < 0.01
+
+
+def test_graph_replay_is_deterministic(dev):
+    import urnn_amd.weights as uw
+    from urnn_amd.rollout import RolloutEngine
+    H, W, nums, T = 32, 48, 3, 10
+    net, _ = make_net(H, W, 9, 3, dev)
+    ev = uw.make_event(T, H, W, 60.0, seed=1)
+    eng = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T)
+    a = eng.rollout(ev).clone()
+    b = eng.rollout(ev).clone()
+    assert torch.equal(a, b), "fixed-order GroupNorm/LayerNorm reductions must make rollouts bit-reproducible"
+    eng2 = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T, use_graph=False)
+    c = eng2.rollout(ev)
+    assert torch.equal(a, c), "graph replay and eager launches must agree bit for bit"
+
+
+def test_batched_events_match_single_events(dev):
+    """Event batching (a build-side extension): per-sample semantics -- a batch of two events must
+    equal the two events rolled out one by one."""
+    import urnn_amd.weights as uw
+    from urnn_amd.rollout import RolloutEngine
+    H, W, nums, T = 40, 24, 3, 6
+    net, _ = make_net(H, W, 9, 4, dev)
+    ev2 = uw.make_event(T, H, W, 60.0, seed=7, batch=2)
+    # the reference normalises every sample with sample 0's DEM range (Dynamic2DFlood.py:305-306); mirror that here
+    eng2 = RolloutEngine(net, H, W, nums, 60.0, 250.0, batch=2, max_frames=T)
+    both = eng2.rollout(ev2).clone()
+    eng1 = RolloutEngine(net, H, W, nums, 60.0, 250.0, batch=1, max_frames=T)
+    for b in range(2):
+        ev1 = {k: (v[b:b + 1] if k not in ("max_DEM", "min_DEM") else v[0:1]) for k, v in ev2.items()}
+        one = eng1.rollout(ev1)
+        assert torch.equal(one[:, 0], both[:, b])
+
+
+def test_full_size_step_properties(dev):
+    """BASELINE config 2 size (500x500, C=63): two timesteps through the engine; size-independent properties --
+    finite outputs, masked == raw * [cls >= 0.5] exactly, cls in [0,1], states bounded by the GRU convex blend
+    (|h'| <= max(|h|, 1)), and the run is bit-reproducible."""
+    import urnn_amd.weights as uw
+    from urnn_amd.rollout import RolloutEngine
+    H = W = 500
+    nums, T = 30, 3
+    net, _ = make_net(H, W, 63, 0, dev)
+    ev = uw.make_event(T, H, W, 6.0, seed=42)
+    eng = RolloutEngine(net, H, W, nums, 6.0, 250.0, max_frames=T, keep_raw=True)
+    a = eng.rollout(ev).clone()
+    cls, raw = eng.out_cls[:T].clone(), eng.out_raw[:T].clone()
+    assert torch.isfinite(a).all() and torch.isfinite(raw).all()
+    assert (cls >= 0).all() and (cls <= 1).all()
+    assert torch.equal(a, raw * (cls >= 0.5).float())
+    for s in eng.states:
+        assert torch.isfinite(s).all() and s.abs().max() <= 1.0 + 1e-6
+    b = eng.rollout(ev)
+    assert torch.equal(a, b)
+
+
+def test_full_size_cell_vs_oracle(dev):
+    """The largest GEMM (decoder stage-1 Skip-ConvGRU, 500x500, K=224) against the CPU oracle on a 500x500 plane."""
+    import urnn_amd.weights as uw
+    from oracle import oracle as orc
+    H = W = 500
+    net, sd = make_net(H, W, 63, 0, dev)
+    rs = np.random.RandomState(11)
+    x = (0.5 * rs.standard_normal((1, 96, H, W))).astype(np.float32)
+    e = (0.5 * rs.standard_normal((1, 64, H, W))).astype(np.float32)
+    d = (0.5 * rs.standard_normal((1, 64, H, W))).astype(np.float32)
+    got = net.decoder.rnn1.step(*(torch.from_numpy(v).to(dev) for v in (x, e, d))).cpu().numpy()
+    ref = orc.gru_cell(x, e, d, orc.OracleNet(sd).dec[1])
+    assert_close(got, ref, 1e-4, "dec1 cell at 500x500")

@@ -164,9 +164,10 @@ extern "C" size_t urnn_gru_cell_workspace_bytes(int B, int F, int H, int W)
     return carve_gru(nullptr, B, F, (long)H * W).bytes;
 }
 
-extern "C" int urnn_gru_cell_f32(const float *x, const float *e, const float *h, const float *packed, const float *gn1_w,
-                                 const float *gn1_b, const float *gn2_w, const float *gn2_b, float *h_out, void *workspace,
-                                 size_t workspace_bytes, int B, int I, int F, int H, int W, float eps, void *stream)
+extern "C" int urnn_gru_cell_phases_f32(const float *x, const float *e, const float *h, const float *packed, const float *gn1_w,
+                                        const float *gn1_b, const float *gn2_w, const float *gn2_b, float *h_out, void *workspace,
+                                        size_t workspace_bytes, int B, int I, int F, int H, int W, float eps, int phase_mask,
+                                        void *stream)
 {
     if (!h || !packed || !gn1_w || !gn1_b || !gn2_w || !gn2_b || !h_out || !workspace)
         return fail(URNN_ENULL, "urnn_gru_cell_f32: NULL argument");
@@ -210,8 +211,9 @@ extern "C" int urnn_gru_cell_f32(const float *x, const float *e, const float *h,
     bool vec1;
     const int pb1 = pick_pb((long)B * P, F / 32, P % 4 == 0, P % 2 == 0, &vec1);
     const int tiles1 = (int)((P + 32 * pb1 - 1) / (32 * pb1));
-    CHECK_HIP(urnn_launch_gru1(p, B, pb1, vec1, st), "gru gates");
-    CHECK_HIP(urnn_launch_gn_finalize(ws.part1, tiles1, 32.0 * (double)P, gn1_w, gn1_b, eps, ws.ss1, B, 2 * F, st), "gn finalize 1");
+    if (phase_mask & URNN_PHASE_GATES) CHECK_HIP(urnn_launch_gru1(p, B, pb1, vec1, st), "gru gates");
+    if (phase_mask & URNN_PHASE_GN1)
+        CHECK_HIP(urnn_launch_gn_finalize(ws.part1, tiles1, 32.0 * (double)P, gn1_w, gn1_b, eps, ws.ss1, B, 2 * F, st), "gn finalize 1");
 
     // K2: candidate = cx + W2h . (sigmoid(GN(r)) * h), GroupNorm partials of the candidate
     GruCandParams c = {};
@@ -225,12 +227,21 @@ extern "C" int urnn_gru_cell_f32(const float *x, const float *e, const float *h,
     bool vec2;
     const int pb2 = pick_pb((long)B * P, 1, P % 4 == 0, P % 2 == 0, &vec2);
     const int tiles2 = (int)((P + 32 * pb2 - 1) / (32 * pb2));
-    CHECK_HIP(urnn_launch_cand(c, B, F, pb2, vec2, st), "gru candidate");
-    CHECK_HIP(urnn_launch_gn_finalize(ws.part2, tiles2, 32.0 * (double)P, gn2_w, gn2_b, eps, ws.ss2, B, F, st), "gn finalize 2");
+    if (phase_mask & URNN_PHASE_CAND) CHECK_HIP(urnn_launch_cand(c, B, F, pb2, vec2, st), "gru candidate");
+    if (phase_mask & URNN_PHASE_GN2)
+        CHECK_HIP(urnn_launch_gn_finalize(ws.part2, tiles2, 32.0 * (double)P, gn2_w, gn2_b, eps, ws.ss2, B, F, st), "gn finalize 2");
 
     // K3: blend
-    CHECK_HIP(urnn_launch_blend(ws.g1, ws.cx, h, ws.ss1, ws.ss2, h_out, B, F, (int)P, st), "gru blend");
+    if (phase_mask & URNN_PHASE_BLEND) CHECK_HIP(urnn_launch_blend(ws.g1, ws.cx, h, ws.ss1, ws.ss2, h_out, B, F, (int)P, st), "gru blend");
     return URNN_OK;
+}
+
+extern "C" int urnn_gru_cell_f32(const float *x, const float *e, const float *h, const float *packed, const float *gn1_w,
+                                 const float *gn1_b, const float *gn2_w, const float *gn2_b, float *h_out, void *workspace,
+                                 size_t workspace_bytes, int B, int I, int F, int H, int W, float eps, void *stream)
+{
+    return urnn_gru_cell_phases_f32(x, e, h, packed, gn1_w, gn1_b, gn2_w, gn2_b, h_out, workspace, workspace_bytes, B, I, F, H, W,
+                                    eps, URNN_PHASE_ALL, stream);
 }
 
 // ---- deconv ----------------------------------------------------------------------------------------------------------

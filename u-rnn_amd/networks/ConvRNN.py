@@ -43,11 +43,11 @@ class CGRU_cell(nn.Module):
             lambda: ops.pack_gru(c1.weight.detach(), c1.bias.detach(), c2.weight.detach(), c2.bias.detach(),
                                  self.input_channels, self.num_features, self.module == "decoder"))
 
-    def step(self, x, e, h, out=None):
+    def step(self, x, e, h, out=None, phases=ops.PHASE_ALL):
         """One timestep on raw (B,C,H,W) tensors.  ``e`` is the encoder skip state (decoder cells) or None."""
         g1, g2 = self.conv1[1], self.conv2[1]
         return ops.gru_cell(x, e, h, self._packed(), g1.weight.detach(), g1.bias.detach(), g2.weight.detach(),
-                            g2.bias.detach(), self.input_channels, out=out, eps=g1.eps)
+                            g2.bias.detach(), self.input_channels, out=out, eps=g1.eps, phases=phases)
 
     @torch.no_grad()
     def forward(self, inputs=None, hidden_state=None, seq_len=1):

@@ -96,8 +96,12 @@ def stage_conv(x, packed, Cout, pool, out=None, slope=LRELU_SLOPE):
     return out
 
 
-def gru_cell(x, e, h, packed, gn1_w, gn1_b, gn2_w, gn2_b, I, out=None, eps=NORM_EPS):
-    """ConvGRU (e None) / Skip-ConvGRU step.  x may be None (zeros, I channels).  out may be h (in place)."""
+PHASE_GATES, PHASE_GN1, PHASE_CAND, PHASE_GN2, PHASE_BLEND, PHASE_ALL = 1, 2, 4, 8, 16, 31
+
+
+def gru_cell(x, e, h, packed, gn1_w, gn1_b, gn2_w, gn2_b, I, out=None, eps=NORM_EPS, phases=PHASE_ALL):
+    """ConvGRU (e None) / Skip-ConvGRU step.  x may be None (zeros, I channels).  out may be h (in place).
+    ``phases`` enqueues a subset of the cell's five kernels (profiling only)."""
     _dev_check(x, e, h, packed, gn1_w, gn1_b, gn2_w, gn2_b, out)
     B, F, H, W = h.shape
     if x is not None and tuple(x.shape) != (B, I, H, W):
@@ -109,8 +113,9 @@ def gru_cell(x, e, h, packed, gn1_w, gn1_b, gn2_w, gn2_b, I, out=None, eps=NORM_
     ws = WORKSPACE.get(nbytes, h.device)
     if out is None:
         out = torch.empty_like(h)
-    check(L.urnn_gru_cell_f32(_ptr(x), _ptr(e), _ptr(h), _ptr(packed), _ptr(gn1_w), _ptr(gn1_b), _ptr(gn2_w), _ptr(gn2_b),
-                              _ptr(out), _ptr(ws), ws.numel(), B, I, F, H, W, eps, _stream()), "urnn_gru_cell_f32")
+    check(L.urnn_gru_cell_phases_f32(_ptr(x), _ptr(e), _ptr(h), _ptr(packed), _ptr(gn1_w), _ptr(gn1_b), _ptr(gn2_w),
+                                     _ptr(gn2_b), _ptr(out), _ptr(ws), ws.numel(), B, I, F, H, W, eps, int(phases),
+                                     _stream()), "urnn_gru_cell_f32")
     return out
 
 
