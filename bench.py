@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="events per GPU (the reference entry points use 1)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of the captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap", type=int, default=0, help="1: encoder(t+1) || decoder+head(t) on two streams")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -149,7 +150,7 @@ def main():
     B = args.batch
     net, sd, cfg = build_net(H, W, C, dev)
     eng = RolloutEngine(net, H, W, nums, rain_max, cum_max, batch=B, max_frames=T, spatial_rain=spatial, net_cfg=cfg,
-                        use_graph=not args.no_graph, device=dev)
+                        use_graph=not args.no_graph, device=dev, overlap=bool(args.overlap))
     event = uw.make_event(T, H, W, rain_max, seed=42 + rank, spatial_rain=spatial, batch=B)
     eng.load_event(event)
     eng.reset()

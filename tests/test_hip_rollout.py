@@ -89,6 +89,27 @@ def test_graph_replay_is_deterministic(dev):
     assert torch.equal(a, c), "graph replay and eager launches must agree bit for bit"
 
 
+def test_overlapped_chains_match_sequential(dev):
+    """Encoder(t+1) || decoder+head(t) on two streams (graph with forked branches) is a re-scheduling only: the
+    frames and the final states must equal the sequential engine's bit for bit."""
+    import urnn_amd.weights as uw
+    from urnn_amd.rollout import RolloutEngine
+    H, W, nums, T = 32, 48, 3, 9
+    net, _ = make_net(H, W, 9, 3, dev)
+    ev = uw.make_event(T, H, W, 60.0, seed=1)
+    seq = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T)
+    a = seq.rollout(ev).clone()
+    for use_graph in (False, True):
+        ovl = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T, overlap=True, use_graph=use_graph)
+        b = ovl.rollout(ev)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
+        for x, y in zip(seq.final_states(), ovl.final_states()):
+            assert torch.equal(x, y)
+        b2 = ovl.rollout(ev)          # second event through the same captured graphs
+        assert torch.equal(a, b2)
+
+
 def test_batched_events_match_single_events(dev):
     """Event batching (a build-side extension): per-sample semantics -- a batch of two events must
     equal the two events rolled out one by one."""

@@ -1,0 +1,38 @@
+#!/usr/bin/env python
+"""Per-kernel averages of rocprofv3 --pmc counters from a rocpd sqlite database.
+usage: python tools/pmc_summary.py results.db [kernel-substring]"""
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def main(path, filt=""):
+    con = sqlite3.connect(path)
+    tables = [r[0] for r in con.execute("select name from sqlite_master where type='table'")]
+    T = lambda p: next(t for t in tables if t.startswith(p))
+    disp, sym, pmc, info = T("rocpd_kernel_dispatch"), T("rocpd_info_kernel_symbol"), T("rocpd_pmc_event"), T("rocpd_info_pmc")
+    scol = [r[1] for r in con.execute(f"pragma table_info({sym})")]
+    namecol = "display_name" if "display_name" in scol else "kernel_name"
+    pcols = [r[1] for r in con.execute(f"pragma table_info({pmc})")]
+    icols = [r[1] for r in con.execute(f"pragma table_info({info})")]
+    q = (f"select s.{namecol}, i.name, d.id, p.value, (d.end - d.start) from {pmc} p join {disp} d on p.event_id = d.event_id "
+         f"join {sym} s on d.kernel_id = s.id join {info} i on p.pmc_id = i.id")
+    acc = defaultdict(lambda: defaultdict(float))
+    cnt = defaultdict(set)
+    dur = defaultdict(dict)
+    for name, cname, did, val, dt in con.execute(q):
+        name = name.split("(")[0].replace("void ", "")
+        if filt and filt not in name:
+            continue
+        acc[name][cname] += val
+        cnt[name].add(did)
+        dur[name][did] = dt
+    for name in sorted(acc, key=lambda n: -sum(dur[n].values())):
+        n = len(cnt[name])
+        print(f"{name[:100]}  dispatches={n}  avg_us(profiled)={sum(dur[name].values())/n/1e3:.1f}")
+        for c, v in sorted(acc[name].items()):
+            print(f"    {c:32s} {v/n:16.1f}")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "")

@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liburnn_hip.so")
+LIB_PATH = os.environ.get("URNN_LIB") or os.path.join(_HERE, "liburnn_hip.so")   # URNN_LIB: tuning variants
 
 _lib = None
 

@@ -13,19 +13,21 @@ def _newest(paths):
     return max(os.path.getmtime(p) for p in paths)
 
 
-def build(force=False, verbose=False):
-    """Compile the HIP sources to ``u-rnn_amd/liburnn_hip.so``; returns the path."""
+def build(force=False, verbose=False, extra_flags=(), out=None, tag=""):
+    """Compile the HIP sources to ``u-rnn_amd/liburnn_hip.so``; returns the path.  ``extra_flags`` / ``out`` /
+    ``tag`` build tuning variants next to the product library (development only)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    LIB = out or globals()["LIB"]
     if not force and os.path.isfile(LIB) and os.path.getmtime(LIB) >= _newest(deps):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
     for s in srcs:
-        o = os.path.join(CSRC, os.path.basename(s).replace(".hip", ".o"))
+        o = os.path.join(CSRC, os.path.basename(s).replace(".hip", tag + ".o"))
         objs.append(o)
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", s, "-o", o]
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *extra_flags, "-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd))
         procs.append(subprocess.Popen(cmd))

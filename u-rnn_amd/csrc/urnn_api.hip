@@ -6,6 +6,8 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <limits.h>
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 
@@ -36,22 +38,32 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 extern "C" int urnn_abi_version(void) { return URNN_ABI_VERSION; }
 extern "C" const char *urnn_last_error(void) { return g_err; }
 
-// Pixel-block count per wave tile: big planes use 128-pixel tiles; small planes shrink the tile so that the launch still
-// covers the chip (1024 SIMDs) -- the deep stages are 15 625 pixels at 500x500.
-static int pick_pb(long pixels_total, int waves_per_tile, bool vec_ok4, bool vec_ok2, bool *vec)
+// Wave-tile shape.  Big planes use 128-pixel tiles (PB = 4, 16-byte DMA); small planes shrink the tile so that the launch
+// still covers the chip (1024 SIMDs; the deep stages are 15 625 pixels at 500x500).  Planes that are not 16-byte / 8-byte
+// aligned fall back to dword DMA (MAP_PAIR / MAP_STRIDED).
+static int tune_env(const char *name)
+{
+    const char *v = getenv(name);
+    return v ? atoi(v) : 0;
+}
+
+static void pick_tile(long pixels_total, int waves_per_tile, long P, int *pb_out, int *map_out, const char *tune = nullptr)
 {
     int pb = 4;
-    while (pb > 1 && (pixels_total / (32 * pb)) * waves_per_tile < 2048) pb >>= 1;
-    if (pb == 4 && !vec_ok4) pb = 2;   // scalar-load tiles of 128 pixels cost too many address registers
-    *vec = (pb == 4 && vec_ok4) || (pb == 2 && vec_ok2);
-    return pb;
+    const int forced = tune ? tune_env(tune) : 0;   // development knob: URNN_TUNE_PB_* = 1 | 2 | 4
+    if (forced == 1 || forced == 2 || forced == 4) pb = forced;
+    else
+        while (pb > 1 && (pixels_total / (32 * pb)) * waves_per_tile < 2048) pb >>= 1;
+    if (pb == 4 && P % 4 != 0) pb = 2;
+    *pb_out = pb;
+    *map_out = pb == 4 ? MAP_VEC : (pb == 2 && P % 2 == 0 ? MAP_PAIR : MAP_STRIDED);
 }
 
 // ---- packing ---------------------------------------------------------------------------------------------------------
 extern "C" size_t urnn_packed_conv_floats(int Cin, int Cout)
 {
-    const size_t Kpad = urnn_round_up(Cin, URNN_KPAD), Npad = urnn_round_up(Cout, 32);
-    return Kpad * Npad + Npad;
+    const size_t NB = urnn_conv_nb(Cout), NW = ((Cout + 31) / 32) / NB, KT = (Cin + 1) / 2;
+    return NW * KT * ((NB + 3) / 4) * 256 + NW * NB * 32;
 }
 
 extern "C" int urnn_pack_conv_f32(const float *weight, const float *bias, float *packed, int Cin, int Cout, void *stream)
@@ -64,8 +76,8 @@ extern "C" int urnn_pack_conv_f32(const float *weight, const float *bias, float 
 
 extern "C" size_t urnn_packed_gru_floats(int I, int F, int skip)
 {
-    const size_t Kp = (size_t)urnn_round_up(I, URNN_KPAD) + (skip ? F : 0) + F;
-    return Kp * 3 * F + 3 * F + (size_t)F * F;
+    const size_t KT = (size_t)(((I + 1) & ~1) + (skip ? F : 0) + F) / 2;
+    return (size_t)(F / 32) * KT * 256 + 3 * F + (size_t)(F / 2) * 256;
 }
 
 extern "C" int urnn_pack_gru_f32(const float *W1, const float *b1, const float *W2, const float *b2, float *packed, int I, int F,
@@ -80,8 +92,8 @@ extern "C" int urnn_pack_gru_f32(const float *W1, const float *b1, const float *
 
 extern "C" size_t urnn_packed_deconv_floats(int Cin, int Cout)
 {
-    const size_t Kpad = urnn_round_up(Cin, URNN_KPAD), Npad = 4 * (size_t)((Cout + 31) / 32) * 32;
-    return Kpad * Npad + Npad;
+    const size_t NB = 2 * (size_t)((Cout + 31) / 32), KT = (Cin + 1) / 2;
+    return 2 * KT * ((NB + 3) / 4) * 256 + 2 * NB * 32;
 }
 
 extern "C" int urnn_pack_deconv_f32(const float *weight, const float *bias, float *packed, int Cin, int Cout, void *stream)
@@ -102,13 +114,18 @@ extern "C" int urnn_stage_conv_f32(const float *in, const float *packed, float *
     if (pool && (H < 2 || W < 2)) return fail(URNN_EINVAL, "urnn_stage_conv_f32: pool needs H,W >= 2");
     if (!aligned16(in) || !aligned16(out) || !aligned16(packed)) return fail(URNN_EALIGN, "urnn_stage_conv_f32: pointers must be 16-byte aligned");
     const long P = (long)H * W;
+    const int NB = urnn_conv_nb(Cout), NW = ((Cout + 31) / 32) / NB;
+    if (NW > 4) return fail(URNN_EINVAL, "urnn_stage_conv_f32: Cout=%d needs more than 4 waves per tile", Cout);
     ConvGemmParams p = {};
-    p.seg[0] = in;
-    p.segC[0] = Cin;
-    p.hseg = -1;
+    p.seg[0] = p.seg[1] = p.seg[2] = in;
+    p.segC[0] = p.segC[1] = p.segC[2] = Cin;
+    p.segKp0[0] = 0;
+    p.segKp0[1] = p.segKp0[2] = INT_MAX;
+    p.kpBegin = 0;
+    p.KT = (Cin + 1) / 2;
+    p.hKp0 = INT_MAX;
     p.wt = packed;
-    p.ldw = urnn_round_up(Cout, 32);
-    p.Kpad = urnn_round_up(Cin, URNN_KPAD);
+    p.bias = packed + (size_t)NW * p.KT * ((NB + 3) / 4) * 256;
     p.P = (int)P;
     p.W = W;
     p.Cout = Cout;
@@ -118,15 +135,11 @@ extern "C" int urnn_stage_conv_f32(const float *in, const float *packed, float *
     if (pool) {
         p.W2 = W / 2;
         p.P2 = (H / 2) * (W / 2);
-        const bool vec = (W % 2) == 0;
-        CHECK_HIP(urnn_launch_conv_pool(p, B, vec, st), "stage_conv(pool)");
+        CHECK_HIP(urnn_launch_conv_pool(p, B, st), "stage_conv(pool)");
     } else {
-        bool vec;
-        const int nblk = (Cout + 31) / 32;
-        const int nw = nblk <= 3 ? 1 : nblk / (nblk % 3 == 0 ? 3 : (nblk % 2 == 0 ? 2 : 1));
-        if (nw > 4) return fail(URNN_EINVAL, "urnn_stage_conv_f32: Cout=%d needs more than 4 waves per tile", Cout);
-        const int pb = pick_pb((long)B * P, nw, P % 4 == 0, P % 2 == 0, &vec);
-        CHECK_HIP(urnn_launch_conv_flat(p, B, pb, vec, st), "stage_conv");
+        int pb, map;
+        pick_tile((long)B * P, NW, P, &pb, &map, "URNN_TUNE_PB_CONV");
+        CHECK_HIP(urnn_launch_conv_flat(p, B, pb, map, st), "stage_conv");
     }
     return URNN_OK;
 }
@@ -182,36 +195,39 @@ extern "C" int urnn_gru_cell_phases_f32(const float *x, const float *e, const fl
         return fail(URNN_EWORKSPACE, "urnn_gru_cell_f32: workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
     hipStream_t st = (hipStream_t)stream;
     const int skip = e != nullptr;
-    const int Ip = urnn_round_up(I, URNN_KPAD);
-    const int Kp = Ip + (skip ? F : 0) + F;
-    const int N = 3 * F;
+    const int Ie = (I + 1) & ~1;
+    const int KT = (Ie + (skip ? F : 0) + F) / 2;
+    const int NW = F / 32;
 
     // K1: gates (raw) + candidate x/e part, GroupNorm partials of the gates
     ConvGemmParams p = {};
-    p.seg[0] = x;  // may be nullptr: x == 0
+    p.seg[0] = x ? x : h;  // x == nullptr: the segment is skipped via kpBegin, the pointer is never dereferenced
     p.segC[0] = I;
+    p.segKp0[0] = 0;
     if (skip) {
-        p.seg[1] = e; p.segC[1] = F;
-        p.seg[2] = h; p.segC[2] = F;
-        p.hseg = 2;
+        p.seg[1] = e; p.segC[1] = F; p.segKp0[1] = Ie / 2;
+        p.seg[2] = h; p.segC[2] = F; p.segKp0[2] = Ie / 2 + F / 2;
+        p.hKp0 = p.segKp0[2];
     } else {
-        p.seg[1] = h; p.segC[1] = F;
-        p.hseg = 1;
+        p.seg[1] = h; p.segC[1] = F; p.segKp0[1] = Ie / 2;
+        p.seg[2] = h; p.segC[2] = F; p.segKp0[2] = INT_MAX;
+        p.hKp0 = p.segKp0[1];
     }
+    p.kpBegin = x ? 0 : Ie / 2;
+    p.KT = KT;
     p.wt = packed;
-    p.ldw = N;
-    p.Kpad = Kp;
+    p.bias = packed + (size_t)NW * KT * 256;
     p.P = (int)P;
     p.W = W;
     p.F = F;
-    p.Cout = N;
+    p.Cout = 3 * F;
     p.out0 = ws.g1;
     p.out1 = ws.cx;
     p.partial = ws.part1;
-    bool vec1;
-    const int pb1 = pick_pb((long)B * P, F / 32, P % 4 == 0, P % 2 == 0, &vec1);
+    int pb1, map1;
+    pick_tile((long)B * P, NW, P, &pb1, &map1, "URNN_TUNE_PB_GATES");
     const int tiles1 = (int)((P + 32 * pb1 - 1) / (32 * pb1));
-    if (phase_mask & URNN_PHASE_GATES) CHECK_HIP(urnn_launch_gru1(p, B, pb1, vec1, st), "gru gates");
+    if (phase_mask & URNN_PHASE_GATES) CHECK_HIP(urnn_launch_gru1(p, B, pb1, map1, st), "gru gates");
     if (phase_mask & URNN_PHASE_GN1)
         CHECK_HIP(urnn_launch_gn_finalize(ws.part1, tiles1, 32.0 * (double)P, gn1_w, gn1_b, eps, ws.ss1, B, 2 * F, st), "gn finalize 1");
 
@@ -220,14 +236,14 @@ extern "C" int urnn_gru_cell_phases_f32(const float *x, const float *e, const fl
     c.g1 = ws.g1;
     c.h = h;
     c.ss1 = ws.ss1;
-    c.w2h = packed + (size_t)Kp * N + N;
+    c.w2h = packed + (size_t)NW * KT * 256 + 3 * F;
     c.cx = ws.cx;
     c.partial = ws.part2;
     c.P = (int)P;
-    bool vec2;
-    const int pb2 = pick_pb((long)B * P, 1, P % 4 == 0, P % 2 == 0, &vec2);
+    int pb2, map2;
+    pick_tile((long)B * P, 1, P, &pb2, &map2, "URNN_TUNE_PB_CAND");
     const int tiles2 = (int)((P + 32 * pb2 - 1) / (32 * pb2));
-    if (phase_mask & URNN_PHASE_CAND) CHECK_HIP(urnn_launch_cand(c, B, F, pb2, vec2, st), "gru candidate");
+    if (phase_mask & URNN_PHASE_CAND) CHECK_HIP(urnn_launch_cand(c, B, F, pb2, map2, st), "gru candidate");
     if (phase_mask & URNN_PHASE_GN2)
         CHECK_HIP(urnn_launch_gn_finalize(ws.part2, tiles2, 32.0 * (double)P, gn2_w, gn2_b, eps, ws.ss2, B, F, st), "gn finalize 2");
 
@@ -253,22 +269,26 @@ extern "C" int urnn_deconv2x2_f32(const float *in, const float *packed, float *o
         return fail(URNN_EINVAL, "urnn_deconv2x2_f32: bad dims (Cout must be <= 96, got %d)", Cout);
     if (!aligned16(in) || !aligned16(out) || !aligned16(packed)) return fail(URNN_EALIGN, "urnn_deconv2x2_f32: pointers must be 16-byte aligned");
     const long P = (long)H * W;
+    const int NB = 2 * ((Cout + 31) / 32);
     ConvGemmParams p = {};
-    p.seg[0] = in;
-    p.segC[0] = Cin;
-    p.hseg = -1;
+    p.seg[0] = p.seg[1] = p.seg[2] = in;
+    p.segC[0] = p.segC[1] = p.segC[2] = Cin;
+    p.segKp0[0] = 0;
+    p.segKp0[1] = p.segKp0[2] = INT_MAX;
+    p.kpBegin = 0;
+    p.KT = (Cin + 1) / 2;
+    p.hKp0 = INT_MAX;
     p.wt = packed;
-    p.ldw = 4 * ((Cout + 31) / 32) * 32;
-    p.Kpad = urnn_round_up(Cin, URNN_KPAD);
+    p.bias = packed + (size_t)2 * p.KT * ((NB + 3) / 4) * 256;
     p.P = (int)P;
     p.W = W;
     p.Cout = Cout;
     p.slope = slope;
     p.out0 = out;
+    // pairs of horizontally adjacent pixels need an even width; tiny planes use 32-pixel strided tiles to fill the chip
     const bool big = ((long)B * P / 64) * 2 >= 1024;
-    const int pb = big ? 2 : 1;
-    const bool vec = pb == 2 && (W % 2) == 0;
-    CHECK_HIP(urnn_launch_deconv(p, B, pb, vec, (hipStream_t)stream), "deconv2x2");
+    const bool pair = big && (W % 2) == 0;
+    CHECK_HIP(urnn_launch_deconv(p, B, pair ? 2 : 1, pair ? MAP_PAIR : MAP_STRIDED, (hipStream_t)stream), "deconv2x2");
     return URNN_OK;
 }
 

@@ -10,7 +10,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // k-pairs (one v_mfma_f32_32x32x2_f32 consumes a k-pair) per software-pipeline chunk.  Every K segment of a
 // packed weight matrix is padded to a multiple of 2*KU rows.
+#ifndef URNN_KU
 #define URNN_KU 4
+#endif
 #define URNN_KPAD (2 * URNN_KU)
 
 static inline int urnn_round_up(int v, int m) { return (v + m - 1) / m * m; }

@@ -429,108 +429,120 @@ hipError_t urnn_launch_advance(int *counter, int delta, hipStream_t st)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Weight packers (one-off).  See include/urnn_hip.h for the packed layouts.
+// Weight packers (one-off).  Packed layout "Wq": for wave w (a group of NB 32-column blocks), k-pair kp, quad qd and
+// lane l = (half, j):  Wq[w][kp][qd][l][c] = W[row k = 2*kp + half][column n = (w*NB + 4*qd + c)*32 + j]   (0 when padded)
+// i.e. every lane finds the four weights it feeds to its next four MFMAs in one 16-byte word -- the unit the LDS-DMA ring
+// of conv_gemm_kernel moves.  The bias of every packed column follows.
 // ------------------------------------------------------------------------------------------------------------------
 __global__ void pack_conv_kernel(const float *__restrict__ w, const float *__restrict__ bias, float *__restrict__ packed, int Cin,
-                                 int Cout, int Kpad, int Npad)
+                                 int Cout, int NB, int NW, int KT)
 {
+    const int NQ = (NB + 3) / 4;
+    const int nwq = NW * KT * NQ * 256;
+    const int Npad = NW * NB * 32;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int total = Kpad * Npad + Npad;
-    if (idx >= total) return;
-    if (idx < Kpad * Npad) {
-        const int k = idx / Npad, n = idx - k * Npad;
-        packed[idx] = (k < Cin && n < Cout) ? w[(size_t)n * Cin + k] : 0.f;
+    if (idx >= nwq + Npad) return;
+    if (idx < nwq) {
+        const int c = idx & 3, l = (idx >> 2) & 63;
+        int r = idx >> 8;
+        const int qd = r % NQ; r /= NQ;
+        const int kp = r % KT, wv = r / KT;
+        const int nb = 4 * qd + c, k = 2 * kp + (l >> 5), n = (wv * NB + nb) * 32 + (l & 31);
+        packed[idx] = (nb < NB && k < Cin && n < Cout) ? w[(size_t)n * Cin + k] : 0.f;
     } else {
-        const int n = idx - Kpad * Npad;
+        const int n = idx - nwq;
         packed[idx] = (bias && n < Cout) ? bias[n] : 0.f;
     }
 }
 
 hipError_t urnn_launch_pack_conv(const float *w, const float *bias, float *packed, int Cin, int Cout, hipStream_t st)
 {
-    const int Kpad = urnn_round_up(Cin, URNN_KPAD), Npad = urnn_round_up(Cout, 32);
-    const int total = Kpad * Npad + Npad;
-    hipLaunchKernelGGL(pack_conv_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, bias, packed, Cin, Cout, Kpad, Npad);
+    const int NB = urnn_conv_nb(Cout), NW = ((Cout + 31) / 32) / NB, KT = (Cin + 1) / 2;
+    const int total = NW * KT * ((NB + 3) / 4) * 256 + NW * NB * 32;
+    hipLaunchKernelGGL(pack_conv_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, bias, packed, Cin, Cout, NB, NW, KT);
     return hipGetLastError();
 }
 
-// rows: x (Ip = I padded to 8) | e (F, decoder only) | h (F); columns: for i < F/32: [z_i | r_i | c_i]; then bias[3F];
-// then W2h[F][F] (k-major).  Source K index order of W1 / W2 is cat(x, [e,] h) (ConvRNN.py:153,165-168).
+// GRU: wave i owns [z_i | r_i | c_i] (NB = 3, one quad, 4th float zero); rows = x (I padded to even) | e (F, decoder only) |
+// h (F), the candidate column being zero on the h rows.  Then bias[3F] in packed column order, then the candidate's h part
+// W2h as Wq[kp][l][c] = W2[c*32 + j][Koff_h + 2*kp + half].  Source K order of W1 / W2 is cat(x, [e,] h) (ConvRNN.py:153,165-168).
 __global__ void pack_gru_kernel(const float *__restrict__ W1, const float *__restrict__ b1, const float *__restrict__ W2,
                                 const float *__restrict__ b2, float *__restrict__ packed, int I, int F, int skip)
 {
-    const int Ip = (I + URNN_KPAD - 1) / URNN_KPAD * URNN_KPAD;
+    const int Ie = (I + 1) & ~1;
     const int Fe = skip ? F : 0;
-    const int Kp = Ip + Fe + F, N = 3 * F, Ksrc = I + Fe + F;
-    const int total = Kp * N + N + F * F;
+    const int KT = (Ie + Fe + F) / 2, NW = F / 32, Ksrc = I + Fe + F;
+    const int nwq = NW * KT * 256, nbias = 3 * F, nw2 = (F / 2) * 256;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    if (idx < Kp * N + N) {
-        const bool is_bias = idx >= Kp * N;
-        const int k = is_bias ? 0 : idx / N;
-        const int n = is_bias ? idx - Kp * N : idx - k * N;
-        const int i = n / 96, which = (n - i * 96) / 32, j = n & 31;   // which: 0 z, 1 r, 2 c
-        const int ch = i * 32 + j;
-        if (is_bias) {
-            packed[idx] = which == 0 ? b1[ch] : (which == 1 ? b1[F + ch] : b2[ch]);
-            return;
-        }
+    if (idx >= nwq + nbias + nw2) return;
+    if (idx < nwq) {
+        const int c = idx & 3, l = (idx >> 2) & 63;
+        const int r = idx >> 8;
+        const int kp = r % KT, i = r / KT;
+        const int k = 2 * kp + (l >> 5), ch = i * 32 + (l & 31);
         int ks;            // source column, -1: padding
         bool hrow = false;
-        if (k < Ip) ks = k < I ? k : -1;
-        else if (k < Ip + Fe) ks = I + (k - Ip);
-        else { ks = I + Fe + (k - Ip - Fe); hrow = true; }
+        if (k < Ie) ks = k < I ? k : -1;
+        else if (k < Ie + Fe) ks = I + (k - Ie);
+        else { ks = I + Fe + (k - Ie - Fe); hrow = true; }
         float v = 0.f;
-        if (ks >= 0) {
-            if (which == 0) v = W1[(size_t)ch * Ksrc + ks];
-            else if (which == 1) v = W1[(size_t)(F + ch) * Ksrc + ks];
+        if (ks >= 0 && c < 3) {
+            if (c == 0) v = W1[(size_t)ch * Ksrc + ks];
+            else if (c == 1) v = W1[(size_t)(F + ch) * Ksrc + ks];
             else v = hrow ? 0.f : W2[(size_t)ch * Ksrc + ks];
         }
         packed[idx] = v;
+    } else if (idx < nwq + nbias) {
+        const int n = idx - nwq;
+        const int i = n / 96, which = (n - i * 96) / 32, ch = i * 32 + (n & 31);
+        packed[idx] = which == 0 ? b1[ch] : (which == 1 ? b1[F + ch] : b2[ch]);
     } else {
-        const int r = idx - (Kp * N + N);
-        const int k = r / F, n = r - k * F;
-        packed[idx] = W2[(size_t)n * Ksrc + I + Fe + k];
+        const int r = idx - nwq - nbias;
+        const int c = r & 3, l = (r >> 2) & 63, kp = r >> 8;
+        const int n = c * 32 + (l & 31), k = 2 * kp + (l >> 5);
+        packed[idx] = n < F ? W2[(size_t)n * Ksrc + I + Fe + k] : 0.f;
     }
 }
 
 hipError_t urnn_launch_pack_gru(const float *W1, const float *b1, const float *W2, const float *b2, float *packed, int I,
                                 int F, int skip, hipStream_t st)
 {
-    const int Ip = urnn_round_up(I, URNN_KPAD);
-    const int Kp = Ip + (skip ? F : 0) + F, N = 3 * F;
-    const int total = Kp * N + N + F * F;
+    const int Ie = (I + 1) & ~1;
+    const int KT = (Ie + (skip ? F : 0) + F) / 2;
+    const int total = (F / 32) * KT * 256 + 3 * F + (F / 2) * 256;
     hipLaunchKernelGGL(pack_gru_kernel, dim3((total + 255) / 256), dim3(256), 0, st, W1, b1, W2, b2, packed, I, F, skip);
     return hipGetLastError();
 }
 
-// columns: a (2) x [bb (2) x co-block (NBC) x 32]; Wt[ci][n] = w[ci][co][a][bb]; bias replicated per column.
+// Deconv: wave a (output row parity) owns n-blocks nb = bb*NBC + cob (column parity bb, 32-channel block cob):
+// Wq[a][kp][qd][l][c] = w[ci = 2*kp + half][co = cob*32 + j][a][bb]; bias[a][nb][j] = bias[co].
 __global__ void pack_deconv_kernel(const float *__restrict__ w, const float *__restrict__ bias, float *__restrict__ packed, int Cin,
-                                   int Cout, int Kpad, int NBC)
+                                   int Cout, int NBC, int KT)
 {
-    const int Npad = 4 * NBC * 32;
-    const int total = Kpad * Npad + Npad;
+    const int NB = 2 * NBC, NQ = (NB + 3) / 4;
+    const int nwq = 2 * KT * NQ * 256, Npad = 2 * NB * 32;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const bool is_bias = idx >= Kpad * Npad;
-    const int k = is_bias ? 0 : idx / Npad;
-    const int n = is_bias ? idx - Kpad * Npad : idx - k * Npad;
-    const int a = n / (2 * NBC * 32);
-    const int rem = n - a * (2 * NBC * 32);
-    const int bb = rem / (NBC * 32);
-    const int co = rem - bb * (NBC * 32);
-    float v = 0.f;
-    if (co < Cout) {
-        if (is_bias) v = bias ? bias[co] : 0.f;
-        else if (k < Cin) v = w[(((size_t)k * Cout + co) * 2 + a) * 2 + bb];
+    if (idx >= nwq + Npad) return;
+    if (idx < nwq) {
+        const int c = idx & 3, l = (idx >> 2) & 63;
+        int r = idx >> 8;
+        const int qd = r % NQ; r /= NQ;
+        const int kp = r % KT, a = r / KT;
+        const int nb = 4 * qd + c, k = 2 * kp + (l >> 5);
+        const int bb = nb / NBC, co = (nb - bb * NBC) * 32 + (l & 31);
+        packed[idx] = (nb < NB && k < Cin && co < Cout) ? w[(((size_t)k * Cout + co) * 2 + a) * 2 + bb] : 0.f;
+    } else {
+        const int n = idx - nwq;
+        const int nb = (n % (NB * 32)) / 32;
+        const int co = (nb % NBC) * 32 + (n & 31);
+        packed[idx] = (bias && co < Cout) ? bias[co] : 0.f;
     }
-    packed[idx] = v;
 }
 
 hipError_t urnn_launch_pack_deconv(const float *w, const float *bias, float *packed, int Cin, int Cout, hipStream_t st)
 {
-    const int Kpad = urnn_round_up(Cin, URNN_KPAD), NBC = (Cout + 31) / 32;
-    const int total = Kpad * 4 * NBC * 32 + 4 * NBC * 32;
-    hipLaunchKernelGGL(pack_deconv_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, bias, packed, Cin, Cout, Kpad, NBC);
+    const int NBC = (Cout + 31) / 32, NB = 2 * NBC, KT = (Cin + 1) / 2;
+    const int total = 2 * KT * ((NB + 3) / 4) * 256 + 2 * NB * 32;
+    hipLaunchKernelGGL(pack_deconv_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, bias, packed, Cin, Cout, NBC, KT);
     return hipGetLastError();
 }

@@ -3,37 +3,41 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
-enum { MODE_FLAT = 0, MODE_POOL = 1, MODE_DECONV = 2, MODE_GRU1 = 3 };
+enum { MAP_VEC = 0, MAP_PAIR = 1, MAP_STRIDED = 2, MAP_POOL = 3 };          // pixel geometry of a wave tile (urnn_gemm.hip)
+enum { EPI_LRELU = 0, EPI_POOL = 1, EPI_DECONV = 2, EPI_GRU1 = 3 };          // epilogue of conv_gemm_kernel
 
 struct ConvGemmParams {
-    const float *seg[3];  // up to three channel-concatenated inputs (x | e | h); nullptr with segC > 0 == all-zero input
-    int segC[3];
-    int hseg;             // MODE_GRU1: index of the hidden-state segment
-    const float *wt;      // packed Wt[Kpad][ldw] followed by bias[ldw]
-    int ldw, Kpad;
-    int P, W, P2, W2;     // input plane size / width; pooled plane size / width (MODE_POOL)
+    const float *seg[3];  // up to three channel-concatenated inputs (x | e | h)
+    int segC[3];          // real channel counts
+    int segKp0[3];        // first absolute k-pair of each segment in the packed weights (unused segments: INT_MAX)
+    int kpBegin, KT;      // k-pair range to run: [kpBegin, KT)  (kpBegin > 0 skips an all-zero x segment)
+    int hKp0;             // EPI_GRU1: first k-pair of the hidden-state segment (candidate columns are skipped from here)
+    const float *wt;      // packed Wq[wave][kp][quad][lane][4]
+    const float *bias;    // bias per packed column
+    int P, W, P2, W2;     // input plane size / width; pooled plane size / width (EPI_POOL)
     int tilesPerSample;
     int Cout, F;
     float slope;
     float *out0, *out1;
-    float *partial;       // MODE_GRU1: [B][2F/32][tiles][2]
+    float *partial;       // EPI_GRU1: [B][2F/32][tiles][2]
 };
 
 struct GruCandParams {
     const float *g1;   // raw gates (B,2F,P)
     const float *h;    // (B,F,P)
     const float *ss1;  // gate GroupNorm folded to per-channel (scale, shift): [B][2F][2]
-    const float *w2h;  // packed W2 h-part, [F][F] (k-major)
+    const float *w2h;  // packed W2 h-part: Wq[kp][lane][4]
     float *cx;         // in: candidate x/e part + bias; out: full pre-norm candidate (B,F,P)
     float *partial;    // [B][F/32][tiles][2]
     int P, tilesPerSample, blocksPerSample;
 };
 
-hipError_t urnn_launch_conv_flat(ConvGemmParams p, int B, int PB, bool vec, hipStream_t st);
-hipError_t urnn_launch_conv_pool(ConvGemmParams p, int B, bool vec, hipStream_t st);
-hipError_t urnn_launch_deconv(ConvGemmParams p, int B, int PB, bool vec, hipStream_t st);
-hipError_t urnn_launch_gru1(ConvGemmParams p, int B, int PB, bool vec, hipStream_t st);
-hipError_t urnn_launch_cand(GruCandParams p, int B, int F, int PB, bool vec, hipStream_t st);
+int urnn_conv_nb(int Cout);   // n-blocks per wave for a Cout-wide 1x1 conv (packing and launch must agree)
+hipError_t urnn_launch_conv_flat(ConvGemmParams p, int B, int PB, int map, hipStream_t st);
+hipError_t urnn_launch_conv_pool(ConvGemmParams p, int B, hipStream_t st);
+hipError_t urnn_launch_deconv(ConvGemmParams p, int B, int PB, int map, hipStream_t st);
+hipError_t urnn_launch_gru1(ConvGemmParams p, int B, int PB, int map, hipStream_t st);
+hipError_t urnn_launch_cand(GruCandParams p, int B, int F, int PB, int map, hipStream_t st);
 
 // ---- elementwise / reduction kernels (urnn_elem.hip) ----
 hipError_t urnn_launch_gn_finalize(const float *partial, int ntiles, double count, const float *gamma, const float *beta,

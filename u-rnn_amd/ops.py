@@ -32,13 +32,18 @@ def _ptr(t):
 
 
 class Workspace:
-    """Grow-only scratch buffer per device (GroupNorm/LayerNorm partials, gate pre-activations)."""
+    """Grow-only scratch buffers per (device, slot) (GroupNorm/LayerNorm partials, gate pre-activations).  Kernel
+    chains that run concurrently on different streams select different slots (``use_slot``)."""
 
     def __init__(self):
         self._buf = {}
+        self.slot = 0
+
+    def use_slot(self, slot):
+        self.slot = int(slot)
 
     def get(self, nbytes, device):
-        key = (device.type, device.index)
+        key = (device.type, device.index, self.slot)
         buf = self._buf.get(key)
         if buf is None or buf.numel() < nbytes:
             if torch.cuda.is_current_stream_capturing():

@@ -13,7 +13,7 @@ from .general import initialize_states
 class RolloutEngine:
     def __init__(self, net, input_height, input_width, historical_nums, rain_max, cumsum_rain_max, batch=1,
                  max_frames=360, spatial_rain=False, net_cfg=None, use_graph=True, keep_raw=False,
-                 device=None):
+                 device=None, overlap=False):
         self.net = net
         self.H, self.W = int(input_height), int(input_width)
         self.nums = int(historical_nums)
@@ -23,6 +23,9 @@ class RolloutEngine:
         self.Tcap = int(max_frames)
         self.spatial = bool(spatial_rain)
         self.use_graph = bool(use_graph)
+        # overlap=True: encoder(t+1) and decoder+head(t) run as two concurrent kernel chains (two streams forked
+        # inside the captured graph); needs ping-pong encoder states.  Same arithmetic, same results.
+        self.overlap = bool(overlap)
         self.device = torch.device(device) if device is not None else next(net.parameters()).device
         if self.device.type != "cuda":
             raise RuntimeError("RolloutEngine needs the model on a GPU (HIP) device")
@@ -30,7 +33,7 @@ class RolloutEngine:
         B, H, W, dev = self.B, self.H, self.W, self.device
         f32 = dict(dtype=torch.float32, device=dev)
         # static event buffers (filled per event by load_event)
-        rshape = (B, self.Tcap, H, W) if self.spatial else (B, self.Tcap)
+        rshape = (B, self.Tcap + 1, H, W) if self.spatial else (B, self.Tcap + 1)
         self.rain = torch.zeros(rshape, **f32)
         self.cumsum = torch.zeros(rshape, **f32)
         self.dem = torch.zeros((B, H, W), **f32)
@@ -39,6 +42,8 @@ class RolloutEngine:
         self.dem_min, self.dem_max = 0.0, 1.0
         # recurrent state, updated in place
         self.states = list(initialize_states(dev, H, W, net_cfg, batch=B))
+        self.enc_alt = [torch.zeros_like(s) for s in self.states[:3]] if self.overlap else None
+        self._frames_done = 0
         # activations between kernels
         enc, dec = net.encoder, net.decoder
         self.x_in = torch.empty((B, self.C, H, W), **f32)
@@ -53,14 +58,20 @@ class RolloutEngine:
         self.out_cls = torch.zeros((self.Tcap, B, H, W), **f32)
         self.out_raw = torch.zeros((self.Tcap, B, H, W), **f32) if keep_raw else None
         self.t_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.te_dev = torch.zeros(1, dtype=torch.int32, device=dev)   # overlap mode: frame index of the encoder chain
         self.zero_frame = torch.zeros(1, dtype=torch.int32, device=dev)
         # scratch: size for the largest consumer, before any capture
         L = lib()
         need = max([L.urnn_head_workspace_bytes(B, 16, H, W)] +
                    [L.urnn_gru_cell_workspace_bytes(B, c.num_features, c.shape[0], c.shape[1])
                     for c in (enc.rnn1, enc.rnn2, enc.rnn3, dec.rnn3, dec.rnn2, dec.rnn1)])
-        ops.WORKSPACE.reserve(need, dev)
+        for slot in ((0, 1) if self.overlap else (0,)):
+            ops.WORKSPACE.use_slot(slot)
+            ops.WORKSPACE.reserve(need, dev)
+        ops.WORKSPACE.use_slot(0)
         self._graph = None
+        self._graphs2 = None
+        self._side = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)) if self.overlap else None
         self._dem_stamp = None
 
     # -- one timestep, all launches on the current stream ----------------------------------------------
@@ -85,6 +96,97 @@ class RolloutEngine:
         net.head.run(self.feat, out_masked=self.out_masked, out_cls=self.out_cls, out_raw=self.out_raw,
                      frame_index=self.t_dev)
         ops.advance_counter(self.t_dev, 1)
+
+    # -- overlap mode: two concurrent chains -------------------------------------------------------------
+    def _enc_bufs(self, parity):
+        """(read, write) encoder-state triples of E(t) with t % 2 == parity: writes e[parity], reads e[1 - parity]."""
+        bufs = (self.states[:3], self.enc_alt)
+        return bufs[1 - parity], bufs[parity]
+
+    def _enc_chain(self, parity):
+        enc = self.net.encoder
+        (p1, p2, p3), (n1, n2, n3) = self._enc_bufs(parity)
+        ops.WORKSPACE.use_slot(0)
+        ops.preprocess(self.rain, self.cumsum, self.dem, self.imperv, self.manhole, self.dem_min, self.dem_max, 0,
+                       self.nums, self.rain_max, self.cumsum_max, out=self.x_in, t_dev=self.te_dev)
+        enc.stage1(self.x_in, out=self.a1)
+        enc.rnn1.step(self.a1, None, p1, out=n1)
+        enc.stage2(n1, out=self.a2)
+        enc.rnn2.step(self.a2, None, p2, out=n2)
+        enc.stage3(n2, out=self.a3)
+        enc.rnn3.step(self.a3, None, p3, out=n3)
+        ops.advance_counter(self.te_dev, 1)
+
+    def _dec_chain(self, parity):
+        net = self.net
+        dec = net.decoder
+        e1, e2, e3 = self._enc_bufs(parity)[1]   # encoder states of frame t (written by E(t))
+        _, _, _, d1, d2, d3 = self.states
+        ops.WORKSPACE.use_slot(1)
+        dec.rnn3.step(None, e3, d1, out=d1)
+        dec.stage3(d1, out=self.u3)
+        dec.rnn2.step(self.u3, e2, d2, out=d2)
+        dec.stage2(d2, out=self.u2)
+        dec.rnn1.step(self.u2, e1, d3, out=d3)
+        dec.stage1(d3, out=self.feat)
+        net.head.run(self.feat, out_masked=self.out_masked, out_cls=self.out_cls, out_raw=self.out_raw,
+                     frame_index=self.t_dev)
+        ops.advance_counter(self.t_dev, 1)
+        ops.WORKSPACE.use_slot(0)
+
+    def _iter_overlap(self, parity):
+        """Iteration t (parity = t % 2): decoder+head of frame t and encoder of frame t+1, concurrently."""
+        cur = torch.cuda.current_stream(self.device)
+        s1, s2 = self._side
+        s1.wait_stream(cur)
+        s2.wait_stream(cur)
+        with torch.cuda.stream(s1):
+            self._enc_chain(1 - parity)
+        with torch.cuda.stream(s2):
+            self._dec_chain(parity)
+        cur.wait_stream(s1)
+        cur.wait_stream(s2)
+
+    def _capture_overlap(self):
+        self.net.head.flat_params()
+        saved = [s.clone() for s in self.states] + [s.clone() for s in self.enc_alt]
+        t0, t1 = self.t_dev.clone(), self.te_dev.clone()
+        self._enc_chain(0)              # warm-up (packs weights), eager
+        self._iter_overlap(0)
+        self._iter_overlap(1)
+        torch.cuda.synchronize(self.device)
+        graphs = []
+        for parity in (0, 1):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._iter_overlap(parity)
+            graphs.append(g)
+        self._graphs2 = graphs
+        for s, v in zip(self.states + self.enc_alt, saved):
+            s.copy_(v)
+        self.t_dev.copy_(t0)
+        self.te_dev.copy_(t1)
+
+    def _run_overlap(self, frames):
+        if self.use_graph and self._graphs2 is None:
+            self._capture_overlap()
+        for _ in range(frames):
+            t = self._frames_done
+            if t == 0:
+                self._enc_chain(0)      # pipeline prologue: E(0)
+            if self.use_graph:
+                self._graphs2[t % 2].replay()
+            else:
+                self._iter_overlap(t % 2)
+            self._frames_done += 1
+
+    def final_states(self):
+        """The six states after the frames run so far (overlap mode keeps the newest encoder states in the buffer
+        of the last frame's parity)."""
+        if not self.overlap or self._frames_done == 0:
+            return list(self.states)
+        enc = self._enc_bufs((self._frames_done - 1) % 2)[1]
+        return list(enc) + list(self.states[3:])
 
     def _capture(self):
         # warm-up on a side stream (also builds every packed-weight cache), then capture one timestep
@@ -123,15 +225,24 @@ class RolloutEngine:
             # normalisation bounds are kernel arguments frozen into the graph: re-capture when they change
             self.dem_min, self.dem_max = ev["dem_min"], ev["dem_max"]
             self._graph = None
+            self._graphs2 = None
         return T
 
     def reset(self):
         for s in self.states:
             s.zero_()
+        if self.enc_alt is not None:
+            for s in self.enc_alt:
+                s.zero_()
         self.t_dev.zero_()
+        self.te_dev.zero_()
+        self._frames_done = 0
 
     def run(self, frames):
         """Roll ``frames`` timesteps from the current states / frame counter.  Asynchronous."""
+        if self.overlap:
+            return self._run_overlap(frames)
+        self._frames_done += frames
         if self.use_graph:
             if self._graph is None:
                 saved = [s.clone() for s in self.states]
