@@ -1,0 +1,49 @@
+#!/usr/bin/env python
+"""Per-wave phase timeline of the dec1 gate GEMM from s_memtime stamps (tuning build with -DURNN_TRACE)."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench
+from urnn_amd import ops, _lib
+from urnn_amd.rollout import RolloutEngine
+import urnn_amd.weights as uw
+
+which = sys.argv[1] if len(sys.argv) > 1 else "dec1"
+H, W, nums, T, rain_max, cum_max, spatial = bench.CONFIGS["location1"]
+dev = torch.device("cuda:0")
+net, sd, cfg = bench.build_net(H, W, 63, dev)
+eng = RolloutEngine(net, H, W, nums, rain_max, cum_max, max_frames=8, net_cfg=cfg, use_graph=False, device=dev)
+eng.load_event(uw.make_event(8, H, W, rain_max, seed=42)); eng.reset(); eng.run(2)
+e1, e2, e3, d1, d2, d3 = eng.states
+cells = {"enc1": (net.encoder.rnn1, eng.a1, None, e1), "dec1": (net.decoder.rnn1, eng.u2, e1, d3),
+         "enc2": (net.encoder.rnn2, eng.a2, None, e2), "dec2": (net.decoder.rnn2, eng.u3, e2, d2)}
+cell, x, e, h = cells[which]
+tmp = h.clone()
+for _ in range(3):
+    cell.step(x, e, h, out=tmp, phases=ops.PHASE_GATES)
+nw = 512 * 8
+buf = torch.zeros(nw * 8 * 4, dtype=torch.int64, device=dev)
+L = _lib.lib()
+L.urnn_debug_set_trace.argtypes = [ctypes.c_void_p]
+assert L.urnn_debug_set_trace(buf.data_ptr()) == 0
+torch.cuda.synchronize()
+cell.step(x, e, h, out=tmp, phases=ops.PHASE_GATES)
+torch.cuda.synchronize()
+L.urnn_debug_set_trace(0)
+t = buf.cpu().numpy().reshape(nw, 8, 4).astype(np.float64)
+used = t[:, :, 3] > 0
+t0 = t[used][:, 0].min()
+print(which, "waves with work:", int(used[:, 0].sum()), "items:", int(used.sum()))
+tk = t[used]
+clk = 100e6   # s_memtime ticks at 100 MHz on gfx9? report raw and assume
+span = (tk[:, 3].max() - t0)
+print("kernel span ticks:", span)
+for name, a, b in (("prologue (start->first frag)", 0, 1), ("k-loop", 1, 2), ("epilogue (incl. store drain)", 2, 3)):
+    d = tk[:, b] - tk[:, a]
+    print(f"{name:32s} mean {d.mean():10.0f}  p10 {np.percentile(d,10):10.0f}  p50 {np.percentile(d,50):10.0f}  p90 {np.percentile(d,90):10.0f}  max {d.max():10.0f}")
+# per-item index breakdown
+for it in range(4):
+    m = used[:, it]
+    if m.any():
+        d = t[m][:, it]
+        print(f"item#{it}: n={m.sum()} start {d[:,0].mean()-t0:10.0f} kloop {np.mean(d[:,2]-d[:,1]):10.0f} epi {np.mean(d[:,3]-d[:,2]):10.0f} end {d[:,3].mean()-t0:10.0f}")

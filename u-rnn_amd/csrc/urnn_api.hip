@@ -34,6 +34,7 @@ static int hip_fail(hipError_t e, const char *what)
 
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline size_t slab_floats(size_t KT, size_t NB) { return (KT * NB * 64 + 255) / 256 * 256; }
 
 extern "C" int urnn_abi_version(void) { return URNN_ABI_VERSION; }
 extern "C" const char *urnn_last_error(void) { return g_err; }
@@ -62,8 +63,8 @@ static void pick_tile(long pixels_total, int waves_per_tile, long P, int *pb_out
 // ---- packing ---------------------------------------------------------------------------------------------------------
 extern "C" size_t urnn_packed_conv_floats(int Cin, int Cout)
 {
-    const size_t NB = urnn_conv_nb(Cout), NW = ((Cout + 31) / 32) / NB, KT = (Cin + 1) / 2;
-    return NW * KT * ((NB + 3) / 4) * 256 + NW * NB * 32;
+    const size_t NB = urnn_conv_nb(Cout), NG = ((Cout + 31) / 32) / NB, KT = (Cin + 1) / 2;
+    return NG * slab_floats(KT, NB) + NG * NB * 32;
 }
 
 extern "C" int urnn_pack_conv_f32(const float *weight, const float *bias, float *packed, int Cin, int Cout, void *stream)
@@ -77,7 +78,7 @@ extern "C" int urnn_pack_conv_f32(const float *weight, const float *bias, float 
 extern "C" size_t urnn_packed_gru_floats(int I, int F, int skip)
 {
     const size_t KT = (size_t)(((I + 1) & ~1) + (skip ? F : 0) + F) / 2;
-    return (size_t)(F / 32) * KT * 256 + 3 * F + (size_t)(F / 2) * 256;
+    return (size_t)(F / 32) * slab_floats(KT, 3) + 3 * F + (size_t)F * F;
 }
 
 extern "C" int urnn_pack_gru_f32(const float *W1, const float *b1, const float *W2, const float *b2, float *packed, int I, int F,
@@ -93,7 +94,7 @@ extern "C" int urnn_pack_gru_f32(const float *W1, const float *b1, const float *
 extern "C" size_t urnn_packed_deconv_floats(int Cin, int Cout)
 {
     const size_t NB = 2 * (size_t)((Cout + 31) / 32), KT = (Cin + 1) / 2;
-    return 2 * KT * ((NB + 3) / 4) * 256 + 2 * NB * 32;
+    return 2 * slab_floats(KT, NB) + 2 * NB * 32;
 }
 
 extern "C" int urnn_pack_deconv_f32(const float *weight, const float *bias, float *packed, int Cin, int Cout, void *stream)
@@ -114,8 +115,7 @@ extern "C" int urnn_stage_conv_f32(const float *in, const float *packed, float *
     if (pool && (H < 2 || W < 2)) return fail(URNN_EINVAL, "urnn_stage_conv_f32: pool needs H,W >= 2");
     if (!aligned16(in) || !aligned16(out) || !aligned16(packed)) return fail(URNN_EALIGN, "urnn_stage_conv_f32: pointers must be 16-byte aligned");
     const long P = (long)H * W;
-    const int NB = urnn_conv_nb(Cout), NW = ((Cout + 31) / 32) / NB;
-    if (NW > 4) return fail(URNN_EINVAL, "urnn_stage_conv_f32: Cout=%d needs more than 4 waves per tile", Cout);
+    const int NB = urnn_conv_nb(Cout), NG = ((Cout + 31) / 32) / NB;
     ConvGemmParams p = {};
     p.seg[0] = p.seg[1] = p.seg[2] = in;
     p.segC[0] = p.segC[1] = p.segC[2] = Cin;
@@ -125,7 +125,9 @@ extern "C" int urnn_stage_conv_f32(const float *in, const float *packed, float *
     p.KT = (Cin + 1) / 2;
     p.hKp0 = INT_MAX;
     p.wt = packed;
-    p.bias = packed + (size_t)NW * p.KT * ((NB + 3) / 4) * 256;
+    p.aFloats = (int)slab_floats(p.KT, NB);
+    p.NG = NG;
+    p.bias = packed + (size_t)NG * p.aFloats;
     p.P = (int)P;
     p.W = W;
     p.Cout = Cout;
@@ -138,7 +140,7 @@ extern "C" int urnn_stage_conv_f32(const float *in, const float *packed, float *
         CHECK_HIP(urnn_launch_conv_pool(p, B, st), "stage_conv(pool)");
     } else {
         int pb, map;
-        pick_tile((long)B * P, NW, P, &pb, &map, "URNN_TUNE_PB_CONV");
+        pick_tile((long)B * P, NG, P, &pb, &map, "URNN_TUNE_PB_CONV");
         CHECK_HIP(urnn_launch_conv_flat(p, B, pb, map, st), "stage_conv");
     }
     return URNN_OK;
@@ -216,7 +218,9 @@ extern "C" int urnn_gru_cell_phases_f32(const float *x, const float *e, const fl
     p.kpBegin = x ? 0 : Ie / 2;
     p.KT = KT;
     p.wt = packed;
-    p.bias = packed + (size_t)NW * KT * 256;
+    p.aFloats = (int)slab_floats(KT, 3);
+    p.NG = NW;
+    p.bias = packed + (size_t)NW * p.aFloats;
     p.P = (int)P;
     p.W = W;
     p.F = F;
@@ -236,7 +240,7 @@ extern "C" int urnn_gru_cell_phases_f32(const float *x, const float *e, const fl
     c.g1 = ws.g1;
     c.h = h;
     c.ss1 = ws.ss1;
-    c.w2h = packed + (size_t)NW * KT * 256 + 3 * F;
+    c.w2h = packed + (size_t)NW * p.aFloats + 3 * F;
     c.cx = ws.cx;
     c.partial = ws.part2;
     c.P = (int)P;
@@ -279,7 +283,9 @@ extern "C" int urnn_deconv2x2_f32(const float *in, const float *packed, float *o
     p.KT = (Cin + 1) / 2;
     p.hKp0 = INT_MAX;
     p.wt = packed;
-    p.bias = packed + (size_t)2 * p.KT * ((NB + 3) / 4) * 256;
+    p.aFloats = (int)slab_floats(p.KT, NB);
+    p.NG = 2;
+    p.bias = packed + (size_t)2 * p.aFloats;
     p.P = (int)P;
     p.W = W;
     p.Cout = Cout;

@@ -429,78 +429,83 @@ hipError_t urnn_launch_advance(int *counter, int delta, hipStream_t st)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Weight packers (one-off).  Packed layout "Wq": for wave w (a group of NB 32-column blocks), k-pair kp, quad qd and
-// lane l = (half, j):  Wq[w][kp][qd][l][c] = W[row k = 2*kp + half][column n = (w*NB + 4*qd + c)*32 + j]   (0 when padded)
-// i.e. every lane finds the four weights it feeds to its next four MFMAs in one 16-byte word -- the unit the LDS-DMA ring
-// of conv_gemm_kernel moves.  The bias of every packed column follows.
+// Weight packers (one-off).  Packed layout: one slab per n-group g (NB 32-column blocks), [KT][NB][64] floats padded to a
+// multiple of 256 floats:  slab[g][(kp*NB + nb)*64 + l] = W[row k = 2*kp + (l >> 5)][column n = (g*NB + nb)*32 + (l & 31)]
+// i.e. exactly the image conv_gemm_kernel keeps in LDS (every lane reads its MFMA A operand with one conflict-free
+// ds_read_b32).  The bias of every packed column follows the slabs.
 // ------------------------------------------------------------------------------------------------------------------
+__host__ __device__ static inline int slab_floats(int KT, int NB) { return (KT * NB * 64 + 255) / 256 * 256; }
+
 __global__ void pack_conv_kernel(const float *__restrict__ w, const float *__restrict__ bias, float *__restrict__ packed, int Cin,
-                                 int Cout, int NB, int NW, int KT)
+                                 int Cout, int NB, int NG, int KT)
 {
-    const int NQ = (NB + 3) / 4;
-    const int nwq = NW * KT * NQ * 256;
-    const int Npad = NW * NB * 32;
+    const int slab = slab_floats(KT, NB);
+    const int nw = NG * slab, Npad = NG * NB * 32;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= nwq + Npad) return;
-    if (idx < nwq) {
-        const int c = idx & 3, l = (idx >> 2) & 63;
-        int r = idx >> 8;
-        const int qd = r % NQ; r /= NQ;
-        const int kp = r % KT, wv = r / KT;
-        const int nb = 4 * qd + c, k = 2 * kp + (l >> 5), n = (wv * NB + nb) * 32 + (l & 31);
-        packed[idx] = (nb < NB && k < Cin && n < Cout) ? w[(size_t)n * Cin + k] : 0.f;
+    if (idx >= nw + Npad) return;
+    if (idx < nw) {
+        const int g = idx / slab, r = idx - g * slab;
+        const int l = r & 63, row = r >> 6;
+        const int kp = row / NB, nb = row - kp * NB;
+        const int k = 2 * kp + (l >> 5), n = (g * NB + nb) * 32 + (l & 31);
+        packed[idx] = (kp < KT && k < Cin && n < Cout) ? w[(size_t)n * Cin + k] : 0.f;
     } else {
-        const int n = idx - nwq;
+        const int n = idx - nw;
         packed[idx] = (bias && n < Cout) ? bias[n] : 0.f;
     }
 }
 
 hipError_t urnn_launch_pack_conv(const float *w, const float *bias, float *packed, int Cin, int Cout, hipStream_t st)
 {
-    const int NB = urnn_conv_nb(Cout), NW = ((Cout + 31) / 32) / NB, KT = (Cin + 1) / 2;
-    const int total = NW * KT * ((NB + 3) / 4) * 256 + NW * NB * 32;
-    hipLaunchKernelGGL(pack_conv_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, bias, packed, Cin, Cout, NB, NW, KT);
+    const int NB = urnn_conv_nb(Cout), NG = ((Cout + 31) / 32) / NB, KT = (Cin + 1) / 2;
+    const int total = NG * slab_floats(KT, NB) + NG * NB * 32;
+    hipLaunchKernelGGL(pack_conv_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, bias, packed, Cin, Cout, NB, NG, KT);
     return hipGetLastError();
 }
 
-// GRU: wave i owns [z_i | r_i | c_i] (NB = 3, one quad, 4th float zero); rows = x (I padded to even) | e (F, decoder only) |
-// h (F), the candidate column being zero on the h rows.  Then bias[3F] in packed column order, then the candidate's h part
-// W2h as Wq[kp][l][c] = W2[c*32 + j][Koff_h + 2*kp + half].  Source K order of W1 / W2 is cat(x, [e,] h) (ConvRNN.py:153,165-168).
+// GRU: group i owns [z_i | r_i | c_i] (NB = 3); rows = x (I padded to even) | e (F, decoder only) | h (F), the candidate
+// column being zero on the h rows.  Then bias[3F] in packed column order, then the candidate's h part W2h as one slab
+// [F/2][F/32][64]: W2[nb*32 + j][Koff_h + 2*kp + half].  Source K order of W1 / W2 is cat(x, [e,] h) (ConvRNN.py:153,165-168).
 __global__ void pack_gru_kernel(const float *__restrict__ W1, const float *__restrict__ b1, const float *__restrict__ W2,
                                 const float *__restrict__ b2, float *__restrict__ packed, int I, int F, int skip)
 {
     const int Ie = (I + 1) & ~1;
     const int Fe = skip ? F : 0;
-    const int KT = (Ie + Fe + F) / 2, NW = F / 32, Ksrc = I + Fe + F;
-    const int nwq = NW * KT * 256, nbias = 3 * F, nw2 = (F / 2) * 256;
+    const int KT = (Ie + Fe + F) / 2, NG = F / 32, Ksrc = I + Fe + F;
+    const int slab = slab_floats(KT, 3);
+    const int nw = NG * slab, nbias = 3 * F, nw2 = F * F;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= nwq + nbias + nw2) return;
-    if (idx < nwq) {
-        const int c = idx & 3, l = (idx >> 2) & 63;
-        const int r = idx >> 8;
-        const int kp = r % KT, i = r / KT;
+    if (idx >= nw + nbias + nw2) return;
+    if (idx < nw) {
+        const int i = idx / slab, r = idx - i * slab;
+        const int l = r & 63, row = r >> 6;
+        const int kp = row / 3, c = row - kp * 3;
         const int k = 2 * kp + (l >> 5), ch = i * 32 + (l & 31);
-        int ks;            // source column, -1: padding
-        bool hrow = false;
-        if (k < Ie) ks = k < I ? k : -1;
-        else if (k < Ie + Fe) ks = I + (k - Ie);
-        else { ks = I + Fe + (k - Ie - Fe); hrow = true; }
         float v = 0.f;
-        if (ks >= 0 && c < 3) {
-            if (c == 0) v = W1[(size_t)ch * Ksrc + ks];
-            else if (c == 1) v = W1[(size_t)(F + ch) * Ksrc + ks];
-            else v = hrow ? 0.f : W2[(size_t)ch * Ksrc + ks];
+        if (kp < KT) {
+            int ks;            // source column, -1: padding
+            bool hrow = false;
+            if (k < Ie) ks = k < I ? k : -1;
+            else if (k < Ie + Fe) ks = I + (k - Ie);
+            else { ks = I + Fe + (k - Ie - Fe); hrow = true; }
+            if (ks >= 0) {
+                if (c == 0) v = W1[(size_t)ch * Ksrc + ks];
+                else if (c == 1) v = W1[(size_t)(F + ch) * Ksrc + ks];
+                else v = hrow ? 0.f : W2[(size_t)ch * Ksrc + ks];
+            }
         }
         packed[idx] = v;
-    } else if (idx < nwq + nbias) {
-        const int n = idx - nwq;
+    } else if (idx < nw + nbias) {
+        const int n = idx - nw;
         const int i = n / 96, which = (n - i * 96) / 32, ch = i * 32 + (n & 31);
         packed[idx] = which == 0 ? b1[ch] : (which == 1 ? b1[F + ch] : b2[ch]);
     } else {
-        const int r = idx - nwq - nbias;
-        const int c = r & 3, l = (r >> 2) & 63, kp = r >> 8;
-        const int n = c * 32 + (l & 31), k = 2 * kp + (l >> 5);
-        packed[idx] = n < F ? W2[(size_t)n * Ksrc + I + Fe + k] : 0.f;
+        const int r = idx - nw - nbias;
+        const int l = r & 63, row = r >> 6;
+        const int NBF = F / 32;
+        const int kp = row / NBF, nb = row - kp * NBF;
+        const int n = nb * 32 + (l & 31), k = 2 * kp + (l >> 5);
+        packed[idx] = W2[(size_t)n * Ksrc + I + Fe + k];
     }
 }
 
@@ -509,30 +514,30 @@ hipError_t urnn_launch_pack_gru(const float *W1, const float *b1, const float *W
 {
     const int Ie = (I + 1) & ~1;
     const int KT = (Ie + (skip ? F : 0) + F) / 2;
-    const int total = (F / 32) * KT * 256 + 3 * F + (F / 2) * 256;
+    const int total = (F / 32) * slab_floats(KT, 3) + 3 * F + F * F;
     hipLaunchKernelGGL(pack_gru_kernel, dim3((total + 255) / 256), dim3(256), 0, st, W1, b1, W2, b2, packed, I, F, skip);
     return hipGetLastError();
 }
 
-// Deconv: wave a (output row parity) owns n-blocks nb = bb*NBC + cob (column parity bb, 32-channel block cob):
-// Wq[a][kp][qd][l][c] = w[ci = 2*kp + half][co = cob*32 + j][a][bb]; bias[a][nb][j] = bias[co].
+// Deconv: group a (output row parity) owns n-blocks nb = bb*NBC + cob (column parity bb, 32-channel block cob):
+// slab[a][(kp*NB + nb)*64 + l] = w[ci = 2*kp + half][co = cob*32 + j][a][bb]; bias[a][nb][j] = bias[co].
 __global__ void pack_deconv_kernel(const float *__restrict__ w, const float *__restrict__ bias, float *__restrict__ packed, int Cin,
                                    int Cout, int NBC, int KT)
 {
-    const int NB = 2 * NBC, NQ = (NB + 3) / 4;
-    const int nwq = 2 * KT * NQ * 256, Npad = 2 * NB * 32;
+    const int NB = 2 * NBC;
+    const int slab = slab_floats(KT, NB);
+    const int nw = 2 * slab, Npad = 2 * NB * 32;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= nwq + Npad) return;
-    if (idx < nwq) {
-        const int c = idx & 3, l = (idx >> 2) & 63;
-        int r = idx >> 8;
-        const int qd = r % NQ; r /= NQ;
-        const int kp = r % KT, a = r / KT;
-        const int nb = 4 * qd + c, k = 2 * kp + (l >> 5);
+    if (idx >= nw + Npad) return;
+    if (idx < nw) {
+        const int a = idx / slab, r = idx - a * slab;
+        const int l = r & 63, row = r >> 6;
+        const int kp = row / NB, nb = row - kp * NB;
+        const int k = 2 * kp + (l >> 5);
         const int bb = nb / NBC, co = (nb - bb * NBC) * 32 + (l & 31);
-        packed[idx] = (nb < NB && k < Cin && co < Cout) ? w[(((size_t)k * Cout + co) * 2 + a) * 2 + bb] : 0.f;
+        packed[idx] = (kp < KT && k < Cin && co < Cout) ? w[(((size_t)k * Cout + co) * 2 + a) * 2 + bb] : 0.f;
     } else {
-        const int n = idx - nwq;
+        const int n = idx - nw;
         const int nb = (n % (NB * 32)) / 32;
         const int co = (nb % NBC) * 32 + (n & 31);
         packed[idx] = (bias && co < Cout) ? bias[co] : 0.f;
@@ -542,7 +547,7 @@ __global__ void pack_deconv_kernel(const float *__restrict__ w, const float *__r
 hipError_t urnn_launch_pack_deconv(const float *w, const float *bias, float *packed, int Cin, int Cout, hipStream_t st)
 {
     const int NBC = (Cout + 31) / 32, NB = 2 * NBC, KT = (Cin + 1) / 2;
-    const int total = 2 * KT * ((NB + 3) / 4) * 256 + 2 * NB * 32;
+    const int total = 2 * slab_floats(KT, NB) + 2 * NB * 32;
     hipLaunchKernelGGL(pack_deconv_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, bias, packed, Cin, Cout, NBC, KT);
     return hipGetLastError();
 }

@@ -1,26 +1,39 @@
-// urnn_gemm.hip -- the per-pixel contractions of U-RNN as fp32 MFMA GEMMs on gfx950.
+// urnn_gemm.hip -- the per-pixel contractions of U-RNN as weights-stationary fp32 MFMA GEMMs on gfx950.
 //
-// Every convolution of the network is 1x1, i.e. out[n][p] = sum_k W[n][k] * in[k][p] over the pixels p of an
-// NCHW plane.  One wavefront owns a tile of 32*PB pixels x NB*32 output channels and runs v_mfma_f32_32x32x2_f32 with
-//   A = packed weights  (lane l: n = n0 + nb*32 + (l & 31), k = 2*kp + (l >> 5))
-//   B = activations     (lane l: p = pixel(l & 31, pb),     k = 2*kp + (l >> 5))
-//   D[n][p] accumulates in registers (AGPRs); epilogues fuse bias, LeakyReLU, AvgPool, the ConvTranspose scatter, or the
-//   GroupNorm partial statistics.  fp32-input MFMA is bit-exact fp32 FMA (gfx950 has no TF32 path) at the fp32 peak rate.
+// Every convolution of the network is 1x1: out[n][p] = sum_k W[n][k] * in[k][p] over the pixels p of an NCHW
+// plane.  A wavefront owns a tile of 32*PB pixels x NB*32 output channels ("n-group") and runs v_mfma_f32_32x32x2_f32 with
+//   A = weights      (lane l: n = g*NB*32 + nb*32 + (l & 31), k = 2*kp + (l >> 5))
+//   B = activations  (lane l: p = pixel(l & 31, pb),          k = 2*kp + (l >> 5))
+//   D[n][p] accumulates in AGPRs; epilogues fuse bias, LeakyReLU, AvgPool, the ConvTranspose scatter or the GroupNorm
+//   partial statistics.  fp32-input MFMA is bit-exact fp32 FMA (gfx950 has no TF32 path) and sustains 2.4 GHz.
 //
-// Operand streaming: both operands are laid out so that EVERY LANE CONSUMES EXACTLY THE BYTES IT LOADS (activations are used
-// by one wave tile only; the packed weights are pre-arranged per lane).  Each wave therefore owns a private LDS ring of D
-// k-pair slots filled by asynchronous LDS-DMA (global_load_lds) D k-pairs ahead of use and drained with ds_read of the
-// lane's own 16 B: a per-lane FIFO -- no bank conflicts, no barriers, no VGPRs spent on prefetch, counted s_waitcnt vmcnt.
-// The first version of this kernel prefetched one chunk into registers and measured 25-45 % of the MFMA peak because HBM
-// latency (>1 us under load) exceeded the prefetch distance at 1 wave/SIMD (profiles/r01_kernel_bench_v1.txt).
+// Structure (third iteration; measurements in profiles/r01_kernel_bench_*.txt and DESIGN.md):
+//   * WEIGHTS STATIONARY: a block stages the whole weight slab of ONE n-group (<= 110 KiB, K x 96 columns) into LDS once and
+//     then loops over pixel tiles (persistent blocks, 4 waves, one tile per wave at a time).  Streaming the weights per tile
+//     (v2) doubled the bytes through the L2->CU load path, which saturates near 4.7 TB/s and was the measured bottleneck.
+//   * ACTIVATIONS are consumed by exactly the lane that loads them, so each wave owns a private LDS ring of D k-pair slots
+//     filled by asynchronous LDS-DMA (global_load_lds) D k-pairs ahead and drained with ds_read of the lane's own bytes:
+//     a per-lane FIFO -- no bank conflicts, no barriers, no VGPRs spent on prefetch, counted s_waitcnt vmcnt.
+//   * blocks b and b + 8 run on the same XCD (observed dispatch b % 8), so the NG n-groups that read the same pixel tiles are
+//     placed there: the second group's activation reads hit that XCD's L2.  Placement only affects speed.
 //
-// Kernels here: conv_gemm_kernel (stage convs, deconvs, GRU gate GEMM) and gru_cand_kernel (candidate GEMM whose B operand
-// is sigmoid(GN(r)) * h computed on the fly from two DMA streams).
+// Kernels: conv_gemm_kernel (stage convs, deconvs, GRU gate GEMM) and gru_cand_kernel (candidate GEMM whose B operand is
+// sigmoid(GN(r)) * h computed on the fly from two DMA streams).
 #include "urnn_common.h"
 #include "urnn_kernels.h"
 
+#include <stdlib.h>
+#include <type_traits>
+
 #ifndef URNN_ABL
-#define URNN_ABL 0   // tuning builds only: 1 skip weight DMA, 2 skip activation DMA, 4 skip epilogue stores
+#define URNN_ABL 0   // tuning builds only: 2 skip activation DMA, 4 skip epilogue stores
+#endif
+#ifdef URNN_TRACE
+__device__ unsigned long long *urnn_trace_buf = nullptr;   // tuning builds: [wave slot][item][4] s_memtime stamps
+extern "C" int urnn_debug_set_trace(unsigned long long *p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(urnn_trace_buf), &p, sizeof(p)); }
+#define TRACE_STAMP(k) do { if (urnn_trace_buf && lane == 0 && tr_n < 8) urnn_trace_buf[((size_t)(blockIdx.x * WPB + wave) * 8 + tr_n) * 4 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TRACE_STAMP(k) do { } while (0)
 #endif
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
@@ -117,403 +130,477 @@ __device__ __forceinline__ void store_row(float *row, const PixelMap<MAP, PB> &p
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Per-wave LDS ring.  One slot = one k-pair: NQ KiB of weights (4 floats per lane per quad of n-blocks) followed by
-// PB*256 B of activations.  Lane l's own bytes sit at  quad*1024 + l*16  (16-B DMA) or  pb*256 + l*4  (dword DMA).
+// Per-wave activation ring.  One slot = one k-pair = PB*256 B; lane l's own bytes sit at  quad*1024 + l*16  (16-B DMA) or
+// pb*256 + l*4  (dword DMA).
 // ------------------------------------------------------------------------------------------------------------------
-template <int NB, int PB, int MAP>
+template <int PB, int MAP>
 struct Ring {
-    static constexpr int NQ = (NB + 3) / 4;
     static constexpr bool VEC = (MAP == MAP_VEC);
-    static constexpr int NBLOAD = VEC ? PB / 4 : PB;
-#if (URNN_ABL & 3) == 3
+#if (URNN_ABL & 2)
     static constexpr int NLOAD = 0;
-#elif (URNN_ABL & 1)
-    static constexpr int NLOAD = NBLOAD;
-#elif (URNN_ABL & 2)
-    static constexpr int NLOAD = NQ;
 #else
-    static constexpr int NLOAD = NQ + NBLOAD;               // DMA instructions per slot
+    static constexpr int NLOAD = VEC ? PB / 4 : PB;         // DMA instructions per slot
 #endif
-    static constexpr int SLOT = NQ * 1024 + PB * 256;       // bytes
+    static constexpr int SLOT = PB * 256;                   // bytes
 
-    // issue the DMA loads of one k-pair: weights (this lane's 4 floats per quad) and the activation row
-    __device__ static __forceinline__ void issue(char *slot, const float *wq_lane, const float *row, const PixelMap<MAP, PB> &pm)
+    __device__ static __forceinline__ void issue(char *slot, const float *row, const PixelMap<MAP, PB> &pm)
     {
-#if !(URNN_ABL & 1)
-#pragma unroll
-        for (int qd = 0; qd < NQ; ++qd) dma16(wq_lane + qd * 256, slot + qd * 1024);
-#endif
-        char *bslot = slot + NQ * 1024;
 #if (URNN_ABL & 2)
         return;
 #endif
         if constexpr (VEC) {
 #pragma unroll
-            for (int qd = 0; qd < PB / 4; ++qd) dma16(row + pm.off[4 * qd], bslot + qd * 1024);
+            for (int qd = 0; qd < PB / 4; ++qd) dma16(row + pm.off[4 * qd], slot + qd * 1024);
         } else {
 #pragma unroll
-            for (int pb = 0; pb < PB; ++pb) dma4(row + pm.off[pb], bslot + pb * 256);
+            for (int pb = 0; pb < PB; ++pb) dma4(row + pm.off[pb], slot + pb * 256);
         }
     }
 
-    __device__ static __forceinline__ void read(const char *slot, int lane, float (&a)[NQ * 4], float (&b)[PB])
+    __device__ static __forceinline__ void read(const char *slot, int lane, float (&b)[PB])
     {
-#pragma unroll
-        for (int qd = 0; qd < NQ; ++qd) {
-            const f32x4 t = *reinterpret_cast<const f32x4 *>(slot + qd * 1024 + lane * 16);
-            a[4 * qd] = t.x; a[4 * qd + 1] = t.y; a[4 * qd + 2] = t.z; a[4 * qd + 3] = t.w;
-        }
-        const char *bslot = slot + NQ * 1024;
         if constexpr (VEC) {
 #pragma unroll
             for (int qd = 0; qd < PB / 4; ++qd) {
-                const f32x4 t = *reinterpret_cast<const f32x4 *>(bslot + qd * 1024 + lane * 16);
+                const f32x4 t = *reinterpret_cast<const f32x4 *>(slot + qd * 1024 + lane * 16);
                 b[4 * qd] = t.x; b[4 * qd + 1] = t.y; b[4 * qd + 2] = t.z; b[4 * qd + 3] = t.w;
             }
         } else {
 #pragma unroll
-            for (int pb = 0; pb < PB; ++pb) b[pb] = *reinterpret_cast<const float *>(bslot + pb * 256 + lane * 4);
+            for (int pb = 0; pb < PB; ++pb) b[pb] = *reinterpret_cast<const float *>(slot + pb * 256 + lane * 4);
         }
     }
 };
 
-// ------------------------------------------------------------------------------------------------------------------
-// conv_gemm_kernel: blockDim = 64 * NW; wave w owns output n-blocks [w*NB, (w+1)*NB) for one pixel tile.
-// grid.x = B * tilesPerSample.  Dynamic LDS = NW * D * SLOT.
-// ------------------------------------------------------------------------------------------------------------------
-#ifndef URNN_GEMM_MINWAVES
-#define URNN_GEMM_MINWAVES 1
-#endif
-
-template <int NB, int PB, int MAP, int EPI, int D>
-__global__ __launch_bounds__(256, URNN_GEMM_MINWAVES) void conv_gemm_kernel(const ConvGemmParams prm)
+// Stage `nfloats` (a multiple of 256) floats from global into LDS with the block's 4 waves, 1 KiB per DMA instruction.
+__device__ __forceinline__ void stage_weights(const float *src, char *dst, int nfloats, int wave, int nwaves, int lane)
 {
-    using R = Ring<NB, PB, MAP>;
+    for (int c = wave; c < nfloats / 256; c += nwaves) dma16(src + (size_t)c * 256 + lane * 4, dst + c * 1024);
+}
+
+// block -> (n-group, tile slot): blocks b and b + 8 share an XCD; the NG groups of one tile slot are placed there.
+__device__ __forceinline__ void block_role(int NG, int &g, int &slot, int &nslots)
+{
+    const int xcd = blockIdx.x & 7, r = blockIdx.x >> 3;
+    g = r % NG;
+    slot = (r / NG) * 8 + xcd;
+    nslots = gridDim.x / NG;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// conv_gemm_kernel: persistent blocks of 4 waves; block owns n-group g (weights resident in LDS), each wave loops over
+// pixel tiles.  gridDim.x is a multiple of 8 * NG.  Dynamic LDS = aFloats*4 + WPB * (D + 1) * SLOT.
+// ------------------------------------------------------------------------------------------------------------------
+template <int NB, int PB, int MAP, int EPI, int D, int WPB>
+__global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const ConvGemmParams prm)
+{
+    using R = Ring<PB, MAP>;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, half = lane >> 5;
-    const int b = blockIdx.x / prm.tilesPerSample;
-    const int tile = blockIdx.x - b * prm.tilesPerSample;
+    int g, slot0, nslots;
+    block_role(prm.NG, g, slot0, nslots);
 
-    PixelMap<MAP, PB> pm;
-    pm.init(tile, j, prm.P, prm.W, prm.P2, prm.W2);
-
-    f32x16 acc[NB][PB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int pb = 0; pb < PB; ++pb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nb][pb][r] = 0.f;
-
-    char *ring = urnn_smem + wave * (D * R::SLOT);
-    // this lane's weights: Wq[wave][kp][quad][lane][4]
-    const float *wq = prm.wt + ((size_t)wave * prm.KT * R::NQ) * 256 + lane * 4;
-    const int kp_begin = prm.kpBegin, KT = prm.KT;
-
-    // activation row of absolute k-pair kp (segments are concatenated, each padded to an even channel count)
-    auto row_of = [&](int kp) -> const float * {
-        int s = 0;
-        if (kp >= prm.segKp0[1]) s = 1;
-        if (kp >= prm.segKp0[2]) s = 2;
-        const int C = prm.segC[s];
-        int c = 2 * (kp - prm.segKp0[s]) + half;
-        c = c < C ? c : C - 1;                       // pad row: weight is zero, any finite activation does
-        return prm.seg[s] + ((size_t)b * C + c) * prm.P;
-    };
-    auto issue = [&](int kp, int slot) { R::issue(ring + slot * R::SLOT, wq + (size_t)kp * (R::NQ * 256), row_of(kp), pm); };
-    auto consume = [&](int kp, int slot) {
-        float a[R::NQ * 4], bv[PB];
-        R::read(ring + slot * R::SLOT, lane, a, bv);
-        // the hidden-state rows feed the z / r gates only; the candidate's h part waits for r (gru_cand_kernel)
-        const bool hrow = (EPI == EPI_GRU1) && kp >= prm.hKp0;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            if (EPI == EPI_GRU1 && nb == 2 && hrow) continue;
-#pragma unroll
-            for (int pb = 0; pb < PB; ++pb) acc[nb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nb], bv[pb], acc[nb][pb], 0, 0, 0);
-        }
-    };
-
-    const int nk = KT - kp_begin;
-    {
-        const int npro = nk < D ? nk : D;
-        for (int i = 0; i < npro; ++i) issue(kp_begin + i, i);
-    }
-    int slot = 0;
-    int kp = kp_begin;
-    // steady state: D slots in flight; the oldest has landed once at most (D-1) slots' loads are outstanding
-    for (; kp + D <= KT; ++kp) {
-        wait_vmcnt<(D - 1) * R::NLOAD>();
-        consume(kp, slot);
-        asm volatile("" ::: "memory");
-        if (kp + D < KT) issue(kp + D, slot);
-        slot = slot + 1 == D ? 0 : slot + 1;
-    }
-    // drain: everything left is already in flight
+    const float *A = reinterpret_cast<const float *>(urnn_smem);       // [KT][NB][64]
+    char *ring = urnn_smem + (size_t)prm.aFloats * 4 + wave * ((D + 1) * R::SLOT);
+    char *scratch = ring + D * R::SLOT;                                // one extra slot: sink for the count-keeping dummy DMAs
+    stage_weights(prm.wt + (size_t)g * prm.aFloats, urnn_smem, prm.aFloats, wave, WPB, lane);
     wait_vmcnt<0>();
-    for (; kp < KT; ++kp) {
-        consume(kp, slot);
-        slot = slot + 1 == D ? 0 : slot + 1;
-    }
+    __syncthreads();
 
-    const int n0 = wave * (NB * 32);
+    const int kp_begin = prm.kpBegin, KT = prm.KT;
+    const int n0 = g * (NB * 32);
     const float *bias = prm.bias + n0;
 
-    if constexpr (EPI == EPI_LRELU) {
-        // out[b][n][p] = lrelu(acc + bias)
+    if constexpr (WPB == 8) {
+        // Waves w and w + 4 share a SIMD.  Identical tiles would keep them in lockstep: both in the MFMA loop (sharing the
+        // pipe), then both in the store epilogue (pipe idle, and the whole chip bursting stores at once).  Holding the second
+        // wave back by half a tile puts the pair in anti-phase for the rest of the kernel: one wave's epilogue always hides
+        // behind the other's MFMAs.  The first wave runs alone (at full pipe rate) meanwhile, so no work is lost.
+        if (wave >= 4) {
+            int mf = (KT - kp_begin) * NB * PB;
+            if (EPI == EPI_GRU1 && prm.hKp0 < KT) mf -= (KT - prm.hKp0) * PB;
+            const int naps = (mf * 64 / 2) / (64 * 64);          // s_sleep 64 ~ 64*64 cycles
+            for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(64);
+        }
+    }
+
+    int tr_n = 0;
+    (void)tr_n;
+    for (int item = slot0 * WPB + wave; item < prm.totalTiles; item += nslots * WPB) {
+        TRACE_STAMP(0);
+        const int b = item / prm.tilesPerSample;
+        const int tile = item - b * prm.tilesPerSample;
+        PixelMap<MAP, PB> pm;
+        pm.init(tile, j, prm.P, prm.W, prm.P2, prm.W2);
+
+        f32x16 acc[NB][PB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int cib = mfma_row(r, half);
-                const int n = n0 + nb * 32 + cib;
-                if (n < prm.Cout) {
+            for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nb][pb][r] = 0.f;
+
+        // Activation rows are addressed as  uniform segment base (SGPR pair) + 32-bit per-lane byte offset : row k-pair kp of
+        // a segment sits at offset (2*(kp - kp0) + half) * P * 4 + pixel offset.  Walking K costs one v_add per k-pair; a
+        // segment switch resets the offset and swaps the scalar base.  A segment with an odd channel count ends in a pad row
+        // (zero weight): there the upper half-wave re-reads the last real row.
+        const int k1 = prm.segKp0[1], k2 = prm.segKp0[2];
+        const int C0 = prm.segC[0], C1 = prm.segC[1], C2 = prm.segC[2];
+        const char *base0 = reinterpret_cast<const char *>(prm.seg[0] + (size_t)b * C0 * prm.P);
+        const char *base1 = reinterpret_cast<const char *>(prm.seg[1] + (size_t)b * C1 * prm.P);
+        const char *base2 = reinterpret_cast<const char *>(prm.seg[2] + (size_t)b * C2 * prm.P);
+        const unsigned rstep = 8u * (unsigned)prm.P;                       // two channel rows, bytes
+        const unsigned voff0 = half ? 4u * (unsigned)prm.P : 0u;           // first k-pair of any segment
+        const unsigned padsub = half ? 4u * (unsigned)prm.P : 0u;
+        int kp_issue = kp_begin;                                           // next k-pair whose DMA will be issued
+        const int s_begin = kp_begin >= k2 ? 2 : (kp_begin >= k1 ? 1 : 0);
+        const char *sbase = s_begin == 2 ? base2 : (s_begin == 1 ? base1 : base0);
+        int skp0 = s_begin == 2 ? k2 : (s_begin == 1 ? k1 : 0);
+        int sC = s_begin == 2 ? C2 : (s_begin == 1 ? C1 : C0);
+        unsigned voff = voff0 + rstep * (unsigned)(kp_begin - skp0);
+        // Branch-free refill (the k loop must stay one basic block so that its instruction order can be pinned): past the
+        // end of K the DMA is redirected to a scratch slot, which keeps the outstanding-DMA count -- and therefore every
+        // s_waitcnt immediate -- exact.
+        auto refill = [&](int slot) {
+            const bool live = kp_issue < KT;
+            char *dst = live ? ring + slot * R::SLOT : scratch;
+            const bool pad = 2 * (kp_issue - skp0) + 1 >= sC;              // uniform; true only on the last k-pair of an odd C
+            const unsigned vo = live ? voff - (pad ? padsub : 0u) : voff0;
+            R::issue(dst, reinterpret_cast<const float *>(sbase + vo), pm);
+            ++kp_issue;
+            voff += rstep;
+            const bool sw1 = kp_issue == k1, sw2 = kp_issue == k2;
+            sbase = sw2 ? base2 : (sw1 ? base1 : sbase);
+            skp0 = sw2 ? k2 : (sw1 ? k1 : skp0);
+            sC = sw2 ? C2 : (sw1 ? C1 : sC);
+            voff = (sw1 || sw2) ? voff0 : voff;
+        };
+        auto read_frag = [&](int kp, int slot, float (&a)[NB], float (&bv)[PB]) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) a[nb] = A[(kp * NB + nb) * 64 + lane];
+            R::read(ring + slot * R::SLOT, lane, bv);
+        };
+
+        // Software pipeline.  A wave issues in order and each fp32 MFMA occupies the pipe for 64 cycles, so everything that is
+        // not an MFMA must sit BETWEEN MFMAs (about ten instruction slots hide behind each one) -- traced with s_memtime, the
+        // version that did its LDS reads, pointer math and DMA issue after the last MFMA of a k-pair lost 300 of every 1070
+        // cycles.  Order per k-pair, pinned with sched_barrier: [wait + LDS reads of the NEXT k-pair] MFMAs(nb 0) [refill DMA of
+        // the slot just consumed] MFMAs(nb 1) [bookkeeping] MFMAs(nb 2) [fragment hand-over].
+        for (int i = 0; i < D; ++i) refill(i);
+        float a_cur[NB], b_cur[PB], a_nxt[NB], b_nxt[PB];
+        wait_vmcnt<(D - 1) * R::NLOAD>();
+        read_frag(kp_begin, 0, a_cur, b_cur);
+        TRACE_STAMP(1);
+        int slot = 0;
+        auto k_range = [&](int kp_lo, int kp_hi, auto nba_tag) {
+            constexpr int NBA = decltype(nba_tag)::value;            // n-blocks that take MFMAs in this range
+            for (int kp = kp_lo; kp < kp_hi; ++kp) {
+                const int nslot = slot + 1 == D ? 0 : slot + 1;
+                wait_vmcnt<(D - 2) * R::NLOAD>();                   // slot kp+1 has landed (or is a dummy)
+                read_frag(kp + 1 < KT ? kp + 1 : kp, nslot, a_nxt, b_nxt);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb) acc[0][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0], b_cur[pb], acc[0][pb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                refill(slot);                                        // its fragments are already in registers
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (NBA >= 2) {
+#pragma unroll
+                    for (int pb = 0; pb < PB; ++pb) acc[1][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1], b_cur[pb], acc[1][pb], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int nb = 2; nb < NBA; ++nb) {
+#pragma unroll
+                    for (int pb = 0; pb < PB; ++pb) acc[nb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[nb], b_cur[pb], acc[nb][pb], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) a_cur[nb] = a_nxt[nb];
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb) b_cur[pb] = b_nxt[pb];
+                slot = nslot;
+            }
+        };
+        if constexpr (EPI == EPI_GRU1) {
+            // the hidden-state rows feed the z / r gates only; the candidate's h part waits for r (gru_cand_kernel)
+            const int hk = prm.hKp0 < KT ? prm.hKp0 : KT;
+            k_range(kp_begin, hk, std::integral_constant<int, NB>{});
+            k_range(hk, KT, std::integral_constant<int, 2>{});
+        } else {
+            k_range(kp_begin, KT, std::integral_constant<int, NB>{});
+        }
+        wait_vmcnt<0>();
+        TRACE_STAMP(2);
+
+        if constexpr (EPI == EPI_LRELU) {
+            // out[b][n][p] = lrelu(acc + bias)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cib = mfma_row(r, half);
+                    const int n = n0 + nb * 32 + cib;
+                    if (n < prm.Cout) {
+                        const float bv = bias[nb * 32 + cib];
+                        float v[PB];
+#pragma unroll
+                        for (int pb = 0; pb < PB; ++pb) v[pb] = lrelu(acc[nb][pb][r] + bv, prm.slope);
+                        store_row<MAP, PB>(prm.out0 + ((size_t)b * prm.Cout + n) * prm.P, pm, v);
+                    }
+                }
+        } else if constexpr (EPI == EPI_POOL) {
+            // out[b][n][q] = 0.25 * sum_{2x2} lrelu(acc + bias)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cib = mfma_row(r, half);
+                    const int n = n0 + nb * 32 + cib;
+                    if (n < prm.Cout && pm.valid[0]) {
+                        const float bv = bias[nb * 32 + cib];
+                        float s = 0.f;
+#pragma unroll
+                        for (int pb = 0; pb < 4; ++pb) s += lrelu(acc[nb][pb][r] + bv, prm.slope);
+                        prm.out0[((size_t)b * prm.Cout + n) * prm.P2 + pm.q] = 0.25f * s;
+                    }
+                }
+        } else if constexpr (EPI == EPI_DECONV) {
+            // group = output row parity a; n-blocks = (bb, co-block); out[b][co][2y+a][2x+bb] = lrelu(acc + bias)
+            static_assert(NB % 2 == 0, "deconv group holds both column parities");
+            constexpr int NBC = NB / 2;
+            const int a = g;
+            const int W2 = 2 * prm.W;
+            int oy[PB], ox[PB];
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) {
+                const int y = pm.off[pb] / prm.W;
+                oy[pb] = 2 * y + a;
+                ox[pb] = 2 * (pm.off[pb] - y * prm.W);
+            }
+#pragma unroll
+            for (int cob = 0; cob < NBC; ++cob)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cib = mfma_row(r, half);
+                    const int co = cob * 32 + cib;
+                    if (co < prm.Cout) {
+                        const float bv = bias[cob * 32 + cib];
+                        float *oplane = prm.out0 + ((size_t)b * prm.Cout + co) * (4 * (size_t)prm.P);
+                        if constexpr (MAP == MAP_PAIR) {
+                            // two horizontally adjacent input pixels -> four consecutive output floats (W even, p even)
+                            if (pm.valid[0]) {
+                                f32x4 v;
+                                v.x = lrelu(acc[cob][0][r] + bv, prm.slope);
+                                v.y = lrelu(acc[NBC + cob][0][r] + bv, prm.slope);
+                                v.z = lrelu(acc[cob][1][r] + bv, prm.slope);
+                                v.w = lrelu(acc[NBC + cob][1][r] + bv, prm.slope);
+                                *reinterpret_cast<f32x4 *>(oplane + (size_t)oy[0] * W2 + ox[0]) = v;
+                            }
+                        } else {
+#pragma unroll
+                            for (int pb = 0; pb < PB; ++pb)
+                                if (pm.valid[pb]) {
+                                    f32x2 v;
+                                    v.x = lrelu(acc[cob][pb][r] + bv, prm.slope);
+                                    v.y = lrelu(acc[NBC + cob][pb][r] + bv, prm.slope);
+                                    *reinterpret_cast<f32x2 *>(oplane + (size_t)oy[pb] * W2 + ox[pb]) = v;
+                                }
+                        }
+                    }
+                }
+        } else if constexpr (EPI == EPI_GRU1) {
+            // group i owns [z_i | r_i | c_i]: raw (pre-GroupNorm) gates -> out0 (B,2F,P), candidate x/e part + b2 -> out1
+            // (B,F,P), and the GroupNorm partial sums of z_i (group i) and r_i (group F/32 + i) -> partial[b][grp][tile][2].
+            static_assert(NB == 3, "gate tile is z|r|c");
+            const int F = prm.F;
+            const int i = g;
+#pragma unroll
+            for (int nb = 0; nb < 3; ++nb) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cib = mfma_row(r, half);
                     const float bv = bias[nb * 32 + cib];
+                    float *orow;
+                    if (nb == 0) orow = prm.out0 + ((size_t)b * 2 * F + i * 32 + cib) * prm.P;
+                    else if (nb == 1) orow = prm.out0 + ((size_t)b * 2 * F + F + i * 32 + cib) * prm.P;
+                    else orow = prm.out1 + ((size_t)b * F + i * 32 + cib) * prm.P;
                     float v[PB];
 #pragma unroll
-                    for (int pb = 0; pb < PB; ++pb) v[pb] = lrelu(acc[nb][pb][r] + bv, prm.slope);
-                    store_row<MAP, PB>(prm.out0 + ((size_t)b * prm.Cout + n) * prm.P, pm, v);
-                }
-            }
-    } else if constexpr (EPI == EPI_POOL) {
-        // out[b][n][q] = 0.25 * sum_{2x2} lrelu(acc + bias)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int cib = mfma_row(r, half);
-                const int n = n0 + nb * 32 + cib;
-                if (n < prm.Cout && pm.valid[0]) {
-                    const float bv = bias[nb * 32 + cib];
-                    float s = 0.f;
-#pragma unroll
-                    for (int pb = 0; pb < 4; ++pb) s += lrelu(acc[nb][pb][r] + bv, prm.slope);
-                    prm.out0[((size_t)b * prm.Cout + n) * prm.P2 + pm.q] = 0.25f * s;
-                }
-            }
-    } else if constexpr (EPI == EPI_DECONV) {
-        // wave = output row parity a; n-blocks = (bb, co-block); out[b][co][2y+a][2x+bb] = lrelu(acc + bias)
-        static_assert(NB % 2 == 0, "deconv wave holds both column parities");
-        constexpr int NBC = NB / 2;
-        const int a = wave;
-        const int W2 = 2 * prm.W;
-        int oy[PB], ox[PB];
-#pragma unroll
-        for (int pb = 0; pb < PB; ++pb) {
-            const int y = pm.off[pb] / prm.W;
-            oy[pb] = 2 * y + a;
-            ox[pb] = 2 * (pm.off[pb] - y * prm.W);
-        }
-#pragma unroll
-        for (int cob = 0; cob < NBC; ++cob)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int cib = mfma_row(r, half);
-                const int co = cob * 32 + cib;
-                if (co < prm.Cout) {
-                    const float bv = bias[cob * 32 + cib];
-                    float *oplane = prm.out0 + ((size_t)b * prm.Cout + co) * (4 * (size_t)prm.P);
-                    if constexpr (MAP == MAP_PAIR) {
-                        // two horizontally adjacent input pixels -> four consecutive output floats (W even, p even)
-                        if (pm.valid[0]) {
-                            f32x4 v;
-                            v.x = lrelu(acc[cob][0][r] + bv, prm.slope);
-                            v.y = lrelu(acc[NBC + cob][0][r] + bv, prm.slope);
-                            v.z = lrelu(acc[cob][1][r] + bv, prm.slope);
-                            v.w = lrelu(acc[NBC + cob][1][r] + bv, prm.slope);
-                            *reinterpret_cast<f32x4 *>(oplane + (size_t)oy[0] * W2 + ox[0]) = v;
+                    for (int pb = 0; pb < PB; ++pb) {
+                        v[pb] = acc[nb][pb][r] + bv;
+                        if (nb < 2 && pm.valid[pb]) {
+                            s1 += v[pb];
+                            s2 += v[pb] * v[pb];
                         }
-                    } else {
-#pragma unroll
-                        for (int pb = 0; pb < PB; ++pb)
-                            if (pm.valid[pb]) {
-                                f32x2 v;
-                                v.x = lrelu(acc[cob][pb][r] + bv, prm.slope);
-                                v.y = lrelu(acc[NBC + cob][pb][r] + bv, prm.slope);
-                                *reinterpret_cast<f32x2 *>(oplane + (size_t)oy[pb] * W2 + ox[pb]) = v;
-                            }
                     }
+                    store_row<MAP, PB>(orow, pm, v);
                 }
-            }
-    } else if constexpr (EPI == EPI_GRU1) {
-        // wave i owns [z_i | r_i | c_i]: raw (pre-GroupNorm) gates -> out0 (B,2F,P), candidate x/e part + b2 -> out1 (B,F,P),
-        // and the GroupNorm partial sums of z_i (group i) and r_i (group F/32 + i) -> partial[b][group][tile][2].
-        static_assert(NB == 3, "gate tile is z|r|c");
-        const int F = prm.F;
-        const int i = wave;
-#pragma unroll
-        for (int nb = 0; nb < 3; ++nb) {
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int cib = mfma_row(r, half);
-                const float bv = bias[nb * 32 + cib];
-                float *orow;
-                if (nb == 0) orow = prm.out0 + ((size_t)b * 2 * F + i * 32 + cib) * prm.P;
-                else if (nb == 1) orow = prm.out0 + ((size_t)b * 2 * F + F + i * 32 + cib) * prm.P;
-                else orow = prm.out1 + ((size_t)b * F + i * 32 + cib) * prm.P;
-                float v[PB];
-#pragma unroll
-                for (int pb = 0; pb < PB; ++pb) {
-                    v[pb] = acc[nb][pb][r] + bv;
-                    if (nb < 2 && pm.valid[pb]) {
-                        s1 += v[pb];
-                        s2 += v[pb] * v[pb];
+                if (nb < 2) {
+                    s1 = wave_sum(s1);
+                    s2 = wave_sum(s2);
+                    if (lane == 0) {
+                        const int G = 2 * F / 32;
+                        const int grp = nb * (F / 32) + i;
+                        float *pp = prm.partial + (((size_t)b * G + grp) * prm.tilesPerSample + tile) * 2;
+                        pp[0] = s1;
+                        pp[1] = s2;
                     }
-                }
-                store_row<MAP, PB>(orow, pm, v);
-            }
-            if (nb < 2) {
-                s1 = wave_sum(s1);
-                s2 = wave_sum(s2);
-                if (lane == 0) {
-                    const int G = 2 * F / 32;
-                    const int g = nb * (F / 32) + i;
-                    float *pp = prm.partial + (((size_t)b * G + g) * prm.tilesPerSample + tile) * 2;
-                    pp[0] = s1;
-                    pp[1] = s2;
                 }
             }
         }
+#ifdef URNN_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TRACE_STAMP(3);
+        ++tr_n;
+#endif
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // gru_cand_kernel: C = Cx + W2h . (r * h),  r = sigmoid(g_r * scale + shift)  (GroupNorm folded into scale/shift).
-// One wave = 32*PB pixels x all F candidate channels (NBF = F/32 n-blocks); Cx is added in the epilogue and the sum goes
-// back in place; GroupNorm partial sums of C per 32-channel group.  blockDim = 64 * WPB waves, one tile per wave.
-// Ring slot = [weights 1 KiB | raw r gate PB*256 B | h PB*256 B]; dynamic LDS = 8*F (scale/shift) + WPB * D * SLOT.
+// Persistent blocks of 4 waves; W2h (F x F) and every sample's r-gate scale/shift stay in LDS; a wave tile = 32*PB pixels
+// x all F candidate channels (NBF = F/32 n-blocks); Cx is added in the epilogue, the sum goes back in place; GroupNorm
+// partial sums of C per 32-channel group.  Ring slot = [raw r gate PB*256 B | h PB*256 B].
+// Dynamic LDS = F*F*4 + B*F*8 + 4 * D * SLOT.
 // ------------------------------------------------------------------------------------------------------------------
 template <int NBF, int PB, int MAP, int D>
 __global__ __launch_bounds__(256) void gru_cand_kernel(const GruCandParams prm)
 {
     constexpr int F = NBF * 32;
     constexpr bool VEC = (MAP == MAP_VEC);
-    constexpr int NBLOAD = VEC ? PB / 4 : PB;
-    constexpr int NLOAD = 1 + 2 * NBLOAD;
-    constexpr int SLOT = 1024 + 2 * PB * 256;
+    constexpr int NLOAD = 2 * (VEC ? PB / 4 : PB);
+    constexpr int SLOT = 2 * PB * 256;
+    constexpr int KT = F / 2;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wpb = blockDim.x >> 6;
     const int j = lane & 31, half = lane >> 5;
-    const int b = blockIdx.x / prm.blocksPerSample;
-    const int tile = (blockIdx.x - b * prm.blocksPerSample) * wpb + wave;
 
-    float *ssm = reinterpret_cast<float *>(urnn_smem);               // [F][2] scale/shift of the r gate for this sample
-    char *ring = urnn_smem + 8 * F + wave * (D * SLOT);
-    for (int c = threadIdx.x; c < 2 * F; c += blockDim.x) ssm[c] = prm.ss1[((size_t)b * 2 * F + F) * 2 + c];
+    const float *A = reinterpret_cast<const float *>(urnn_smem);                     // [KT][NBF][64]
+    float *ssm = reinterpret_cast<float *>(urnn_smem + F * F * 4);                   // [B][F][2] r-gate scale/shift
+    char *ring = urnn_smem + F * F * 4 + prm.B * F * 8 + wave * (D * SLOT);
+    stage_weights(prm.w2h, urnn_smem, F * F, wave, 4, lane);
+    for (int c = threadIdx.x; c < prm.B * 2 * F; c += 256) {
+        const int b = c / (2 * F), r = c - b * 2 * F;
+        ssm[c] = prm.ss1[((size_t)b * 2 * F + F) * 2 + r];
+    }
+    wait_vmcnt<0>();
     __syncthreads();
-    if (tile >= prm.tilesPerSample) return;
 
-    PixelMap<MAP, PB> pm;
-    pm.init(tile, j, prm.P, 0, 0, 0);
+    for (int item = blockIdx.x * 4 + wave; item < prm.totalTiles; item += gridDim.x * 4) {
+        const int b = item / prm.tilesPerSample;
+        const int tile = item - b * prm.tilesPerSample;
+        PixelMap<MAP, PB> pm;
+        pm.init(tile, j, prm.P, 0, 0, 0);
 
-    f32x16 acc[NBF][PB];
-#pragma unroll
-    for (int nb = 0; nb < NBF; ++nb)
-#pragma unroll
-        for (int pb = 0; pb < PB; ++pb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nb][pb][r] = 0.f;
-
-    const float *gr = prm.g1 + ((size_t)b * 2 * F + F + half) * prm.P;   // raw r-gate planes (row k = 2*kp + half)
-    const float *hh = prm.h + ((size_t)b * F + half) * prm.P;
-    const float *wq = prm.w2h + lane * 4;
-    constexpr int KT = F / 2;
-
-    auto issue = [&](int kp, int slot) {
-        char *s = ring + slot * SLOT;
-        dma16(wq + (size_t)kp * 256, s);
-        const float *grow = gr + (size_t)(2 * kp) * prm.P;
-        const float *hrow = hh + (size_t)(2 * kp) * prm.P;
-        if constexpr (VEC) {
-#pragma unroll
-            for (int qd = 0; qd < PB / 4; ++qd) {
-                dma16(grow + pm.off[4 * qd], s + 1024 + qd * 1024);
-                dma16(hrow + pm.off[4 * qd], s + 1024 + PB * 256 + qd * 1024);
-            }
-        } else {
-#pragma unroll
-            for (int pb = 0; pb < PB; ++pb) {
-                dma4(grow + pm.off[pb], s + 1024 + pb * 256);
-                dma4(hrow + pm.off[pb], s + 1024 + PB * 256 + pb * 256);
-            }
-        }
-    };
-    auto consume = [&](int kp, int slot) {
-        const char *s = ring + slot * SLOT;
-        const f32x4 av = *reinterpret_cast<const f32x4 *>(s + lane * 16);
-        const float a[4] = {av.x, av.y, av.z, av.w};
-        float g[PB], h[PB];
-        if constexpr (VEC) {
-#pragma unroll
-            for (int qd = 0; qd < PB / 4; ++qd) {
-                const f32x4 tg = *reinterpret_cast<const f32x4 *>(s + 1024 + qd * 1024 + lane * 16);
-                const f32x4 th = *reinterpret_cast<const f32x4 *>(s + 1024 + PB * 256 + qd * 1024 + lane * 16);
-                g[4 * qd] = tg.x; g[4 * qd + 1] = tg.y; g[4 * qd + 2] = tg.z; g[4 * qd + 3] = tg.w;
-                h[4 * qd] = th.x; h[4 * qd + 1] = th.y; h[4 * qd + 2] = th.z; h[4 * qd + 3] = th.w;
-            }
-        } else {
-#pragma unroll
-            for (int pb = 0; pb < PB; ++pb) {
-                g[pb] = *reinterpret_cast<const float *>(s + 1024 + pb * 256 + lane * 4);
-                h[pb] = *reinterpret_cast<const float *>(s + 1024 + PB * 256 + pb * 256 + lane * 4);
-            }
-        }
-        const f32x2 st = *reinterpret_cast<const f32x2 *>(ssm + 2 * (2 * kp + half));
-        float bop[PB];
-#pragma unroll
-        for (int pb = 0; pb < PB; ++pb) bop[pb] = sigmoidf_fast(g[pb] * st.x + st.y) * h[pb];
+        f32x16 acc[NBF][PB];
 #pragma unroll
         for (int nb = 0; nb < NBF; ++nb)
 #pragma unroll
-            for (int pb = 0; pb < PB; ++pb) acc[nb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nb], bop[pb], acc[nb][pb], 0, 0, 0);
-    };
+            for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nb][pb][r] = 0.f;
 
-    static_assert(KT >= D, "ring deeper than the K loop");
-    for (int i = 0; i < D; ++i) issue(i, i);
-    int slot = 0, kp = 0;
-    for (; kp + D <= KT; ++kp) {
-        wait_vmcnt<(D - 1) * NLOAD>();
-        consume(kp, slot);
-        asm volatile("" ::: "memory");
-        if (kp + D < KT) issue(kp + D, slot);
-        slot = slot + 1 == D ? 0 : slot + 1;
-    }
-    wait_vmcnt<0>();
-    for (; kp < KT; ++kp) {
-        consume(kp, slot);
-        slot = slot + 1 == D ? 0 : slot + 1;
-    }
+        const float *gr = prm.g1 + ((size_t)b * 2 * F + F + half) * prm.P;   // raw r-gate planes (row k = 2*kp + half)
+        const float *hh = prm.h + ((size_t)b * F + half) * prm.P;
+        const float *ssb = ssm + (size_t)b * 2 * F;
 
-    // epilogue: add the x/e part (+ bias) written by the gate GEMM, store C in place, partial sums per 32-channel group
-    float *cx = prm.cx + (size_t)b * F * prm.P;
+        auto issue = [&](int kp, int slot) {
+            char *s = ring + slot * SLOT;
+            const float *grow = gr + (size_t)(2 * kp) * prm.P;
+            const float *hrow = hh + (size_t)(2 * kp) * prm.P;
+            if constexpr (VEC) {
 #pragma unroll
-    for (int nb = 0; nb < NBF; ++nb) {
-        float s1 = 0.f, s2 = 0.f;
+                for (int qd = 0; qd < PB / 4; ++qd) {
+                    dma16(grow + pm.off[4 * qd], s + qd * 1024);
+                    dma16(hrow + pm.off[4 * qd], s + PB * 256 + qd * 1024);
+                }
+            } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float *orow = cx + (size_t)(nb * 32 + mfma_row(r, half)) * prm.P;
-            float v[PB];
-            load_row<MAP, PB>(orow, pm, v);
-#pragma unroll
-            for (int pb = 0; pb < PB; ++pb) {
-                v[pb] += acc[nb][pb][r];
-                if (pm.valid[pb]) {
-                    s1 += v[pb];
-                    s2 += v[pb] * v[pb];
+                for (int pb = 0; pb < PB; ++pb) {
+                    dma4(grow + pm.off[pb], s + pb * 256);
+                    dma4(hrow + pm.off[pb], s + PB * 256 + pb * 256);
                 }
             }
-            store_row<MAP, PB>(orow, pm, v);
+        };
+        auto consume = [&](int kp, int slot) {
+            const char *s = ring + slot * SLOT;
+            float a[NBF], g[PB], h[PB];
+#pragma unroll
+            for (int nb = 0; nb < NBF; ++nb) a[nb] = A[(kp * NBF + nb) * 64 + lane];
+            if constexpr (VEC) {
+#pragma unroll
+                for (int qd = 0; qd < PB / 4; ++qd) {
+                    const f32x4 tg = *reinterpret_cast<const f32x4 *>(s + qd * 1024 + lane * 16);
+                    const f32x4 th = *reinterpret_cast<const f32x4 *>(s + PB * 256 + qd * 1024 + lane * 16);
+                    g[4 * qd] = tg.x; g[4 * qd + 1] = tg.y; g[4 * qd + 2] = tg.z; g[4 * qd + 3] = tg.w;
+                    h[4 * qd] = th.x; h[4 * qd + 1] = th.y; h[4 * qd + 2] = th.z; h[4 * qd + 3] = th.w;
+                }
+            } else {
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb) {
+                    g[pb] = *reinterpret_cast<const float *>(s + pb * 256 + lane * 4);
+                    h[pb] = *reinterpret_cast<const float *>(s + PB * 256 + pb * 256 + lane * 4);
+                }
+            }
+            const f32x2 st = *reinterpret_cast<const f32x2 *>(ssb + 2 * (2 * kp + half));
+            float bop[PB];
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) bop[pb] = sigmoidf_fast(g[pb] * st.x + st.y) * h[pb];
+#pragma unroll
+            for (int nb = 0; nb < NBF; ++nb)
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb) acc[nb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nb], bop[pb], acc[nb][pb], 0, 0, 0);
+        };
+
+        static_assert(KT >= D, "ring deeper than the K loop");
+        for (int i = 0; i < D; ++i) issue(i, i);
+        int slot = 0, kp = 0;
+        for (; kp + D <= KT; ++kp) {
+            wait_vmcnt<(D - 1) * NLOAD>();
+            consume(kp, slot);
+            asm volatile("" ::: "memory");
+            if (kp + D < KT) issue(kp + D, slot);
+            slot = slot + 1 == D ? 0 : slot + 1;
         }
-        s1 = wave_sum(s1);
-        s2 = wave_sum(s2);
-        if (lane == 0) {
-            float *pp = prm.partial + (((size_t)b * NBF + nb) * prm.tilesPerSample + tile) * 2;
-            pp[0] = s1;
-            pp[1] = s2;
+        wait_vmcnt<0>();
+        for (; kp < KT; ++kp) {
+            consume(kp, slot);
+            slot = slot + 1 == D ? 0 : slot + 1;
         }
+
+        // epilogue: add the x/e part (+ bias) written by the gate GEMM, store C in place, partial sums per 32-channel group
+        float *cx = prm.cx + (size_t)b * F * prm.P;
+#pragma unroll
+        for (int nb = 0; nb < NBF; ++nb) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float *orow = cx + (size_t)(nb * 32 + mfma_row(r, half)) * prm.P;
+                float v[PB];
+                load_row<MAP, PB>(orow, pm, v);
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb) {
+                    v[pb] += acc[nb][pb][r];
+                    if (pm.valid[pb]) {
+                        s1 += v[pb];
+                        s2 += v[pb] * v[pb];
+                    }
+                }
+                store_row<MAP, PB>(orow, pm, v);
+            }
+            s1 = wave_sum(s1);
+            s2 = wave_sum(s2);
+            if (lane == 0) {
+                float *pp = prm.partial + (((size_t)b * NBF + nb) * prm.tilesPerSample + tile) * 2;
+                pp[0] = s1;
+                pp[1] = s2;
+            }
+        }
+        wait_vmcnt<0>();   // the epilogue's own loads/stores must not be miscounted by the next tile's ring waits
     }
 }
 
@@ -521,24 +608,75 @@ __global__ __launch_bounds__(256) void gru_cand_kernel(const GruCandParams prm)
 // host-side dispatch
 // ------------------------------------------------------------------------------------------------------------------
 static constexpr int RING_D = 8;
+static constexpr int NUM_CUS = 256;                   // MI355X
+static constexpr size_t LDS_PER_CU = 160 * 1024;
 
-template <int NB, int PB, int MAP, int EPI>
-static hipError_t launch_conv(const ConvGemmParams &p, int nblocks, int nwaves, hipStream_t st)
+// Persistent grid: as many blocks as fit (LDS-limited, at most 2 per CU), a multiple of 8*NG, no more than the work needs.
+static int tune_block_waves()
 {
-    using R = Ring<NB, PB, MAP>;
-    const size_t lds = (size_t)nwaves * RING_D * R::SLOT;
-    hipLaunchKernelGGL((conv_gemm_kernel<NB, PB, MAP, EPI, RING_D>), dim3(nblocks), dim3(64 * nwaves), lds, st, p);
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("URNN_TUNE_WPB");   // development knob: 4 forces 4-wave blocks
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
+static int persistent_grid(size_t lds_bytes, int NG, int total_tiles, int wpb = 4)
+{
+    int bpc = (int)(LDS_PER_CU / lds_bytes);
+    const int cap = wpb >= 8 ? 1 : 2;
+    bpc = bpc < 1 ? 1 : (bpc > cap ? cap : bpc);
+    const int unit = 8 * NG;
+    int n = (NUM_CUS * bpc) / unit * unit;
+    int need = ((total_tiles + wpb - 1) / wpb) * NG;
+    need = (need + unit - 1) / unit * unit;
+    n = n < need ? n : need;
+    return n < unit ? unit : n;
+}
+
+template <typename K>
+static hipError_t allow_big_lds(K kernel, size_t lds)
+{
+    if (lds <= 64 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+template <int NB, int PB, int MAP, int EPI, int D, int WPB>
+static hipError_t launch_conv_cfg(const ConvGemmParams &p, hipStream_t st)
+{
+    using R = Ring<PB, MAP>;
+    const size_t lds = (size_t)p.aFloats * 4 + (size_t)WPB * ((D + 1) * R::SLOT);
+    if (lds > LDS_PER_CU) return hipErrorInvalidValue;
+    auto kern = conv_gemm_kernel<NB, PB, MAP, EPI, D, WPB>;
+    hipError_t e = allow_big_lds(kern, lds);
+    if (e != hipSuccess) return e;
+    const int grid = persistent_grid(lds, p.NG, p.totalTiles, WPB);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WPB), lds, st, p);
     return hipGetLastError();
+}
+
+// Block shape: 8 waves (two per SIMD: one wave's epilogue / stalls hide behind the other's MFMAs) with a 4-deep ring when
+// the weight slab leaves room, else 4 waves with an 8-deep ring.
+template <int NB, int PB, int MAP, int EPI>
+static hipError_t launch_conv(const ConvGemmParams &p, hipStream_t st)
+{
+    using R = Ring<PB, MAP>;
+    const size_t lds8 = (size_t)p.aFloats * 4 + (size_t)8 * (5 * R::SLOT);
+    if constexpr (NB * PB * 16 <= 192 && EPI != EPI_DECONV) {   // accumulators + loop state fit the 256-register budget
+        if (lds8 <= LDS_PER_CU && tune_block_waves() != 4) return launch_conv_cfg<NB, PB, MAP, EPI, 4, 8>(p, st);
+    }
+    return launch_conv_cfg<NB, PB, MAP, EPI, 8, 4>(p, st);
 }
 
 // tile shape -> (PB, MAP): 16-B DMA on aligned planes, pair/strided dword DMA otherwise
 template <int NB, int EPI>
-static hipError_t launch_flat(const ConvGemmParams &p, int pb, int map, int nblocks, int nwaves, hipStream_t st)
+static hipError_t launch_flat(const ConvGemmParams &p, int pb, int map, hipStream_t st)
 {
-    if (map == MAP_VEC && pb == 4) return launch_conv<NB, 4, MAP_VEC, EPI>(p, nblocks, nwaves, st);
-    if (map == MAP_PAIR && pb == 2) return launch_conv<NB, 2, MAP_PAIR, EPI>(p, nblocks, nwaves, st);
-    if (map == MAP_STRIDED && pb == 2) return launch_conv<NB, 2, MAP_STRIDED, EPI>(p, nblocks, nwaves, st);
-    if (map == MAP_STRIDED && pb == 1) return launch_conv<NB, 1, MAP_STRIDED, EPI>(p, nblocks, nwaves, st);
+    if (map == MAP_VEC && pb == 4) return launch_conv<NB, 4, MAP_VEC, EPI>(p, st);
+    if (map == MAP_PAIR && pb == 2) return launch_conv<NB, 2, MAP_PAIR, EPI>(p, st);
+    if (map == MAP_STRIDED && pb == 2) return launch_conv<NB, 2, MAP_STRIDED, EPI>(p, st);
+    if (map == MAP_STRIDED && pb == 1) return launch_conv<NB, 1, MAP_STRIDED, EPI>(p, st);
     return hipErrorInvalidValue;
 }
 
@@ -548,91 +686,90 @@ int urnn_conv_nb(int Cout)
     return nblk <= 3 ? nblk : (nblk % 3 == 0 ? 3 : (nblk % 2 == 0 ? 2 : 1));
 }
 
-// Flat 1x1 conv + LeakyReLU.  NB n-blocks per wave chosen from Cout; NW waves cover all columns.
+// Flat 1x1 conv + LeakyReLU.  NB n-blocks per group chosen from Cout; NG groups cover all columns.
 hipError_t urnn_launch_conv_flat(ConvGemmParams p, int B, int PB, int map, hipStream_t st)
 {
-    const int nblk = (p.Cout + 31) / 32;
     const int NB = urnn_conv_nb(p.Cout);
-    const int NW = nblk / NB;
-    if (NW > 4) return hipErrorInvalidValue;
     p.tilesPerSample = (p.P + 32 * PB - 1) / (32 * PB);
-    const int nblocks = B * p.tilesPerSample;
-    if (NB == 1) return launch_flat<1, EPI_LRELU>(p, PB, map, nblocks, NW, st);
-    if (NB == 2) return launch_flat<2, EPI_LRELU>(p, PB, map, nblocks, NW, st);
-    return launch_flat<3, EPI_LRELU>(p, PB, map, nblocks, NW, st);
+    p.totalTiles = B * p.tilesPerSample;
+    if (NB == 1) return launch_flat<1, EPI_LRELU>(p, PB, map, st);
+    if (NB == 2) return launch_flat<2, EPI_LRELU>(p, PB, map, st);
+    return launch_flat<3, EPI_LRELU>(p, PB, map, st);
 }
 
 hipError_t urnn_launch_conv_pool(ConvGemmParams p, int B, hipStream_t st)
 {
-    const int nblk = (p.Cout + 31) / 32;
     const int NB = urnn_conv_nb(p.Cout);
-    const int NW = nblk / NB;
-    if (NW > 4) return hipErrorInvalidValue;
     p.tilesPerSample = (p.P2 + 31) / 32;
-    const int nblocks = B * p.tilesPerSample;
-    if (NB == 1) return launch_conv<1, 4, MAP_POOL, EPI_POOL>(p, nblocks, NW, st);
-    if (NB == 2) return launch_conv<2, 4, MAP_POOL, EPI_POOL>(p, nblocks, NW, st);
-    return launch_conv<3, 4, MAP_POOL, EPI_POOL>(p, nblocks, NW, st);
+    p.totalTiles = B * p.tilesPerSample;
+    if (NB == 1) return launch_conv<1, 4, MAP_POOL, EPI_POOL>(p, st);
+    if (NB == 2) return launch_conv<2, 4, MAP_POOL, EPI_POOL>(p, st);
+    return launch_conv<3, 4, MAP_POOL, EPI_POOL>(p, st);
 }
 
-// Deconv: two waves (output row parity), each 2 * ceil(Cout/32) n-blocks, PB = 2 pairs (1 strided for tiny/odd planes).
+// Deconv: two groups (output row parity), each 2 * ceil(Cout/32) n-blocks, PB = 2 pairs (1 strided for tiny/odd planes).
 hipError_t urnn_launch_deconv(ConvGemmParams p, int B, int PB, int map, hipStream_t st)
 {
     const int nbc = (p.Cout + 31) / 32;
     if (nbc < 1 || nbc > 3) return hipErrorInvalidValue;
     p.tilesPerSample = (p.P + 32 * PB - 1) / (32 * PB);
-    const int nblocks = B * p.tilesPerSample;
+    p.totalTiles = B * p.tilesPerSample;
     if (PB == 2 && map == MAP_PAIR) {
-        if (nbc == 1) return launch_conv<2, 2, MAP_PAIR, EPI_DECONV>(p, nblocks, 2, st);
-        if (nbc == 2) return launch_conv<4, 2, MAP_PAIR, EPI_DECONV>(p, nblocks, 2, st);
-        return launch_conv<6, 2, MAP_PAIR, EPI_DECONV>(p, nblocks, 2, st);
+        if (nbc == 1) return launch_conv<2, 2, MAP_PAIR, EPI_DECONV>(p, st);
+        if (nbc == 2) return launch_conv<4, 2, MAP_PAIR, EPI_DECONV>(p, st);
+        return launch_conv<6, 2, MAP_PAIR, EPI_DECONV>(p, st);
     }
     if (PB != 1 || map != MAP_STRIDED) return hipErrorInvalidValue;
-    if (nbc == 1) return launch_conv<2, 1, MAP_STRIDED, EPI_DECONV>(p, nblocks, 2, st);
-    if (nbc == 2) return launch_conv<4, 1, MAP_STRIDED, EPI_DECONV>(p, nblocks, 2, st);
-    return launch_conv<6, 1, MAP_STRIDED, EPI_DECONV>(p, nblocks, 2, st);
+    if (nbc == 1) return launch_conv<2, 1, MAP_STRIDED, EPI_DECONV>(p, st);
+    if (nbc == 2) return launch_conv<4, 1, MAP_STRIDED, EPI_DECONV>(p, st);
+    return launch_conv<6, 1, MAP_STRIDED, EPI_DECONV>(p, st);
 }
 
-// GRU gate GEMM: F/32 waves of [z|r|c].
+// GRU gate GEMM: F/32 groups of [z|r|c].
 hipError_t urnn_launch_gru1(ConvGemmParams p, int B, int PB, int map, hipStream_t st)
 {
-    const int NW = p.F / 32;
-    if (NW < 1 || NW > 4) return hipErrorInvalidValue;
+    if (p.NG < 1 || p.NG > 4) return hipErrorInvalidValue;
     p.tilesPerSample = (p.P + 32 * PB - 1) / (32 * PB);
-    const int nblocks = B * p.tilesPerSample;
-    return launch_flat<3, EPI_GRU1>(p, PB, map, nblocks, NW, st);
+    p.totalTiles = B * p.tilesPerSample;
+    return launch_flat<3, EPI_GRU1>(p, PB, map, st);
 }
 
 template <int NBF, int PB, int MAP>
-static hipError_t launch_cand_one(const GruCandParams &p, int nblocks, int wpb, hipStream_t st)
+static hipError_t launch_cand_one(const GruCandParams &p, hipStream_t st)
 {
-    constexpr int SLOT = 1024 + 2 * PB * 256;
-    const size_t lds = (size_t)8 * NBF * 32 + (size_t)wpb * RING_D * SLOT;
-    hipLaunchKernelGGL((gru_cand_kernel<NBF, PB, MAP, RING_D>), dim3(nblocks), dim3(64 * wpb), lds, st, p);
+    constexpr int F = NBF * 32;
+    constexpr int D = 4;
+    constexpr int SLOT = 2 * PB * 256;
+    const size_t lds = (size_t)F * F * 4 + (size_t)p.B * F * 8 + (size_t)4 * D * SLOT;
+    if (lds > LDS_PER_CU) return hipErrorInvalidValue;
+    auto kern = gru_cand_kernel<NBF, PB, MAP, D>;
+    hipError_t e = allow_big_lds(kern, lds);
+    if (e != hipSuccess) return e;
+    const int grid = persistent_grid(lds, 1, p.totalTiles);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, p);
     return hipGetLastError();
 }
 
 template <int NBF>
-static hipError_t launch_cand_nbf(const GruCandParams &p, int PB, int map, int nblocks, int wpb, hipStream_t st)
+static hipError_t launch_cand_nbf(const GruCandParams &p, int PB, int map, hipStream_t st)
 {
-    if (map == MAP_VEC && PB == 4) return launch_cand_one<NBF, 4, MAP_VEC>(p, nblocks, wpb, st);
-    if (map == MAP_PAIR && PB == 2) return launch_cand_one<NBF, 2, MAP_PAIR>(p, nblocks, wpb, st);
-    if (map == MAP_STRIDED && PB == 2) return launch_cand_one<NBF, 2, MAP_STRIDED>(p, nblocks, wpb, st);
-    if (map == MAP_STRIDED && PB == 1) return launch_cand_one<NBF, 1, MAP_STRIDED>(p, nblocks, wpb, st);
+    if (map == MAP_VEC && PB == 4) return launch_cand_one<NBF, 4, MAP_VEC>(p, st);
+    if (map == MAP_PAIR && PB == 2) return launch_cand_one<NBF, 2, MAP_PAIR>(p, st);
+    if (map == MAP_STRIDED && PB == 2) return launch_cand_one<NBF, 2, MAP_STRIDED>(p, st);
+    if (map == MAP_STRIDED && PB == 1) return launch_cand_one<NBF, 1, MAP_STRIDED>(p, st);
     return hipErrorInvalidValue;
 }
 
 hipError_t urnn_launch_cand(GruCandParams p, int B, int F, int PB, int map, hipStream_t st)
 {
-    const int wpb = 2;   // 2 waves x 8 slots x <= 3 KiB stays under the 64 KiB dynamic-LDS default
+    p.B = B;
     p.tilesPerSample = (p.P + 32 * PB - 1) / (32 * PB);
-    p.blocksPerSample = (p.tilesPerSample + wpb - 1) / wpb;
-    const int nblocks = B * p.blocksPerSample;
+    p.totalTiles = B * p.tilesPerSample;
     switch (F / 32) {
-    case 1: return launch_cand_nbf<1>(p, PB, map, nblocks, wpb, st);
-    case 2: return launch_cand_nbf<2>(p, PB, map, nblocks, wpb, st);
-    case 3: return launch_cand_nbf<3>(p, PB, map, nblocks, wpb, st);
-    case 4: return launch_cand_nbf<4>(p, PB, map, nblocks, wpb, st);
+    case 1: return launch_cand_nbf<1>(p, PB, map, st);
+    case 2: return launch_cand_nbf<2>(p, PB, map, st);
+    case 3: return launch_cand_nbf<3>(p, PB, map, st);
+    case 4: return launch_cand_nbf<4>(p, PB, map, st);
     default: return hipErrorInvalidValue;
     }
 }

@@ -12,10 +12,13 @@ struct ConvGemmParams {
     int segKp0[3];        // first absolute k-pair of each segment in the packed weights (unused segments: INT_MAX)
     int kpBegin, KT;      // k-pair range to run: [kpBegin, KT)  (kpBegin > 0 skips an all-zero x segment)
     int hKp0;             // EPI_GRU1: first k-pair of the hidden-state segment (candidate columns are skipped from here)
-    const float *wt;      // packed Wq[wave][kp][quad][lane][4]
-    const float *bias;    // bias per packed column
+    const float *wt;      // packed weights [NG][KT][NB][64] (group stride aFloats); lane l of row (kp, nb) holds
+                          // W[k = 2*kp + (l >> 5)][n = (g*NB + nb)*32 + (l & 31)]
+    const float *bias;    // bias per packed column [NG*NB*32]
+    int aFloats;          // floats per n-group slab, a multiple of 256 (one LDS-DMA instruction moves 256 floats)
+    int NG;               // number of n-groups (blocks are specialised per group)
     int P, W, P2, W2;     // input plane size / width; pooled plane size / width (EPI_POOL)
-    int tilesPerSample;
+    int tilesPerSample, totalTiles;
     int Cout, F;
     float slope;
     float *out0, *out1;
@@ -26,10 +29,10 @@ struct GruCandParams {
     const float *g1;   // raw gates (B,2F,P)
     const float *h;    // (B,F,P)
     const float *ss1;  // gate GroupNorm folded to per-channel (scale, shift): [B][2F][2]
-    const float *w2h;  // packed W2 h-part: Wq[kp][lane][4]
+    const float *w2h;  // packed W2 h-part [F/2][F/32][64]: lane l of row (kp, nb) holds W2[nb*32 + (l & 31)][Koff_h + 2*kp + (l >> 5)]
     float *cx;         // in: candidate x/e part + bias; out: full pre-norm candidate (B,F,P)
     float *partial;    // [B][F/32][tiles][2]
-    int P, tilesPerSample, blocksPerSample;
+    int P, B, tilesPerSample, totalTiles;
 };
 
 int urnn_conv_nb(int Cout);   // n-blocks per wave for a Cout-wide 1x1 conv (packing and launch must agree)
