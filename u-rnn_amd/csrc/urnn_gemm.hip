@@ -664,7 +664,9 @@ static hipError_t launch_conv(const ConvGemmParams &p, hipStream_t st)
     using R = Ring<PB, MAP>;
     const size_t lds8 = (size_t)p.aFloats * 4 + (size_t)8 * (5 * R::SLOT);
     if constexpr (NB * PB * 16 <= 192 && EPI != EPI_DECONV) {   // accumulators + loop state fit the 256-register budget
-        if (lds8 <= LDS_PER_CU && tune_block_waves() != 4) return launch_conv_cfg<NB, PB, MAP, EPI, 4, 8>(p, st);
+        // 8-wave blocks only pay when there is enough work to fill 2048 wave slots; small planes keep 4-wave blocks
+        const bool enough = (long)p.totalTiles * p.NG >= 1024;
+        if (lds8 <= LDS_PER_CU && enough && tune_block_waves() != 4) return launch_conv_cfg<NB, PB, MAP, EPI, 4, 8>(p, st);
     }
     return launch_conv_cfg<NB, PB, MAP, EPI, 8, 4>(p, st);
 }
