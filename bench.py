@@ -11,8 +11,9 @@ N>1: one process per GPU (torchrun), one independent event per rank, no data-pat
 independent: test.py:741-746) -> weak scaling; value = total frames of all ranks / max-over-ranks time.
 
 Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel = the fp32-MFMA gate GEMM of the
-full-resolution ConvGRU cells, timed live with events on the launch stream) and "cpu_baseline" (the C oracle
-on the host cores, bounded sample, rank 0 at N=1 only).
+full-resolution ConvGRU cells, timed live with events on the launch streams while the rollout runs in the same
+scheduling mode as the timed region) and "cpu_baseline" (the C oracle on the host cores, bounded sample, rank 0
+at N=1 only).
 """
 import argparse
 import json
@@ -72,27 +73,6 @@ def build_net(H, W, C, dev, seed=0):
     return net.to(dev).eval(), sd, cfg
 
 
-def time_gate_gemm(net, eng, iters=20):
-    """Average duration (s) of the gate-GEMM kernel alone, for the enc1 and dec1 call sites, measured with
-    events on the stream the kernel is launched on (torch's current stream == the stream handed to the C ABI)."""
-    from urnn_amd import ops
-    e1, _, _, _, _, d3 = eng.states
-    sites = [("enc1", lambda: net.encoder.rnn1.step(eng.a1, None, e1, out=e1, phases=ops.PHASE_GATES)),
-             ("dec1", lambda: net.decoder.rnn1.step(eng.u2, e1, d3, out=d3, phases=ops.PHASE_GATES))]
-    out = {}
-    for name, fn in sites:
-        for _ in range(3):
-            fn()
-        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        start.record()
-        for _ in range(iters):
-            fn()
-        stop.record()
-        stop.synchronize()
-        out[name] = start.elapsed_time(stop) / 1e3 / iters
-    return out
-
-
 def cpu_baseline(sd, cfgname, budget_s=15.0, max_frames=8):
     """The C oracle (oracle/urnn_oracle.c, OpenMP) on the host cores: same synthetic event, first frames of the
     rollout, input assembly included -- frames/s like the reference's Inference timer."""
@@ -125,7 +105,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="events per GPU (the reference entry points use 1)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of the captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--overlap", type=int, default=0, help="1: encoder(t+1) || decoder+head(t) on two streams")
+    ap.add_argument("--overlap", type=int, default=1,
+                    help="1 (default): encoder(t+1) || decoder+head(t) as two concurrent kernel chains; 0: one chain")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -180,10 +161,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    from urnn_amd.distributed import max_over_ranks
+    elapsed = max_over_ranks(elapsed, device=dev)
 
     frames = args.steps * B * world
     fps = frames / elapsed
@@ -205,7 +184,7 @@ def main():
         "config": {"workload": f"{args.config}: {H}x{W} grid, historical_nums={nums} (C={C}), T={T}, "
                                f"{B} event(s) per GPU, inference rollout incl. per-frame input assembly",
                    "events_per_gpu": B, "parallelism": f"event-parallel x{world} (no collective)",
-                   "graph": not args.no_graph},
+                   "graph": not args.no_graph, "overlap_chains": bool(args.overlap)},
         "gflop_per_frame": gflop,
         "step_mfma_frac": fps / world * gflop / 1e3 / PEAK_MFMA_F32_TFLOPS,
     }
@@ -213,7 +192,7 @@ def main():
     if rank == 0:
         # dominant kernel: fp32-MFMA gate GEMM at full resolution (2 launches per frame: enc1, dec1)
         try:
-            dur = time_gate_gemm(net, eng)
+            dur = eng.probe_gate_gemm()          # live, events on the launch streams, same scheduling mode as the timed region
             f_enc1, f_dec1 = gate_gemm_flops(H * W * B)
             flops_per_launch = 0.5 * (f_enc1 + f_dec1)
             avg = 0.5 * (dur["enc1"] + dur["dec1"])
@@ -224,7 +203,8 @@ def main():
                 with open(pmc) as fh:
                     traffic = json.load(fh).get("hbm_bytes_per_launch")
             result["roofline"] = {
-                "bound": "mfma", "kernel": "conv_gemm_kernel<NB=3,PB=4,MODE_GRU1,VEC> (ConvGRU gate GEMM, fp32 MFMA 32x32x2)",
+                "bound": "mfma", "kernel": "conv_gemm_kernel<NB=3,PB=4,MAP_VEC,EPI_GRU1,D=4,WPB=8> (full-resolution ConvGRU gate GEMM, fp32 MFMA 32x32x2; "
+                          "2 launches per frame: enc1, dec1)",
                 "achieved": achieved, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_F32_TFLOPS,
                 "traffic": traffic,
                 "avg_launch_us": avg * 1e6, "launch_us": {k: v * 1e6 for k, v in dur.items()},

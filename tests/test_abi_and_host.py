@@ -1,0 +1,119 @@
+"""CPU-only checks: the C-ABI library builds, loads and exports every symbol include/urnn_hip.h declares (no compute
+calls without a GPU); host-side logic (architecture table, state shapes, checkpoint key handling, event sharding);
+the product path fails loudly instead of falling back when there is no GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="session")
+def built():
+    import __graft_entry__ as g
+    g.build()
+    from urnn_amd import _lib
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(built):
+    header = open(os.path.join(REPO, "include", "urnn_hip.h")).read()
+    declared = set(re.findall(r"\b(urnn_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 15
+    lib = built.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"liburnn_hip.so does not export {name}"
+    assert declared == set(built.SIGNATURES), "ctypes signature table and header disagree"
+    assert lib.urnn_abi_version() == 1
+
+
+def test_packed_sizes_and_argument_errors_without_gpu(built):
+    lib = built.lib()
+    # pure host-side size arithmetic
+    assert lib.urnn_packed_conv_floats(63, 16) == 32 * 1 * 64 + 32
+    assert lib.urnn_packed_gru_floats(16, 64, 0) == 2 * (40 * 3 * 64) + 192 + 64 * 64
+    assert lib.urnn_packed_gru_floats(96, 64, 1) == 2 * (112 * 3 * 64) + 192 + 64 * 64
+    assert lib.urnn_gru_cell_workspace_bytes(1, 64, 500, 500) > 3 * 64 * 250000 * 4
+    # argument validation happens before any HIP call
+    assert lib.urnn_stage_conv_f32(0, 0, 0, 1, 8, 16, 4, 4, 0, 0.2, 0) == -2      # URNN_ENULL
+    assert b"NULL" in lib.urnn_last_error()
+    assert lib.urnn_gru_cell_f32(0, 0, 16, 16, 16, 16, 16, 16, 16, 16, 1 << 30, 1, 16, 48, 4, 4, 1e-5, 0) == -1  # F % 32
+    assert b"multiple of 32" in lib.urnn_last_error()
+
+
+def test_no_cpu_fallback():
+    from urnn_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.stage_conv(torch.zeros(1, 8, 4, 4), torch.zeros(8), 16, False)
+
+
+def test_architecture_table_and_state_shapes():
+    from urnn_amd.net_config import get_input_channels, get_state_shapes, load_net_config
+    cfg = load_net_config()
+    assert get_input_channels(cfg, 30) == 63 and get_input_channels(cfg, 3) == 9
+    assert get_state_shapes(cfg, 500, 500) == [(1, 64, 500, 500), (1, 96, 250, 250), (1, 96, 125, 125),
+                                               (1, 96, 125, 125), (1, 96, 250, 250), (1, 64, 500, 500)]
+    assert get_state_shapes(cfg, 64, 64, batch=8)[2] == (8, 96, 16, 16)
+
+
+def test_parameter_counts_match_reference():
+    import urnn_amd.weights as uw
+    assert sum(v.size for v in uw.make_state_dict(64, 64, 9).values()) == 1_075_506
+    assert len(uw.make_state_dict(16, 16, 9)) == 79
+
+
+def test_model_mirror_has_reference_keys_and_loads_alias_checkpoints():
+    import urnn_amd.weights as uw
+    from urnn_amd.net_config import load_net_config
+    from urnn_amd.networks import ED, get_network_params
+    ep, dp = get_network_params(False, 16, 16, 9, load_net_config())
+    net = ED(False, ep, dp, 0.5, False, 16, 16)
+    sd = uw.make_state_dict(16, 16, 9, seed=1)
+    assert set(net.state_dict()) == set(sd)
+    # a reference checkpoint carries alias keys for every checkpoint wrapper and (under DDP) a "module." prefix
+    ckpt = {}
+    for k, v in sd.items():
+        t = torch.from_numpy(v)
+        ckpt["module." + k] = t
+        head, _, tail = k.partition(".")
+        parts = k.split(".")
+        ckpt["module." + parts[0] + "." + parts[1] + "_wrapper.module." + ".".join(parts[2:])] = t
+        if ".conv1." in k or ".conv2." in k:
+            ckpt["module." + k.replace(".conv1.", ".conv1_module_wrapper.module.").replace(".conv2.", ".conv2_module_wrapper.module.")] = t
+    assert len(ckpt) > 2 * len(sd)
+    res = net.load_state_dict(ckpt)
+    assert not res.missing_keys and not res.unexpected_keys
+    for k, v in net.state_dict().items():
+        assert np.array_equal(v.numpy(), sd[k])
+
+
+def test_unsupported_architectures_fail_loudly():
+    from urnn_amd.networks import CGRU_cell
+    from urnn_amd.networks.utils import make_layers
+    with pytest.raises(NotImplementedError):
+        CGRU_cell(False, (8, 8), 16, 3, 64, "encoder")            # only 1x1 gate convs exist in the published net
+    with pytest.raises(NotImplementedError):
+        make_layers({"conv1_leaky_1": [9, 16, 3, 1, 1]})
+
+
+def test_event_flattening_matches_reference_layout():
+    import urnn_amd.weights as uw
+    from urnn_amd.dataset import event_to_device
+    ev = uw.make_event(7, 8, 12, 6.0, seed=0, batch=2)
+    flat = event_to_device(ev, torch.device("cpu"))
+    assert flat["rain"].shape == (2, 7) and flat["dem"].shape == (2, 8, 12) and flat["T"] == 7
+    sp = event_to_device(uw.make_event(7, 8, 12, 6.0, seed=0, spatial_rain=True), torch.device("cpu"))
+    assert sp["rain"].shape == (1, 7, 8, 12)
+    assert np.allclose(np.cumsum(ev["rainfall"], axis=1), ev["cumsum_rainfall"], rtol=1e-6)
+
+
+def test_shard_events_is_distributed_sampler():
+    from torch.utils.data.distributed import DistributedSampler
+    from urnn_amd.distributed import shard_events
+    for n, world in ((10, 4), (3, 8), (8, 8), (17, 2)):
+        for rank in range(world):
+            ref = list(DistributedSampler(range(n), num_replicas=world, rank=rank, shuffle=False))
+            assert shard_events(n, rank, world) == ref

@@ -1,0 +1,44 @@
+"""world_size-2 gloo test (CPU) of the N>1 path: event sharding without a data-path collective, the max-over-ranks
+timing reduction and the optional result gather -- the same code bench.py / a multi-GPU driver run over RCCL."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, num_events, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from urnn_amd.distributed import env_ranks, gather_event_results, max_over_ranks, shard_events
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    assert env_ranks() == (rank, rank, world)
+    mine = shard_events(num_events, rank, world)
+    # stand-in for a rollout: a (T,H,W) result that encodes the event index
+    results = [torch.full((3, 4, 5), float(idx)) for idx in mine]
+    slowest = max_over_ranks(1.0 + rank)
+    gathered = gather_event_results(results, num_events)
+    dist.barrier()
+    ok = slowest == float(world) and len(gathered) == num_events and all(float(g[0, 0, 0]) == i for i, g in enumerate(gathered))
+    np.save(os.path.join(out_dir, f"rank{rank}.npy"), np.array([int(ok)] + mine))
+    dist.destroy_process_group()
+
+
+def test_two_rank_event_sharding(tmp_path):
+    world, num_events = 2, 5
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, num_events, str(tmp_path)), nprocs=world, join=True)
+    seen = []
+    for r in range(world):
+        data = np.load(os.path.join(str(tmp_path), f"rank{r}.npy"))
+        assert data[0] == 1, f"rank {r} failed its checks"
+        seen += list(data[1:])
+    assert set(seen) == set(range(num_events))          # every event processed
+    assert len(seen) == 6                               # padded to a multiple of world, as DistributedSampler does

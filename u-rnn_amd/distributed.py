@@ -1,0 +1,59 @@
+"""Event-parallel multi-GPU helpers (one process per GPU, torch.distributed: RCCL on GPUs, gloo on CPU tests).
+
+Inference shards naturally over independent rainfall events and needs NO data-path collective: the reference
+uses ``DistributedSampler(shuffle=False)`` over events and never gathers (test.py:741-746).  The
+helpers here reproduce that partition and add the two control-plane reductions a benchmark/driver needs (max of the
+per-rank wall time, optional gather of per-event results to rank 0)."""
+import math
+import os
+
+import torch
+
+
+def env_ranks():
+    """(local_rank, rank, world_size) from the torchrun environment; (0, 0, 1) when not launched distributed
+    (the reference reads the same variables: general.py:25-27)."""
+    return (int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)))
+
+
+def shard_events(num_events, rank, world_size):
+    """Indices of the events rank ``rank`` processes: ``DistributedSampler(dataset, shuffle=False, drop_last=False)``
+    semantics -- the index list is padded by wrapping around to a multiple of world_size, then strided."""
+    if num_events <= 0:
+        return []
+    per_rank = math.ceil(num_events / world_size)
+    total = per_rank * world_size
+    indices = list(range(num_events))
+    while len(indices) < total:
+        indices += indices[: total - len(indices)]
+    return indices[rank:total:world_size]
+
+
+def max_over_ranks(value, device=None):
+    """Max of a python float over all ranks (bench timing contract); identity when not distributed."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_event_results(local_results, num_events, device=None):
+    """Gather per-event tensors (same shape on every rank) onto every rank in GLOBAL event order.
+
+    ``local_results`` is the list produced by this rank for ``shard_events(num_events, rank, world)`` (padding
+    duplicates included).  Returns a list of ``num_events`` tensors (on CPU); duplicates from padding are dropped."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [r.cpu() for r in local_results[:num_events]]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    stacked = torch.stack([r.to(device) if device is not None else r for r in local_results])
+    bucket = [torch.empty_like(stacked) for _ in range(world)]
+    dist.all_gather(bucket, stacked)
+    out = [None] * num_events
+    for r in range(world):
+        for k, idx in enumerate(shard_events(num_events, r, world)):
+            if out[idx] is None:
+                out[idx] = bucket[r][k].cpu()
+    return out

@@ -69,6 +69,7 @@ class RolloutEngine:
             ops.WORKSPACE.use_slot(slot)
             ops.WORKSPACE.reserve(need, dev)
         ops.WORKSPACE.use_slot(0)
+        self._probe = None          # {"enc1": [(start, stop), ...], "dec1": [...]} while probing
         self._graph = None
         self._graphs2 = None
         self._side = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)) if self.overlap else None
@@ -82,7 +83,7 @@ class RolloutEngine:
         ops.preprocess(self.rain, self.cumsum, self.dem, self.imperv, self.manhole, self.dem_min, self.dem_max, 0,
                        self.nums, self.rain_max, self.cumsum_max, out=self.x_in, t_dev=self.t_dev)
         enc.stage1(self.x_in, out=self.a1)
-        enc.rnn1.step(self.a1, None, e1, out=e1)
+        self._cell("enc1", enc.rnn1, self.a1, None, e1, e1)
         enc.stage2(e1, out=self.a2)
         enc.rnn2.step(self.a2, None, e2, out=e2)
         enc.stage3(e2, out=self.a3)
@@ -91,11 +92,38 @@ class RolloutEngine:
         dec.stage3(d1, out=self.u3)
         dec.rnn2.step(self.u3, e2, d2, out=d2)
         dec.stage2(d2, out=self.u2)
-        dec.rnn1.step(self.u2, e1, d3, out=d3)
+        self._cell("dec1", dec.rnn1, self.u2, e1, d3, d3)
         dec.stage1(d3, out=self.feat)
         net.head.run(self.feat, out_masked=self.out_masked, out_cls=self.out_cls, out_raw=self.out_raw,
                      frame_index=self.t_dev)
         ops.advance_counter(self.t_dev, 1)
+
+    def _cell(self, name, cell, x, e, h, out):
+        """One GRU cell; when a probe is active the gate GEMM of the named full-resolution cells is launched on its
+        own, bracketed by events on the launch stream (bench.py's live roofline measurement)."""
+        if self._probe is not None and name in self._probe:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            cell.step(x, e, h, out=out, phases=ops.PHASE_GATES)
+            b.record()
+            self._probe[name].append((a, b))
+            cell.step(x, e, h, out=out, phases=ops.PHASE_ALL & ~ops.PHASE_GATES)
+        else:
+            cell.step(x, e, h, out=out)
+
+    def probe_gate_gemm(self, frames=12):
+        """Average duration (seconds) of the enc1 / dec1 gate-GEMM launches while the rollout runs in this engine's
+        scheduling mode (eager launches, same streams and co-running kernels as the captured graph)."""
+        saved_graph, self.use_graph = self.use_graph, False
+        self.reset()
+        self.run(2)
+        self._probe = {"enc1": [], "dec1": []}
+        self.run(frames)
+        torch.cuda.synchronize(self.device)
+        probe, self._probe = self._probe, None
+        self.use_graph = saved_graph
+        self.reset()
+        return {k: sum(a.elapsed_time(b) for a, b in v) / len(v) / 1e3 for k, v in probe.items()}
 
     # -- overlap mode: two concurrent chains -------------------------------------------------------------
     def _enc_bufs(self, parity):
@@ -110,7 +138,7 @@ class RolloutEngine:
         ops.preprocess(self.rain, self.cumsum, self.dem, self.imperv, self.manhole, self.dem_min, self.dem_max, 0,
                        self.nums, self.rain_max, self.cumsum_max, out=self.x_in, t_dev=self.te_dev)
         enc.stage1(self.x_in, out=self.a1)
-        enc.rnn1.step(self.a1, None, p1, out=n1)
+        self._cell("enc1", enc.rnn1, self.a1, None, p1, n1)
         enc.stage2(n1, out=self.a2)
         enc.rnn2.step(self.a2, None, p2, out=n2)
         enc.stage3(n2, out=self.a3)
@@ -127,7 +155,7 @@ class RolloutEngine:
         dec.stage3(d1, out=self.u3)
         dec.rnn2.step(self.u3, e2, d2, out=d2)
         dec.stage2(d2, out=self.u2)
-        dec.rnn1.step(self.u2, e1, d3, out=d3)
+        self._cell("dec1", dec.rnn1, self.u2, e1, d3, d3)
         dec.stage1(d3, out=self.feat)
         net.head.run(self.feat, out_masked=self.out_masked, out_cls=self.out_cls, out_raw=self.out_raw,
                      frame_index=self.t_dev)
