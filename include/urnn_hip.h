@@ -116,6 +116,20 @@ int urnn_preprocess_f32(const float *rain, const float *cumsum, const float *dem
                         const float *manhole, float dem_min, float dem_max, float *out, int t, const int *t_dev, int B,
                         int T, int nums, int H, int W, int spatial, float rain_max, float cumsum_max, void *stream);
 
+/* Scalar-rainfall fast path of encoder stage 1: preprocess_inputs + Encoder.stage1 fused for events whose
+ * rainfall is one value per frame (Dynamic2DFlood.py:181-216 "scalar" case; encoder.py:140-151; net_params.py:80-81).
+ * With scalar rain 2*nums of the 2*nums+3 input channels are spatial constants, so
+ *   stage1(preprocess_inputs(t))[n][p] = LeakyReLU( S[n][p] + v_t[n] )
+ *   S   = W[:, 2*nums:] . [(DEM-min)/(max-min), (imp-0.05)/0.9, manhole]      urnn_stage1_static_f32, once per event
+ *   v_t = b + W[:, :2*nums] . [rain hist / rain_max, cumsum hist / cumsum_max]  computed inside urnn_stage1_scalar_rain_f32
+ * weight is the nn.Conv2d weight (Cout, 2*nums+3) in its reference layout; rain / cumsum are (B,T); S and out (B,Cout,H,W).
+ * The (B, 2*nums+3, H, W) input tensor never materialises (63 MB per frame at 500x500). */
+int urnn_stage1_static_f32(const float *dem, const float *imperv, const float *manhole, float dem_min, float dem_max,
+                           const float *weight, float *S, int B, int nums, int Cout, int H, int W, void *stream);
+int urnn_stage1_scalar_rain_f32(const float *S, const float *rain, const float *cumsum, const float *weight, const float *bias,
+                                float *out, int t, const int *t_dev, int B, int T, int nums, int Cout, int H, int W,
+                                float rain_max, float cumsum_max, float slope, void *stream);
+
 /* Device-side frame counter helper for graph-captured rollouts: *counter += delta. */
 int urnn_advance_counter(int *counter, int delta, void *stream);
 

@@ -384,6 +384,29 @@ extern "C" int urnn_preprocess_f32(const float *rain, const float *cumsum, const
     return URNN_OK;
 }
 
+extern "C" int urnn_stage1_static_f32(const float *dem, const float *imperv, const float *manhole, float dem_min, float dem_max,
+                                      const float *weight, float *S, int B, int nums, int Cout, int H, int W, void *stream)
+{
+    if (!dem || !imperv || !manhole || !weight || !S) return fail(URNN_ENULL, "urnn_stage1_static_f32: NULL argument");
+    if (B < 1 || nums < 1 || Cout < 1 || H < 1 || W < 1) return fail(URNN_EINVAL, "urnn_stage1_static_f32: bad dims");
+    CHECK_HIP(urnn_launch_stage1_static(dem, imperv, manhole, dem_min, dem_max, weight, S, B, nums, Cout, H * W, (hipStream_t)stream),
+              "stage1_static");
+    return URNN_OK;
+}
+
+extern "C" int urnn_stage1_scalar_rain_f32(const float *S, const float *rain, const float *cumsum, const float *weight,
+                                           const float *bias, float *out, int t, const int *t_dev, int B, int T, int nums, int Cout,
+                                           int H, int W, float rain_max, float cumsum_max, float slope, void *stream)
+{
+    if (!S || !rain || !cumsum || !weight || !bias || !out) return fail(URNN_ENULL, "urnn_stage1_scalar_rain_f32: NULL argument");
+    if (B < 1 || T < 1 || nums < 1 || Cout < 1 || H < 1 || W < 1) return fail(URNN_EINVAL, "urnn_stage1_scalar_rain_f32: bad dims");
+    if (!aligned16(S) || !aligned16(out)) return fail(URNN_EALIGN, "urnn_stage1_scalar_rain_f32: pointers must be 16-byte aligned");
+    CHECK_HIP(urnn_launch_stage1_scalar(S, rain, cumsum, weight, bias, out, t, t_dev, B, T, nums, Cout, H * W, rain_max, cumsum_max,
+                                        slope, (hipStream_t)stream),
+              "stage1_scalar_rain");
+    return URNN_OK;
+}
+
 extern "C" int urnn_advance_counter(int *counter, int delta, void *stream)
 {
     if (!counter) return fail(URNN_ENULL, "urnn_advance_counter: NULL counter");

@@ -420,6 +420,94 @@ hipError_t urnn_launch_preprocess(const float *rain, const float *cumsum, const 
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Scalar-rainfall fast path of the first encoder stage.  With one rainfall value per frame
+// (UrbanFlood24), 2*nums of the 2*nums+3 input channels are spatial constants, so
+//   stage1(x_t)[n][p] = lrelu( S[n][p] + v_t[n] ),   S = W[:, static] . [norm DEM, norm impervious, manhole]   (once per event)
+//                                                     v_t = b + W[:, rain] . rain history(t) / max           (16 numbers per frame)
+// and the (B, 2*nums+3, H, W) input tensor of preprocess_inputs (63 MB per frame at 500x500) never materialises.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stage1_static_kernel(const float *__restrict__ dem, const float *__restrict__ imperv,
+                                                            const float *__restrict__ manhole, float dem_min, float dem_max,
+                                                            const float *__restrict__ w /* (Cout, 2*nums+3) */, float *__restrict__ S,
+                                                            int nums, int Cout, int P)
+{
+    const int b = blockIdx.y;
+    const int C = 2 * nums + 3;
+    const float span = dem_max - dem_min;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += gridDim.x * 256) {
+        const float d = (dem[(size_t)b * P + p] - dem_min) / span;
+        const float im = (imperv[(size_t)b * P + p] - 0.05f) / 0.9f;
+        const float mh = manhole[(size_t)b * P + p];
+        for (int n = 0; n < Cout; ++n) {
+            const float *wr = w + (size_t)n * C + 2 * nums;
+            S[((size_t)b * Cout + n) * P + p] = fmaf(wr[2], mh, fmaf(wr[1], im, wr[0] * d));
+        }
+    }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void stage1_scalar_kernel(const float *__restrict__ S, const float *__restrict__ rain,
+                                                            const float *__restrict__ cumsum, const float *__restrict__ w,
+                                                            const float *__restrict__ bias, float *__restrict__ out, int t_host,
+                                                            const int *__restrict__ t_dev, int T, int nums, int Cout, int P,
+                                                            float rain_max, float cumsum_max, float slope)
+{
+    __shared__ float vt[64];
+    const int bn = blockIdx.y;                    // (sample, output channel)
+    const int b = bn / Cout, n = bn - b * Cout;
+    const int C = 2 * nums + 3;
+    const int t = t_dev ? *t_dev : t_host;
+    if (threadIdx.x < 64) {
+        // rain-history part of channel n, one history slot per lane (get_past_rainfall: left zero padding for t < nums)
+        const int start = max(0, t - nums + 1), end = min(t + 1, T), nsteps = end - start;
+        float acc = 0.f;
+        for (int c = threadIdx.x; c < 2 * nums; c += 64) {
+            const int which = c / nums, slot = c - which * nums;
+            const int k = slot - (nums - nsteps);
+            if (k >= 0) {
+                const float v = (which ? cumsum : rain)[(size_t)b * T + start + k] / (which ? cumsum_max : rain_max);
+                acc = fmaf(w[(size_t)n * C + c], v, acc);
+            }
+        }
+        acc = wave_sum(acc);
+        if (threadIdx.x == 0) vt[0] = acc + bias[n];
+    }
+    __syncthreads();
+    const float v = vt[0];
+    const float *src = S + (size_t)bn * P;
+    float *dst = out + (size_t)bn * P;
+    for (int p = (blockIdx.x * 256 + threadIdx.x) * V; p < P; p += gridDim.x * 256 * V) {
+        if constexpr (V == 4) {
+            f32x4 x = *reinterpret_cast<const f32x4 *>(src + p);
+            x.x = lrelu(x.x + v, slope); x.y = lrelu(x.y + v, slope); x.z = lrelu(x.z + v, slope); x.w = lrelu(x.w + v, slope);
+            *reinterpret_cast<f32x4 *>(dst + p) = x;
+        } else {
+            dst[p] = lrelu(src[p] + v, slope);
+        }
+    }
+}
+
+hipError_t urnn_launch_stage1_static(const float *dem, const float *imperv, const float *manhole, float dem_min, float dem_max,
+                                     const float *w, float *S, int B, int nums, int Cout, int P, hipStream_t st)
+{
+    dim3 grid(min((P + 255) / 256, 2048), B);
+    hipLaunchKernelGGL(stage1_static_kernel, grid, dim3(256), 0, st, dem, imperv, manhole, dem_min, dem_max, w, S, nums, Cout, P);
+    return hipGetLastError();
+}
+
+hipError_t urnn_launch_stage1_scalar(const float *S, const float *rain, const float *cumsum, const float *w, const float *bias,
+                                     float *out, int t, const int *t_dev, int B, int T, int nums, int Cout, int P, float rain_max,
+                                     float cumsum_max, float slope, hipStream_t st)
+{
+    const bool v4 = (P % 4) == 0;
+    const int per = 256 * (v4 ? 4 : 1);
+    dim3 grid(min((P + per - 1) / per, 64), B * Cout);
+    if (v4) hipLaunchKernelGGL(stage1_scalar_kernel<4>, grid, dim3(256), 0, st, S, rain, cumsum, w, bias, out, t, t_dev, T, nums, Cout, P, rain_max, cumsum_max, slope);
+    else hipLaunchKernelGGL(stage1_scalar_kernel<1>, grid, dim3(256), 0, st, S, rain, cumsum, w, bias, out, t, t_dev, T, nums, Cout, P, rain_max, cumsum_max, slope);
+    return hipGetLastError();
+}
+
 __global__ void advance_kernel(int *counter, int delta) { *counter += delta; }
 
 hipError_t urnn_launch_advance(int *counter, int delta, hipStream_t st)

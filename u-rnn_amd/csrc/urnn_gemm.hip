@@ -622,10 +622,20 @@ static int tune_block_waves()
     return v;
 }
 
-static int persistent_grid(size_t lds_bytes, int NG, int total_tiles, int wpb = 4)
+static int tune_cand_bpc()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("URNN_TUNE_CAND_BPC");   // development knob
+        v = e ? atoi(e) : 4;
+    }
+    return v;
+}
+
+static int persistent_grid(size_t lds_bytes, int NG, int total_tiles, int wpb = 4, int max_blocks_per_cu = 2)
 {
     int bpc = (int)(LDS_PER_CU / lds_bytes);
-    const int cap = wpb >= 8 ? 1 : 2;
+    const int cap = wpb >= 8 ? 1 : max_blocks_per_cu;
     bpc = bpc < 1 ? 1 : (bpc > cap ? cap : bpc);
     const int unit = 8 * NG;
     int n = (NUM_CUS * bpc) / unit * unit;
@@ -747,7 +757,8 @@ static hipError_t launch_cand_one(const GruCandParams &p, hipStream_t st)
     auto kern = gru_cand_kernel<NBF, PB, MAP, D>;
     hipError_t e = allow_big_lds(kern, lds);
     if (e != hipSuccess) return e;
-    const int grid = persistent_grid(lds, 1, p.totalTiles);
+    // small accumulators (<= 96 registers): up to 4 blocks = 16 waves per CU hide the DMA / transform latency by TLP
+    const int grid = persistent_grid(lds, 1, p.totalTiles, 4, tune_cand_bpc());
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, p);
     return hipGetLastError();
 }

@@ -69,6 +69,11 @@ hipError_t urnn_launch_preprocess(const float *rain, const float *cumsum, const 
                                   int B, int T, int nums, int P, int spatial, float rain_max, float cumsum_max,
                                   hipStream_t st);
 hipError_t urnn_launch_advance(int *counter, int delta, hipStream_t st);
+hipError_t urnn_launch_stage1_static(const float *dem, const float *imperv, const float *manhole, float dem_min, float dem_max,
+                                     const float *w, float *S, int B, int nums, int Cout, int P, hipStream_t st);
+hipError_t urnn_launch_stage1_scalar(const float *S, const float *rain, const float *cumsum, const float *w, const float *bias,
+                                     float *out, int t, const int *t_dev, int B, int T, int nums, int Cout, int P, float rain_max,
+                                     float cumsum_max, float slope, hipStream_t st);
 
 hipError_t urnn_launch_pack_conv(const float *w, const float *bias, float *packed, int Cin, int Cout, hipStream_t st);
 hipError_t urnn_launch_pack_gru(const float *W1, const float *b1, const float *W2, const float *b2, float *packed, int I,

@@ -172,5 +172,29 @@ def preprocess(rain, cumsum, dem, imperv, manhole, dem_min, dem_max, t, nums, ra
     return out
 
 
+def stage1_static(dem, imperv, manhole, dem_min, dem_max, weight, nums, out=None):
+    """Static part of encoder stage 1 for scalar-rain events: S (B,Cout,H,W), once per event."""
+    _dev_check(dem, imperv, manhole, weight, out)
+    B, H, W = dem.shape
+    Cout = weight.shape[0]
+    if out is None:
+        out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=dem.device)
+    check(lib().urnn_stage1_static_f32(_ptr(dem), _ptr(imperv), _ptr(manhole), float(dem_min), float(dem_max), _ptr(weight),
+                                       _ptr(out), B, int(nums), Cout, H, W, _stream()), "urnn_stage1_static_f32")
+    return out
+
+
+def stage1_scalar_rain(S, rain, cumsum, weight, bias, t, nums, rain_max, cumsum_max, out=None, t_dev=None, slope=LRELU_SLOPE):
+    """preprocess_inputs + Encoder.stage1 for scalar rain: LeakyReLU(S + v_t) -> (B,Cout,H,W)."""
+    _dev_check(S, rain, cumsum, weight, bias, out)
+    B, Cout, H, W = S.shape
+    if out is None:
+        out = torch.empty_like(S)
+    check(lib().urnn_stage1_scalar_rain_f32(_ptr(S), _ptr(rain), _ptr(cumsum), _ptr(weight), _ptr(bias), _ptr(out), int(t),
+                                            _ptr(t_dev), B, rain.shape[1], int(nums), Cout, H, W, float(rain_max),
+                                            float(cumsum_max), slope, _stream()), "urnn_stage1_scalar_rain_f32")
+    return out
+
+
 def advance_counter(counter, delta=1):
     check(lib().urnn_advance_counter(_ptr(counter), int(delta), _stream()), "urnn_advance_counter")

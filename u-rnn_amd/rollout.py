@@ -48,11 +48,16 @@ class RolloutEngine:
         enc, dec = net.encoder, net.decoder
         self.x_in = torch.empty((B, self.C, H, W), **f32)
         self.a1 = torch.empty((B, enc.stage1.out_channels, H, W), **f32)
+        # scalar rain: stage 1 collapses to LeakyReLU(S + v_t); S is refreshed by load_event
+        self.S1 = None if self.spatial else torch.zeros((B, enc.stage1.out_channels, H, W), **f32)
+        c1 = enc.stage1.layer
+        self._w1 = c1.weight.detach().reshape(c1.out_channels, -1).clone()    # pointer-stable copy (captured in the graph)
         self.a2 = torch.empty((B, enc.stage2.out_channels, H // 2, W // 2), **f32)
         self.a3 = torch.empty((B, enc.stage3.out_channels, H // 4, W // 4), **f32)
         self.u3 = torch.empty((B, dec.stage3.out_channels, H // 2, W // 2), **f32)
         self.u2 = torch.empty((B, dec.stage2.out_channels, H, W), **f32)
         self.feat = torch.empty((B, dec.stage1.out_channels, H, W), **f32)
+        self.feat_alt = torch.empty_like(self.feat) if self.overlap else None   # overlap mode: head(t-1) || decoder(t)
         # outputs for every frame
         self.out_masked = torch.zeros((self.Tcap, B, H, W), **f32)
         self.out_cls = torch.zeros((self.Tcap, B, H, W), **f32)
@@ -80,9 +85,7 @@ class RolloutEngine:
         net = self.net
         enc, dec = net.encoder, net.decoder
         e1, e2, e3, d1, d2, d3 = self.states
-        ops.preprocess(self.rain, self.cumsum, self.dem, self.imperv, self.manhole, self.dem_min, self.dem_max, 0,
-                       self.nums, self.rain_max, self.cumsum_max, out=self.x_in, t_dev=self.t_dev)
-        enc.stage1(self.x_in, out=self.a1)
+        self._stage1(self.t_dev)
         self._cell("enc1", enc.rnn1, self.a1, None, e1, e1)
         enc.stage2(e1, out=self.a2)
         enc.rnn2.step(self.a2, None, e2, out=e2)
@@ -97,6 +100,17 @@ class RolloutEngine:
         net.head.run(self.feat, out_masked=self.out_masked, out_cls=self.out_cls, out_raw=self.out_raw,
                      frame_index=self.t_dev)
         ops.advance_counter(self.t_dev, 1)
+
+    def _stage1(self, t_dev):
+        """Frame input assembly + encoder stage-1 conv -> self.a1."""
+        conv = self.net.encoder.stage1.layer
+        if self.S1 is not None:
+            ops.stage1_scalar_rain(self.S1, self.rain, self.cumsum, self._w1, conv.bias.detach(), 0, self.nums, self.rain_max,
+                                   self.cumsum_max, out=self.a1, t_dev=t_dev)
+        else:
+            ops.preprocess(self.rain, self.cumsum, self.dem, self.imperv, self.manhole, self.dem_min, self.dem_max, 0,
+                           self.nums, self.rain_max, self.cumsum_max, out=self.x_in, t_dev=t_dev)
+            self.net.encoder.stage1(self.x_in, out=self.a1)
 
     def _cell(self, name, cell, x, e, h, out):
         """One GRU cell; when a probe is active the gate GEMM of the named full-resolution cells is launched on its
@@ -135,9 +149,7 @@ class RolloutEngine:
         enc = self.net.encoder
         (p1, p2, p3), (n1, n2, n3) = self._enc_bufs(parity)
         ops.WORKSPACE.use_slot(0)
-        ops.preprocess(self.rain, self.cumsum, self.dem, self.imperv, self.manhole, self.dem_min, self.dem_max, 0,
-                       self.nums, self.rain_max, self.cumsum_max, out=self.x_in, t_dev=self.te_dev)
-        enc.stage1(self.x_in, out=self.a1)
+        self._stage1(self.te_dev)
         self._cell("enc1", enc.rnn1, self.a1, None, p1, n1)
         enc.stage2(n1, out=self.a2)
         enc.rnn2.step(self.a2, None, p2, out=n2)
@@ -146,8 +158,8 @@ class RolloutEngine:
         ops.advance_counter(self.te_dev, 1)
 
     def _dec_chain(self, parity):
-        net = self.net
-        dec = net.decoder
+        """decoder(t) for t % 2 == parity: reads encoder states e[parity], writes feat[parity]."""
+        dec = self.net.decoder
         e1, e2, e3 = self._enc_bufs(parity)[1]   # encoder states of frame t (written by E(t))
         _, _, _, d1, d2, d3 = self.states
         ops.WORKSPACE.use_slot(1)
@@ -156,19 +168,26 @@ class RolloutEngine:
         dec.rnn2.step(self.u3, e2, d2, out=d2)
         dec.stage2(d2, out=self.u2)
         self._cell("dec1", dec.rnn1, self.u2, e1, d3, d3)
-        dec.stage1(d3, out=self.feat)
-        net.head.run(self.feat, out_masked=self.out_masked, out_cls=self.out_cls, out_raw=self.out_raw,
-                     frame_index=self.t_dev)
-        ops.advance_counter(self.t_dev, 1)
+        dec.stage1(d3, out=self.feat if parity == 0 else self.feat_alt)
         ops.WORKSPACE.use_slot(0)
 
-    def _iter_overlap(self, parity):
-        """Iteration t (parity = t % 2): decoder+head of frame t and encoder of frame t+1, concurrently."""
+    def _head_chain(self, parity):
+        """head(t) for t % 2 == parity (reads feat[parity]); shares the encoder chain's stream and workspace slot."""
+        ops.WORKSPACE.use_slot(0)
+        self.net.head.run(self.feat if parity == 0 else self.feat_alt, out_masked=self.out_masked, out_cls=self.out_cls,
+                          out_raw=self.out_raw, frame_index=self.t_dev)
+        ops.advance_counter(self.t_dev, 1)
+
+    def _iter_overlap(self, parity, with_head=True):
+        """Iteration t (parity = t % 2): chain 1 = head(t-1) then encoder(t+1); chain 2 = decoder(t).  The decoder chain is
+        the longer one, so the head of the previous frame rides with the encoder."""
         cur = torch.cuda.current_stream(self.device)
         s1, s2 = self._side
         s1.wait_stream(cur)
         s2.wait_stream(cur)
         with torch.cuda.stream(s1):
+            if with_head:
+                self._head_chain(1 - parity)
             self._enc_chain(1 - parity)
         with torch.cuda.stream(s2):
             self._dec_chain(parity)
@@ -180,15 +199,16 @@ class RolloutEngine:
         saved = [s.clone() for s in self.states] + [s.clone() for s in self.enc_alt]
         t0, t1 = self.t_dev.clone(), self.te_dev.clone()
         self._enc_chain(0)              # warm-up (packs weights), eager
-        self._iter_overlap(0)
+        self._iter_overlap(0, with_head=False)
         self._iter_overlap(1)
+        self._head_chain(1)
         torch.cuda.synchronize(self.device)
-        graphs = []
-        for parity in (0, 1):
+        graphs = {}
+        for key, parity, with_head in (("first", 0, False), (0, 0, True), (1, 1, True)):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self._iter_overlap(parity)
-            graphs.append(g)
+                self._iter_overlap(parity, with_head=with_head)
+            graphs[key] = g
         self._graphs2 = graphs
         for s, v in zip(self.states + self.enc_alt, saved):
             s.copy_(v)
@@ -196,17 +216,28 @@ class RolloutEngine:
         self.te_dev.copy_(t1)
 
     def _run_overlap(self, frames):
+        """Software pipeline over frames: E(0) | {D(0) || E(1)} | {H(0),E(2) || D(1)} | ... | H(last).  The trailing head is
+        flushed before returning, so after run(n) all n frames are complete."""
+        if frames <= 0:
+            return
         if self.use_graph and self._graphs2 is None:
             self._capture_overlap()
-        for _ in range(frames):
+        for i in range(frames):
             t = self._frames_done
             if t == 0:
                 self._enc_chain(0)      # pipeline prologue: E(0)
-            if self.use_graph:
+            first = i == 0              # no head pending at the start of a run() call
+            if first:
+                if self.use_graph and t % 2 == 0:
+                    self._graphs2["first"].replay()
+                else:
+                    self._iter_overlap(t % 2, with_head=False)   # eager: only when a run() resumes at an odd frame
+            elif self.use_graph:
                 self._graphs2[t % 2].replay()
             else:
                 self._iter_overlap(t % 2)
             self._frames_done += 1
+        self._head_chain((self._frames_done - 1) % 2)
 
     def final_states(self):
         """The six states after the frames run so far (overlap mode keeps the newest encoder states in the buffer
@@ -249,6 +280,10 @@ class RolloutEngine:
         self.dem.copy_(ev["dem"])
         self.imperv.copy_(ev["imperv"])
         self.manhole.copy_(ev["manhole"])
+        if self.S1 is not None:
+            conv = self.net.encoder.stage1.layer
+            self._w1.copy_(conv.weight.detach().reshape(conv.out_channels, -1))
+            ops.stage1_static(self.dem, self.imperv, self.manhole, ev["dem_min"], ev["dem_max"], self._w1, self.nums, out=self.S1)
         if (ev["dem_min"], ev["dem_max"]) != (self.dem_min, self.dem_max):
             # normalisation bounds are kernel arguments frozen into the graph: re-capture when they change
             self.dem_min, self.dem_max = ev["dem_min"], ev["dem_max"]
