@@ -57,7 +57,7 @@ static void pick_tile(long pixels_total, int waves_per_tile, long P, int *pb_out
         while (pb > 1 && (pixels_total / (32 * pb)) * waves_per_tile < 2048) pb >>= 1;
     if (pb == 4 && P % 4 != 0) pb = 2;
     *pb_out = pb;
-    *map_out = pb == 4 ? MAP_VEC : (pb == 2 && P % 2 == 0 ? MAP_PAIR : MAP_STRIDED);
+    *map_out = pb == 4 ? MAP_VEC : (pb == 2 && P % 4 == 0 ? MAP_PAIR16 : (pb == 2 && P % 2 == 0 ? MAP_PAIR : MAP_STRIDED));
 }
 
 // ---- packing ---------------------------------------------------------------------------------------------------------
@@ -294,7 +294,8 @@ extern "C" int urnn_deconv2x2_f32(const float *in, const float *packed, float *o
     // pairs of horizontally adjacent pixels need an even width; tiny planes use 32-pixel strided tiles to fill the chip
     const bool big = ((long)B * P / 64) * 2 >= 1024;
     const bool pair = big && (W % 2) == 0;
-    CHECK_HIP(urnn_launch_deconv(p, B, pair ? 2 : 1, pair ? MAP_PAIR : MAP_STRIDED, (hipStream_t)stream), "deconv2x2");
+    CHECK_HIP(urnn_launch_deconv(p, B, pair ? 2 : 1, pair ? (P % 4 == 0 ? MAP_PAIR16 : MAP_PAIR) : MAP_STRIDED, (hipStream_t)stream),
+              "deconv2x2");
     return URNN_OK;
 }
 

@@ -54,18 +54,27 @@ __device__ __forceinline__ void wait_vmcnt()
 // pixel geometry: which plane offset does (lane column j, pixel block pb) of tile t address?
 //   MAP_VEC      p = t*32*PB + (pb/4)*128 + 4*j + pb%4     16-byte loads/stores (planes 16-B aligned, P % 4 == 0)
 //   MAP_PAIR     p = t*64 + 2*j + pb            (PB == 2)  8-byte stores, dword DMA (P % 2 == 0)
+//   MAP_PAIR16   same pixels; the k-pair's 2 x 64 floats arrive as ONE 16-byte DMA issued by lanes 0-31 (P % 4 == 0)
 //   MAP_STRIDED  p = t*32*PB + 32*pb + j                    dword everything (any P)
 //   MAP_POOL     pooled pixel q = t*32 + j, input pixel (2*y2 + pb/2, 2*x2 + pb%2)   (PB == 4)
 // ------------------------------------------------------------------------------------------------------------------
+constexpr bool is_pair(int map) { return map == MAP_PAIR || map == MAP_PAIR16; }
+
 template <int MAP, int PB>
 struct PixelMap {
     int off[PB];     // clamped (always in-bounds) offsets inside an input plane
     bool valid[PB];  // false: out of range, contributes nothing and is never stored
     int q;           // MAP_POOL: pooled output pixel index
+    int dma_off;     // MAP_PAIR16: plane offset of the 4 pixels this lane's DMA moves (lanes 0-31 only)
 
     __device__ __forceinline__ void init(int tile, int j, int P, int W, int P2, int W2)
     {
         q = 0;
+        dma_off = 0;
+        if constexpr (MAP == MAP_PAIR16) {
+            const int p4 = tile * 64 + 4 * (j & 15);          // lanes 0-15 -> row k, lanes 16-31 -> row k+1 (same pixels)
+            dma_off = p4 < P ? p4 : 0;
+        }
         if constexpr (MAP == MAP_POOL) {
             static_assert(PB == 4, "pool tiles are 2x2 input pixels per lane");
             q = tile * 32 + j;
@@ -82,7 +91,7 @@ struct PixelMap {
             for (int pb = 0; pb < PB; ++pb) {
                 int p;
                 if constexpr (MAP == MAP_VEC) p = tile * (32 * PB) + (pb >> 2) * 128 + 4 * j + (pb & 3);
-                else if constexpr (MAP == MAP_PAIR) p = tile * 64 + 2 * j + pb;
+                else if constexpr (is_pair(MAP)) p = tile * 64 + 2 * j + pb;
                 else p = tile * (32 * PB) + 32 * pb + j;
                 valid[pb] = p < P;
                 off[pb] = valid[pb] ? p : 0;
@@ -101,7 +110,7 @@ __device__ __forceinline__ void load_row(const float *row, const PixelMap<MAP, P
             const f32x4 t = *reinterpret_cast<const f32x4 *>(row + pm.off[4 * qd]);
             v[4 * qd] = t.x; v[4 * qd + 1] = t.y; v[4 * qd + 2] = t.z; v[4 * qd + 3] = t.w;
         }
-    } else if constexpr (MAP == MAP_PAIR) {
+    } else if constexpr (is_pair(MAP)) {
         const f32x2 t = *reinterpret_cast<const f32x2 *>(row + pm.off[0]);
         v[0] = t.x; v[1] = t.y;
     } else {
@@ -120,7 +129,7 @@ __device__ __forceinline__ void store_row(float *row, const PixelMap<MAP, PB> &p
 #pragma unroll
         for (int qd = 0; qd < PB / 4; ++qd)
             if (pm.valid[4 * qd]) *reinterpret_cast<f32x4 *>(row + pm.off[4 * qd]) = f32x4{v[4 * qd], v[4 * qd + 1], v[4 * qd + 2], v[4 * qd + 3]};
-    } else if constexpr (MAP == MAP_PAIR) {
+    } else if constexpr (is_pair(MAP)) {
         if (pm.valid[0]) *reinterpret_cast<f32x2 *>(row + pm.off[0]) = f32x2{v[0], v[1]};
     } else {
 #pragma unroll
@@ -136,19 +145,27 @@ __device__ __forceinline__ void store_row(float *row, const PixelMap<MAP, PB> &p
 template <int PB, int MAP>
 struct Ring {
     static constexpr bool VEC = (MAP == MAP_VEC);
+    static constexpr bool P16 = (MAP == MAP_PAIR16);
 #if (URNN_ABL & 2)
     static constexpr int NLOAD = 0;
 #else
-    static constexpr int NLOAD = VEC ? PB / 4 : PB;         // DMA instructions per slot
+    static constexpr int NLOAD = P16 ? 1 : (VEC ? PB / 4 : PB);   // DMA instructions per slot
 #endif
     static constexpr int SLOT = PB * 256;                   // bytes
 
-    __device__ static __forceinline__ void issue(char *slot, const float *row, const PixelMap<MAP, PB> &pm)
+    // `row` is this lane's channel row: lanes 32-63 one row below lanes 0-31, except MAP_PAIR16 where lanes 16-31 are the
+    // lower row (the caller folds that into `row` via row_select()).
+    __device__ static __forceinline__ int row_select(int lane) { return P16 ? (lane >> 4) & 1 : lane >> 5; }
+
+    __device__ static __forceinline__ void issue(char *slot, const float *row, const PixelMap<MAP, PB> &pm, int lane)
     {
 #if (URNN_ABL & 2)
         return;
 #endif
-        if constexpr (VEC) {
+        if constexpr (P16) {
+            static_assert(PB == 2, "pair tiles");
+            if (lane < 32) dma16(row + pm.dma_off, slot);     // 32 lanes x 16 B = rows k and k+1 of the 64-pixel tile
+        } else if constexpr (VEC) {
 #pragma unroll
             for (int qd = 0; qd < PB / 4; ++qd) dma16(row + pm.off[4 * qd], slot + qd * 1024);
         } else {
@@ -159,7 +176,10 @@ struct Ring {
 
     __device__ static __forceinline__ void read(const char *slot, int lane, float (&b)[PB])
     {
-        if constexpr (VEC) {
+        if constexpr (P16) {
+            const f32x2 t = *reinterpret_cast<const f32x2 *>(slot + ((lane >> 5) * 64 + 2 * (lane & 31)) * 4);
+            b[0] = t.x; b[1] = t.y;
+        } else if constexpr (VEC) {
 #pragma unroll
             for (int qd = 0; qd < PB / 4; ++qd) {
                 const f32x4 t = *reinterpret_cast<const f32x4 *>(slot + qd * 1024 + lane * 16);
@@ -252,8 +272,9 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
         const char *base1 = reinterpret_cast<const char *>(prm.seg[1] + (size_t)b * C1 * prm.P);
         const char *base2 = reinterpret_cast<const char *>(prm.seg[2] + (size_t)b * C2 * prm.P);
         const unsigned rstep = 8u * (unsigned)prm.P;                       // two channel rows, bytes
-        const unsigned voff0 = half ? 4u * (unsigned)prm.P : 0u;           // first k-pair of any segment
-        const unsigned padsub = half ? 4u * (unsigned)prm.P : 0u;
+        const int rsel = R::row_select(lane);                              // which of the k-pair's two rows this lane fetches
+        const unsigned voff0 = rsel ? 4u * (unsigned)prm.P : 0u;           // first k-pair of any segment
+        const unsigned padsub = rsel ? 4u * (unsigned)prm.P : 0u;
         int kp_issue = kp_begin;                                           // next k-pair whose DMA will be issued
         const int s_begin = kp_begin >= k2 ? 2 : (kp_begin >= k1 ? 1 : 0);
         const char *sbase = s_begin == 2 ? base2 : (s_begin == 1 ? base1 : base0);
@@ -268,7 +289,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
             char *dst = live ? ring + slot * R::SLOT : scratch;
             const bool pad = 2 * (kp_issue - skp0) + 1 >= sC;              // uniform; true only on the last k-pair of an odd C
             const unsigned vo = live ? voff - (pad ? padsub : 0u) : voff0;
-            R::issue(dst, reinterpret_cast<const float *>(sbase + vo), pm);
+            R::issue(dst, reinterpret_cast<const float *>(sbase + vo), pm, lane);
             ++kp_issue;
             voff += rstep;
             const bool sw1 = kp_issue == k1, sw2 = kp_issue == k2;
@@ -389,7 +410,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
                     if (co < prm.Cout) {
                         const float bv = bias[cob * 32 + cib];
                         float *oplane = prm.out0 + ((size_t)b * prm.Cout + co) * (4 * (size_t)prm.P);
-                        if constexpr (MAP == MAP_PAIR) {
+                        if constexpr (is_pair(MAP)) {
                             // two horizontally adjacent input pixels -> four consecutive output floats (W even, p even)
                             if (pm.valid[0]) {
                                 f32x4 v;
@@ -472,7 +493,8 @@ __global__ __launch_bounds__(256) void gru_cand_kernel(const GruCandParams prm)
 {
     constexpr int F = NBF * 32;
     constexpr bool VEC = (MAP == MAP_VEC);
-    constexpr int NLOAD = 2 * (VEC ? PB / 4 : PB);
+    constexpr bool P16 = (MAP == MAP_PAIR16);
+    constexpr int NLOAD = 2 * (P16 ? 1 : (VEC ? PB / 4 : PB));
     constexpr int SLOT = 2 * PB * 256;
     constexpr int KT = F / 2;
     const int lane = threadIdx.x & 63;
@@ -504,15 +526,21 @@ __global__ __launch_bounds__(256) void gru_cand_kernel(const GruCandParams prm)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[nb][pb][r] = 0.f;
 
-        const float *gr = prm.g1 + ((size_t)b * 2 * F + F + half) * prm.P;   // raw r-gate planes (row k = 2*kp + half)
-        const float *hh = prm.h + ((size_t)b * F + half) * prm.P;
+        const int rsel = P16 ? (lane >> 4) & 1 : half;                       // which row of the k-pair this lane fetches
+        const float *gr = prm.g1 + ((size_t)b * 2 * F + F + rsel) * prm.P;   // raw r-gate planes (row k = 2*kp + rsel)
+        const float *hh = prm.h + ((size_t)b * F + rsel) * prm.P;
         const float *ssb = ssm + (size_t)b * 2 * F;
 
         auto issue = [&](int kp, int slot) {
             char *s = ring + slot * SLOT;
             const float *grow = gr + (size_t)(2 * kp) * prm.P;
             const float *hrow = hh + (size_t)(2 * kp) * prm.P;
-            if constexpr (VEC) {
+            if constexpr (P16) {
+                if (lane < 32) {
+                    dma16(grow + pm.dma_off, s);
+                    dma16(hrow + pm.dma_off, s + PB * 256);
+                }
+            } else if constexpr (VEC) {
 #pragma unroll
                 for (int qd = 0; qd < PB / 4; ++qd) {
                     dma16(grow + pm.off[4 * qd], s + qd * 1024);
@@ -531,7 +559,12 @@ __global__ __launch_bounds__(256) void gru_cand_kernel(const GruCandParams prm)
             float a[NBF], g[PB], h[PB];
 #pragma unroll
             for (int nb = 0; nb < NBF; ++nb) a[nb] = A[(kp * NBF + nb) * 64 + lane];
-            if constexpr (VEC) {
+            if constexpr (P16) {
+                const int o = ((lane >> 5) * 64 + 2 * (lane & 31)) * 4;
+                const f32x2 tg = *reinterpret_cast<const f32x2 *>(s + o);
+                const f32x2 th = *reinterpret_cast<const f32x2 *>(s + PB * 256 + o);
+                g[0] = tg.x; g[1] = tg.y; h[0] = th.x; h[1] = th.y;
+            } else if constexpr (VEC) {
 #pragma unroll
                 for (int qd = 0; qd < PB / 4; ++qd) {
                     const f32x4 tg = *reinterpret_cast<const f32x4 *>(s + qd * 1024 + lane * 16);
@@ -686,6 +719,7 @@ template <int NB, int EPI>
 static hipError_t launch_flat(const ConvGemmParams &p, int pb, int map, hipStream_t st)
 {
     if (map == MAP_VEC && pb == 4) return launch_conv<NB, 4, MAP_VEC, EPI>(p, st);
+    if (map == MAP_PAIR16 && pb == 2) return launch_conv<NB, 2, MAP_PAIR16, EPI>(p, st);
     if (map == MAP_PAIR && pb == 2) return launch_conv<NB, 2, MAP_PAIR, EPI>(p, st);
     if (map == MAP_STRIDED && pb == 2) return launch_conv<NB, 2, MAP_STRIDED, EPI>(p, st);
     if (map == MAP_STRIDED && pb == 1) return launch_conv<NB, 1, MAP_STRIDED, EPI>(p, st);
@@ -726,6 +760,11 @@ hipError_t urnn_launch_deconv(ConvGemmParams p, int B, int PB, int map, hipStrea
     if (nbc < 1 || nbc > 3) return hipErrorInvalidValue;
     p.tilesPerSample = (p.P + 32 * PB - 1) / (32 * PB);
     p.totalTiles = B * p.tilesPerSample;
+    if (PB == 2 && map == MAP_PAIR16) {
+        if (nbc == 1) return launch_conv<2, 2, MAP_PAIR16, EPI_DECONV>(p, st);
+        if (nbc == 2) return launch_conv<4, 2, MAP_PAIR16, EPI_DECONV>(p, st);
+        return launch_conv<6, 2, MAP_PAIR16, EPI_DECONV>(p, st);
+    }
     if (PB == 2 && map == MAP_PAIR) {
         if (nbc == 1) return launch_conv<2, 2, MAP_PAIR, EPI_DECONV>(p, st);
         if (nbc == 2) return launch_conv<4, 2, MAP_PAIR, EPI_DECONV>(p, st);
@@ -767,6 +806,7 @@ template <int NBF>
 static hipError_t launch_cand_nbf(const GruCandParams &p, int PB, int map, hipStream_t st)
 {
     if (map == MAP_VEC && PB == 4) return launch_cand_one<NBF, 4, MAP_VEC>(p, st);
+    if (map == MAP_PAIR16 && PB == 2) return launch_cand_one<NBF, 2, MAP_PAIR16>(p, st);
     if (map == MAP_PAIR && PB == 2) return launch_cand_one<NBF, 2, MAP_PAIR>(p, st);
     if (map == MAP_STRIDED && PB == 2) return launch_cand_one<NBF, 2, MAP_STRIDED>(p, st);
     if (map == MAP_STRIDED && PB == 1) return launch_cand_one<NBF, 1, MAP_STRIDED>(p, st);

@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
-enum { MAP_VEC = 0, MAP_PAIR = 1, MAP_STRIDED = 2, MAP_POOL = 3 };          // pixel geometry of a wave tile (urnn_gemm.hip)
+enum { MAP_VEC = 0, MAP_PAIR = 1, MAP_STRIDED = 2, MAP_POOL = 3, MAP_PAIR16 = 4 };   // pixel geometry of a wave tile (urnn_gemm.hip)
 enum { EPI_LRELU = 0, EPI_POOL = 1, EPI_DECONV = 2, EPI_GRU1 = 3 };          // epilogue of conv_gemm_kernel
 
 struct ConvGemmParams {
