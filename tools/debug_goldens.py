@@ -1,7 +1,7 @@
 """Ad-hoc GPU debugging: per-kernel error table against the goldens (not part of the test-suite)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch
 from conftest import rel_err
 import urnn_amd.weights as uw
