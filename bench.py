@@ -105,6 +105,9 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="events per GPU (the reference entry points use 1)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of the captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="control-plane backend for N>1 (nccl = RCCL over xGMI; gloo only for single-GPU dry runs of the N>1 path)")
+    ap.add_argument("--share-gpu", action="store_true", help="dry run: every rank uses cuda:0 (needs --dist-backend gloo)")
     ap.add_argument("--overlap", type=int, default=1,
                     help="1 (default): encoder(t+1) || decoder+head(t) as two concurrent kernel chains; 0: one chain")
     args = ap.parse_args()
@@ -113,13 +116,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", 0 if args.share_gpu else local_rank)
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI; used for the barrier + max-reduce only
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI; used for the barrier + max-reduce only
+        else:
+            dist.init_process_group("gloo")
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
@@ -162,7 +168,7 @@ def main():
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     from urnn_amd.distributed import max_over_ranks
-    elapsed = max_over_ranks(elapsed, device=dev)
+    elapsed = max_over_ranks(elapsed, device=dev if args.dist_backend == "nccl" else None)
 
     frames = args.steps * B * world
     fps = frames / elapsed

@@ -27,7 +27,7 @@ def Inference(net, inputs, device, historical_nums=30, rain_max=6.0, cumsum_rain
         if eng is None or eng.Tcap < Frames:
             eng = RolloutEngine(net, input_height, input_width, historical_nums, rain_max, cumsum_rain_max, batch=B,
                                 max_frames=Frames, spatial_rain=spatial, net_cfg=net_cfg, use_graph=use_graph,
-                                device=device)
+                                device=device, overlap=True)
             _ENGINES.clear()   # one live engine: its frame buffers are sized for whole events
             _ENGINES[key] = eng
         eng.load_event(inputs)
