@@ -163,3 +163,68 @@ def test_full_size_cell_vs_oracle(dev):
     got = net.decoder.rnn1.step(*(torch.from_numpy(v).to(dev) for v in (x, e, d))).cpu().numpy()
     ref = orc.gru_cell(x, e, d, orc.OracleNet(sd).dec[1])
     assert_close(got, ref, 1e-4, "dec1 cell at 500x500")
+
+
+def test_batched_spatial_rollout_vs_oracle(dev):
+    """Two events with spatial rainfall, ragged (non-square, tail tiles) grid, against the CPU oracle over T=5 frames."""
+    import urnn_amd.weights as uw
+    from oracle import oracle as orc
+    from urnn_amd.rollout import RolloutEngine
+    H, W, nums, T, B = 28, 44, 4, 5, 2
+    net, sd = make_net(H, W, 2 * nums + 3, 21, dev)
+    ev = uw.make_event(T, H, W, 5.0, seed=13, spatial_rain=True, batch=B)
+    eng = RolloutEngine(net, H, W, nums, 5.0, 100.0, batch=B, max_frames=T, spatial_rain=True, keep_raw=True, overlap=True)
+    frames = eng.rollout(ev).cpu().numpy()
+    ref_frames, ref_states, aux = orc.rollout(orc.OracleNet(sd), ev, T, nums, 5.0, 100.0, want_aux=True)
+    raw = eng.out_raw[:T].cpu().numpy()
+    cls = eng.out_cls[:T].cpu().numpy()
+    ref_raw = np.stack([a["reg_raw"] for a in aux])
+    ref_cls = np.stack([a["cls"] for a in aux])
+    assert_close(raw, ref_raw, 1e-4, "pre-mask reg")
+    assert_close(cls, ref_cls, 1e-4, "cls")
+    for k, (got, ref) in enumerate(zip(eng.final_states(), ref_states)):
+        assert_close(got.cpu().numpy(), ref, 1e-4, f"final state {k}")
+    masked_parity(frames, ref_frames, ref_cls, ref_raw, 1e-4)
+
+
+def test_short_event_and_long_history(dev):
+    """T shorter than the rainfall history window (left zero padding all the way, Dynamic2DFlood.py:347-364)."""
+    import urnn_amd.weights as uw
+    from oracle import oracle as orc
+    from urnn_amd.rollout import RolloutEngine
+    H, W, nums, T = 16, 16, 10, 3
+    net, sd = make_net(H, W, 2 * nums + 3, 5, dev)
+    ev = uw.make_event(T, H, W, 6.0, seed=2)
+    eng = RolloutEngine(net, H, W, nums, 6.0, 250.0, max_frames=T, keep_raw=True)
+    eng.rollout(ev)
+    _, ref_states, aux = orc.rollout(orc.OracleNet(sd), ev, T, nums, 6.0, 250.0, want_aux=True)
+    assert_close(eng.out_raw[:T, 0].cpu().numpy(), np.stack([a["reg_raw"][0] for a in aux]), 1e-4, "pre-mask reg")
+    for k in range(6):
+        assert_close(eng.states[k].cpu().numpy(), ref_states[k], 1e-4, f"state {k}")
+
+
+def test_grid_not_multiple_of_four_is_rejected(dev):
+    """The reference only works on grids that are multiples of 4 (its decoder torch.cat fails otherwise); the HIP path
+    raises as well instead of producing garbage."""
+    net, _ = make_net(18, 22, 9, 1, dev)
+    from urnn_amd.general import initialize_states
+    x = torch.zeros(1, 1, 9, 18, 22, device=dev)
+    with pytest.raises(RuntimeError):
+        net(x, *initialize_states(dev, 18, 22))
+
+
+def test_large_grid_addressing(dev):
+    """1024 x 768 (3x the benchmark plane): 32-bit lane offsets and tile arithmetic stay in range; one step, finite, masked
+    output consistent, bit-reproducible."""
+    import urnn_amd.weights as uw
+    from urnn_amd.rollout import RolloutEngine
+    H, W, nums, T = 1024, 768, 3, 2
+    net, _ = make_net(H, W, 9, 2, dev)
+    ev = uw.make_event(T, H, W, 60.0, seed=4)
+    eng = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T, keep_raw=True)
+    a = eng.rollout(ev).clone()
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, eng.out_raw[:T] * (eng.out_cls[:T] >= 0.5).float())
+    for s in eng.states:
+        assert torch.isfinite(s).all() and s.abs().max() <= 1.0 + 1e-6
+    assert torch.equal(a, eng.rollout(ev))
