@@ -43,6 +43,17 @@ extern __shared__ __attribute__((aligned(16))) char urnn_smem[];
 __device__ __forceinline__ void dma16(const float *g, char *l) { __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)l, 16, 0, 0); }
 __device__ __forceinline__ void dma4(const float *g, char *l) { __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)l, 4, 0, 0); }
 
+// Buffer-addressed LDS-DMA: address = descriptor base (SGPRs) + per-lane byte offset (tile constant + the uniform row walk,
+// one v_add per issue).  Reads past the descriptor's size return 0 -- exactly what the zero-weight pad row of an odd
+// channel count and the count-keeping dummy issues need.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void *base, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void bdma16(rsrc_t r, unsigned voff, unsigned soff, char *l) { __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)l, 16, voff, soff, 0, 0); }
+__device__ __forceinline__ void bdma4(rsrc_t r, unsigned voff, unsigned soff, char *l) { __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)l, 4, voff, soff, 0, 0); }
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt()
 {
@@ -153,24 +164,40 @@ struct Ring {
 #endif
     static constexpr int SLOT = PB * 256;                   // bytes
 
-    // `row` is this lane's channel row: lanes 32-63 one row below lanes 0-31, except MAP_PAIR16 where lanes 16-31 are the
-    // lower row (the caller folds that into `row` via row_select()).
+    // Which of the k-pair's two channel rows a lane fetches: lanes 32-63 the lower one, except MAP_PAIR16 where lanes 16-31 do.
     __device__ static __forceinline__ int row_select(int lane) { return P16 ? (lane >> 4) & 1 : lane >> 5; }
 
-    __device__ static __forceinline__ void issue(char *slot, const float *row, const PixelMap<MAP, PB> &pm, int lane)
+    // Per-lane byte offsets (constant for a tile) of the DMA pieces of one k-pair, relative to the k-pair's first row.
+    static constexpr int NV = P16 ? 1 : (VEC ? PB / 4 : PB);
+    __device__ static __forceinline__ void lane_offsets(const PixelMap<MAP, PB> &pm, int lane, unsigned P, unsigned (&vo)[NV])
+    {
+        const unsigned rowb = row_select(lane) ? 4u * P : 0u;
+        if constexpr (P16) vo[0] = rowb + 4u * (unsigned)pm.dma_off;
+        else if constexpr (VEC) {
+#pragma unroll
+            for (int qd = 0; qd < PB / 4; ++qd) vo[qd] = rowb + 4u * (unsigned)pm.off[4 * qd];
+        } else {
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) vo[pb] = rowb + 4u * (unsigned)pm.off[pb];
+        }
+    }
+
+    __device__ static __forceinline__ void issue(char *slot, rsrc_t r, const unsigned (&vo)[NV], unsigned soff, int lane)
     {
 #if (URNN_ABL & 2)
         return;
 #endif
+        // the row walk rides in the VECTOR offset (one v_add): gfx9 range-checks only vector + immediate offset, and the pad
+        // row / past-the-end dummies rely on out-of-range reads returning 0 instead of touching memory
         if constexpr (P16) {
             static_assert(PB == 2, "pair tiles");
-            if (lane < 32) dma16(row + pm.dma_off, slot);     // 32 lanes x 16 B = rows k and k+1 of the 64-pixel tile
+            if (lane < 32) bdma16(r, vo[0] + soff, 0, slot);  // 32 lanes x 16 B = rows k and k+1 of the 64-pixel tile
         } else if constexpr (VEC) {
 #pragma unroll
-            for (int qd = 0; qd < PB / 4; ++qd) dma16(row + pm.off[4 * qd], slot + qd * 1024);
+            for (int qd = 0; qd < PB / 4; ++qd) bdma16(r, vo[qd] + soff, 0, slot + qd * 1024);
         } else {
 #pragma unroll
-            for (int pb = 0; pb < PB; ++pb) dma4(row + pm.off[pb], slot + pb * 256);
+            for (int pb = 0; pb < PB; ++pb) bdma4(r, vo[pb] + soff, 0, slot + pb * 256);
         }
     }
 
@@ -262,41 +289,32 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[nb][pb][r] = 0.f;
 
-        // Activation rows are addressed as  uniform segment base (SGPR pair) + 32-bit per-lane byte offset : row k-pair kp of
-        // a segment sits at offset (2*(kp - kp0) + half) * P * 4 + pixel offset.  Walking K costs one v_add per k-pair; a
-        // segment switch resets the offset and swaps the scalar base.  A segment with an odd channel count ends in a pad row
-        // (zero weight): there the upper half-wave re-reads the last real row.
+        // Activation rows are addressed through one buffer descriptor per K segment (x | e | h): row k-pair kp of a segment sits
+        // at uniform offset 2*(kp - kp0)*P*4; the per-lane part (row select + pixel offset) is constant for the tile.  A
+        // segment with an odd channel count ends in a pad row (zero weight): it lies past the descriptor and reads as 0.
         const int k1 = prm.segKp0[1], k2 = prm.segKp0[2];
-        const int C0 = prm.segC[0], C1 = prm.segC[1], C2 = prm.segC[2];
-        const char *base0 = reinterpret_cast<const char *>(prm.seg[0] + (size_t)b * C0 * prm.P);
-        const char *base1 = reinterpret_cast<const char *>(prm.seg[1] + (size_t)b * C1 * prm.P);
-        const char *base2 = reinterpret_cast<const char *>(prm.seg[2] + (size_t)b * C2 * prm.P);
+        const rsrc_t rs0 = make_rsrc(prm.seg[0] + (size_t)b * prm.segC[0] * prm.P, 4u * (unsigned)prm.segC[0] * (unsigned)prm.P);
+        const rsrc_t rs1 = make_rsrc(prm.seg[1] + (size_t)b * prm.segC[1] * prm.P, 4u * (unsigned)prm.segC[1] * (unsigned)prm.P);
+        const rsrc_t rs2 = make_rsrc(prm.seg[2] + (size_t)b * prm.segC[2] * prm.P, 4u * (unsigned)prm.segC[2] * (unsigned)prm.P);
+        unsigned vo[R::NV];
+        R::lane_offsets(pm, lane, (unsigned)prm.P, vo);
         const unsigned rstep = 8u * (unsigned)prm.P;                       // two channel rows, bytes
-        const int rsel = R::row_select(lane);                              // which of the k-pair's two rows this lane fetches
-        const unsigned voff0 = rsel ? 4u * (unsigned)prm.P : 0u;           // first k-pair of any segment
-        const unsigned padsub = rsel ? 4u * (unsigned)prm.P : 0u;
         int kp_issue = kp_begin;                                           // next k-pair whose DMA will be issued
         const int s_begin = kp_begin >= k2 ? 2 : (kp_begin >= k1 ? 1 : 0);
-        const char *sbase = s_begin == 2 ? base2 : (s_begin == 1 ? base1 : base0);
-        int skp0 = s_begin == 2 ? k2 : (s_begin == 1 ? k1 : 0);
-        int sC = s_begin == 2 ? C2 : (s_begin == 1 ? C1 : C0);
-        unsigned voff = voff0 + rstep * (unsigned)(kp_begin - skp0);
+        rsrc_t rs = s_begin == 2 ? rs2 : (s_begin == 1 ? rs1 : rs0);
+        unsigned soff = rstep * (unsigned)(kp_begin - (s_begin == 2 ? k2 : (s_begin == 1 ? k1 : 0)));
         // Branch-free refill (the k loop must stay one basic block so that its instruction order can be pinned): past the
-        // end of K the DMA is redirected to a scratch slot, which keeps the outstanding-DMA count -- and therefore every
-        // s_waitcnt immediate -- exact.
+        // end of K the DMA goes to a scratch slot (and reads out of range = zeros), which keeps the outstanding-DMA count --
+        // and therefore every s_waitcnt immediate -- exact.  Scalar ALU only.
         auto refill = [&](int slot) {
             const bool live = kp_issue < KT;
             char *dst = live ? ring + slot * R::SLOT : scratch;
-            const bool pad = 2 * (kp_issue - skp0) + 1 >= sC;              // uniform; true only on the last k-pair of an odd C
-            const unsigned vo = live ? voff - (pad ? padsub : 0u) : voff0;
-            R::issue(dst, reinterpret_cast<const float *>(sbase + vo), pm, lane);
+            R::issue(dst, rs, vo, live ? soff : 0xF0000000u, lane);
             ++kp_issue;
-            voff += rstep;
+            soff += rstep;
             const bool sw1 = kp_issue == k1, sw2 = kp_issue == k2;
-            sbase = sw2 ? base2 : (sw1 ? base1 : sbase);
-            skp0 = sw2 ? k2 : (sw1 ? k1 : skp0);
-            sC = sw2 ? C2 : (sw1 ? C1 : sC);
-            voff = (sw1 || sw2) ? voff0 : voff;
+            rs = sw2 ? rs2 : (sw1 ? rs1 : rs);
+            soff = (sw1 || sw2) ? 0u : soff;
         };
         auto read_frag = [&](int kp, int slot, float (&a)[NB], float (&bv)[PB]) {
 #pragma unroll
