@@ -544,31 +544,44 @@ __global__ __launch_bounds__(256) void gru_cand_kernel(const GruCandParams prm)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[nb][pb][r] = 0.f;
 
-        const int rsel = P16 ? (lane >> 4) & 1 : half;                       // which row of the k-pair this lane fetches
-        const float *gr = prm.g1 + ((size_t)b * 2 * F + F + rsel) * prm.P;   // raw r-gate planes (row k = 2*kp + rsel)
-        const float *hh = prm.h + ((size_t)b * F + rsel) * prm.P;
+        // two activation streams (raw r gate, hidden state) through buffer descriptors: row k-pair kp at uniform offset
+        // 2*kp*P*4, per-lane part (row select + pixel offset) constant for the tile
+        const rsrc_t rsg = make_rsrc(prm.g1 + ((size_t)b * 2 * F + F) * prm.P, 4u * (unsigned)F * (unsigned)prm.P);
+        const rsrc_t rsh = make_rsrc(prm.h + (size_t)b * F * prm.P, 4u * (unsigned)F * (unsigned)prm.P);
+        constexpr int NV = P16 ? 1 : (VEC ? PB / 4 : PB);
+        unsigned vo[NV];
+        {
+            const unsigned rowb = (P16 ? (lane >> 4) & 1 : half) ? 4u * (unsigned)prm.P : 0u;
+            if constexpr (P16) vo[0] = rowb + 4u * (unsigned)pm.dma_off;
+            else if constexpr (VEC) {
+#pragma unroll
+                for (int qd = 0; qd < PB / 4; ++qd) vo[qd] = rowb + 4u * (unsigned)pm.off[4 * qd];
+            } else {
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb) vo[pb] = rowb + 4u * (unsigned)pm.off[pb];
+            }
+        }
         const float *ssb = ssm + (size_t)b * 2 * F;
 
         auto issue = [&](int kp, int slot) {
             char *s = ring + slot * SLOT;
-            const float *grow = gr + (size_t)(2 * kp) * prm.P;
-            const float *hrow = hh + (size_t)(2 * kp) * prm.P;
+            const unsigned soff = 8u * (unsigned)prm.P * (unsigned)kp;
             if constexpr (P16) {
                 if (lane < 32) {
-                    dma16(grow + pm.dma_off, s);
-                    dma16(hrow + pm.dma_off, s + PB * 256);
+                    bdma16(rsg, vo[0] + soff, 0, s);
+                    bdma16(rsh, vo[0] + soff, 0, s + PB * 256);
                 }
             } else if constexpr (VEC) {
 #pragma unroll
                 for (int qd = 0; qd < PB / 4; ++qd) {
-                    dma16(grow + pm.off[4 * qd], s + qd * 1024);
-                    dma16(hrow + pm.off[4 * qd], s + PB * 256 + qd * 1024);
+                    bdma16(rsg, vo[qd] + soff, 0, s + qd * 1024);
+                    bdma16(rsh, vo[qd] + soff, 0, s + PB * 256 + qd * 1024);
                 }
             } else {
 #pragma unroll
                 for (int pb = 0; pb < PB; ++pb) {
-                    dma4(grow + pm.off[pb], s + pb * 256);
-                    dma4(hrow + pm.off[pb], s + PB * 256 + pb * 256);
+                    bdma4(rsg, vo[pb] + soff, 0, s + pb * 256);
+                    bdma4(rsh, vo[pb] + soff, 0, s + PB * 256 + pb * 256);
                 }
             }
         };
