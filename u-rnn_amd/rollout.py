@@ -88,12 +88,12 @@ class RolloutEngine:
         self._stage1(self.t_dev)
         self._cell("enc1", enc.rnn1, self.a1, None, e1, e1)
         enc.stage2(e1, out=self.a2)
-        enc.rnn2.step(self.a2, None, e2, out=e2)
+        self._cell("enc2", enc.rnn2, self.a2, None, e2, e2)
         enc.stage3(e2, out=self.a3)
         enc.rnn3.step(self.a3, None, e3, out=e3)
         dec.rnn3.step(None, e3, d1, out=d1)
         dec.stage3(d1, out=self.u3)
-        dec.rnn2.step(self.u3, e2, d2, out=d2)
+        self._cell("dec2", dec.rnn2, self.u3, e2, d2, d2)
         dec.stage2(d2, out=self.u2)
         self._cell("dec1", dec.rnn1, self.u2, e1, d3, d3)
         dec.stage1(d3, out=self.feat)
@@ -126,12 +126,12 @@ class RolloutEngine:
             cell.step(x, e, h, out=out)
 
     def probe_gate_gemm(self, frames=12):
-        """Average duration (seconds) of the enc1 / dec1 gate-GEMM launches while the rollout runs in this engine's
+        """Average duration (seconds) of the full- and half-resolution gate-GEMM launches while the rollout runs in this engine's
         scheduling mode (eager launches, same streams and co-running kernels as the captured graph)."""
         saved_graph, self.use_graph = self.use_graph, False
         self.reset()
         self.run(2)
-        self._probe = {"enc1": [], "dec1": []}
+        self._probe = {"enc1": [], "dec1": [], "enc2": [], "dec2": []}
         self.run(frames)
         torch.cuda.synchronize(self.device)
         probe, self._probe = self._probe, None
@@ -152,7 +152,7 @@ class RolloutEngine:
         self._stage1(self.te_dev)
         self._cell("enc1", enc.rnn1, self.a1, None, p1, n1)
         enc.stage2(n1, out=self.a2)
-        enc.rnn2.step(self.a2, None, p2, out=n2)
+        self._cell("enc2", enc.rnn2, self.a2, None, p2, n2)
         enc.stage3(n2, out=self.a3)
         enc.rnn3.step(self.a3, None, p3, out=n3)
         ops.advance_counter(self.te_dev, 1)
@@ -165,7 +165,7 @@ class RolloutEngine:
         ops.WORKSPACE.use_slot(1)
         dec.rnn3.step(None, e3, d1, out=d1)
         dec.stage3(d1, out=self.u3)
-        dec.rnn2.step(self.u3, e2, d2, out=d2)
+        self._cell("dec2", dec.rnn2, self.u3, e2, d2, d2)
         dec.stage2(d2, out=self.u2)
         self._cell("dec1", dec.rnn1, self.u2, e1, d3, d3)
         dec.stage1(d3, out=self.feat if parity == 0 else self.feat_alt)
