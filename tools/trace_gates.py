@@ -32,7 +32,15 @@ torch.cuda.synchronize()
 L.urnn_debug_set_trace(0)
 t = buf.cpu().numpy().reshape(nw, 8, 4).astype(np.float64)
 used = t[:, :, 3] > 0
-t0 = t[used][:, 0].min()
+# s_memtime bases differ across the chip: reference every wave to the earliest stamp of its own block
+tb = t.reshape(nw // 8, 8 * 8, 4)
+ub = used.reshape(nw // 8, 8 * 8)
+for i in range(nw // 8):
+    if ub[i].any():
+        t0b = tb[i][ub[i]][:, 0].min()
+        tb[i][ub[i]] -= t0b
+t = tb.reshape(nw, 8, 4)
+t0 = 0.0
 print(which, "waves with work:", int(used[:, 0].sum()), "items:", int(used.sum()))
 tk = t[used]
 clk = 100e6   # s_memtime ticks at 100 MHz on gfx9? report raw and assume
@@ -41,6 +49,15 @@ print("kernel span ticks:", span)
 for name, a, b in (("prologue (start->first frag)", 0, 1), ("k-loop", 1, 2), ("epilogue (incl. store drain)", 2, 3)):
     d = tk[:, b] - tk[:, a]
     print(f"{name:32s} mean {d.mean():10.0f}  p10 {np.percentile(d,10):10.0f}  p50 {np.percentile(d,50):10.0f}  p90 {np.percentile(d,90):10.0f}  max {d.max():10.0f}")
+# per wave class (A = first wave on its SIMD, B = second, held back half a tile), times relative to the kernel start
+wave_id = np.arange(nw) % 8
+for cls, sel in (("A", wave_id < 4), ("B", wave_id >= 4)):
+    for it in range(4):
+        m = used[:, it] & sel
+        if m.any():
+            d = t[m][:, it]
+            print(f"{cls} item#{it}: n={m.sum():5d} start {d[:,0].mean()-t0:9.0f} frag {np.mean(d[:,1]-d[:,0]):7.0f} kloop {np.mean(d[:,2]-d[:,1]):9.0f} "
+                  f"(p10 {np.percentile(d[:,2]-d[:,1],10):9.0f} p90 {np.percentile(d[:,2]-d[:,1],90):9.0f}) epi {np.mean(d[:,3]-d[:,2]):8.0f} end {d[:,3].mean()-t0:9.0f} (max {d[:,3].max()-t0:9.0f})")
 # per-item index breakdown
 for it in range(4):
     m = used[:, it]

@@ -26,7 +26,7 @@
 #include <type_traits>
 
 #ifndef URNN_ABL
-#define URNN_ABL 0   // tuning builds only: 2 skip activation DMA, 4 skip epilogue stores
+#define URNN_ABL 0   // tuning builds only: 2 skip activation DMA, 4 skip epilogue stores, 8 skip LDS fragment reads
 #endif
 #ifdef URNN_TRACE
 __device__ unsigned long long *urnn_trace_buf = nullptr;   // tuning builds: [wave slot][item][4] s_memtime stamps
@@ -236,7 +236,7 @@ __device__ __forceinline__ void block_role(int NG, int &g, int &slot, int &nslot
 
 // ------------------------------------------------------------------------------------------------------------------
 // conv_gemm_kernel: persistent blocks of 4 waves; block owns n-group g (weights resident in LDS), each wave loops over
-// pixel tiles.  gridDim.x is a multiple of 8 * NG.  Dynamic LDS = aFloats*4 + WPB * (D + 1) * SLOT.
+// pixel tiles.  gridDim.x is a multiple of 8 * NG.  Dynamic LDS = aFloats*4 + WPB * (D + 1) * SLOT + NB * 128 (bias).
 // ------------------------------------------------------------------------------------------------------------------
 template <int NB, int PB, int MAP, int EPI, int D, int WPB>
 __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const ConvGemmParams prm)
@@ -251,15 +251,18 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
     const float *A = reinterpret_cast<const float *>(urnn_smem);       // [KT][NB][64]
     char *ring = urnn_smem + (size_t)prm.aFloats * 4 + wave * ((D + 1) * R::SLOT);
     char *scratch = ring + D * R::SLOT;                                // one extra slot: sink for the count-keeping dummy DMAs
+    const int kp_begin = prm.kpBegin, KT = prm.KT;
+    const int n0 = g * (NB * 32);
+    // The group's bias row lives in LDS too: a GLOBAL load inside the epilogue would put an s_waitcnt vmcnt(0) in front of
+    // every store (loads and stores share the counter), i.e. one full memory round trip per stored row -- measured 1000
+    // cycles per store instruction, 49k cycles per 48-KiB tile epilogue.
+    float *bias = reinterpret_cast<float *>(urnn_smem + (size_t)prm.aFloats * 4 + WPB * ((D + 1) * R::SLOT));
     stage_weights(prm.wt + (size_t)g * prm.aFloats, urnn_smem, prm.aFloats, wave, WPB, lane);
+    if (threadIdx.x < NB * 32) bias[threadIdx.x] = prm.bias[n0 + threadIdx.x];
     wait_vmcnt<0>();
     __syncthreads();
 
-    const int kp_begin = prm.kpBegin, KT = prm.KT;
-    const int n0 = g * (NB * 32);
-    const float *bias = prm.bias + n0;
-
-    if constexpr (WPB == 8) {
+    if constexpr (WPB > 4) {
         // Waves w and w + 4 share a SIMD.  Identical tiles would keep them in lockstep: both in the MFMA loop (sharing the
         // pipe), then both in the store epilogue (pipe idle, and the whole chip bursting stores at once).  Holding the second
         // wave back by half a tile puts the pair in anti-phase for the rest of the kernel: one wave's epilogue always hides
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
         if (wave >= 4) {
             int mf = (KT - kp_begin) * NB * PB;
             if (EPI == EPI_GRU1 && prm.hKp0 < KT) mf -= (KT - prm.hKp0) * PB;
-            const int naps = (mf * 64 / 2) / (64 * 64);          // s_sleep 64 ~ 64*64 cycles
+            const int naps = (mf * 64 * (wave >> 2) / (WPB / 4)) / (64 * 64);   // s_sleep 64 ~ 64*64 cycles
             for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(64);
         }
     }
@@ -317,6 +320,15 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
             soff = (sw1 || sw2) ? 0u : soff;
         };
         auto read_frag = [&](int kp, int slot, float (&a)[NB], float (&bv)[PB]) {
+#if (URNN_ABL & 8)
+            if (kp > kp_begin) {   // tuning build: keep the first fragments, skip the LDS traffic
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) asm volatile("" : "+v"(a[nb]));
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb) asm volatile("" : "+v"(bv[pb]));
+                return;
+            }
+#endif
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) a[nb] = A[(kp * NB + nb) * 64 + lane];
             R::read(ring + slot * R::SLOT, lane, bv);
@@ -536,13 +548,21 @@ __global__ __launch_bounds__(256) void gru_cand_kernel(const GruCandParams prm)
         PixelMap<MAP, PB> pm;
         pm.init(tile, j, prm.P, 0, 0, 0);
 
+        // The accumulators START from the x/e part of the candidate (+ bias) written by the gate GEMM: these loads are issued
+        // ahead of the ring's first DMAs and return (in order) before them, so their latency is the prologue's -- and the
+        // epilogue is left with stores only.  (Loads between the stores would each wait, through the shared vmcnt, for the
+        // previous store to complete: a serial chain of 16*NBF memory round trips per tile.)
+        float *cx = prm.cx + (size_t)b * F * prm.P;
         f32x16 acc[NBF][PB];
 #pragma unroll
         for (int nb = 0; nb < NBF; ++nb)
 #pragma unroll
-            for (int pb = 0; pb < PB; ++pb)
+            for (int r = 0; r < 16; ++r) {
+                float v[PB];
+                load_row<MAP, PB>(cx + (size_t)(nb * 32 + mfma_row(r, half)) * prm.P, pm, v);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[nb][pb][r] = 0.f;
+                for (int pb = 0; pb < PB; ++pb) acc[nb][pb][r] = v[pb];
+            }
 
         // two activation streams (raw r gate, hidden state) through buffer descriptors: row k-pair kp at uniform offset
         // 2*kp*P*4, per-lane part (row select + pixel offset) constant for the tile
@@ -636,8 +656,7 @@ __global__ __launch_bounds__(256) void gru_cand_kernel(const GruCandParams prm)
             slot = slot + 1 == D ? 0 : slot + 1;
         }
 
-        // epilogue: add the x/e part (+ bias) written by the gate GEMM, store C in place, partial sums per 32-channel group
-        float *cx = prm.cx + (size_t)b * F * prm.P;
+        // epilogue: store C in place of its x/e part, partial sums per 32-channel group
 #pragma unroll
         for (int nb = 0; nb < NBF; ++nb) {
             float s1 = 0.f, s2 = 0.f;
@@ -645,10 +664,9 @@ __global__ __launch_bounds__(256) void gru_cand_kernel(const GruCandParams prm)
             for (int r = 0; r < 16; ++r) {
                 float *orow = cx + (size_t)(nb * 32 + mfma_row(r, half)) * prm.P;
                 float v[PB];
-                load_row<MAP, PB>(orow, pm, v);
 #pragma unroll
                 for (int pb = 0; pb < PB; ++pb) {
-                    v[pb] += acc[nb][pb][r];
+                    v[pb] = acc[nb][pb][r];
                     if (pm.valid[pb]) {
                         s1 += v[pb];
                         s2 += v[pb] * v[pb];
@@ -720,7 +738,7 @@ template <int NB, int PB, int MAP, int EPI, int D, int WPB>
 static hipError_t launch_conv_cfg(const ConvGemmParams &p, hipStream_t st)
 {
     using R = Ring<PB, MAP>;
-    const size_t lds = (size_t)p.aFloats * 4 + (size_t)WPB * ((D + 1) * R::SLOT);
+    const size_t lds = (size_t)p.aFloats * 4 + (size_t)WPB * ((D + 1) * R::SLOT) + NB * 128;
     if (lds > LDS_PER_CU) return hipErrorInvalidValue;
     auto kern = conv_gemm_kernel<NB, PB, MAP, EPI, D, WPB>;
     hipError_t e = allow_big_lds(kern, lds);
@@ -736,7 +754,7 @@ template <int NB, int PB, int MAP, int EPI>
 static hipError_t launch_conv(const ConvGemmParams &p, hipStream_t st)
 {
     using R = Ring<PB, MAP>;
-    const size_t lds8 = (size_t)p.aFloats * 4 + (size_t)8 * (5 * R::SLOT);
+    const size_t lds8 = (size_t)p.aFloats * 4 + (size_t)8 * (5 * R::SLOT) + NB * 128;
     if constexpr (NB * PB * 16 <= 192 && EPI != EPI_DECONV) {   // accumulators + loop state fit the 256-register budget
         // 8-wave blocks only pay when there is enough work to fill 2048 wave slots; small planes keep 4-wave blocks
         const bool enough = (long)p.totalTiles * p.NG >= 1024;
