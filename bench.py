@@ -54,12 +54,11 @@ def algorithmic_work(H, W, C):
 
 
 def gate_gemm_flops(H, W, B=1):
-    """Algorithmic FLOP of the four launches per frame of conv_gemm_kernel<NB=3,PB=4,MAP_VEC,EPI_GRU1,D=4,WPB=8>
-    (gates 2F x K plus the candidate's x/e part F x (K - F), two FLOP per MAC):
+    """Algorithmic FLOP of the four launches per frame of conv_gemm_kernel<NB=2,PB=4,MAP_VEC,EPI_GRU1,D=4,WPB=8>
+    (the z|r gates: 2F output channels x K input channels, two FLOP per MAC):
     enc1 (I=16,F=64) and dec1 (I=96,F=64, skip) at full resolution, enc2 (I=64,F=96) and dec2 (I=96,F=96, skip) at half."""
     P1, P2 = B * H * W, B * (H // 2) * (W // 2)
-    return {"enc1": P1 * (128 * 80 + 64 * 16) * 2.0, "dec1": P1 * (128 * 224 + 64 * 160) * 2.0,
-            "enc2": P2 * (192 * 160 + 96 * 64) * 2.0, "dec2": P2 * (192 * 288 + 96 * 192) * 2.0}
+    return {"enc1": P1 * 128 * 80 * 2.0, "dec1": P1 * 128 * 224 * 2.0, "enc2": P2 * 192 * 160 * 2.0, "dec2": P2 * 192 * 288 * 2.0}
 
 
 def build_net(H, W, C, dev, seed=0):
@@ -210,7 +209,7 @@ def main():
                 with open(pmc) as fh:
                     traffic = json.load(fh).get("hbm_bytes_per_launch")
             result["roofline"] = {
-                "bound": "mfma", "kernel": "conv_gemm_kernel<3, 4, 0, 3, 4, 8> = <NB=3,PB=4,MAP_VEC,EPI_GRU1,D=4,WPB=8> (ConvGRU gate GEMM, fp32 MFMA "
+                "bound": "mfma", "kernel": "conv_gemm_kernel<2, 4, 0, 3, 4, 8> = <NB=2,PB=4,MAP_VEC,EPI_GRU1,D=4,WPB=8> (ConvGRU gate GEMM, fp32 MFMA "
                           "32x32x2; 4 launches per frame: enc1, dec1 at full and enc2, dec2 at half resolution)",
                 "achieved": achieved, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_F32_TFLOPS,
                 "traffic": traffic,

@@ -78,8 +78,10 @@ extern "C" int urnn_pack_conv_f32(const float *weight, const float *bias, float 
 
 extern "C" size_t urnn_packed_gru_floats(int I, int F, int skip)
 {
+    if (I < 1 || F < 32 || F % 32 != 0 || F > 128) return 0;
     const size_t KT = (size_t)(((I + 1) & ~1) + (skip ? F : 0) + F) / 2;
-    return (size_t)(F / 32) * slab_floats(KT, 3) + 3 * F + (size_t)F * F;
+    const size_t NB2 = urnn_cand_nb(F);
+    return (size_t)(F / 32) * slab_floats(KT, 2) + 2 * F + (size_t)((F / 32) / NB2) * slab_floats(KT, NB2) + F;
 }
 
 extern "C" int urnn_pack_gru_f32(const float *W1, const float *b1, const float *W2, const float *b2, float *packed, int I, int F,
@@ -202,7 +204,7 @@ extern "C" int urnn_gru_cell_phases_f32(const float *x, const float *e, const fl
     const int KT = (Ie + (skip ? F : 0) + F) / 2;
     const int NW = F / 32;
 
-    // K1: gates (raw) + candidate x/e part, GroupNorm partials of the gates
+    // K1: raw gates z | r = W1 . [x; e; h] + b1, GroupNorm partials
     ConvGemmParams p = {};
     p.seg[0] = x ? x : h;  // x == nullptr: the segment is skipped via kpBegin, the pointer is never dereferenced
     p.segC[0] = I;
@@ -210,47 +212,51 @@ extern "C" int urnn_gru_cell_phases_f32(const float *x, const float *e, const fl
     if (skip) {
         p.seg[1] = e; p.segC[1] = F; p.segKp0[1] = Ie / 2;
         p.seg[2] = h; p.segC[2] = F; p.segKp0[2] = Ie / 2 + F / 2;
-        p.hKp0 = p.segKp0[2];
     } else {
         p.seg[1] = h; p.segC[1] = F; p.segKp0[1] = Ie / 2;
         p.seg[2] = h; p.segC[2] = F; p.segKp0[2] = INT_MAX;
-        p.hKp0 = p.segKp0[1];
     }
+    p.hKp0 = INT_MAX;
     p.kpBegin = x ? 0 : Ie / 2;
     p.KT = KT;
     p.wt = packed;
-    p.aFloats = (int)slab_floats(KT, 3);
+    p.aFloats = (int)slab_floats(KT, 2);
     p.NG = NW;
     p.bias = packed + (size_t)NW * p.aFloats;
     p.P = (int)P;
     p.W = W;
     p.F = F;
-    p.Cout = 3 * F;
+    p.Cout = 2 * F;
     p.out0 = ws.g1;
-    p.out1 = ws.cx;
     p.partial = ws.part1;
     int pb1, map1;
-    // the gate GEMM prefers 128-pixel tiles (one 1-KiB DMA per 12 MFMAs) even when they only fill half the wave slots:
-    // measured 129 vs 153 us on the 250x250 decoder cell
+    // the gate GEMM prefers 128-pixel tiles (one 1-KiB DMA per 8 MFMAs) even when they only fill half the wave slots
     pick_tile((long)B * P, NW, P, &pb1, &map1, "URNN_TUNE_PB_GATES", 1024);
     const int tiles1 = (int)((P + 32 * pb1 - 1) / (32 * pb1));
     if (phase_mask & URNN_PHASE_GATES) CHECK_HIP(urnn_launch_gru1(p, B, pb1, map1, st), "gru gates");
     if (phase_mask & URNN_PHASE_GN1)
         CHECK_HIP(urnn_launch_gn_finalize(ws.part1, tiles1, 32.0 * (double)P, gn1_w, gn1_b, eps, ws.ss1, B, 2 * F, st), "gn finalize 1");
 
-    // K2: candidate = cx + W2h . (sigmoid(GN(r)) * h), GroupNorm partials of the candidate
-    GruCandParams c = {};
-    c.g1 = ws.g1;
-    c.h = h;
-    c.ss1 = ws.ss1;
-    c.w2h = packed + (size_t)NW * p.aFloats + 3 * F;
-    c.cx = ws.cx;
+    // K2: candidate (pre-norm) = W2 . [x; e; sigmoid(GN(r)) * h] + b2, GroupNorm partials.  The hidden-state rows are gated
+    // on the fly from the raw reset gate and K1's folded (scale, shift).
+    const int NB2 = urnn_cand_nb(F), NG2 = NW / NB2;
+    ConvGemmParams c = p;
+    if (!skip) { c.segKp0[1] = INT_MAX; }
+    c.segKp0[2] = INT_MAX;                       // h only enters through the gated slots
+    c.hKp0 = Ie / 2 + (skip ? F / 2 : 0);
+    c.gate = ws.g1;
+    c.ss = ws.ss1;
+    c.wt = packed + (size_t)NW * p.aFloats + 2 * F;
+    c.aFloats = (int)slab_floats(KT, NB2);
+    c.NG = NG2;
+    c.bias = c.wt + (size_t)NG2 * c.aFloats;
+    c.Cout = F;
+    c.out0 = ws.cx;
     c.partial = ws.part2;
-    c.P = (int)P;
     int pb2, map2;
-    pick_tile((long)B * P, 1, P, &pb2, &map2, "URNN_TUNE_PB_CAND");
+    pick_tile((long)B * P, NG2, P, &pb2, &map2, "URNN_TUNE_PB_CAND", 1024);
     const int tiles2 = (int)((P + 32 * pb2 - 1) / (32 * pb2));
-    if (phase_mask & URNN_PHASE_CAND) CHECK_HIP(urnn_launch_cand(c, B, F, pb2, map2, st), "gru candidate");
+    if (phase_mask & URNN_PHASE_CAND) CHECK_HIP(urnn_launch_cand(c, B, pb2, map2, st), "gru candidate");
     if (phase_mask & URNN_PHASE_GN2)
         CHECK_HIP(urnn_launch_gn_finalize(ws.part2, tiles2, 32.0 * (double)P, gn2_w, gn2_b, eps, ws.ss2, B, F, st), "gn finalize 2");
 

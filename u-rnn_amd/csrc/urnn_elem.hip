@@ -551,50 +551,46 @@ hipError_t urnn_launch_pack_conv(const float *w, const float *bias, float *packe
     return hipGetLastError();
 }
 
-// GRU: group i owns [z_i | r_i | c_i] (NB = 3); rows = x (I padded to even) | e (F, decoder only) | h (F), the candidate
-// column being zero on the h rows.  Then bias[3F] in packed column order, then the candidate's h part W2h as one slab
-// [F/2][F/32][64]: W2[nb*32 + j][Koff_h + 2*kp + half].  Source K order of W1 / W2 is cat(x, [e,] h) (ConvRNN.py:153,165-168).
+// GRU.  Rows (K) of both GEMMs = x (I padded to even) | e (F, decoder only) | h (F); source K order of W1 / W2 is
+// cat(x, [e,] h) (ConvRNN.py:153,165-168).
+//   gate GEMM:      F/32 groups [z_i | r_i] (NB = 2) from W1, then bias [F/32][z_i(32) | r_i(32)]
+//   candidate GEMM: NG2 groups of NB2 = urnn_cand_nb(F) 32-channel blocks from W2, then bias b2 [F]
 __global__ void pack_gru_kernel(const float *__restrict__ W1, const float *__restrict__ b1, const float *__restrict__ W2,
-                                const float *__restrict__ b2, float *__restrict__ packed, int I, int F, int skip)
+                                const float *__restrict__ b2, float *__restrict__ packed, int I, int F, int skip, int NB2)
 {
     const int Ie = (I + 1) & ~1;
     const int Fe = skip ? F : 0;
     const int KT = (Ie + Fe + F) / 2, NG = F / 32, Ksrc = I + Fe + F;
-    const int slab = slab_floats(KT, 3);
-    const int nw = NG * slab, nbias = 3 * F, nw2 = F * F;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= nw + nbias + nw2) return;
-    if (idx < nw) {
-        const int i = idx / slab, r = idx - i * slab;
+    const int slab1 = slab_floats(KT, 2), slab2 = slab_floats(KT, NB2), NG2 = NG / NB2;
+    const int n1 = NG * slab1, nb1 = 2 * F, n2 = NG2 * slab2, nb2 = F;
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n1 + nb1 + n2 + nb2) return;
+    auto src_col = [&](int k) {   // packed row k -> source column of W1 / W2, -1: padding row
+        if (k < Ie) return k < I ? k : -1;
+        return I + (k - Ie);
+    };
+    float v = 0.f;
+    if (idx < n1) {
+        const int i = idx / slab1, r = idx - i * slab1;
         const int l = r & 63, row = r >> 6;
-        const int kp = row / 3, c = row - kp * 3;
-        const int k = 2 * kp + (l >> 5), ch = i * 32 + (l & 31);
-        float v = 0.f;
-        if (kp < KT) {
-            int ks;            // source column, -1: padding
-            bool hrow = false;
-            if (k < Ie) ks = k < I ? k : -1;
-            else if (k < Ie + Fe) ks = I + (k - Ie);
-            else { ks = I + Fe + (k - Ie - Fe); hrow = true; }
-            if (ks >= 0) {
-                if (c == 0) v = W1[(size_t)ch * Ksrc + ks];
-                else if (c == 1) v = W1[(size_t)(F + ch) * Ksrc + ks];
-                else v = hrow ? 0.f : W2[(size_t)ch * Ksrc + ks];
-            }
-        }
-        packed[idx] = v;
-    } else if (idx < nw + nbias) {
-        const int n = idx - nw;
-        const int i = n / 96, which = (n - i * 96) / 32, ch = i * 32 + (n & 31);
-        packed[idx] = which == 0 ? b1[ch] : (which == 1 ? b1[F + ch] : b2[ch]);
+        const int kp = row / 2, c = row - kp * 2;
+        const int ks = kp < KT ? src_col(2 * kp + (l >> 5)) : -1;
+        if (ks >= 0) v = W1[(size_t)(c * F + i * 32 + (l & 31)) * Ksrc + ks];
+    } else if (idx < n1 + nb1) {
+        const int n = idx - n1;
+        const int i = n / 64, c = (n >> 5) & 1;
+        v = b1[c * F + i * 32 + (n & 31)];
+    } else if (idx < n1 + nb1 + n2) {
+        const int q = idx - n1 - nb1;
+        const int g = q / slab2, r = q - g * slab2;
+        const int l = r & 63, row = r >> 6;
+        const int kp = row / NB2, nb = row - kp * NB2;
+        const int ks = kp < KT ? src_col(2 * kp + (l >> 5)) : -1;
+        if (ks >= 0) v = W2[(size_t)((g * NB2 + nb) * 32 + (l & 31)) * Ksrc + ks];
     } else {
-        const int r = idx - nw - nbias;
-        const int l = r & 63, row = r >> 6;
-        const int NBF = F / 32;
-        const int kp = row / NBF, nb = row - kp * NBF;
-        const int n = nb * 32 + (l & 31), k = 2 * kp + (l >> 5);
-        packed[idx] = W2[(size_t)n * Ksrc + I + Fe + k];
+        v = b2[idx - n1 - nb1 - n2];
     }
+    packed[idx] = v;
 }
 
 hipError_t urnn_launch_pack_gru(const float *W1, const float *b1, const float *W2, const float *b2, float *packed, int I,
@@ -602,8 +598,9 @@ hipError_t urnn_launch_pack_gru(const float *W1, const float *b1, const float *W
 {
     const int Ie = (I + 1) & ~1;
     const int KT = (Ie + (skip ? F : 0) + F) / 2;
-    const int total = (F / 32) * slab_floats(KT, 3) + 3 * F + F * F;
-    hipLaunchKernelGGL(pack_gru_kernel, dim3((total + 255) / 256), dim3(256), 0, st, W1, b1, W2, b2, packed, I, F, skip);
+    const int NB2 = urnn_cand_nb(F);
+    const int total = (F / 32) * slab_floats(KT, 2) + 2 * F + ((F / 32) / NB2) * slab_floats(KT, NB2) + F;
+    hipLaunchKernelGGL(pack_gru_kernel, dim3((total + 255) / 256), dim3(256), 0, st, W1, b1, W2, b2, packed, I, F, skip, NB2);
     return hipGetLastError();
 }
 

@@ -17,8 +17,8 @@
 //   * blocks b and b + 8 run on the same XCD (observed dispatch b % 8), so the NG n-groups that read the same pixel tiles are
 //     placed there: the second group's activation reads hit that XCD's L2.  Placement only affects speed.
 //
-// Kernels: conv_gemm_kernel (stage convs, deconvs, GRU gate GEMM) and gru_cand_kernel (candidate GEMM whose B operand is
-// sigmoid(GN(r)) * h computed on the fly from two DMA streams).
+// One kernel template, conv_gemm_kernel, with five epilogues: stage convs, pooled convs, deconvs, the GRU gate GEMM and the
+// GRU candidate GEMM (whose hidden-state rows enter as sigmoid(GN(r)) * h, formed on the fly from two DMA streams).
 #include "urnn_common.h"
 #include "urnn_kernels.h"
 
@@ -257,8 +257,17 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
     // every store (loads and stores share the counter), i.e. one full memory round trip per stored row -- measured 1000
     // cycles per store instruction, 49k cycles per 48-KiB tile epilogue.
     float *bias = reinterpret_cast<float *>(urnn_smem + (size_t)prm.aFloats * 4 + WPB * ((D + 1) * R::SLOT));
+    float *ssm = bias + NB * 32;                                       // EPI_CAND: [B][F][2] r-gate (scale, shift)
+    constexpr bool GATED = (EPI == EPI_CAND);
     stage_weights(prm.wt + (size_t)g * prm.aFloats, urnn_smem, prm.aFloats, wave, WPB, lane);
     if (threadIdx.x < NB * 32) bias[threadIdx.x] = prm.bias[n0 + threadIdx.x];
+    if constexpr (GATED) {
+        const int F2 = 2 * prm.F;
+        for (int c = threadIdx.x; c < prm.B * F2; c += 64 * WPB) {
+            const int b = c / F2, r = c - b * F2;
+            ssm[c] = prm.ss[((size_t)b * F2 + prm.F) * 2 + r];
+        }
+    }
     wait_vmcnt<0>();
     __syncthreads();
 
@@ -267,9 +276,8 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
         // pipe), then both in the store epilogue (pipe idle, and the whole chip bursting stores at once).  Holding the second
         // wave back by half a tile puts the pair in anti-phase for the rest of the kernel: one wave's epilogue always hides
         // behind the other's MFMAs.  The first wave runs alone (at full pipe rate) meanwhile, so no work is lost.
-        if (wave >= 4) {
-            int mf = (KT - kp_begin) * NB * PB;
-            if (EPI == EPI_GRU1 && prm.hKp0 < KT) mf -= (KT - prm.hKp0) * PB;
+        if (wave >= 4 && prm.stagger) {
+            const int mf = (KT - kp_begin) * NB * PB;
             const int naps = (mf * 64 * (wave >> 2) / (WPB / 4)) / (64 * 64);   // s_sleep 64 ~ 64*64 cycles
             for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(64);
         }
@@ -295,31 +303,50 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
         // Activation rows are addressed through one buffer descriptor per K segment (x | e | h): row k-pair kp of a segment sits
         // at uniform offset 2*(kp - kp0)*P*4; the per-lane part (row select + pixel offset) is constant for the tile.  A
         // segment with an odd channel count ends in a pad row (zero weight): it lies past the descriptor and reads as 0.
+        //
+        // The ring is fed by a SLOT STREAM: one slot = one row pair of one input.  A plain k-pair takes one slot.  In the
+        // candidate GEMM (EPI_CAND) the k-pairs of the hidden-state segment are GATED: B = sigmoid(GN(r)) * h, so they take
+        // two consecutive slots (raw r-gate rows, then h rows) and the product is formed when the fragment is read.
         const int k1 = prm.segKp0[1], k2 = prm.segKp0[2];
+        const int kpe = GATED ? (prm.hKp0 < KT ? prm.hKp0 : KT) : KT;      // end of the plain k-pairs
+        const int nplain = kpe > kp_begin ? kpe - kp_begin : 0;
+        const int total = nplain + (GATED ? 2 * (KT - kpe) : 0);           // slots this tile streams
         const rsrc_t rs0 = make_rsrc(prm.seg[0] + (size_t)b * prm.segC[0] * prm.P, 4u * (unsigned)prm.segC[0] * (unsigned)prm.P);
         const rsrc_t rs1 = make_rsrc(prm.seg[1] + (size_t)b * prm.segC[1] * prm.P, 4u * (unsigned)prm.segC[1] * (unsigned)prm.P);
         const rsrc_t rs2 = make_rsrc(prm.seg[2] + (size_t)b * prm.segC[2] * prm.P, 4u * (unsigned)prm.segC[2] * (unsigned)prm.P);
+        const rsrc_t rsg = GATED ? make_rsrc(prm.gate + ((size_t)b * 2 * prm.F + prm.F) * prm.P, 4u * (unsigned)prm.F * (unsigned)prm.P) : rs0;
+        const float *ssb = ssm + (size_t)b * 2 * prm.F;
         unsigned vo[R::NV];
         R::lane_offsets(pm, lane, (unsigned)prm.P, vo);
         const unsigned rstep = 8u * (unsigned)prm.P;                       // two channel rows, bytes
-        int kp_issue = kp_begin;                                           // next k-pair whose DMA will be issued
+        int si = 0;                                                        // next slot of the stream to issue
         const int s_begin = kp_begin >= k2 ? 2 : (kp_begin >= k1 ? 1 : 0);
-        rsrc_t rs = s_begin == 2 ? rs2 : (s_begin == 1 ? rs1 : rs0);
+        rsrc_t rs = s_begin == 2 ? rs2 : (s_begin == 1 ? rs1 : rs0);       // current plain segment
         unsigned soff = rstep * (unsigned)(kp_begin - (s_begin == 2 ? k2 : (s_begin == 1 ? k1 : 0)));
-        // Branch-free refill (the k loop must stay one basic block so that its instruction order can be pinned): past the
-        // end of K the DMA goes to a scratch slot (and reads out of range = zeros), which keeps the outstanding-DMA count --
-        // and therefore every s_waitcnt immediate -- exact.  Scalar ALU only.
-        auto refill = [&](int slot) {
-            const bool live = kp_issue < KT;
+        unsigned soff_g = 0;                                               // gated part: byte offset of the next row pair
+        // Branch-free refills (the k loop must stay one basic block so that its instruction order can be pinned): past the
+        // end of the stream the DMA goes to a scratch slot (and reads out of range = zeros), which keeps the outstanding-DMA
+        // count -- and therefore every s_waitcnt immediate -- exact.  Scalar ALU only.
+        auto refill_plain = [&](int slot) {
+            const bool live = si < total;
             char *dst = live ? ring + slot * R::SLOT : scratch;
             R::issue(dst, rs, vo, live ? soff : 0xF0000000u, lane);
-            ++kp_issue;
+            ++si;
             soff += rstep;
-            const bool sw1 = kp_issue == k1, sw2 = kp_issue == k2;
+            const bool sw1 = si == k1 - kp_begin, sw2 = !GATED && si == k2 - kp_begin;
             rs = sw2 ? rs2 : (sw1 ? rs1 : rs);
             soff = (sw1 || sw2) ? 0u : soff;
         };
-        auto read_frag = [&](int kp, int slot, float (&a)[NB], float (&bv)[PB]) {
+        // gated part of the stream: slots alternate r-gate rows / h rows of the same row pair
+        auto refill_gate = [&](int slot, bool hrows) {
+            const bool live = si < total;
+            char *dst = live ? ring + slot * R::SLOT : scratch;
+            R::issue(dst, hrows ? rs2 : rsg, vo, live ? soff_g : 0xF0000000u, lane);
+            ++si;
+            soff_g += hrows ? rstep : 0u;
+        };
+        auto wrap = [](int s_) { return s_ >= D ? s_ - D : s_; };
+        auto read_plain = [&](int kp, int slot, float (&a)[NB], float (&bv)[PB]) {
 #if (URNN_ABL & 8)
             if (kp > kp_begin) {   // tuning build: keep the first fragments, skip the LDS traffic
 #pragma unroll
@@ -333,55 +360,88 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
             for (int nb = 0; nb < NB; ++nb) a[nb] = A[(kp * NB + nb) * 64 + lane];
             R::read(ring + slot * R::SLOT, lane, bv);
         };
+        auto read_gated = [&](int kp, int slot, float (&a)[NB], float (&bv)[PB]) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) a[nb] = A[(kp * NB + nb) * 64 + lane];
+            float gg[PB], hh[PB];
+            R::read(ring + slot * R::SLOT, lane, gg);
+            R::read(ring + wrap(slot + 1) * R::SLOT, lane, hh);
+            const f32x2 st = *reinterpret_cast<const f32x2 *>(ssb + 2 * (2 * (kp - kpe) + half));
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) bv[pb] = sigmoidf_fast(gg[pb] * st.x + st.y) * hh[pb];
+        };
 
         // Software pipeline.  A wave issues in order and each fp32 MFMA occupies the pipe for 64 cycles, so everything that is
         // not an MFMA must sit BETWEEN MFMAs (about ten instruction slots hide behind each one) -- traced with s_memtime, the
         // version that did its LDS reads, pointer math and DMA issue after the last MFMA of a k-pair lost 300 of every 1070
         // cycles.  Order per k-pair, pinned with sched_barrier: [wait + LDS reads of the NEXT k-pair] MFMAs(nb 0) [refill DMA of
-        // the slot just consumed] MFMAs(nb 1) [bookkeeping] MFMAs(nb 2) [fragment hand-over].
-        for (int i = 0; i < D; ++i) refill(i);
+        // the slot(s) just consumed] MFMAs(nb 1) [bookkeeping] MFMAs(nb 2) [fragment hand-over].
+        for (int i = 0; i < D; ++i) {
+            if (!GATED || si < nplain) refill_plain(i);
+            else refill_gate(i, ((si - nplain) & 1) != 0);
+        }
         float a_cur[NB], b_cur[PB], a_nxt[NB], b_nxt[PB];
-        wait_vmcnt<(D - 1) * R::NLOAD>();
-        read_frag(kp_begin, 0, a_cur, b_cur);
+        if (!GATED || nplain > 0) {
+            wait_vmcnt<(D - 1) * R::NLOAD>();
+            read_plain(kp_begin, 0, a_cur, b_cur);
+        } else {
+            wait_vmcnt<(D - 2) * R::NLOAD>();
+            read_gated(kp_begin, 0, a_cur, b_cur);
+        }
         TRACE_STAMP(1);
         int slot = 0;
-        auto k_range = [&](int kp_lo, int kp_hi, auto nba_tag) {
-            constexpr int NBA = decltype(nba_tag)::value;            // n-blocks that take MFMAs in this range
-            for (int kp = kp_lo; kp < kp_hi; ++kp) {
-                const int nslot = slot + 1 == D ? 0 : slot + 1;
-                wait_vmcnt<(D - 2) * R::NLOAD>();                   // slot kp+1 has landed (or is a dummy)
-                read_frag(kp + 1 < KT ? kp + 1 : kp, nslot, a_nxt, b_nxt);
-                __builtin_amdgcn_sched_barrier(0);
+        // One k-pair.  CG / NGT: the current / next k-pair is gated (two slots).  RF: which part of the stream the slots issued
+        // here belong to -- 0 plain, 1 gated with run-time parity (the last D plain k-pairs already prefetch the gated part),
+        // 2 gated with static parity (inside the gated part si - nplain is even at the top of every k-pair, D being even).
+        auto step = [&](int kp, auto cur_tag, auto nxt_tag, auto rf_tag) {
+            constexpr bool CG = decltype(cur_tag)::value, NGT = decltype(nxt_tag)::value;
+            constexpr int RF = decltype(rf_tag)::value;
+            const int nslot = wrap(slot + (CG ? 2 : 1));
+            wait_vmcnt<(D - (CG ? 2 : 1) - (NGT ? 2 : 1)) * R::NLOAD>();       // the next k-pair's slot(s) have landed (or are dummies)
+            const int kn = kp + 1 < KT ? kp + 1 : kp;
+            if constexpr (NGT) read_gated(kn, nslot, a_nxt, b_nxt);
+            else read_plain(kn, nslot, a_nxt, b_nxt);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int pb = 0; pb < PB; ++pb) acc[0][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0], b_cur[pb], acc[0][pb], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                refill(slot);                                        // its fragments are already in registers
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (NBA >= 2) {
-#pragma unroll
-                    for (int pb = 0; pb < PB; ++pb) acc[1][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1], b_cur[pb], acc[1][pb], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int nb = 2; nb < NBA; ++nb) {
-#pragma unroll
-                    for (int pb = 0; pb < PB; ++pb) acc[nb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[nb], b_cur[pb], acc[nb][pb], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) a_cur[nb] = a_nxt[nb];
-#pragma unroll
-                for (int pb = 0; pb < PB; ++pb) b_cur[pb] = b_nxt[pb];
-                slot = nslot;
+            for (int pb = 0; pb < PB; ++pb) acc[0][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0], b_cur[pb], acc[0][pb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // refill the slot(s) just consumed: their fragments are already in registers
+            if constexpr (RF == 0) refill_plain(slot);
+            else if constexpr (RF == 1) refill_gate(slot, ((si - nplain) & 1) != 0);
+            else {
+                refill_gate(slot, false);
+                refill_gate(wrap(slot + 1), true);
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nb = 1; nb < NB; ++nb) {
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb) acc[nb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[nb], b_cur[pb], acc[nb][pb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) a_cur[nb] = a_nxt[nb];
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) b_cur[pb] = b_nxt[pb];
+            slot = nslot;
         };
-        if constexpr (EPI == EPI_GRU1) {
-            // the hidden-state rows feed the z / r gates only; the candidate's h part waits for r (gru_cand_kernel)
-            const int hk = prm.hKp0 < KT ? prm.hKp0 : KT;
-            k_range(kp_begin, hk, std::integral_constant<int, NB>{});
-            k_range(hk, KT, std::integral_constant<int, 2>{});
+        using std::false_type;
+        using std::true_type;
+        using RF0 = std::integral_constant<int, 0>;
+        using RF1 = std::integral_constant<int, 1>;
+        using RF2 = std::integral_constant<int, 2>;
+        if constexpr (GATED) {
+            static_assert(D >= 6 && D % 2 == 0, "a gated k-pair and its successor hold four slots; static parity needs an even ring");
+            int kp = kp_begin;
+            for (; kp + D < kpe; ++kp) step(kp, false_type{}, false_type{}, RF0{});       // slots issued here are still plain
+            for (; kp + 1 < kpe; ++kp) step(kp, false_type{}, false_type{}, RF1{});
+            if (kp < kpe) {
+                step(kp, false_type{}, true_type{}, RF1{});                               // (the candidate always has gated rows)
+                ++kp;
+            }
+            for (; kp < KT; ++kp) step(kp, true_type{}, true_type{}, RF2{});
         } else {
-            k_range(kp_begin, KT, std::integral_constant<int, NB>{});
+            for (int kp = kp_begin; kp < KT; ++kp) step(kp, false_type{}, false_type{}, RF0{});
         }
         wait_vmcnt<0>();
         TRACE_STAMP(2);
@@ -463,43 +523,70 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
                     }
                 }
         } else if constexpr (EPI == EPI_GRU1) {
-            // group i owns [z_i | r_i | c_i]: raw (pre-GroupNorm) gates -> out0 (B,2F,P), candidate x/e part + b2 -> out1
-            // (B,F,P), and the GroupNorm partial sums of z_i (group i) and r_i (group F/32 + i) -> partial[b][grp][tile][2].
-            static_assert(NB == 3, "gate tile is z|r|c");
+            // group i owns [z_i | r_i]: raw (pre-GroupNorm) gates -> out0 (B,2F,P) and the GroupNorm partial sums of z_i
+            // (group i) and r_i (group F/32 + i) -> partial[b][grp][tile][2].
+            static_assert(NB == 2, "gate tile is z|r");
             const int F = prm.F;
             const int i = g;
 #pragma unroll
-            for (int nb = 0; nb < 3; ++nb) {
+            for (int nb = 0; nb < 2; ++nb) {
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int cib = mfma_row(r, half);
                     const float bv = bias[nb * 32 + cib];
-                    float *orow;
-                    if (nb == 0) orow = prm.out0 + ((size_t)b * 2 * F + i * 32 + cib) * prm.P;
-                    else if (nb == 1) orow = prm.out0 + ((size_t)b * 2 * F + F + i * 32 + cib) * prm.P;
-                    else orow = prm.out1 + ((size_t)b * F + i * 32 + cib) * prm.P;
+                    float *orow = prm.out0 + ((size_t)b * 2 * F + nb * F + i * 32 + cib) * prm.P;
                     float v[PB];
 #pragma unroll
                     for (int pb = 0; pb < PB; ++pb) {
                         v[pb] = acc[nb][pb][r] + bv;
-                        if (nb < 2 && pm.valid[pb]) {
+                        if (pm.valid[pb]) {
                             s1 += v[pb];
                             s2 += v[pb] * v[pb];
                         }
                     }
                     store_row<MAP, PB>(orow, pm, v);
                 }
-                if (nb < 2) {
-                    s1 = wave_sum(s1);
-                    s2 = wave_sum(s2);
-                    if (lane == 0) {
-                        const int G = 2 * F / 32;
-                        const int grp = nb * (F / 32) + i;
-                        float *pp = prm.partial + (((size_t)b * G + grp) * prm.tilesPerSample + tile) * 2;
-                        pp[0] = s1;
-                        pp[1] = s2;
+                s1 = wave_sum(s1);
+                s2 = wave_sum(s2);
+                if (lane == 0) {
+                    const int G = 2 * F / 32;
+                    const int grp = nb * (F / 32) + i;
+                    float *pp = prm.partial + (((size_t)b * G + grp) * prm.tilesPerSample + tile) * 2;
+                    pp[0] = s1;
+                    pp[1] = s2;
+                }
+            }
+        } else if constexpr (EPI == EPI_CAND) {
+            // group g owns candidate channels [g*NB*32, (g+1)*NB*32): pre-GroupNorm candidate -> out0 (B,F,P), partial sums per
+            // 32-channel GroupNorm group -> partial[b][F/32][tile][2]
+            const int F = prm.F;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                float s1 = 0.f, s2 = 0.f;
+                const int grp = g * NB + nb;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cib = mfma_row(r, half);
+                    const float bv = bias[nb * 32 + cib];
+                    float *orow = prm.out0 + ((size_t)b * F + grp * 32 + cib) * prm.P;
+                    float v[PB];
+#pragma unroll
+                    for (int pb = 0; pb < PB; ++pb) {
+                        v[pb] = acc[nb][pb][r] + bv;
+                        if (pm.valid[pb]) {
+                            s1 += v[pb];
+                            s2 += v[pb] * v[pb];
+                        }
                     }
+                    store_row<MAP, PB>(orow, pm, v);
+                }
+                s1 = wave_sum(s1);
+                s2 = wave_sum(s2);
+                if (lane == 0) {
+                    float *pp = prm.partial + (((size_t)b * (F / 32) + grp) * prm.tilesPerSample + tile) * 2;
+                    pp[0] = s1;
+                    pp[1] = s2;
                 }
             }
         }
@@ -508,181 +595,6 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
         TRACE_STAMP(3);
         ++tr_n;
 #endif
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// gru_cand_kernel: C = Cx + W2h . (r * h),  r = sigmoid(g_r * scale + shift)  (GroupNorm folded into scale/shift).
-// Persistent blocks of 4 waves; W2h (F x F) and every sample's r-gate scale/shift stay in LDS; a wave tile = 32*PB pixels
-// x all F candidate channels (NBF = F/32 n-blocks); Cx is added in the epilogue, the sum goes back in place; GroupNorm
-// partial sums of C per 32-channel group.  Ring slot = [raw r gate PB*256 B | h PB*256 B].
-// Dynamic LDS = F*F*4 + B*F*8 + 4 * D * SLOT.
-// ------------------------------------------------------------------------------------------------------------------
-template <int NBF, int PB, int MAP, int D>
-__global__ __launch_bounds__(256) void gru_cand_kernel(const GruCandParams prm)
-{
-    constexpr int F = NBF * 32;
-    constexpr bool VEC = (MAP == MAP_VEC);
-    constexpr bool P16 = (MAP == MAP_PAIR16);
-    constexpr int NLOAD = 2 * (P16 ? 1 : (VEC ? PB / 4 : PB));
-    constexpr int SLOT = 2 * PB * 256;
-    constexpr int KT = F / 2;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j = lane & 31, half = lane >> 5;
-
-    const float *A = reinterpret_cast<const float *>(urnn_smem);                     // [KT][NBF][64]
-    float *ssm = reinterpret_cast<float *>(urnn_smem + F * F * 4);                   // [B][F][2] r-gate scale/shift
-    char *ring = urnn_smem + F * F * 4 + prm.B * F * 8 + wave * (D * SLOT);
-    stage_weights(prm.w2h, urnn_smem, F * F, wave, 4, lane);
-    for (int c = threadIdx.x; c < prm.B * 2 * F; c += 256) {
-        const int b = c / (2 * F), r = c - b * 2 * F;
-        ssm[c] = prm.ss1[((size_t)b * 2 * F + F) * 2 + r];
-    }
-    wait_vmcnt<0>();
-    __syncthreads();
-
-    for (int item = blockIdx.x * 4 + wave; item < prm.totalTiles; item += gridDim.x * 4) {
-        const int b = item / prm.tilesPerSample;
-        const int tile = item - b * prm.tilesPerSample;
-        PixelMap<MAP, PB> pm;
-        pm.init(tile, j, prm.P, 0, 0, 0);
-
-        // The accumulators START from the x/e part of the candidate (+ bias) written by the gate GEMM: these loads are issued
-        // ahead of the ring's first DMAs and return (in order) before them, so their latency is the prologue's -- and the
-        // epilogue is left with stores only.  (Loads between the stores would each wait, through the shared vmcnt, for the
-        // previous store to complete: a serial chain of 16*NBF memory round trips per tile.)
-        float *cx = prm.cx + (size_t)b * F * prm.P;
-        f32x16 acc[NBF][PB];
-#pragma unroll
-        for (int nb = 0; nb < NBF; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v[PB];
-                load_row<MAP, PB>(cx + (size_t)(nb * 32 + mfma_row(r, half)) * prm.P, pm, v);
-#pragma unroll
-                for (int pb = 0; pb < PB; ++pb) acc[nb][pb][r] = v[pb];
-            }
-
-        // two activation streams (raw r gate, hidden state) through buffer descriptors: row k-pair kp at uniform offset
-        // 2*kp*P*4, per-lane part (row select + pixel offset) constant for the tile
-        const rsrc_t rsg = make_rsrc(prm.g1 + ((size_t)b * 2 * F + F) * prm.P, 4u * (unsigned)F * (unsigned)prm.P);
-        const rsrc_t rsh = make_rsrc(prm.h + (size_t)b * F * prm.P, 4u * (unsigned)F * (unsigned)prm.P);
-        constexpr int NV = P16 ? 1 : (VEC ? PB / 4 : PB);
-        unsigned vo[NV];
-        {
-            const unsigned rowb = (P16 ? (lane >> 4) & 1 : half) ? 4u * (unsigned)prm.P : 0u;
-            if constexpr (P16) vo[0] = rowb + 4u * (unsigned)pm.dma_off;
-            else if constexpr (VEC) {
-#pragma unroll
-                for (int qd = 0; qd < PB / 4; ++qd) vo[qd] = rowb + 4u * (unsigned)pm.off[4 * qd];
-            } else {
-#pragma unroll
-                for (int pb = 0; pb < PB; ++pb) vo[pb] = rowb + 4u * (unsigned)pm.off[pb];
-            }
-        }
-        const float *ssb = ssm + (size_t)b * 2 * F;
-
-        auto issue = [&](int kp, int slot) {
-            char *s = ring + slot * SLOT;
-            const unsigned soff = 8u * (unsigned)prm.P * (unsigned)kp;
-            if constexpr (P16) {
-                if (lane < 32) {
-                    bdma16(rsg, vo[0] + soff, 0, s);
-                    bdma16(rsh, vo[0] + soff, 0, s + PB * 256);
-                }
-            } else if constexpr (VEC) {
-#pragma unroll
-                for (int qd = 0; qd < PB / 4; ++qd) {
-                    bdma16(rsg, vo[qd] + soff, 0, s + qd * 1024);
-                    bdma16(rsh, vo[qd] + soff, 0, s + PB * 256 + qd * 1024);
-                }
-            } else {
-#pragma unroll
-                for (int pb = 0; pb < PB; ++pb) {
-                    bdma4(rsg, vo[pb] + soff, 0, s + pb * 256);
-                    bdma4(rsh, vo[pb] + soff, 0, s + PB * 256 + pb * 256);
-                }
-            }
-        };
-        auto consume = [&](int kp, int slot) {
-            const char *s = ring + slot * SLOT;
-            float a[NBF], g[PB], h[PB];
-#pragma unroll
-            for (int nb = 0; nb < NBF; ++nb) a[nb] = A[(kp * NBF + nb) * 64 + lane];
-            if constexpr (P16) {
-                const int o = ((lane >> 5) * 64 + 2 * (lane & 31)) * 4;
-                const f32x2 tg = *reinterpret_cast<const f32x2 *>(s + o);
-                const f32x2 th = *reinterpret_cast<const f32x2 *>(s + PB * 256 + o);
-                g[0] = tg.x; g[1] = tg.y; h[0] = th.x; h[1] = th.y;
-            } else if constexpr (VEC) {
-#pragma unroll
-                for (int qd = 0; qd < PB / 4; ++qd) {
-                    const f32x4 tg = *reinterpret_cast<const f32x4 *>(s + qd * 1024 + lane * 16);
-                    const f32x4 th = *reinterpret_cast<const f32x4 *>(s + PB * 256 + qd * 1024 + lane * 16);
-                    g[4 * qd] = tg.x; g[4 * qd + 1] = tg.y; g[4 * qd + 2] = tg.z; g[4 * qd + 3] = tg.w;
-                    h[4 * qd] = th.x; h[4 * qd + 1] = th.y; h[4 * qd + 2] = th.z; h[4 * qd + 3] = th.w;
-                }
-            } else {
-#pragma unroll
-                for (int pb = 0; pb < PB; ++pb) {
-                    g[pb] = *reinterpret_cast<const float *>(s + pb * 256 + lane * 4);
-                    h[pb] = *reinterpret_cast<const float *>(s + PB * 256 + pb * 256 + lane * 4);
-                }
-            }
-            const f32x2 st = *reinterpret_cast<const f32x2 *>(ssb + 2 * (2 * kp + half));
-            float bop[PB];
-#pragma unroll
-            for (int pb = 0; pb < PB; ++pb) bop[pb] = sigmoidf_fast(g[pb] * st.x + st.y) * h[pb];
-#pragma unroll
-            for (int nb = 0; nb < NBF; ++nb)
-#pragma unroll
-                for (int pb = 0; pb < PB; ++pb) acc[nb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nb], bop[pb], acc[nb][pb], 0, 0, 0);
-        };
-
-        static_assert(KT >= D, "ring deeper than the K loop");
-        for (int i = 0; i < D; ++i) issue(i, i);
-        int slot = 0, kp = 0;
-        for (; kp + D <= KT; ++kp) {
-            wait_vmcnt<(D - 1) * NLOAD>();
-            consume(kp, slot);
-            asm volatile("" ::: "memory");
-            if (kp + D < KT) issue(kp + D, slot);
-            slot = slot + 1 == D ? 0 : slot + 1;
-        }
-        wait_vmcnt<0>();
-        for (; kp < KT; ++kp) {
-            consume(kp, slot);
-            slot = slot + 1 == D ? 0 : slot + 1;
-        }
-
-        // epilogue: store C in place of its x/e part, partial sums per 32-channel group
-#pragma unroll
-        for (int nb = 0; nb < NBF; ++nb) {
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float *orow = cx + (size_t)(nb * 32 + mfma_row(r, half)) * prm.P;
-                float v[PB];
-#pragma unroll
-                for (int pb = 0; pb < PB; ++pb) {
-                    v[pb] = acc[nb][pb][r];
-                    if (pm.valid[pb]) {
-                        s1 += v[pb];
-                        s2 += v[pb] * v[pb];
-                    }
-                }
-                store_row<MAP, PB>(orow, pm, v);
-            }
-            s1 = wave_sum(s1);
-            s2 = wave_sum(s2);
-            if (lane == 0) {
-                float *pp = prm.partial + (((size_t)b * NBF + nb) * prm.tilesPerSample + tile) * 2;
-                pp[0] = s1;
-                pp[1] = s2;
-            }
-        }
-        wait_vmcnt<0>();   // the epilogue's own loads/stores must not be miscounted by the next tile's ring waits
     }
 }
 
@@ -704,12 +616,12 @@ static int tune_block_waves()
     return v;
 }
 
-static int tune_cand_bpc()
+static int tune_stagger()
 {
     static int v = -1;
     if (v < 0) {
-        const char *e = getenv("URNN_TUNE_CAND_BPC");   // development knob
-        v = e ? atoi(e) : 4;
+        const char *e = getenv("URNN_TUNE_STAGGER");   // development knob: 0 starts both waves of a SIMD together
+        v = e ? atoi(e) : 1;
     }
     return v;
 }
@@ -734,17 +646,27 @@ static hipError_t allow_big_lds(K kernel, size_t lds)
     return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
+// dynamic LDS: weight slab + per-wave rings (D slots + the dummy sink) + bias row + (candidate GEMM) the r-gate scale/shift table
+template <int NB, int PB, int MAP, int EPI>
+static size_t conv_lds_bytes(const ConvGemmParams &p, int D, int WPB)
+{
+    using R = Ring<PB, MAP>;
+    return (size_t)p.aFloats * 4 + (size_t)WPB * ((D + 1) * R::SLOT) + NB * 128 + (EPI == EPI_CAND ? (size_t)p.B * p.F * 8 : 0);
+}
+
 template <int NB, int PB, int MAP, int EPI, int D, int WPB>
 static hipError_t launch_conv_cfg(const ConvGemmParams &p, hipStream_t st)
 {
     using R = Ring<PB, MAP>;
-    const size_t lds = (size_t)p.aFloats * 4 + (size_t)WPB * ((D + 1) * R::SLOT) + NB * 128;
+    const size_t lds = conv_lds_bytes<NB, PB, MAP, EPI>(p, D, WPB);
     if (lds > LDS_PER_CU) return hipErrorInvalidValue;
     auto kern = conv_gemm_kernel<NB, PB, MAP, EPI, D, WPB>;
     hipError_t e = allow_big_lds(kern, lds);
     if (e != hipSuccess) return e;
     const int grid = persistent_grid(lds, p.NG, p.totalTiles, WPB);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WPB), lds, st, p);
+    ConvGemmParams q = p;
+    q.stagger = tune_stagger();
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WPB), lds, st, q);
     return hipGetLastError();
 }
 
@@ -753,14 +675,22 @@ static hipError_t launch_conv_cfg(const ConvGemmParams &p, hipStream_t st)
 template <int NB, int PB, int MAP, int EPI>
 static hipError_t launch_conv(const ConvGemmParams &p, hipStream_t st)
 {
-    using R = Ring<PB, MAP>;
-    const size_t lds8 = (size_t)p.aFloats * 4 + (size_t)8 * (5 * R::SLOT) + NB * 128;
-    if constexpr (NB * PB * 16 <= 192 && EPI != EPI_DECONV) {   // accumulators + loop state fit the 256-register budget
-        // 8-wave blocks only pay when there is enough work to fill 2048 wave slots; small planes keep 4-wave blocks
-        const bool enough = (long)p.totalTiles * p.NG >= 1024;
-        if (lds8 <= LDS_PER_CU && enough && tune_block_waves() != 4) return launch_conv_cfg<NB, PB, MAP, EPI, 4, 8>(p, st);
+    // 8-wave blocks only pay when there is enough work to fill 2048 wave slots; small planes keep 4-wave blocks
+    const bool enough = (long)p.totalTiles * p.NG >= 1024;
+    if constexpr (EPI == EPI_CAND) {
+        // gated k-pairs hold two ring slots each: 8-deep rings
+        if constexpr (NB * PB * 16 <= 128) {   // + the gate/hidden fragments of the gated rows: 192 accumulators would spill
+            if (conv_lds_bytes<NB, PB, MAP, EPI>(p, 8, 8) <= LDS_PER_CU && enough && tune_block_waves() != 4)
+                return launch_conv_cfg<NB, PB, MAP, EPI, 8, 8>(p, st);
+        }
+        return launch_conv_cfg<NB, PB, MAP, EPI, 8, 4>(p, st);
+    } else {
+        if constexpr (NB * PB * 16 <= 192 && EPI != EPI_DECONV) {   // accumulators + loop state fit the 256-register budget
+            if (conv_lds_bytes<NB, PB, MAP, EPI>(p, 4, 8) <= LDS_PER_CU && enough && tune_block_waves() != 4)
+                return launch_conv_cfg<NB, PB, MAP, EPI, 4, 8>(p, st);
+        }
+        return launch_conv_cfg<NB, PB, MAP, EPI, 8, 4>(p, st);
     }
-    return launch_conv_cfg<NB, PB, MAP, EPI, 8, 4>(p, st);
 }
 
 // tile shape -> (PB, MAP): 16-B DMA on aligned planes, pair/strided dword DMA otherwise
@@ -825,53 +755,31 @@ hipError_t urnn_launch_deconv(ConvGemmParams p, int B, int PB, int map, hipStrea
     return launch_conv<6, 1, MAP_STRIDED, EPI_DECONV>(p, st);
 }
 
-// GRU gate GEMM: F/32 groups of [z|r|c].
+// GRU gate GEMM: F/32 groups of [z|r].
 hipError_t urnn_launch_gru1(ConvGemmParams p, int B, int PB, int map, hipStream_t st)
 {
     if (p.NG < 1 || p.NG > 4) return hipErrorInvalidValue;
     p.tilesPerSample = (p.P + 32 * PB - 1) / (32 * PB);
     p.totalTiles = B * p.tilesPerSample;
-    return launch_flat<3, EPI_GRU1>(p, PB, map, st);
+    return launch_flat<2, EPI_GRU1>(p, PB, map, st);
 }
 
-template <int NBF, int PB, int MAP>
-static hipError_t launch_cand_one(const GruCandParams &p, hipStream_t st)
+// Candidate GEMM: C = W2 . [x; e; sigmoid(GN(r)) * h] + b2, NG groups of NB n-blocks (urnn_cand_nb).
+int urnn_cand_nb(int F)
 {
-    constexpr int F = NBF * 32;
-    constexpr int D = 4;
-    constexpr int SLOT = 2 * PB * 256;
-    const size_t lds = (size_t)F * F * 4 + (size_t)p.B * F * 8 + (size_t)4 * D * SLOT;
-    if (lds > LDS_PER_CU) return hipErrorInvalidValue;
-    auto kern = gru_cand_kernel<NBF, PB, MAP, D>;
-    hipError_t e = allow_big_lds(kern, lds);
-    if (e != hipSuccess) return e;
-    // small accumulators (<= 96 registers): up to 4 blocks = 16 waves per CU hide the DMA / transform latency by TLP
-    const int grid = persistent_grid(lds, 1, p.totalTiles, 4, tune_cand_bpc());
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, p);
-    return hipGetLastError();
+    const int nblk = F / 32;
+    return nblk <= 3 ? nblk : 2;
 }
 
-template <int NBF>
-static hipError_t launch_cand_nbf(const GruCandParams &p, int PB, int map, hipStream_t st)
+hipError_t urnn_launch_cand(ConvGemmParams p, int B, int PB, int map, hipStream_t st)
 {
-    if (map == MAP_VEC && PB == 4) return launch_cand_one<NBF, 4, MAP_VEC>(p, st);
-    if (map == MAP_PAIR16 && PB == 2) return launch_cand_one<NBF, 2, MAP_PAIR16>(p, st);
-    if (map == MAP_PAIR && PB == 2) return launch_cand_one<NBF, 2, MAP_PAIR>(p, st);
-    if (map == MAP_STRIDED && PB == 2) return launch_cand_one<NBF, 2, MAP_STRIDED>(p, st);
-    if (map == MAP_STRIDED && PB == 1) return launch_cand_one<NBF, 1, MAP_STRIDED>(p, st);
-    return hipErrorInvalidValue;
-}
-
-hipError_t urnn_launch_cand(GruCandParams p, int B, int F, int PB, int map, hipStream_t st)
-{
+    const int NB = urnn_cand_nb(p.F);
+    if (p.F % 32 != 0 || (p.F / 32) % NB != 0) return hipErrorInvalidValue;
     p.B = B;
+    p.NG = (p.F / 32) / NB;
     p.tilesPerSample = (p.P + 32 * PB - 1) / (32 * PB);
     p.totalTiles = B * p.tilesPerSample;
-    switch (F / 32) {
-    case 1: return launch_cand_nbf<1>(p, PB, map, st);
-    case 2: return launch_cand_nbf<2>(p, PB, map, st);
-    case 3: return launch_cand_nbf<3>(p, PB, map, st);
-    case 4: return launch_cand_nbf<4>(p, PB, map, st);
-    default: return hipErrorInvalidValue;
-    }
+    if (NB == 1) return launch_flat<1, EPI_CAND>(p, PB, map, st);
+    if (NB == 2) return launch_flat<2, EPI_CAND>(p, PB, map, st);
+    return launch_flat<3, EPI_CAND>(p, PB, map, st);
 }

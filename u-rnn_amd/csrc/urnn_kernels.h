@@ -4,14 +4,17 @@
 #include <stddef.h>
 
 enum { MAP_VEC = 0, MAP_PAIR = 1, MAP_STRIDED = 2, MAP_POOL = 3, MAP_PAIR16 = 4 };   // pixel geometry of a wave tile (urnn_gemm.hip)
-enum { EPI_LRELU = 0, EPI_POOL = 1, EPI_DECONV = 2, EPI_GRU1 = 3 };          // epilogue of conv_gemm_kernel
+enum { EPI_LRELU = 0, EPI_POOL = 1, EPI_DECONV = 2, EPI_GRU1 = 3, EPI_CAND = 4 };   // epilogue of conv_gemm_kernel
 
 struct ConvGemmParams {
     const float *seg[3];  // up to three channel-concatenated inputs (x | e | h)
     int segC[3];          // real channel counts
     int segKp0[3];        // first absolute k-pair of each segment in the packed weights (unused segments: INT_MAX)
     int kpBegin, KT;      // k-pair range to run: [kpBegin, KT)  (kpBegin > 0 skips an all-zero x segment)
-    int hKp0;             // EPI_GRU1: first k-pair of the hidden-state segment (candidate columns are skipped from here)
+    int hKp0;             // EPI_CAND: first k-pair of the hidden-state segment (its rows are gated by the reset gate)
+    const float *gate;    // EPI_CAND: raw gates (B,2F,P); rows F..2F-1 are the reset gate
+    const float *ss;      // EPI_CAND: gate GroupNorm folded to per-channel (scale, shift) [B][2F][2]
+    int B;                // EPI_CAND: samples (size of the scale/shift table kept in LDS)
     const float *wt;      // packed weights [NG][KT][NB][64] (group stride aFloats); lane l of row (kp, nb) holds
                           // W[k = 2*kp + (l >> 5)][n = (g*NB + nb)*32 + (l & 31)]
     const float *bias;    // bias per packed column [NG*NB*32]
@@ -21,18 +24,9 @@ struct ConvGemmParams {
     int tilesPerSample, totalTiles;
     int Cout, F;
     float slope;
-    float *out0, *out1;
-    float *partial;       // EPI_GRU1: [B][2F/32][tiles][2]
-};
-
-struct GruCandParams {
-    const float *g1;   // raw gates (B,2F,P)
-    const float *h;    // (B,F,P)
-    const float *ss1;  // gate GroupNorm folded to per-channel (scale, shift): [B][2F][2]
-    const float *w2h;  // packed W2 h-part [F/2][F/32][64]: lane l of row (kp, nb) holds W2[nb*32 + (l & 31)][Koff_h + 2*kp + (l >> 5)]
-    float *cx;         // in: candidate x/e part + bias; out: full pre-norm candidate (B,F,P)
-    float *partial;    // [B][F/32][tiles][2]
-    int P, B, tilesPerSample, totalTiles;
+    float *out0;
+    int stagger;          // 8-wave blocks: hold the second wave of each SIMD back by half a tile (set by the launcher)
+    float *partial;       // EPI_GRU1: [B][2F/32][tiles][2]; EPI_CAND: [B][F/32][tiles][2]
 };
 
 int urnn_conv_nb(int Cout);   // n-blocks per wave for a Cout-wide 1x1 conv (packing and launch must agree)
@@ -40,7 +34,8 @@ hipError_t urnn_launch_conv_flat(ConvGemmParams p, int B, int PB, int map, hipSt
 hipError_t urnn_launch_conv_pool(ConvGemmParams p, int B, hipStream_t st);
 hipError_t urnn_launch_deconv(ConvGemmParams p, int B, int PB, int map, hipStream_t st);
 hipError_t urnn_launch_gru1(ConvGemmParams p, int B, int PB, int map, hipStream_t st);
-hipError_t urnn_launch_cand(GruCandParams p, int B, int F, int PB, int map, hipStream_t st);
+int urnn_cand_nb(int F);      // n-blocks per group of the candidate GEMM
+hipError_t urnn_launch_cand(ConvGemmParams p, int B, int PB, int map, hipStream_t st);
 
 // ---- elementwise / reduction kernels (urnn_elem.hip) ----
 hipError_t urnn_launch_gn_finalize(const float *partial, int ntiles, double count, const float *gamma, const float *beta,
