@@ -76,9 +76,9 @@ int urnn_gru_cell_f32(const float *x, const float *e, const float *h, const floa
 
 /* The same cell with a subset of its five kernels enqueued (profiling / roofline measurement: bench.py times the
  * gate GEMM alone with this).  phase_mask is an OR of URNN_PHASE_*; URNN_PHASE_ALL == urnn_gru_cell_f32. */
-#define URNN_PHASE_GATES 1  /* gate GEMM: raw z|r gates, candidate x/e part, GroupNorm partial sums */
-#define URNN_PHASE_GN1 2    /* GroupNorm finalise of the gates                                       */
-#define URNN_PHASE_CAND 4   /* candidate GEMM on sigmoid(GN(r)) * h, GroupNorm partial sums          */
+#define URNN_PHASE_GATES 1  /* gate GEMM: raw z|r gates, GroupNorm partial sums                          */
+#define URNN_PHASE_GN1 2    /* GroupNorm finalise of the gates (part of the CAND kernel when both set) */
+#define URNN_PHASE_CAND 4   /* candidate GEMM W2.[x;e;sigmoid(GN(r))*h], GroupNorm partial sums       */
 #define URNN_PHASE_GN2 8    /* GroupNorm finalise of the candidate                                   */
 #define URNN_PHASE_BLEND 16 /* h' = (1 - z) * h + z * tanh(GN(c))                                    */
 #define URNN_PHASE_ALL 31

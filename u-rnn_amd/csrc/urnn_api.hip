@@ -234,7 +234,9 @@ extern "C" int urnn_gru_cell_phases_f32(const float *x, const float *e, const fl
     pick_tile((long)B * P, NW, P, &pb1, &map1, "URNN_TUNE_PB_GATES", 1024);
     const int tiles1 = (int)((P + 32 * pb1 - 1) / (32 * pb1));
     if (phase_mask & URNN_PHASE_GATES) CHECK_HIP(urnn_launch_gru1(p, B, pb1, map1, st), "gru gates");
-    if (phase_mask & URNN_PHASE_GN1)
+    // GroupNorm finalise of the gates: folded into the candidate GEMM's prologue; launched on its own only when asked for
+    // without the candidate phase (profiling)
+    if ((phase_mask & URNN_PHASE_GN1) && !(phase_mask & URNN_PHASE_CAND))
         CHECK_HIP(urnn_launch_gn_finalize(ws.part1, tiles1, 32.0 * (double)P, gn1_w, gn1_b, eps, ws.ss1, B, 2 * F, st), "gn finalize 1");
 
     // K2: candidate (pre-norm) = W2 . [x; e; sigmoid(GN(r)) * h] + b2, GroupNorm partials.  The hidden-state rows are gated
@@ -245,7 +247,13 @@ extern "C" int urnn_gru_cell_phases_f32(const float *x, const float *e, const fl
     c.segKp0[2] = INT_MAX;                       // h only enters through the gated slots
     c.hKp0 = Ie / 2 + (skip ? F / 2 : 0);
     c.gate = ws.g1;
-    c.ss = ws.ss1;
+    c.gpart = ws.part1;
+    c.gtiles = tiles1;
+    c.gcount = 32.0 * (double)P;
+    c.gn_w = gn1_w;
+    c.gn_b = gn1_b;
+    c.eps = eps;
+    c.ss_out = ws.ss1;
     c.wt = packed + (size_t)NW * p.aFloats + 2 * F;
     c.aFloats = (int)slab_floats(KT, NB2);
     c.NG = NG2;

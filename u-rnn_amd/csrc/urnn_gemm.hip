@@ -262,10 +262,50 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
     stage_weights(prm.wt + (size_t)g * prm.aFloats, urnn_smem, prm.aFloats, wave, WPB, lane);
     if (threadIdx.x < NB * 32) bias[threadIdx.x] = prm.bias[n0 + threadIdx.x];
     if constexpr (GATED) {
-        const int F2 = 2 * prm.F;
-        for (int c = threadIdx.x; c < prm.B * F2; c += 64 * WPB) {
-            const int b = c / F2, r = c - b * F2;
-            ssm[c] = prm.ss[((size_t)b * F2 + prm.F) * 2 + r];
+        // GroupNorm of the gates is finalised HERE instead of in a launch of its own: one wave per (sample, 32-channel
+        // group) folds the gate GEMM's per-tile (sum, sumsq) partials in double, in a fixed order (lane-strided, then an xor
+        // butterfly) -- every block computes identical bits.  The reset-gate rows' (scale, shift) stay in LDS for the gated
+        // fragments; block 0 also publishes the whole table for the blend kernel.
+        const int F = prm.F, G1 = 2 * F / 32;
+        for (int q = wave; q < prm.B * G1; q += WPB) {
+            const int b = q / G1, grp = q - b * G1;
+            const float *pp = prm.gpart + ((size_t)b * G1 + grp) * prm.gtiles * 2;
+            double s1 = 0.0, s2 = 0.0;
+            for (int t0 = 0; t0 < prm.gtiles; t0 += 64 * 32) {          // 32 independent loads in flight, summed in order
+                f32x2 v[32];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) {
+                    const int t = t0 + u * 64 + lane;
+                    v[u] = t < prm.gtiles ? *reinterpret_cast<const f32x2 *>(pp + 2 * t) : f32x2{0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < 32; ++u) {
+                    s1 += (double)v[u].x;
+                    s2 += (double)v[u].y;
+                }
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                s1 += __shfl_xor(s1, m, 64);
+                s2 += __shfl_xor(s2, m, 64);
+            }
+            const double mean = s1 / prm.gcount;
+            double var = s2 / prm.gcount - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            const double rstd = 1.0 / sqrt(var + (double)prm.eps);
+            if (lane < 32) {
+                const int c = grp * 32 + lane;
+                const double sc = (double)prm.gn_w[c] * rstd;
+                const float fsc = (float)sc, fsh = (float)((double)prm.gn_b[c] - mean * sc);
+                if (c >= F) {
+                    ssm[((size_t)b * F + (c - F)) * 2] = fsc;
+                    ssm[((size_t)b * F + (c - F)) * 2 + 1] = fsh;
+                }
+                if (blockIdx.x == 0) {
+                    prm.ss_out[((size_t)b * 2 * F + c) * 2] = fsc;
+                    prm.ss_out[((size_t)b * 2 * F + c) * 2 + 1] = fsh;
+                }
+            }
         }
     }
     wait_vmcnt<0>();
@@ -629,7 +669,7 @@ static int tune_stagger()
 static int persistent_grid(size_t lds_bytes, int NG, int total_tiles, int wpb = 4, int max_blocks_per_cu = 2)
 {
     int bpc = (int)(LDS_PER_CU / lds_bytes);
-    const int cap = wpb >= 8 ? 1 : max_blocks_per_cu;
+    const int cap = (wpb >= 8 && max_blocks_per_cu <= 2) ? 1 : (max_blocks_per_cu > 2 ? 2 : max_blocks_per_cu);
     bpc = bpc < 1 ? 1 : (bpc > cap ? cap : bpc);
     const int unit = 8 * NG;
     int n = (NUM_CUS * bpc) / unit * unit;
@@ -655,7 +695,7 @@ static size_t conv_lds_bytes(const ConvGemmParams &p, int D, int WPB)
 }
 
 template <int NB, int PB, int MAP, int EPI, int D, int WPB>
-static hipError_t launch_conv_cfg(const ConvGemmParams &p, hipStream_t st)
+static hipError_t launch_conv_cfg(const ConvGemmParams &p, hipStream_t st, int max_bpc = 2)
 {
     using R = Ring<PB, MAP>;
     const size_t lds = conv_lds_bytes<NB, PB, MAP, EPI>(p, D, WPB);
@@ -663,7 +703,7 @@ static hipError_t launch_conv_cfg(const ConvGemmParams &p, hipStream_t st)
     auto kern = conv_gemm_kernel<NB, PB, MAP, EPI, D, WPB>;
     hipError_t e = allow_big_lds(kern, lds);
     if (e != hipSuccess) return e;
-    const int grid = persistent_grid(lds, p.NG, p.totalTiles, WPB);
+    const int grid = persistent_grid(lds, p.NG, p.totalTiles, WPB, max_bpc);
     ConvGemmParams q = p;
     q.stagger = tune_stagger();
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WPB), lds, st, q);
@@ -679,13 +719,22 @@ static hipError_t launch_conv(const ConvGemmParams &p, hipStream_t st)
     const bool enough = (long)p.totalTiles * p.NG >= 1024;
     if constexpr (EPI == EPI_CAND) {
         // gated k-pairs hold two ring slots each: 8-deep rings
+        if constexpr (NB * PB * 16 <= 64) {
+            // small accumulators: two 8-wave blocks per CU (4 waves per SIMD) when the LDS allows (6-deep rings)
+            if (2 * conv_lds_bytes<NB, PB, MAP, EPI>(p, 6, 8) <= LDS_PER_CU && enough && tune_block_waves() == 16)
+                return launch_conv_cfg<NB, PB, MAP, EPI, 6, 8>(p, st, 3);
+        }
         if constexpr (NB * PB * 16 <= 128) {   // + the gate/hidden fragments of the gated rows: 192 accumulators would spill
             if (conv_lds_bytes<NB, PB, MAP, EPI>(p, 8, 8) <= LDS_PER_CU && enough && tune_block_waves() != 4)
                 return launch_conv_cfg<NB, PB, MAP, EPI, 8, 8>(p, st);
         }
         return launch_conv_cfg<NB, PB, MAP, EPI, 8, 4>(p, st);
     } else {
-        if constexpr (NB * PB * 16 <= 192 && EPI != EPI_DECONV) {   // accumulators + loop state fit the 256-register budget
+        if constexpr (NB * PB * 16 <= 192) {   // accumulators + loop state fit the 256-register budget
+            if constexpr (NB * PB * 16 <= 64) {
+                if (2 * conv_lds_bytes<NB, PB, MAP, EPI>(p, 4, 8) <= LDS_PER_CU && enough && tune_block_waves() == 16)
+                    return launch_conv_cfg<NB, PB, MAP, EPI, 4, 8>(p, st, 3);
+            }
             if (conv_lds_bytes<NB, PB, MAP, EPI>(p, 4, 8) <= LDS_PER_CU && enough && tune_block_waves() != 4)
                 return launch_conv_cfg<NB, PB, MAP, EPI, 4, 8>(p, st);
         }

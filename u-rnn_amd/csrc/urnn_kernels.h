@@ -13,8 +13,13 @@ struct ConvGemmParams {
     int kpBegin, KT;      // k-pair range to run: [kpBegin, KT)  (kpBegin > 0 skips an all-zero x segment)
     int hKp0;             // EPI_CAND: first k-pair of the hidden-state segment (its rows are gated by the reset gate)
     const float *gate;    // EPI_CAND: raw gates (B,2F,P); rows F..2F-1 are the reset gate
-    const float *ss;      // EPI_CAND: gate GroupNorm folded to per-channel (scale, shift) [B][2F][2]
-    int B;                // EPI_CAND: samples (size of the scale/shift table kept in LDS)
+    const float *gpart;   // EPI_CAND: the gate GEMM's GroupNorm partials [B][2F/32][gtiles][2]; finalised in this kernel's prologue
+    int gtiles;           //           tiles per sample of the gate GEMM
+    double gcount;        //           values per (sample, group) = 32 * P
+    const float *gn_w, *gn_b;   //     GroupNorm affine of the gates [2F]
+    float eps;
+    float *ss_out;        // EPI_CAND: out -- gates' per-channel (scale, shift) [B][2F][2] for the blend kernel (written by block 0)
+    int B;                // EPI_CAND: samples (size of the reset-gate scale/shift table kept in LDS)
     const float *wt;      // packed weights [NG][KT][NB][64] (group stride aFloats); lane l of row (kp, nb) holds
                           // W[k = 2*kp + (l >> 5)][n = (g*NB + nb)*32 + (l & 31)]
     const float *bias;    // bias per packed column [NG*NB*32]
