@@ -730,7 +730,7 @@ static hipError_t launch_conv(const ConvGemmParams &p, hipStream_t st)
         }
         return launch_conv_cfg<NB, PB, MAP, EPI, 8, 4>(p, st);
     } else {
-        if constexpr (NB * PB * 16 <= 192) {   // accumulators + loop state fit the 256-register budget
+        if constexpr (NB * PB * 16 <= 192 && EPI != EPI_DECONV) {   // accumulators + loop state fit the 256-register budget (the deconv scatter does not)
             if constexpr (NB * PB * 16 <= 64) {
                 if (2 * conv_lds_bytes<NB, PB, MAP, EPI>(p, 4, 8) <= LDS_PER_CU && enough && tune_block_waves() == 16)
                     return launch_conv_cfg<NB, PB, MAP, EPI, 4, 8>(p, st, 3);
