@@ -2,6 +2,8 @@
 in HBM -- six hidden states updated in place, per-frame input assembly, the whole timestep (about 45 kernel
 launches) captured once as a hipGraph and replayed T times while a device-side frame counter advances.
 No host round trip inside the loop; one D2H of the (T,B,H,W) result at the end if the caller wants numpy."""
+import os
+
 import torch
 
 from . import ops
@@ -145,30 +147,55 @@ class RolloutEngine:
         bufs = (self.states[:3], self.enc_alt)
         return bufs[1 - parity], bufs[parity]
 
-    def _enc_chain(self, parity):
+    # The two chains as lists of segments (closures), so that an overlapped iteration can interleave their ENQUEUE order:
+    # a graph replay hands its kernel nodes to the hardware queues in creation order at a few microseconds each, so a chain
+    # enqueued entirely after the other starts ~100 us late.
+    def _enc_segments(self, parity):
         enc = self.net.encoder
         (p1, p2, p3), (n1, n2, n3) = self._enc_bufs(parity)
-        ops.WORKSPACE.use_slot(0)
-        self._stage1(self.te_dev)
-        self._cell("enc1", enc.rnn1, self.a1, None, p1, n1)
-        enc.stage2(n1, out=self.a2)
-        self._cell("enc2", enc.rnn2, self.a2, None, p2, n2)
-        enc.stage3(n2, out=self.a3)
-        enc.rnn3.step(self.a3, None, p3, out=n3)
-        ops.advance_counter(self.te_dev, 1)
 
-    def _dec_chain(self, parity):
+        def e1():
+            self._stage1(self.te_dev)
+            self._cell("enc1", enc.rnn1, self.a1, None, p1, n1)
+
+        def e2():
+            enc.stage2(n1, out=self.a2)
+            self._cell("enc2", enc.rnn2, self.a2, None, p2, n2)
+
+        def e3():
+            enc.stage3(n2, out=self.a3)
+            enc.rnn3.step(self.a3, None, p3, out=n3)
+            ops.advance_counter(self.te_dev, 1)
+        return [e1, e2, e3]
+
+    def _dec_segments(self, parity):
         """decoder(t) for t % 2 == parity: reads encoder states e[parity], writes feat[parity]."""
         dec = self.net.decoder
         e1, e2, e3 = self._enc_bufs(parity)[1]   # encoder states of frame t (written by E(t))
         _, _, _, d1, d2, d3 = self.states
+
+        def s3():
+            dec.rnn3.step(None, e3, d1, out=d1)
+            dec.stage3(d1, out=self.u3)
+
+        def s2():
+            self._cell("dec2", dec.rnn2, self.u3, e2, d2, d2)
+            dec.stage2(d2, out=self.u2)
+
+        def s1():
+            self._cell("dec1", dec.rnn1, self.u2, e1, d3, d3)
+            dec.stage1(d3, out=self.feat if parity == 0 else self.feat_alt)
+        return [s3, s2, s1]
+
+    def _enc_chain(self, parity):
+        ops.WORKSPACE.use_slot(0)
+        for seg in self._enc_segments(parity):
+            seg()
+
+    def _dec_chain(self, parity):
         ops.WORKSPACE.use_slot(1)
-        dec.rnn3.step(None, e3, d1, out=d1)
-        dec.stage3(d1, out=self.u3)
-        self._cell("dec2", dec.rnn2, self.u3, e2, d2, d2)
-        dec.stage2(d2, out=self.u2)
-        self._cell("dec1", dec.rnn1, self.u2, e1, d3, d3)
-        dec.stage1(d3, out=self.feat if parity == 0 else self.feat_alt)
+        for seg in self._dec_segments(parity):
+            seg()
         ops.WORKSPACE.use_slot(0)
 
     def _head_chain(self, parity):
@@ -179,20 +206,38 @@ class RolloutEngine:
         ops.advance_counter(self.t_dev, 1)
 
     def _iter_overlap(self, parity, with_head=True):
-        """Iteration t (parity = t % 2): chain 1 = head(t-1) then encoder(t+1); chain 2 = decoder(t).  The decoder chain is
-        the longer one, so the head of the previous frame rides with the encoder."""
+        """Iteration t (parity = t % 2): chain 1 = head(t-1) then encoder(t+1); chain 2 = decoder(t); enqueued segment by
+        segment in the order ENQUEUE_ORDER (H head, E encoder segment, D decoder segment)."""
         cur = torch.cuda.current_stream(self.device)
         s1, s2 = self._side
         s1.wait_stream(cur)
         s2.wait_stream(cur)
-        with torch.cuda.stream(s1):
-            if with_head:
-                self._head_chain(1 - parity)
-            self._enc_chain(1 - parity)
-        with torch.cuda.stream(s2):
-            self._dec_chain(parity)
+        enc = self._enc_segments(1 - parity)
+        dec = self._dec_segments(parity)
+        order = os.environ.get("URNN_TUNE_CHAIN_ORDER", self.ENQUEUE_ORDER)
+        ie = idd = 0
+        for ch in order:
+            if ch == "H":
+                if with_head:
+                    with torch.cuda.stream(s1):
+                        self._head_chain(1 - parity)
+            elif ch == "E":
+                with torch.cuda.stream(s1):
+                    ops.WORKSPACE.use_slot(0)
+                    enc[ie]()
+                ie += 1
+            elif ch == "D":
+                with torch.cuda.stream(s2):
+                    ops.WORKSPACE.use_slot(1)
+                    dec[idd]()
+                idd += 1
+        if ie != 3 or idd != 3 or order.count("H") != 1:
+            raise RuntimeError("enqueue order must hold one H, three E and three D")
+        ops.WORKSPACE.use_slot(0)
         cur.wait_stream(s1)
         cur.wait_stream(s2)
+
+    ENQUEUE_ORDER = "HEEEDDD"
 
     def _capture_overlap(self):
         self.net.head.flat_params()
