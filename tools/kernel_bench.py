@@ -66,9 +66,10 @@ def main():
         Kx = I + (F if skip else 0)
         tmp = h.clone()
         add(f"{name} gates GEMM", lambda: cell.step(x, e, h, out=tmp, phases=ops.PHASE_GATES),
-            P * (2 * F * (Kx + F) + F * Kx), P * (Kx + F + 3 * F) * 4 / 1e6)
-        add(f"{name} GN finalize x2", lambda: cell.step(x, e, h, out=tmp, phases=ops.PHASE_GN1 | ops.PHASE_GN2), 0, 0)
-        add(f"{name} cand GEMM", lambda: cell.step(x, e, h, out=tmp, phases=ops.PHASE_CAND), P * F * F, P * 4 * F * 4 / 1e6)
+            P * 2 * F * (Kx + F), P * (Kx + F + 2 * F) * 4 / 1e6)
+        add(f"{name} cand GEMM (+GN1)", lambda: cell.step(x, e, h, out=tmp, phases=ops.PHASE_CAND), P * F * (Kx + F),
+            P * (Kx + 2 * F + F) * 4 / 1e6)
+        add(f"{name} GN2 finalize", lambda: cell.step(x, e, h, out=tmp, phases=ops.PHASE_GN2), 0, 0)
         add(f"{name} blend", lambda: cell.step(x, e, h, out=tmp, phases=ops.PHASE_BLEND), 0, P * 4 * F * 4 / 1e6)
         add(f"{name} whole cell", lambda: cell.step(x, e, h, out=tmp), P * 3 * F * (Kx + F), P * (Kx + 2 * F) * 4 / 1e6)
     add("head (7 launches)", lambda: net.head.run(eng.feat, out_masked=eng.out_masked, out_cls=eng.out_cls),
