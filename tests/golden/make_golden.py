@@ -224,6 +224,41 @@ def gen_inference_entry(path):
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def gen_events_metrics(path):
+    """Reference Dynamic2DFlood over the synthetic folder tree of tests/synth_dataset.py, and reference compute_metrics on
+    seeded arrays (needs the wandb shim to import test.py)."""
+    import tempfile
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import synth_dataset as sd
+    from src.lib.dataset.Dynamic2DFlood import Dynamic2DFlood
+    out = {}
+    with tempfile.TemporaryDirectory() as root:
+        lst = sd.write_tree(root)
+        ds = Dynamic2DFlood(root, "test", event_list_file=lst, duration=sd.DURATION)
+        out["len"] = len(ds)
+        out["locations"] = np.array(ds.locations)
+        out["event_names"] = np.array(ds.event_names)
+        for i in range(len(ds)):
+            inp, tgt, event_dir = ds[i]
+            out[f"item{i}_dir"] = np.array(os.path.relpath(event_dir, root))
+            out[f"item{i}_target"] = tgt.numpy()
+            for k, v in inp.items():
+                out[f"item{i}_{k}"] = v.numpy()
+        one = Dynamic2DFlood(root, "test", event_list_file=lst, duration=sd.DURATION, location="location16")
+        out["one_len"] = len(one)
+    sys.modules.setdefault("wandb", types.ModuleType("wandb"))
+    import test as ref_test
+    rs = np.random.RandomState(77)
+    gt = (rs.uniform(0, 1, (6, 9, 11)) ** 3 * 900).astype(np.float32)
+    pred = (gt * rs.uniform(0.7, 1.2, gt.shape) + rs.normal(0, 20, gt.shape)).astype(np.float32)
+    out["m_pred"], out["m_gt"] = pred, gt
+    for thr in (150.0, 600.0):
+        m = ref_test.compute_metrics(pred, gt, flood_thres=thr)
+        for k, v in m.items():
+            out[f"m_{int(thr)}_{k}"] = np.float64(v)
+    np.savez_compressed(path, **out)
+
+
 if __name__ == "__main__":
     gen_kernels(os.path.join(HERE, "kernels_16x16.npz"))
     gen_preprocess(os.path.join(HERE, "preprocess.npz"))
@@ -236,3 +271,7 @@ if __name__ == "__main__":
         gen_inference_entry(os.path.join(HERE, "inference_entry_16x16_T6.npz"))
     except Exception as exc:  # pragma: no cover - depends on optional reference imports
         print("test.Inference import failed, skipped:", repr(exc))
+    try:
+        gen_events_metrics(os.path.join(HERE, "events_metrics.npz"))
+    except Exception as exc:  # noqa: BLE001
+        print("events/metrics goldens failed:", repr(exc))

@@ -228,3 +228,45 @@ def test_large_grid_addressing(dev):
     for s in eng.states:
         assert torch.isfinite(s).all() and s.abs().max() <= 1.0 + 1e-6
     assert torch.equal(a, eng.rollout(ev))
+
+
+def test_event_folder_evaluation_end_to_end(dev, tmp_path):
+    """`.npy` event folders -> loader -> Inference on the GPU -> metrics (test.py:411-520), against the oracle run over the
+    same loader items: scalar- and spatial-rain locations, events shorter than the duration, rank sharding."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import synth_dataset as sd
+    from oracle import oracle as orc
+    from urnn_amd.dataset import r_MinMaxScaler
+    from urnn_amd.evaluate import evaluate_events
+    from urnn_amd.events import Dynamic2DFlood
+    from urnn_amd.metrics import compute_metrics
+    root = str(tmp_path)
+    lst = sd.write_tree(root)
+    ds = Dynamic2DFlood(root, "test", event_list_file=lst, duration=sd.DURATION)
+    nums, rain_max, cum_max, flood_max = 3, 6.0, 30.0, 5000.0
+    net, sdict = make_net(sd.H, sd.W, 2 * nums + 3, 5, dev)
+    m0, s0, out0 = evaluate_events(net, ds, dev, historical_nums=nums, rain_max=rain_max, cumsum_rain_max=cum_max,
+                                   flood_max=flood_max, flood_thres=100.0, rank=0, world_size=2, keep_outputs=True)
+    m1, _, out1 = evaluate_events(net, ds, dev, historical_nums=nums, rain_max=rain_max, cumsum_rain_max=cum_max,
+                                  flood_max=flood_max, flood_thres=100.0, rank=1, world_size=2, keep_outputs=True)
+    assert len(m0) == len(m1) == 3 and not set(m0) & set(m1)
+    assert set(s0) == {"mean", "std"}
+    onet = orc.OracleNet(sdict)
+    outs = {**out0, **out1}
+    mets = {**m0, **m1}
+    for index in range(len(ds)):
+        inputs, target, event_dir = ds.batched(index)
+        name = os.path.join(os.path.basename(os.path.dirname(event_dir)), os.path.basename(event_dir))
+        ev = {k: v.numpy() for k, v in inputs.items()}
+        frames, _, auxs = orc.rollout(onet, ev, sd.DURATION, nums, rain_max, cum_max, want_aux=True)
+        ref = frames[:, 0]
+        got = outs[name] / flood_max
+        # thresholded output: compare away from the wet/dry decision boundary (SURVEY F10)
+        cls = np.stack([a["cls"][0] for a in auxs]) if isinstance(auxs[0], dict) and "cls" in auxs[0] else None
+        keep = np.abs(cls - 0.5) > 1e-5 if cls is not None else np.ones_like(ref, bool)
+        assert_close(np.where(keep, got, 0), np.where(keep, ref, 0), 1e-4, f"evaluate {name}")
+        want = compute_metrics(r_MinMaxScaler(ref, max=flood_max, min=0), target[0].numpy(), flood_thres=100.0)
+        for k, v in mets[name].items():
+            assert v == pytest.approx(want[k], rel=1e-3, abs=1e-6), (name, k)
