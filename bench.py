@@ -37,6 +37,8 @@ CONFIGS = {
     "ukea": (52, 120, 6, 36, 10.0, 150.0, True),
 }
 
+MIXED = ("futian", "ukea")     # BASELINE configs[4]: mixed-resolution events on every rank
+
 PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X fp32 matrix peak (MI355X_MICROARCH.md)
 PEAK_HBM_TBS = 8.0
 
@@ -101,7 +103,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=360)
     ap.add_argument("--warmup", type=int, default=36)
-    ap.add_argument("--config", default="location1", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="location1", choices=sorted(CONFIGS) + ["mixed"])
     ap.add_argument("--batch", type=int, default=1, help="events per GPU (the reference entry points use 1)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of the captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -132,28 +134,40 @@ def main():
     import urnn_amd.weights as uw
     from urnn_amd.rollout import RolloutEngine
 
-    H, W, nums, T, rain_max, cum_max, spatial = CONFIGS[args.config]
-    C = 2 * nums + 3
+    # "mixed" = BASELINE configs[4]: Futian + UKEA events alternating on every rank, one engine (and one captured hipGraph)
+    # per grid shape; every other config is a single shape
+    names = MIXED if args.config == "mixed" else (args.config,)
     B = args.batch
-    net, sd, cfg = build_net(H, W, C, dev)
-    eng = RolloutEngine(net, H, W, nums, rain_max, cum_max, batch=B, max_frames=T, spatial_rain=spatial, net_cfg=cfg,
-                        use_graph=not args.no_graph, device=dev, overlap=bool(args.overlap))
-    event = uw.make_event(T, H, W, rain_max, seed=42 + rank, spatial_rain=spatial, batch=B)
-    eng.load_event(event)
-    eng.reset()
+    engines = []
+    for i, name in enumerate(names):
+        H, W, nums, T, rain_max, cum_max, spatial = CONFIGS[name]
+        net_i, sd_i, cfg = build_net(H, W, 2 * nums + 3, dev)
+        eng_i = RolloutEngine(net_i, H, W, nums, rain_max, cum_max, batch=B, max_frames=T, spatial_rain=spatial, net_cfg=cfg,
+                              use_graph=not args.no_graph, device=dev, overlap=bool(args.overlap))
+        eng_i.load_event(uw.make_event(T, H, W, rain_max, seed=42 + rank + 100 * i, spatial_rain=spatial, batch=B))
+        eng_i.reset()
+        engines.append((eng_i, T))
+    H, W, nums, T, rain_max, cum_max, spatial = CONFIGS[names[0]]
+    C = 2 * nums + 3
+    eng = engines[0][0]
+    sd = sd_i   # state dict of the (single) shape: the CPU baseline runs the same weights
 
     def run_steps(k):
-        """k timesteps; a new event starts (states zeroed, frame counter reset) whenever T frames are done."""
+        """k timesteps; a new event starts (states zeroed, frame counter reset) whenever an event's T frames are done; with
+        several shapes the events alternate between the engines."""
         done = 0
         while done < k:
-            n = min(k - done, T - run_steps.t)
-            eng.run(n)
+            e, Te = engines[run_steps.which]
+            n = min(k - done, Te - run_steps.t)
+            e.run(n)
             run_steps.t += n
             done += n
-            if run_steps.t == T:
-                eng.reset()
+            if run_steps.t == Te:
+                e.reset()
                 run_steps.t = 0
+                run_steps.which = (run_steps.which + 1) % len(engines)
     run_steps.t = 0
+    run_steps.which = 0
 
     run_steps(args.warmup)
     torch.cuda.synchronize(dev)
@@ -172,7 +186,11 @@ def main():
 
     frames = args.steps * B * world
     fps = frames / elapsed
-    gflop = algorithmic_work(H, W, C)
+    if len(names) == 1:
+        gflop = algorithmic_work(H, W, C)
+    else:   # frame-weighted over one cycle of events
+        tot = sum(CONFIGS[n][3] for n in names)
+        gflop = sum(algorithmic_work(CONFIGS[n][0], CONFIGS[n][1], 2 * CONFIGS[n][2] + 3) * CONFIGS[n][3] for n in names) / tot
 
     result = {
         "metric": "flood-map frames/s (HxW water-depth grids), whole job",
@@ -187,8 +205,10 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"{args.config}: {H}x{W} grid, historical_nums={nums} (C={C}), T={T}, "
-                               f"{B} event(s) per GPU, inference rollout incl. per-frame input assembly",
+        "config": {"workload": (f"{args.config}: {H}x{W} grid, historical_nums={nums} (C={C}), T={T}, "
+                                f"{B} event(s) per GPU, inference rollout incl. per-frame input assembly") if len(names) == 1 else
+                               ("mixed: " + " + ".join(f"{n} {CONFIGS[n][0]}x{CONFIGS[n][1]} T={CONFIGS[n][3]}" for n in names) +
+                                f" events alternating, {B} event(s) per GPU, one hipGraph per shape"),
                    "events_per_gpu": B, "parallelism": f"event-parallel x{world} (no collective)",
                    "graph": not args.no_graph, "overlap_chains": bool(args.overlap)},
         "gflop_per_frame": gflop,
@@ -218,7 +238,7 @@ def main():
             }
         except Exception as exc:  # keep the headline number even if the side measurement fails
             result["roofline"] = {"error": repr(exc)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and len(names) == 1:
             try:
                 result["cpu_baseline"] = cpu_baseline(sd, args.config)
             except Exception as exc:

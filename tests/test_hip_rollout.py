@@ -270,3 +270,28 @@ def test_event_folder_evaluation_end_to_end(dev, tmp_path):
         want = compute_metrics(r_MinMaxScaler(ref, max=flood_max, min=0), target[0].numpy(), flood_thres=100.0)
         for k, v in mets[name].items():
             assert v == pytest.approx(want[k], rel=1e-3, abs=1e-6), (name, k)
+
+
+def test_inference_keeps_one_engine_per_shape(dev):
+    """Mixed-resolution event streams (BASELINE configs[4]): alternating shapes reuse their engines (no re-capture) and give
+    the same frames as the first visit."""
+    import urnn_amd.inference as inf
+    import urnn_amd.weights as uw
+    shapes = [(16, 24, 3, 5, False), (8, 12, 6, 4, True)]
+    nets = [make_net(H, W, 2 * n + 3, 3, dev)[0] for H, W, n, _, _ in shapes]
+    events = [uw.make_event(T, H, W, 6.0, seed=7 + i, spatial_rain=sp) for i, (H, W, n, T, sp) in enumerate(shapes)]
+    inf._ENGINES.clear()
+    first, engines = [], []
+    for rnd in range(3):
+        for i, (H, W, n, T, sp) in enumerate(shapes):
+            out = inf.Inference(nets[i], events[i], dev, historical_nums=n, rain_max=6.0, cumsum_rain_max=100.0,
+                                input_height=H, input_width=W)
+            assert out.shape == (T, H, W)
+            if rnd == 0:
+                first.append(out)
+                engines.append(next(reversed(inf._ENGINES.values())))
+            else:
+                assert np.array_equal(out, first[i])
+                assert next(reversed(inf._ENGINES.values())) is engines[i]
+    assert len(inf._ENGINES) == 2
+    inf._ENGINES.clear()

@@ -5,14 +5,15 @@
 //   A = weights      (lane l: n = g*NB*32 + nb*32 + (l & 31), k = 2*kp + (l >> 5))
 //   B = activations  (lane l: p = pixel(l & 31, pb),          k = 2*kp + (l >> 5))
 //   D[n][p] accumulates in AGPRs; epilogues fuse bias, LeakyReLU, AvgPool, the ConvTranspose scatter or the GroupNorm
-//   partial statistics.  fp32-input MFMA is bit-exact fp32 FMA (gfx950 has no TF32 path) and sustains 2.4 GHz.
+//   partial statistics.  fp32-input MFMA is bit-exact fp32 FMA (gfx950 has no TF32 path); under this load the chip clocks
+//   to about 2.1 GHz.
 //
-// Structure (third iteration; measurements in profiles/r01_kernel_bench_*.txt and DESIGN.md):
+// Structure (measurements in profiles/ and DESIGN.md):
 //   * WEIGHTS STATIONARY: a block stages the whole weight slab of ONE n-group (<= 110 KiB, K x 96 columns) into LDS once and
-//     then loops over pixel tiles (persistent blocks, 4 waves, one tile per wave at a time).  Streaming the weights per tile
+//     then loops over pixel tiles (persistent blocks of 4 or 8 waves, one tile per wave at a time).  Streaming the weights per tile
 //     (v2) doubled the bytes through the L2->CU load path, which saturates near 4.7 TB/s and was the measured bottleneck.
 //   * ACTIVATIONS are consumed by exactly the lane that loads them, so each wave owns a private LDS ring of D k-pair slots
-//     filled by asynchronous LDS-DMA (global_load_lds) D k-pairs ahead and drained with ds_read of the lane's own bytes:
+//     filled by asynchronous LDS-DMA (buffer_load ... lds) D slots ahead and drained with ds_read of the lane's own bytes:
 //     a per-lane FIFO -- no bank conflicts, no barriers, no VGPRs spent on prefetch, counted s_waitcnt vmcnt.
 //   * blocks b and b + 8 run on the same XCD (observed dispatch b % 8), so the NG n-groups that read the same pixel tiles are
 //     placed there: the second group's activation reads hit that XCD's L2.  Placement only affects speed.
@@ -235,7 +236,7 @@ __device__ __forceinline__ void block_role(int NG, int &g, int &slot, int &nslot
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// conv_gemm_kernel: persistent blocks of 4 waves; block owns n-group g (weights resident in LDS), each wave loops over
+// conv_gemm_kernel: persistent blocks of WPB waves; block owns n-group g (weights resident in LDS), each wave loops over
 // pixel tiles.  gridDim.x is a multiple of 8 * NG.  Dynamic LDS = aFloats*4 + WPB * (D + 1) * SLOT + NB * 128 (bias).
 // ------------------------------------------------------------------------------------------------------------------
 template <int NB, int PB, int MAP, int EPI, int D, int WPB>

@@ -18,7 +18,7 @@ def evaluate_events(net, dataset, device, historical_nums=30, rain_max=6.0, cums
     Event names are ``<location>/<event>`` (the reference keys on the event folder name, which collides across
     locations)."""
     metrics, outputs = {}, {}
-    for index in dataset.shard(rank, world_size):
+    for index in dataset.shard(rank, world_size):   # mixed grid shapes: Inference keeps one engine + hipGraph per shape
         inputs, target, event_dir = dataset.batched(int(index))
         H, W = inputs["absolute_DEM"].shape[-2], inputs["absolute_DEM"].shape[-1]
         frames = Inference(net, inputs, device, historical_nums=historical_nums, rain_max=rain_max,

@@ -10,7 +10,11 @@ import torch
 from .networks.model import ED
 from .rollout import RolloutEngine
 
+# One RolloutEngine (resident states, frame buffers, captured hipGraphs) per (net, grid, history, batch, rain kind): mixed-
+# resolution event streams (Futian / UKEA) switch between them without re-capturing.  Least recently used
+# engines are dropped beyond MAX_ENGINES (their frame buffers are sized for whole events: ~1.1 GB at 500x500, T=360).
 _ENGINES = {}
+MAX_ENGINES = 4
 
 
 def Inference(net, inputs, device, historical_nums=30, rain_max=6.0, cumsum_rain_max=250.0,
@@ -23,13 +27,14 @@ def Inference(net, inputs, device, historical_nums=30, rain_max=6.0, cumsum_rain
         spatial = not (rain.shape[-1] == 1 and rain.shape[-2] == 1)
         key = (id(net), input_height, input_width, historical_nums, float(rain_max), float(cumsum_rain_max), B, spatial,
                bool(use_graph))
-        eng = _ENGINES.get(key)
+        eng = _ENGINES.pop(key, None)
         if eng is None or eng.Tcap < Frames:
             eng = RolloutEngine(net, input_height, input_width, historical_nums, rain_max, cumsum_rain_max, batch=B,
                                 max_frames=Frames, spatial_rain=spatial, net_cfg=net_cfg, use_graph=use_graph,
                                 device=device, overlap=True)
-            _ENGINES.clear()   # one live engine: its frame buffers are sized for whole events
-            _ENGINES[key] = eng
+        _ENGINES[key] = eng                       # most recently used last
+        while len(_ENGINES) > MAX_ENGINES:
+            _ENGINES.pop(next(iter(_ENGINES)))
         eng.load_event(inputs)
         eng.reset()
         torch.cuda.synchronize(eng.device)
