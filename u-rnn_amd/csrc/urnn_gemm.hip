@@ -313,13 +313,13 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
     __syncthreads();
 
     if constexpr (WPB > 4) {
-        // Waves w and w + 4 share a SIMD.  Identical tiles would keep them in lockstep: both in the MFMA loop (sharing the
-        // pipe), then both in the store epilogue (pipe idle, and the whole chip bursting stores at once).  Holding the second
-        // wave back by half a tile puts the pair in anti-phase for the rest of the kernel: one wave's epilogue always hides
-        // behind the other's MFMAs.  The first wave runs alone (at full pipe rate) meanwhile, so no work is lost.
+        // Waves w and w + 4 share a SIMD.  Optional start offset for the later waves (prm.stagger eighths of an even split of
+        // one tile's MFMA time), meant to put the pair in anti-phase so that one wave's store epilogue hides behind the
+        // other's MFMAs.  Measured after the cell re-split: with one or two tiles per wave the offset costs more as tail than
+        // it hides (whole rollout 1070 frames/s at 0, 1047 at half a tile, 1020 at a full tile) -- the launcher passes 0.
         if (wave >= 4 && prm.stagger) {
             const int mf = (KT - kp_begin) * NB * PB;
-            const int naps = (mf * 64 * (wave >> 2) / (WPB / 4)) / (64 * 64);   // s_sleep 64 ~ 64*64 cycles
+            const int naps = (mf * 64 * (wave >> 2) / (WPB / 4)) * prm.stagger / 8 / (64 * 64);   // s_sleep 64 ~ 64*64 cycles; stagger/8 of the even split
             for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(64);
         }
     }
@@ -661,8 +661,8 @@ static int tune_stagger()
 {
     static int v = -1;
     if (v < 0) {
-        const char *e = getenv("URNN_TUNE_STAGGER");   // development knob: 0 starts both waves of a SIMD together
-        v = e ? atoi(e) : 1;
+        const char *e = getenv("URNN_TUNE_STAGGER");   // development knob: start offset of the second wave per SIMD
+        v = e ? atoi(e) : 0;   // in eighths of the even split (8 = half a tile for two waves per SIMD)
     }
     return v;
 }

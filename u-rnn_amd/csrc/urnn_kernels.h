@@ -30,7 +30,7 @@ struct ConvGemmParams {
     int Cout, F;
     float slope;
     float *out0;
-    int stagger;          // 8-wave blocks: hold the second wave of each SIMD back by half a tile (set by the launcher)
+    int stagger;          // 8-wave blocks: start offset of the second wave of each SIMD, in eighths of half a tile (launcher: 0)
     float *partial;       // EPI_GRU1: [B][2F/32][tiles][2]; EPI_CAND: [B][F/32][tiles][2]
 };
 
