@@ -55,6 +55,18 @@ def algorithmic_work(H, W, C):
     return 2.0 * mac / 1e9
 
 
+def a_stage_bytes(H, W, C):
+    """SURVEY 8d's A_stage: every one of the 13 stages reads its inputs once, writes its outputs once and reads its
+    parameters once (bytes per frame, B=1).  1225.7 MB at 500x500, C=63."""
+    P1, P2, P4 = H * W, (H // 2) * (W // 2), (H // 4) * (W // 4)
+    rd = P1 * (C + 80 + 64 + 224 + 64 + 16) + P2 * (160 + 96 + 288 + 96) + P4 * (192 + 192 + 96)
+    wr = P1 * (16 + 64 + 96 + 64 + 16 + 1) + P2 * (64 + 96 + 96 + 96) + P4 * (96 + 96 + 96)
+    par = 5 * 2 * 16 * P1                                                      # LayerNorm affines of the head
+    par += (C * 16 + 64 * 64 + 96 * 96) + 2 * 96 * 96 * 4 + 64 * 16 + 5 * 256 + 32            # stage convs, deconvs, head convs
+    par += 3 * (80 * 64 + 160 * 96 + 192 * 96 + 288 * 96 + 288 * 96 + 224 * 64)             # cells: conv1 (2F) + conv2 (F)
+    return 4.0 * (rd + wr + par)
+
+
 def gate_gemm_flops(H, W, B=1):
     """Algorithmic FLOP of the four launches per frame of conv_gemm_kernel<NB=2,PB=4,MAP_VEC,EPI_GRU1,D=4,WPB=8>
     (the z|r gates: 2F output channels x K input channels, two FLOP per MAC):
@@ -213,6 +225,8 @@ def main():
                    "graph": not args.no_graph, "overlap_chains": bool(args.overlap)},
         "gflop_per_frame": gflop,
         "step_mfma_frac": fps / world * gflop / 1e3 / PEAK_MFMA_F32_TFLOPS,
+        # frames/s x A_stage / 8 TB/s -- the unfused per-stage traffic model; the step is MFMA-bound (AI 49 FLOP/B)
+        "step_hbm_frac_a_stage": (fps / world * a_stage_bytes(H, W, C) / (PEAK_HBM_TBS * 1e12)) if len(names) == 1 else None,
     }
 
     if rank == 0:
