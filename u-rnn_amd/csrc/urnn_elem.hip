@@ -5,38 +5,44 @@
 
 // ------------------------------------------------------------------------------------------------------------------
 // GroupNorm finalise: partial (sum, sumsq) per tile -> per-channel (scale, shift) with
-//   y = (v - mean) * rstd * gamma + beta = v * scale + shift.   One block per (sample, 32-channel group).
+//   y = (v - mean) * rstd * gamma + beta = v * scale + shift.   One wavefront per (sample, 32-channel group).
 // Partials are fp32 sums over <= 4096 values; they are combined in double in a fixed order (deterministic).
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restrict__ partial, int ntiles, double count,
-                                                          const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                          float eps, float *__restrict__ ss, int C)
+// One wave per (sample, group): 32 independent partial loads in flight per lane, lane-strided double sums, xor butterfly
+// (the same fixed order as the fold in the candidate GEMM's prologue).
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float *__restrict__ partial, int ntiles, double count,
+                                                         const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                         float eps, float *__restrict__ ss, int C)
 {
-    __shared__ double sh1[256], sh2[256];
     const int G = C / 32;
     const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+    const int lane = threadIdx.x;
     const float *pp = partial + ((size_t)b * G + g) * ntiles * 2;
     double s1 = 0.0, s2 = 0.0;
-    for (int t = threadIdx.x; t < ntiles; t += 256) {
-        s1 += (double)pp[2 * t];
-        s2 += (double)pp[2 * t + 1];
-    }
-    sh1[threadIdx.x] = s1;
-    sh2[threadIdx.x] = s2;
-    __syncthreads();
-    for (int m = 128; m >= 1; m >>= 1) {
-        if ((int)threadIdx.x < m) {
-            sh1[threadIdx.x] += sh1[threadIdx.x + m];
-            sh2[threadIdx.x] += sh2[threadIdx.x + m];
+    for (int t0 = 0; t0 < ntiles; t0 += 64 * 32) {
+        f32x2 v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int t = t0 + u * 64 + lane;
+            v[u] = t < ntiles ? *reinterpret_cast<const f32x2 *>(pp + 2 * t) : f32x2{0.f, 0.f};
         }
-        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            s1 += (double)v[u].x;
+            s2 += (double)v[u].y;
+        }
     }
-    if (threadIdx.x < 32) {
-        const double mean = sh1[0] / count;
-        double var = sh2[0] / count - mean * mean;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        s1 += __shfl_xor(s1, m, 64);
+        s2 += __shfl_xor(s2, m, 64);
+    }
+    if (lane < 32) {
+        const double mean = s1 / count;
+        double var = s2 / count - mean * mean;
         var = var > 0.0 ? var : 0.0;
         const double rstd = 1.0 / sqrt(var + (double)eps);
-        const int c = g * 32 + threadIdx.x;
+        const int c = g * 32 + lane;
         const double sc = (double)gamma[c] * rstd;
         ss[((size_t)b * C + c) * 2] = (float)sc;
         ss[((size_t)b * C + c) * 2 + 1] = (float)((double)beta[c] - mean * sc);
@@ -46,7 +52,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restric
 hipError_t urnn_launch_gn_finalize(const float *partial, int ntiles, double count, const float *gamma, const float *beta,
                                    float eps, float *ss, int B, int C, hipStream_t st)
 {
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * (C / 32)), dim3(256), 0, st, partial, ntiles, count, gamma, beta, eps, ss, C);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * (C / 32)), dim3(64), 0, st, partial, ntiles, count, gamma, beta, eps, ss, C);
     return hipGetLastError();
 }
 
