@@ -314,31 +314,35 @@ __global__ __launch_bounds__(256) void head_k4(const HeadParams prm)
 }
 
 // LayerNorm finalise: one block per (which, sample); which = first + i * stride for i < n (blockIdx.y).
-__global__ __launch_bounds__(256) void ln_finalize_kernel(const HeadParams prm, int first, int stride, int nblk_used)
+__global__ __launch_bounds__(64) void ln_finalize_kernel(const HeadParams prm, int first, int stride, int nblk_used)
 {
-    __shared__ double sh1[256], sh2[256];
     const int which = first + blockIdx.y * stride;
     const int b = blockIdx.x;
+    const int lane = threadIdx.x;
     const float *pp = prm.partial + (((size_t)which * prm.B + b) * prm.nblk) * 2;
     double s1 = 0.0, s2 = 0.0;
-    for (int t = threadIdx.x; t < nblk_used; t += 256) {
-        s1 += (double)pp[2 * t];
-        s2 += (double)pp[2 * t + 1];
-    }
-    sh1[threadIdx.x] = s1;
-    sh2[threadIdx.x] = s2;
-    __syncthreads();
-    for (int m = 128; m >= 1; m >>= 1) {
-        if ((int)threadIdx.x < m) {
-            sh1[threadIdx.x] += sh1[threadIdx.x + m];
-            sh2[threadIdx.x] += sh2[threadIdx.x + m];
+    for (int t0 = 0; t0 < nblk_used; t0 += 64 * 16) {        // 16 independent loads in flight per lane, summed in order
+        f32x2 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int t = t0 + u * 64 + lane;
+            v[u] = t < nblk_used ? *reinterpret_cast<const f32x2 *>(pp + 2 * t) : f32x2{0.f, 0.f};
         }
-        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            s1 += (double)v[u].x;
+            s2 += (double)v[u].y;
+        }
     }
-    if (threadIdx.x == 0) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        s1 += __shfl_xor(s1, m, 64);
+        s2 += __shfl_xor(s2, m, 64);
+    }
+    if (lane == 0) {
         const double count = (double)HEAD_C * (double)prm.P;
-        const double mean = sh1[0] / count;
-        double var = sh2[0] / count - mean * mean;
+        const double mean = s1 / count;
+        double var = s2 / count - mean * mean;
         var = var > 0.0 ? var : 0.0;
         prm.stats[((size_t)which * prm.B + b) * 2] = (float)mean;
         prm.stats[((size_t)which * prm.B + b) * 2 + 1] = (float)(1.0 / sqrt(var + (double)prm.eps));
@@ -353,11 +357,11 @@ static hipError_t launch_head_v(const HeadParams &p, hipStream_t st)
     const int nb = (p.P + 256 * V - 1) / (256 * V);
     dim3 grid(nb, p.B), blk(256);
     hipLaunchKernelGGL(head_k1<V>, grid, blk, 0, st, p);
-    hipLaunchKernelGGL(ln_finalize_kernel, dim3(p.B, 1), blk, 0, st, p, 0, 1, nb);
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3(p.B, 1), dim3(64), 0, st, p, 0, 1, nb);
     hipLaunchKernelGGL(head_k2<V>, grid, blk, 0, st, p);
-    hipLaunchKernelGGL(ln_finalize_kernel, dim3(p.B, 2), blk, 0, st, p, 1, 2, nb);
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3(p.B, 2), dim3(64), 0, st, p, 1, 2, nb);
     hipLaunchKernelGGL(head_k3<V>, grid, blk, 0, st, p);
-    hipLaunchKernelGGL(ln_finalize_kernel, dim3(p.B, 2), blk, 0, st, p, 2, 2, nb);
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3(p.B, 2), dim3(64), 0, st, p, 2, 2, nb);
     hipLaunchKernelGGL(head_k4<V>, grid, blk, 0, st, p);
     return hipGetLastError();
 }
