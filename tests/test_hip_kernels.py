@@ -70,6 +70,35 @@ def test_gru_cells_vs_reference(gnet, dev, B):
         assert_close(y.cpu().numpy(), g[f"dec{i}_out_{t}"], TOL, f"decoder cell {i}")
 
 
+@pytest.mark.parametrize("I,F,skip,H,W,B,with_x", [
+    (5, 32, 0, 12, 20, 2, True),      # odd input width (zero-weight pad row), one norm group per gate
+    (16, 128, 1, 10, 10, 1, True),    # F=128: candidate GEMM in two n-groups of two blocks
+    (7, 128, 0, 6, 14, 3, True),
+    (96, 96, 1, 9, 7, 2, False),      # x == None (decoder stage 3), odd plane: dword DMA tiles
+    (33, 64, 1, 40, 36, 1, True),     # 16-byte DMA tiles, odd I in a skip cell
+    (16, 64, 0, 64, 66, 2, True),     # 128-pixel tiles with a ragged last tile
+])
+def test_gru_cell_shapes_vs_oracle(dev, I, F, skip, H, W, B, with_x):
+    """The cell through the C ABI for widths and planes the published network never builds, against the oracle."""
+    from oracle import oracle as orc
+    from urnn_amd import ops
+    rs = np.random.RandomState(1000 + I + F + H)
+    K = I + (2 * F if skip else F)
+    p = {"W1": rs.normal(0, 1 / np.sqrt(K), (2 * F, K)).astype(np.float32), "b1": rs.normal(0, 0.1, 2 * F).astype(np.float32),
+         "g1": rs.uniform(0.5, 1.5, 2 * F).astype(np.float32), "be1": rs.normal(0, 0.1, 2 * F).astype(np.float32),
+         "W2": rs.normal(0, 1 / np.sqrt(K), (F, K)).astype(np.float32), "b2": rs.normal(0, 0.1, F).astype(np.float32),
+         "g2": rs.uniform(0.5, 1.5, F).astype(np.float32), "be2": rs.normal(0, 0.1, F).astype(np.float32)}
+    x = rs.normal(0, 1, (B, I, H, W)).astype(np.float32) if with_x else None
+    e = rs.normal(0, 1, (B, F, H, W)).astype(np.float32) if skip else None
+    h = rs.normal(0, 1, (B, F, H, W)).astype(np.float32)
+    want = orc.gru_cell(x, e, h, p)
+    packed = ops.pack_gru(T(p["W1"].reshape(2 * F, K, 1, 1), dev), T(p["b1"], dev), T(p["W2"].reshape(F, K, 1, 1), dev),
+                          T(p["b2"], dev), I, F, bool(skip))
+    got = ops.gru_cell(None if x is None else T(x, dev), None if e is None else T(e, dev), T(h, dev), packed,
+                       T(p["g1"], dev), T(p["be1"], dev), T(p["g2"], dev), T(p["be2"], dev), I)
+    assert_close(got.cpu().numpy(), want, TOL, f"gru cell I={I} F={F} skip={skip} {H}x{W} B={B}")
+
+
 def test_gru_cell_in_place(gnet, dev):
     g, net, _ = gnet
     x, h = T(g["enc1_x_B1"], dev), T(g["enc1_h_B1"], dev)
