@@ -6,7 +6,7 @@ import sys
 from collections import defaultdict
 
 
-def main(path, filt=""):
+def main(path, filt="", frames=0):
     con = sqlite3.connect(path)
     tables = [r[0] for r in con.execute("select name from sqlite_master where type='table'")]
     T = lambda p: next(t for t in tables if t.startswith(p))
@@ -32,7 +32,20 @@ def main(path, filt=""):
         print(f"{name[:100]}  dispatches={n}  avg_us(profiled)={sum(dur[name].values())/n/1e3:.1f}")
         for c, v in sorted(acc[name].items()):
             print(f"    {c:32s} {v/n:16.1f}")
+    if frames < 0:   # auto: one advance_kernel per frame in the one-chain schedule
+        frames = max((len(cnt[n]) for n in cnt if "advance_kernel" in n), default=0)
+    if frames:
+        tot = defaultdict(float)
+        for name in acc:
+            for c, v in acc[name].items():
+                tot[c] += v
+        t_all = sum(sum(d.values()) for d in dur.values())
+        print(f"# totals over all kernels above, per frame ({frames} frames): kernel time {t_all/frames/1e3:.1f} us")
+        for c, v in sorted(tot.items()):
+            print(f"#   {c:32s} {v/frames:18.1f}")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "")
+    args = [a for a in sys.argv[1:] if not a.startswith("--frames=")]
+    frames = next((int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--frames=")), 0)
+    main(args[0], args[1] if len(args) > 1 else "", frames)
