@@ -1,0 +1,94 @@
+#!/usr/bin/env python
+"""Goldens for the training rows, produced by running the REFERENCE with autograd in this container:
+
+  * the loss `FocalBCE_and_WMSE` (losses.py:44-249) on seeded predictions/targets: components and d(loss)/d(reg);
+  * one SWP window of `seq_num` = 2 timesteps from zero states (main.py:598-700 `process_window` semantics: pred["reg"] is the
+    network output, pred["cls"] = where(output >= cls_thred, 1, 0), loss on the concatenated steps, one backward through both
+    steps and the recurrent states): loss, the per-step outputs, and the gradient of every one of the 79 unique parameter
+    tensors (`None` gradients -- the cls branch of the head is cut off by the non-differentiable mask -- are stored as flags).
+
+Needs /root/reference; never shipped to the GPU box.  Usage: python tests/golden/make_train_golden.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as mg  # noqa: E402  (reference imports, the .cuda shim, ref_net)
+
+from src.lib.model.networks.losses import FocalBCE_and_WMSE  # noqa: E402
+from src.lib.dataset.Dynamic2DFlood import preprocess_inputs  # noqa: E402
+from src.lib.utils.general import initialize_states  # noqa: E402
+import urnn_amd.weights as uw  # noqa: E402
+
+
+def gen_loss(out):
+    rs = np.random.RandomState(5)
+    tgt = (rs.uniform(0, 1, (1, 3, 10, 12)) ** 4).astype(np.float32)
+    tgt[tgt < 0.05] = 0.0                                      # ~half the cells dry, like a flood map
+    reg = (tgt * rs.uniform(0.5, 1.4, tgt.shape) + (rs.uniform(0, 1, tgt.shape) > 0.8) * 0.02).astype(np.float32)
+    for thr in (0.0, 0.01):
+        r = torch.from_numpy(reg).clone().requires_grad_(True)
+        cls = torch.where(r >= thr, 1, 0)
+        res = FocalBCE_and_WMSE(gamma=2, alpha=0.25)({"reg": r, "cls": cls}, torch.from_numpy(tgt), epoch=0)
+        res["loss"].backward()
+        tag = f"loss_thr{thr}"
+        for k, v in res.items():
+            out[f"{tag}_{k}"] = np.float64(v.item())
+        out[f"{tag}_dreg"] = r.grad.numpy()
+    out["loss_reg"], out["loss_tgt"] = reg, tgt
+
+
+def gen_window(out, H=16, W=16, nums=3, steps=2, wseed=21, eseed=8):
+    C = 2 * nums + 3
+    net, sd = mg.ref_net(H, W, C, wseed)
+    net.train()                                               # nothing in the model depends on the mode (no dropout / BN)
+    ev = uw.make_event(steps + 1, H, W, 60.0, seed=eseed)
+    tev = mg.event_to_torch(ev)
+    rs = np.random.RandomState(eseed)
+    tgt = (rs.uniform(0, 1, (1, steps, H, W)) ** 3).astype(np.float32)
+    tgt[tgt < 0.1] = 0.0
+    states = initialize_states(torch.device("cpu"), input_height=H, input_width=W, net_cfg=mg.CFG)
+    pred = None
+    for t in range(steps):
+        x = preprocess_inputs(t, tev, torch.device("cpu"), nums=nums, rain_max=60.0, cumsum_rain_max=250.0)
+        res = net(x, *states)
+        o, states = res[0], res[1:]
+        cls = torch.where(o >= 0, 1, 0)
+        pred = {"reg": o, "cls": cls} if pred is None else {"reg": torch.cat((pred["reg"], o), 1), "cls": torch.cat((pred["cls"], cls), 1)}
+    res = FocalBCE_and_WMSE(gamma=2, alpha=0.25)(pred, torch.from_numpy(tgt), epoch=0)
+    res["loss"].backward()
+    out.update({"win_H": H, "win_W": W, "win_nums": nums, "win_steps": steps, "win_weights_seed": wseed, "win_event_seed": eseed,
+                "win_rain_max": 60.0, "win_cumsum_max": 250.0, "win_target": tgt, "win_reg": pred["reg"].detach().numpy()})
+    for k, v in res.items():
+        out[f"win_{k}"] = np.float64(v.item())
+    named = dict(net.named_parameters())                       # named_parameters() de-duplicates the alias registrations
+    seen = set()
+    for key in sd:                                            # the 79 canonical names
+        p = named.get(key)
+        if p is None:                                         # registered only under an alias name: find the same storage
+            p = next(v for k, v in net.state_dict(keep_vars=True).items()
+                     if k.replace("_wrapper.module.", ".").replace(".conv1_module.", ".conv1.").replace(".conv2_module.", ".conv2.") == key)
+        assert id(p) not in seen
+        seen.add(id(p))
+        out[f"win_hasgrad_{key}"] = np.int32(p.grad is not None)
+        if p.grad is not None:
+            out[f"win_grad_{key}"] = p.grad.numpy()
+    for i, s in enumerate(states):
+        out[f"win_state{i}"] = s.detach().numpy()
+
+
+if __name__ == "__main__":
+    sys.modules.setdefault("wandb", types.ModuleType("wandb"))
+    out = {}
+    gen_loss(out)
+    gen_window(out)
+    path = os.path.join(HERE, "train_window_16x16.npz")
+    np.savez_compressed(path, **out)
+    ng = sum(1 for k in out if k.startswith("win_grad_"))
+    nn_ = sum(1 for k in out if k.startswith("win_hasgrad_"))
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB;", ng, "of", nn_, "parameters receive a gradient; loss", out["win_loss"])
