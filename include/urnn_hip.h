@@ -43,9 +43,10 @@ const char *urnn_last_error(void);
 size_t urnn_packed_conv_floats(int Cin, int Cout);
 int urnn_pack_conv_f32(const float *weight, const float *bias, float *packed, int Cin, int Cout, void *stream);
 
-/* Packed ConvGRU / Skip-ConvGRU weights: conv1 (2F x K) and conv2 (F x K) fused column-wise as
- * [z_i | r_i | c_i] per 32-channel block, split row-wise into the x | e | h segments; conv2's h part
- * (F x F) is stored separately (it multiplies r*h).  K = I + F (encoder, skip=0) or I + 2F (decoder).
+/* Packed ConvGRU / Skip-ConvGRU weights: the two GEMMs of the cell, each as the LDS image its kernel keeps resident
+ * (rows = input channels x | e | h in k-pairs, x padded to an even count): the gate GEMM conv1 (2F x K) in F/32 groups of
+ * [z_i | r_i] 32-column blocks + b1, then the candidate GEMM conv2 (F x K) in groups of at most three 32-column blocks + b2.
+ * K = I + F (encoder, skip=0) or I + 2F (decoder).  F must be 32, 64, 96 or 128.
  * Source: CGRU_cell.conv1[0] / conv2[0] weight+bias -- ConvRNN.py:94-104. */
 size_t urnn_packed_gru_floats(int I, int F, int skip);
 int urnn_pack_gru_f32(const float *W1, const float *b1, const float *W2, const float *b2, float *packed, int I, int F,
@@ -74,7 +75,7 @@ int urnn_gru_cell_f32(const float *x, const float *e, const float *h, const floa
                       const float *gn1_b, const float *gn2_w, const float *gn2_b, float *h_out, void *workspace,
                       size_t workspace_bytes, int B, int I, int F, int H, int W, float eps, void *stream);
 
-/* The same cell with a subset of its five kernels enqueued (profiling / roofline measurement: bench.py times the
+/* The same cell with a subset of its kernels enqueued (profiling / roofline measurement: bench.py times the
  * gate GEMM alone with this).  phase_mask is an OR of URNN_PHASE_*; URNN_PHASE_ALL == urnn_gru_cell_f32. */
 #define URNN_PHASE_GATES 1  /* gate GEMM: raw z|r gates, GroupNorm partial sums                          */
 #define URNN_PHASE_GN1 2    /* GroupNorm finalise of the gates (part of the CAND kernel when both set) */
