@@ -43,6 +43,11 @@ def test_packed_sizes_and_argument_errors_without_gpu(built):
     assert b"NULL" in lib.urnn_last_error()
     assert lib.urnn_gru_cell_f32(0, 0, 16, 16, 16, 16, 16, 16, 16, 16, 1 << 30, 1, 16, 48, 4, 4, 1e-5, 0) == -1  # F % 32
     assert b"multiple of 32" in lib.urnn_last_error()
+    # planes whose per-sample segments pass 4 GiB (32-bit DMA offsets) are refused, not mis-addressed
+    assert lib.urnn_gru_cell_f32(0, 0, 16, 16, 16, 16, 16, 16, 16, 16, 1 << 30, 1, 16, 128, 4096, 4096, 1e-5, 0) == -1
+    assert b"4-GiB" in lib.urnn_last_error()
+    assert lib.urnn_stage_conv_f32(16, 16, 16, 1, 64, 64, 5000, 5000, 0, 0.2, 0) == -1
+    assert lib.urnn_deconv2x2_f32(16, 16, 16, 1, 96, 96, 2000, 2000, 0.2, 0) == -1
 
 
 def test_no_cpu_fallback():

@@ -33,6 +33,10 @@ static int hip_fail(hipError_t e, const char *what)
     } while (0)
 
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// The activation DMA addresses one input of one sample through a buffer descriptor with 32-bit offsets: channels * P * 4
+// bytes must stay below 4 GiB (P < 8.3 M pixels at 128 channels).  Larger planes need the spatial tiling of SURVEY 8(e).
+static inline bool plane_fits(long P, int channels) { return P > 0 && (double)P * 4.0 * (double)(channels + 2) < 4294967296.0; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline size_t slab_floats(size_t KT, size_t NB) { return (KT * NB * 64 + 255) / 256 * 256; }
 
@@ -118,6 +122,7 @@ extern "C" int urnn_stage_conv_f32(const float *in, const float *packed, float *
     if (pool && (H < 2 || W < 2)) return fail(URNN_EINVAL, "urnn_stage_conv_f32: pool needs H,W >= 2");
     if (!aligned16(in) || !aligned16(out) || !aligned16(packed)) return fail(URNN_EALIGN, "urnn_stage_conv_f32: pointers must be 16-byte aligned");
     const long P = (long)H * W;
+    if (!plane_fits(P, Cin > Cout ? Cin : Cout)) return fail(URNN_EINVAL, "urnn_stage_conv_f32: %d x %d plane with %d channels exceeds the 4-GiB segment limit", H, W, Cin > Cout ? Cin : Cout);
     const int NB = urnn_conv_nb(Cout), NG = ((Cout + 31) / 32) / NB;
     ConvGemmParams p = {};
     p.seg[0] = p.seg[1] = p.seg[2] = in;
@@ -195,6 +200,7 @@ extern "C" int urnn_gru_cell_phases_f32(const float *x, const float *e, const fl
     if (!aligned16(h) || !aligned16(h_out) || !aligned16(packed) || !aligned16(workspace) || (x && !aligned16(x)) || (e && !aligned16(e)))
         return fail(URNN_EALIGN, "urnn_gru_cell_f32: pointers must be 16-byte aligned");
     const long P = (long)H * W;
+    if (!plane_fits(P, 2 * F > I ? 2 * F : I)) return fail(URNN_EINVAL, "urnn_gru_cell_f32: %d x %d plane exceeds the 4-GiB segment limit", H, W);
     const GruWs ws = carve_gru(workspace, B, F, P);
     if (workspace_bytes < ws.bytes)
         return fail(URNN_EWORKSPACE, "urnn_gru_cell_f32: workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
@@ -290,6 +296,8 @@ extern "C" int urnn_deconv2x2_f32(const float *in, const float *packed, float *o
         return fail(URNN_EINVAL, "urnn_deconv2x2_f32: bad dims (Cout must be <= 96, got %d)", Cout);
     if (!aligned16(in) || !aligned16(out) || !aligned16(packed)) return fail(URNN_EALIGN, "urnn_deconv2x2_f32: pointers must be 16-byte aligned");
     const long P = (long)H * W;
+    if (!plane_fits(4 * P, Cin > Cout ? Cin : Cout))
+        return fail(URNN_EINVAL, "urnn_deconv2x2_f32: %d x %d output plane exceeds the 4-GiB segment limit", 2 * H, 2 * W);
     const int NB = 2 * ((Cout + 31) / 32);
     ConvGemmParams p = {};
     p.seg[0] = p.seg[1] = p.seg[2] = in;
