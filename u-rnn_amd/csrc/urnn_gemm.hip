@@ -23,6 +23,7 @@
 #include "urnn_common.h"
 #include "urnn_kernels.h"
 
+#include <atomic>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -702,8 +703,13 @@ static hipError_t launch_conv_cfg(const ConvGemmParams &p, hipStream_t st, int m
     const size_t lds = conv_lds_bytes<NB, PB, MAP, EPI>(p, D, WPB);
     if (lds > LDS_PER_CU) return hipErrorInvalidValue;
     auto kern = conv_gemm_kernel<NB, PB, MAP, EPI, D, WPB>;
-    hipError_t e = allow_big_lds(kern, lds);
-    if (e != hipSuccess) return e;
+    // raise this instantiation's dynamic-LDS cap once (and again only if a launch needs more); one process drives one GPU
+    static std::atomic<size_t> allowed{64 * 1024};
+    if (lds > allowed.load(std::memory_order_relaxed)) {
+        hipError_t e = allow_big_lds(kern, LDS_PER_CU);
+        if (e != hipSuccess) return e;
+        allowed.store(LDS_PER_CU, std::memory_order_relaxed);
+    }
     const int grid = persistent_grid(lds, p.NG, p.totalTiles, WPB, max_bpc);
     ConvGemmParams q = p;
     q.stagger = tune_stagger();
