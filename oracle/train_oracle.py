@@ -47,3 +47,75 @@ def loss_and_grad(reg, tgt, cls_thred=0.0):
     comps = {"loss": loss_reg + CLS_WEIGHT * loss_cls, "loss_reg": loss_reg, "loss_reg_label": flood, "loss_reg_pred": dry,
              "loss_cls": loss_cls}
     return comps, g
+
+
+# ---- ConvGRU / Skip-ConvGRU cell: forward + backward (ConvRNN.py:111-194 with 1x1 gates), float64 -------------------------
+def _gn_forward(v, gamma, beta, eps):
+    """GroupNorm with 32-channel groups over (32, P) per sample.  v (B,C,P) -> y, xhat, rstd (B,G,1,1)."""
+    B, C, P = v.shape
+    G = C // 32
+    vg = v.reshape(B, G, 32 * P)
+    mu = vg.mean(axis=2, keepdims=True)
+    var = vg.var(axis=2, keepdims=True)
+    rstd = 1.0 / np.sqrt(var + eps)
+    xhat = ((vg - mu) * rstd).reshape(B, C, P)
+    return xhat * gamma[None, :, None] + beta[None, :, None], xhat, rstd
+
+
+def _gn_backward(dy, xhat, rstd, gamma):
+    """Returns (dv, dgamma, dbeta)."""
+    B, C, P = dy.shape
+    G = C // 32
+    dxh = dy * gamma[None, :, None]
+    dg, xg = dxh.reshape(B, G, 32 * P), xhat.reshape(B, G, 32 * P)
+    dv = rstd * (dg - dg.mean(axis=2, keepdims=True) - xg * (dg * xg).mean(axis=2, keepdims=True))
+    return dv.reshape(B, C, P), (dy * xhat).sum(axis=(0, 2)), dy.sum(axis=(0, 2))
+
+
+def gru_cell_backward(x, e, h, p, dout, eps=1e-5):
+    """Gradients of sum(h' * dout) for one cell step.  x may be None (zeros, I channels; no dx returned), e None for the
+    encoder cell.  `p` holds W1 (2F,K[,1,1]), b1, g1, be1, W2 (F,K[,1,1]), b2, g2, be2 with K ordered x | e | h.
+    Returns (h', grads) with grads keys dx, de, dh, dW1, db1, dg1, dbe1, dW2, db2, dg2, dbe2 (shapes of the parameters)."""
+    f64 = lambda a: np.asarray(a, np.float64)
+    h = f64(h)
+    B, F, H, W = h.shape
+    P = H * W
+    W1 = f64(p["W1"]).reshape(2 * F, -1)
+    W2 = f64(p["W2"]).reshape(F, -1)
+    K = W1.shape[1]
+    I = K - (2 * F if e is not None else F)
+    xs = f64(x).reshape(B, I, P) if x is not None else np.zeros((B, I, P))
+    parts = [xs] + ([f64(e).reshape(B, F, P)] if e is not None else [])
+    hp = h.reshape(B, F, P)
+    do = f64(dout).reshape(B, F, P)
+    A = np.concatenate(parts + [hp], axis=1)
+    g_raw = np.einsum("nk,bkp->bnp", W1, A) + f64(p["b1"])[None, :, None]
+    y1, xh1, rstd1 = _gn_forward(g_raw, f64(p["g1"]), f64(p["be1"]), eps)
+    s = 1.0 / (1.0 + np.exp(-y1))
+    z, r = s[:, :F], s[:, F:]
+    A2 = np.concatenate(parts + [r * hp], axis=1)
+    c_raw = np.einsum("nk,bkp->bnp", W2, A2) + f64(p["b2"])[None, :, None]
+    y2, xh2, rstd2 = _gn_forward(c_raw, f64(p["g2"]), f64(p["be2"]), eps)
+    n = np.tanh(y2)
+    hnew = (1 - z) * hp + z * n
+    # backward
+    dz, dn, dh = do * (n - hp), do * z, do * (1 - z)
+    dc, dg2, dbe2 = _gn_backward(dn * (1 - n * n), xh2, rstd2, f64(p["g2"]))
+    dW2 = np.einsum("bnp,bkp->nk", dc, A2)
+    dA2 = np.einsum("nk,bnp->bkp", W2, dc)
+    drh = dA2[:, K - F:]
+    dr = drh * hp
+    dh = dh + drh * r
+    dy1 = np.concatenate([dz * z * (1 - z), dr * r * (1 - r)], axis=1)
+    dgr, dg1, dbe1 = _gn_backward(dy1, xh1, rstd1, f64(p["g1"]))
+    dW1 = np.einsum("bnp,bkp->nk", dgr, A)
+    dA = np.einsum("nk,bnp->bkp", W1, dgr)
+    dA[:, :K - F] += dA2[:, :K - F]
+    dh = dh + dA[:, K - F:]
+    grads = {"dh": dh.reshape(B, F, H, W), "dW1": dW1.reshape(np.shape(p["W1"])), "db1": dgr.sum(axis=(0, 2)), "dg1": dg1,
+             "dbe1": dbe1, "dW2": dW2.reshape(np.shape(p["W2"])), "db2": dc.sum(axis=(0, 2)), "dg2": dg2, "dbe2": dbe2}
+    if x is not None:
+        grads["dx"] = dA[:, :I].reshape(B, I, H, W)
+    if e is not None:
+        grads["de"] = dA[:, I:I + F].reshape(B, F, H, W)
+    return hnew.reshape(B, F, H, W), grads

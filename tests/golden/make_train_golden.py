@@ -82,11 +82,53 @@ def gen_window(out, H=16, W=16, nums=3, steps=2, wseed=21, eseed=8):
         out[f"win_state{i}"] = s.detach().numpy()
 
 
+def gen_cell_backward(out):
+    """One ConvGRU / Skip-ConvGRU cell (ConvRNN.py:73-194, 1x1 gates) with seeded parameters and inputs: the gradients of a
+    random upstream dL/dh' w.r.t. every input and parameter, from reference autograd."""
+    from src.lib.model.networks.ConvRNN import CGRU_cell
+    for tag, (I, F, module, H, W, B, with_x) in {
+        "enc": (16, 64, "encoder", 16, 16, 1, True),
+        "dec": (96, 64, "decoder", 8, 12, 2, True),
+        "dec0": (96, 96, "decoder", 4, 4, 1, False),          # x == None (decoder stage 3)
+    }.items():
+        rs = np.random.RandomState(300 + I + F)
+        cell = CGRU_cell(False, (H, W), I, 1, F, module)
+        with torch.no_grad():
+            for prm in cell.parameters():
+                if prm.ndim == 4:
+                    prm.copy_(torch.from_numpy(rs.normal(0, 1 / np.sqrt(prm.shape[1]), prm.shape).astype(np.float32)))
+                else:
+                    prm.copy_(torch.from_numpy(rs.uniform(0.5, 1.5, prm.shape).astype(np.float32)
+                                               if prm is cell.conv1[1].weight or prm is cell.conv2[1].weight
+                                               else rs.normal(0, 0.1, prm.shape).astype(np.float32)))
+        x = torch.from_numpy(rs.normal(0, 1, (B, I, H, W)).astype(np.float32)).requires_grad_(True)
+        h = torch.from_numpy(rs.normal(0, 0.5, (B, F, H, W)).astype(np.float32)).requires_grad_(True)
+        e = torch.from_numpy(rs.normal(0, 0.5, (B, F, H, W)).astype(np.float32)).requires_grad_(True) if module == "decoder" else None
+        hidden = torch.cat((e, h), 1) if e is not None else h
+        y = cell(x[None] if with_x else None, hidden)[0]
+        dout = torch.from_numpy(rs.normal(0, 1, y.shape).astype(np.float32))
+        y.backward(dout)
+        out.update({f"cell_{tag}_I": I, f"cell_{tag}_F": F, f"cell_{tag}_skip": int(e is not None), f"cell_{tag}_with_x": int(with_x),
+                    f"cell_{tag}_x": x.detach().numpy(), f"cell_{tag}_h": h.detach().numpy(), f"cell_{tag}_dout": dout.numpy(),
+                    f"cell_{tag}_out": y.detach().numpy(), f"cell_{tag}_dh": h.grad.numpy()})
+        if with_x:
+            out[f"cell_{tag}_dx"] = x.grad.numpy()
+        if e is not None:
+            out[f"cell_{tag}_e"], out[f"cell_{tag}_de"] = e.detach().numpy(), e.grad.numpy()
+        for name, prm in (("W1", cell.conv1[0].weight), ("b1", cell.conv1[0].bias), ("g1", cell.conv1[1].weight), ("be1", cell.conv1[1].bias),
+                          ("W2", cell.conv2[0].weight), ("b2", cell.conv2[0].bias), ("g2", cell.conv2[1].weight), ("be2", cell.conv2[1].bias)):
+            out[f"cell_{tag}_{name}"] = prm.detach().numpy()
+            out[f"cell_{tag}_d{name}"] = prm.grad.numpy()
+
+
 if __name__ == "__main__":
     sys.modules.setdefault("wandb", types.ModuleType("wandb"))
     out = {}
     gen_loss(out)
     gen_window(out)
+    cells = {}
+    gen_cell_backward(cells)
+    np.savez_compressed(os.path.join(HERE, "train_cell_backward.npz"), **cells)
     path = os.path.join(HERE, "train_window_16x16.npz")
     np.savez_compressed(path, **out)
     ng = sum(1 for k in out if k.startswith("win_grad_"))

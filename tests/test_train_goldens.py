@@ -41,3 +41,20 @@ def test_gradient_golden_covers_every_parameter_and_the_cls_branch_is_cut(gold):
         cls_branch = n.startswith("head.cls_")
         # the wet/dry mask is a non-differentiable comparison: nothing flows into the classification branch
         assert (np.abs(g).max() == 0.0) == cls_branch, n
+
+
+@pytest.mark.parametrize("tag", ["enc", "dec", "dec0"])
+def test_cell_backward_oracle_matches_reference_autograd(tag):
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_cell_backward.npz"))
+    k = lambda n: g[f"cell_{tag}_{n}"]
+    p = {n: k(n) for n in ("W1", "b1", "g1", "be1", "W2", "b2", "g2", "be2")}
+    x = k("x") if int(k("with_x")) else None
+    e = k("e") if int(k("skip")) else None
+    out, grads = tro.gru_cell_backward(x, e, k("h"), p, k("dout"))
+    assert np.abs(out - k("out")).max() <= 2e-6 * np.abs(k("out")).max()
+    for name, got in grads.items():
+        ref = k(name)
+        scale = max(np.abs(ref).max(), 1e-30)
+        assert np.abs(got - ref).max() <= 2e-5 * scale, (tag, name, np.abs(got - ref).max() / scale)
+    if x is None:   # x == 0: its weight columns see no gradient
+        assert np.abs(grads["dW1"].reshape(grads["dW1"].shape[0], -1)[:, :int(k("I"))]).max() == 0.0
