@@ -131,6 +131,22 @@ int urnn_stage1_scalar_rain_f32(const float *S, const float *rain, const float *
                                 float *out, int t, const int *t_dev, int B, int T, int nums, int Cout, int H, int W,
                                 float rain_max, float cumsum_max, float slope, void *stream);
 
+/* ---- training building blocks (the training loop itself is not built yet) ------------------- */
+
+/* Backward of urnn_gru_cell_f32: gradients of every input and parameter of one ConvGRU / Skip-ConvGRU step
+ * (autograd of CGRU_cell.forward -- ConvRNN.py:111-194) given dL/dh' (dh_out).
+ * Call it after the forward of the SAME x / e / h with the forward's workspace untouched (fwd_workspace: it holds the raw
+ * gates, the raw candidate, the folded GroupNorm tables and the group statistics).  W1 (2F,K) / W2 (F,K) are the conv
+ * weights in their reference layout, K ordered x | e | h.  dx / de must be non-NULL exactly when x / e are; dx, de, dh
+ * (B,*,H,W) are overwritten; the parameter gradients (shapes of the parameters) are overwritten, or added to when
+ * accumulate != 0 (BPTT over the steps of an SWP window).  Deterministic: reductions use fixed-order partial sums. */
+size_t urnn_gru_cell_backward_workspace_bytes(int B, int I, int F, int skip, int H, int W);
+int urnn_gru_cell_backward_f32(const float *x, const float *e, const float *h, const float *W1, const float *W2, const float *gn1_w,
+                               const float *gn2_w, const void *fwd_workspace, const float *dh_out, float *dx, float *de, float *dh,
+                               float *dW1, float *db1, float *dgn1_w, float *dgn1_b, float *dW2, float *db2, float *dgn2_w,
+                               float *dgn2_b, void *workspace, size_t workspace_bytes, int B, int I, int F, int H, int W,
+                               int accumulate, void *stream);
+
 /* Device-side frame counter helper for graph-captured rollouts: *counter += delta. */
 int urnn_advance_counter(int *counter, int delta, void *stream);
 

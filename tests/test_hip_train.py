@@ -1,0 +1,100 @@
+"""GPU parity of the training building blocks built so far: the ConvGRU / Skip-ConvGRU cell backward
+through the C ABI against reference-autograd goldens and, on other shapes, against the float64 oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+GRAD_TOL = 2e-4     # fp32 kernels vs float64 / reference fp32 autograd, relative to each tensor's max
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def T(a, dev):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+
+
+def run_cell(dev, x, e, h, p, dout):
+    from urnn_amd import ops, train_ops
+    F = h.shape[1]
+    K = p["W1"].reshape(2 * F, -1).shape[1]
+    I = K - (2 * F if e is not None else F)
+    W1, W2 = T(p["W1"].reshape(2 * F, K, 1, 1), dev), T(p["W2"].reshape(F, K, 1, 1), dev)
+    packed = ops.pack_gru(W1, T(p["b1"], dev), W2, T(p["b2"], dev), I, F, e is not None)
+    xs, es, hs = T(x, dev), T(e, dev), T(h, dev)
+    out = ops.gru_cell(xs, es, hs, packed, T(p["g1"], dev), T(p["be1"], dev), T(p["g2"], dev), T(p["be2"], dev), I)
+    g = train_ops.gru_cell_backward(xs, es, hs, W1, W2, T(p["g1"], dev), T(p["g2"], dev), T(dout, dev), I)
+    return out.cpu().numpy(), {k: v.cpu().numpy() for k, v in g.items() if v is not None}
+
+
+def check_grads(got, want, what):
+    for name, ref in want.items():
+        assert_close(got[name].reshape(ref.shape), ref, GRAD_TOL, f"{what}: {name}")
+
+
+@pytest.mark.parametrize("tag", ["enc", "dec", "dec0"])
+def test_cell_backward_vs_reference_autograd(dev, tag):
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_cell_backward.npz"))
+    k = lambda n: g[f"cell_{tag}_{n}"]
+    p = {n: k(n) for n in ("W1", "b1", "g1", "be1", "W2", "b2", "g2", "be2")}
+    x = k("x") if int(k("with_x")) else None
+    e = k("e") if int(k("skip")) else None
+    out, grads = run_cell(dev, x, e, k("h"), p, k("dout"))
+    assert_close(out, k("out"), 1e-4, f"{tag}: forward")
+    want = {n: k(n) for n in ("dh", "dW1", "db1", "dg1", "dbe1", "dW2", "db2", "dg2", "dbe2")}
+    if x is not None:
+        want["dx"] = k("dx")
+    if e is not None:
+        want["de"] = k("de")
+    check_grads(grads, want, tag)
+
+
+@pytest.mark.parametrize("I,F,skip,H,W,B", [(5, 32, 0, 12, 20, 2), (33, 96, 1, 9, 7, 1), (16, 64, 0, 70, 66, 1), (7, 128, 1, 6, 14, 2)])
+def test_cell_backward_shapes_vs_oracle(dev, I, F, skip, H, W, B):
+    from oracle import train_oracle as tro
+    rs = np.random.RandomState(77 + I + F + H)
+    K = I + (2 * F if skip else F)
+    p = {"W1": rs.normal(0, 1 / np.sqrt(K), (2 * F, K)).astype(np.float32), "b1": rs.normal(0, 0.1, 2 * F).astype(np.float32),
+         "g1": rs.uniform(0.5, 1.5, 2 * F).astype(np.float32), "be1": rs.normal(0, 0.1, 2 * F).astype(np.float32),
+         "W2": rs.normal(0, 1 / np.sqrt(K), (F, K)).astype(np.float32), "b2": rs.normal(0, 0.1, F).astype(np.float32),
+         "g2": rs.uniform(0.5, 1.5, F).astype(np.float32), "be2": rs.normal(0, 0.1, F).astype(np.float32)}
+    x = rs.normal(0, 1, (B, I, H, W)).astype(np.float32)
+    e = rs.normal(0, 0.5, (B, F, H, W)).astype(np.float32) if skip else None
+    h = rs.normal(0, 0.5, (B, F, H, W)).astype(np.float32)
+    dout = rs.normal(0, 1, (B, F, H, W)).astype(np.float32)
+    _, want = tro.gru_cell_backward(x, e, h, p, dout)
+    _, grads = run_cell(dev, x, e, h, p, dout)
+    check_grads(grads, want, f"I={I} F={F} skip={skip} {H}x{W} B={B}")
+
+
+def test_cell_backward_accumulates_parameter_gradients_and_is_deterministic(dev):
+    from urnn_amd import ops, train_ops
+    rs = np.random.RandomState(3)
+    I, F, H, W, B = 16, 64, 20, 28, 1
+    K = I + F
+    mk = lambda *s: T(rs.normal(0, 0.3, s).astype(np.float32), dev)
+    W1, W2 = mk(2 * F, K, 1, 1), mk(F, K, 1, 1)
+    b1, b2, be1, be2 = mk(2 * F), mk(F), mk(2 * F), mk(F)
+    g1, g2 = T(rs.uniform(0.5, 1.5, 2 * F), dev), T(rs.uniform(0.5, 1.5, F), dev)
+    packed = ops.pack_gru(W1, b1, W2, b2, I, F, False)
+    x, h, dout = mk(B, I, H, W), mk(B, F, H, W), mk(B, F, H, W)
+
+    def once(grads=None, acc=False):
+        ops.gru_cell(x, None, h, packed, g1, be1, g2, be2, I)
+        return train_ops.gru_cell_backward(x, None, h, W1, W2, g1, g2, dout, I, grads=grads, accumulate=acc)
+    a = {k: v.clone() for k, v in once().items() if v is not None}
+    b = once()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k                      # bit-reproducible
+    c = once(grads=b, acc=True)
+    for k in ("dW1", "db1", "dg1", "dbe1", "dW2", "db2", "dg2", "dbe2"):
+        assert torch.allclose(c[k], 2 * a[k], rtol=1e-6, atol=0), k
+    assert torch.equal(c["dh"], a["dh"]) and torch.equal(c["dx"], a["dx"])      # input gradients are overwritten

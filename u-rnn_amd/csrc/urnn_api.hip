@@ -157,6 +157,7 @@ extern "C" int urnn_stage_conv_f32(const float *in, const float *packed, float *
 // ---- GRU cell --------------------------------------------------------------------------------------------------------
 struct GruWs {
     float *g1, *cx, *part1, *part2, *ss1, *ss2;
+    float *st1, *st2;   // per (sample, norm group) (mean, rstd) of the gates / the candidate: read by the backward pass
     size_t bytes;
 };
 
@@ -177,6 +178,8 @@ static GruWs carve_gru(void *base, int B, int F, long P)
     w.part2 = take((size_t)B * (F / 32) * tiles * 2);
     w.ss1 = take((size_t)B * 2 * F * 2);
     w.ss2 = take((size_t)B * F * 2);
+    w.st1 = take((size_t)B * (2 * F / 32) * 2);
+    w.st2 = take((size_t)B * (F / 32) * 2);
     w.bytes = off;
     return w;
 }
@@ -243,7 +246,7 @@ extern "C" int urnn_gru_cell_phases_f32(const float *x, const float *e, const fl
     // GroupNorm finalise of the gates: folded into the candidate GEMM's prologue; launched on its own only when asked for
     // without the candidate phase (profiling)
     if ((phase_mask & URNN_PHASE_GN1) && !(phase_mask & URNN_PHASE_CAND))
-        CHECK_HIP(urnn_launch_gn_finalize(ws.part1, tiles1, 32.0 * (double)P, gn1_w, gn1_b, eps, ws.ss1, B, 2 * F, st), "gn finalize 1");
+        CHECK_HIP(urnn_launch_gn_finalize(ws.part1, tiles1, 32.0 * (double)P, gn1_w, gn1_b, eps, ws.ss1, ws.st1, B, 2 * F, st), "gn finalize 1");
 
     // K2: candidate (pre-norm) = W2 . [x; e; sigmoid(GN(r)) * h] + b2, GroupNorm partials.  The hidden-state rows are gated
     // on the fly from the raw reset gate and K1's folded (scale, shift).
@@ -260,6 +263,7 @@ extern "C" int urnn_gru_cell_phases_f32(const float *x, const float *e, const fl
     c.gn_b = gn1_b;
     c.eps = eps;
     c.ss_out = ws.ss1;
+    c.stat_out = ws.st1;
     c.wt = packed + (size_t)NW * p.aFloats + 2 * F;
     c.aFloats = (int)slab_floats(KT, NB2);
     c.NG = NG2;
@@ -272,7 +276,7 @@ extern "C" int urnn_gru_cell_phases_f32(const float *x, const float *e, const fl
     const int tiles2 = (int)((P + 32 * pb2 - 1) / (32 * pb2));
     if (phase_mask & URNN_PHASE_CAND) CHECK_HIP(urnn_launch_cand(c, B, pb2, map2, st), "gru candidate");
     if (phase_mask & URNN_PHASE_GN2)
-        CHECK_HIP(urnn_launch_gn_finalize(ws.part2, tiles2, 32.0 * (double)P, gn2_w, gn2_b, eps, ws.ss2, B, F, st), "gn finalize 2");
+        CHECK_HIP(urnn_launch_gn_finalize(ws.part2, tiles2, 32.0 * (double)P, gn2_w, gn2_b, eps, ws.ss2, ws.st2, B, F, st), "gn finalize 2");
 
     // K3: blend
     if (phase_mask & URNN_PHASE_BLEND) CHECK_HIP(urnn_launch_blend(ws.g1, ws.cx, h, ws.ss1, ws.ss2, h_out, B, F, (int)P, st), "gru blend");
@@ -285,6 +289,116 @@ extern "C" int urnn_gru_cell_f32(const float *x, const float *e, const float *h,
 {
     return urnn_gru_cell_phases_f32(x, e, h, packed, gn1_w, gn1_b, gn2_w, gn2_b, h_out, workspace, workspace_bytes, B, I, F, H, W,
                                     eps, URNN_PHASE_ALL, stream);
+}
+
+// ---- GRU cell backward (training building block) ----------------------------------------------------------------------
+struct GruBwdWs {
+    float *dy1, *dy2, *rh, *dA2, *dA, *wt1, *wt2, *pk1, *pk2, *chpart, *coef, *wpart;
+    double *sums;
+    size_t bytes;
+};
+
+static GruBwdWs carve_gru_bwd(void *base, int B, int I, int F, int skip, long P)
+{
+    const int K = I + (skip ? F : 0) + F;
+    size_t off = 0;
+    auto take = [&](size_t nbytes) {
+        char *p = base ? reinterpret_cast<char *>(base) + off : nullptr;
+        off += align_up(nbytes, 256);
+        return p;
+    };
+    auto takef = [&](size_t nfloats) { return reinterpret_cast<float *>(take(nfloats * sizeof(float))); };
+    GruBwdWs w;
+    w.dy1 = takef((size_t)B * 2 * F * P);
+    w.dy2 = takef((size_t)B * F * P);
+    w.rh = takef((size_t)B * F * P);
+    w.dA2 = takef((size_t)B * K * P);
+    w.dA = takef((size_t)B * K * P);
+    w.wt1 = takef((size_t)2 * F * K);
+    w.wt2 = takef((size_t)F * K);
+    w.pk1 = takef(urnn_packed_conv_floats(2 * F, K));
+    w.pk2 = takef(urnn_packed_conv_floats(F, K));
+    w.chpart = takef((size_t)B * 2 * F * urnn_train_nchunk((int)P) * 2);
+    w.coef = takef((size_t)B * (2 * F / 32) * 2);
+    w.wpart = takef(urnn_train_wgrad_partial_floats(B, 2 * F, K, (int)P));
+    w.sums = reinterpret_cast<double *>(take((size_t)B * 2 * F * 2 * sizeof(double)));
+    w.bytes = off;
+    return w;
+}
+
+extern "C" size_t urnn_gru_cell_backward_workspace_bytes(int B, int I, int F, int skip, int H, int W)
+{
+    if (B < 1 || I < 1 || F < 32 || F % 32 != 0 || F > 128 || H < 1 || W < 1) return 0;
+    return carve_gru_bwd(nullptr, B, I, F, skip ? 1 : 0, (long)H * W).bytes;
+}
+
+// dX = W^T . dY through the forward GEMM kernel: "weight" = W^T (K x N), identity epilogue, no bias.  out (B,K,P).
+static int dx_gemm(const float *dy, const float *w, float *wt, float *packed, float *out, int B, int N, int K, int H, int W, hipStream_t st,
+                   const char *what)
+{
+    CHECK_HIP(urnn_train_transpose(w, wt, N, K, st), what);
+    CHECK_HIP(urnn_launch_pack_conv(wt, nullptr, packed, N, K, st), what);
+    return urnn_stage_conv_f32(dy, packed, out, B, N, K, H, W, 0, 1.0f, st);
+}
+
+extern "C" int urnn_gru_cell_backward_f32(const float *x, const float *e, const float *h, const float *W1, const float *W2,
+                                          const float *gn1_w, const float *gn2_w, const void *fwd_workspace, const float *dh_out,
+                                          float *dx, float *de, float *dh, float *dW1, float *db1, float *dgn1_w, float *dgn1_b,
+                                          float *dW2, float *db2, float *dgn2_w, float *dgn2_b, void *workspace, size_t workspace_bytes,
+                                          int B, int I, int F, int H, int W, int accumulate, void *stream)
+{
+    if (!h || !W1 || !W2 || !gn1_w || !gn2_w || !fwd_workspace || !dh_out || !dh || !dW1 || !db1 || !dgn1_w || !dgn1_b || !dW2 || !db2 ||
+        !dgn2_w || !dgn2_b || !workspace)
+        return fail(URNN_ENULL, "urnn_gru_cell_backward_f32: NULL argument");
+    if ((x != nullptr) != (dx != nullptr) || (e != nullptr) != (de != nullptr))
+        return fail(URNN_EINVAL, "urnn_gru_cell_backward_f32: dx / de must be given exactly when x / e are");
+    if (B < 1 || I < 1 || H < 1 || W < 1 || F < 32 || F % 32 != 0 || F > 128)
+        return fail(URNN_EINVAL, "urnn_gru_cell_backward_f32: bad dims (F=%d must be a multiple of 32 in [32,128])", F);
+    const long P = (long)H * W;
+    if (!plane_fits(P, 2 * F > I ? 2 * F : I)) return fail(URNN_EINVAL, "urnn_gru_cell_backward_f32: plane exceeds the 4-GiB segment limit");
+    const int skip = e != nullptr;
+    const int K = I + (skip ? F : 0) + F;
+    const GruWs fw = carve_gru(const_cast<void *>(fwd_workspace), B, F, P);
+    const GruBwdWs ws = carve_gru_bwd(workspace, B, I, F, skip, P);
+    if (workspace_bytes < ws.bytes)
+        return fail(URNN_EWORKSPACE, "urnn_gru_cell_backward_f32: workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
+    hipStream_t st = (hipStream_t)stream;
+    const int Pi = (int)P;
+
+    // 1. blend: dy2 (normalised candidate), dy1[:, :F] (normalised update gate), dh = dout * (1 - z)
+    CHECK_HIP(urnn_train_blend_bwd(dh_out, fw.g1, fw.cx, h, fw.ss1, fw.ss2, ws.dy2, ws.dy1, dh, B, F, Pi, st), "blend backward");
+    // 2. GroupNorm of the candidate: dy2 -> dc (in place), dgamma2 / dbeta2
+    CHECK_HIP(urnn_train_gn_backward(ws.dy2, fw.cx, fw.st2, gn2_w, B, F, Pi, ws.chpart, ws.sums, ws.coef, dgn2_w, dgn2_b, accumulate, st),
+              "GroupNorm 2 backward");
+    // 3. conv2: dW2 / db2 = dc . [x; e; r*h]^T,  dA2 = W2^T . dc
+    CHECK_HIP(urnn_train_reset_gate(fw.g1, h, fw.ss1, ws.rh, B, F, Pi, st), "reset gate");
+    {
+        const float *seg[3] = {x, e, ws.rh};
+        const int segC[3] = {I, skip ? F : 0, F};
+        CHECK_HIP(urnn_train_wgrad(ws.dy2, seg, segC, B, F, K, Pi, ws.wpart, dW2, db2, accumulate, st), "conv2 weight gradient");
+    }
+    int rc = dx_gemm(ws.dy2, W2, ws.wt2, ws.pk2, ws.dA2, B, F, K, H, W, st, "conv2 input gradient");
+    if (rc) return rc;
+    // 4. reset gate: d(r*h) -> dy1[:, F:], dh += d(r*h) * r
+    CHECK_HIP(urnn_train_reset_gate_bwd(ws.dA2 + (size_t)(K - F) * P, (long)K * P, fw.g1, h, fw.ss1, ws.dy1, dh, B, F, Pi, st),
+              "reset gate backward");
+    // 5. GroupNorm of the gates: dy1 -> dg (in place), dgamma1 / dbeta1
+    CHECK_HIP(urnn_train_gn_backward(ws.dy1, fw.g1, fw.st1, gn1_w, B, 2 * F, Pi, ws.chpart, ws.sums, ws.coef, dgn1_w, dgn1_b, accumulate, st),
+              "GroupNorm 1 backward");
+    // 6. conv1: dW1 / db1 = dg . [x; e; h]^T,  dA = W1^T . dg
+    {
+        const float *seg[3] = {x, e, h};
+        const int segC[3] = {I, skip ? F : 0, F};
+        CHECK_HIP(urnn_train_wgrad(ws.dy1, seg, segC, B, 2 * F, K, Pi, ws.wpart, dW1, db1, accumulate, st), "conv1 weight gradient");
+    }
+    rc = dx_gemm(ws.dy1, W1, ws.wt1, ws.pk1, ws.dA, B, 2 * F, K, H, W, st, "conv1 input gradient");
+    if (rc) return rc;
+    // 7. gather the input gradients: dx = dA[:, :I] + dA2[:, :I], de likewise, dh += dA[:, K-F:]
+    const long kbs = (long)K * P;
+    if (dx) CHECK_HIP(urnn_train_add_slices(dx, (long)I * P, ws.dA, kbs, ws.dA2, kbs, B, I, Pi, 0, st), "dx");
+    if (de) CHECK_HIP(urnn_train_add_slices(de, (long)F * P, ws.dA + (size_t)I * P, kbs, ws.dA2 + (size_t)I * P, kbs, B, F, Pi, 0, st), "de");
+    CHECK_HIP(urnn_train_add_slices(dh, (long)F * P, ws.dA + (size_t)(K - F) * P, kbs, nullptr, 0, B, F, Pi, 1, st), "dh");
+    return URNN_OK;
 }
 
 // ---- deconv ----------------------------------------------------------------------------------------------------------

@@ -12,7 +12,7 @@
 // (the same fixed order as the fold in the candidate GEMM's prologue).
 __global__ __launch_bounds__(64) void gn_finalize_kernel(const float *__restrict__ partial, int ntiles, double count,
                                                          const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                         float eps, float *__restrict__ ss, int C)
+                                                         float eps, float *__restrict__ ss, float *__restrict__ stat, int C)
 {
     const int G = C / 32;
     const int b = blockIdx.x / G, g = blockIdx.x - b * G;
@@ -46,13 +46,17 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float *__restrict
         const double sc = (double)gamma[c] * rstd;
         ss[((size_t)b * C + c) * 2] = (float)sc;
         ss[((size_t)b * C + c) * 2 + 1] = (float)((double)beta[c] - mean * sc);
+        if (stat && lane == 0) {
+            stat[((size_t)b * G + g) * 2] = (float)mean;
+            stat[((size_t)b * G + g) * 2 + 1] = (float)rstd;
+        }
     }
 }
 
 hipError_t urnn_launch_gn_finalize(const float *partial, int ntiles, double count, const float *gamma, const float *beta,
-                                   float eps, float *ss, int B, int C, hipStream_t st)
+                                   float eps, float *ss, float *stat, int B, int C, hipStream_t st)
 {
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * (C / 32)), dim3(64), 0, st, partial, ntiles, count, gamma, beta, eps, ss, C);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * (C / 32)), dim3(64), 0, st, partial, ntiles, count, gamma, beta, eps, ss, stat, C);
     return hipGetLastError();
 }
 

@@ -306,6 +306,10 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
                 if (blockIdx.x == 0) {
                     prm.ss_out[((size_t)b * 2 * F + c) * 2] = fsc;
                     prm.ss_out[((size_t)b * 2 * F + c) * 2 + 1] = fsh;
+                    if (lane == 0 && prm.stat_out) {
+                        prm.stat_out[((size_t)b * G1 + grp) * 2] = (float)mean;
+                        prm.stat_out[((size_t)b * G1 + grp) * 2 + 1] = (float)rstd;
+                    }
                 }
             }
         }

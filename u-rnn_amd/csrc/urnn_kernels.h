@@ -18,6 +18,7 @@ struct ConvGemmParams {
     double gcount;        //           values per (sample, group) = 32 * P
     const float *gn_w, *gn_b;   //     GroupNorm affine of the gates [2F]
     float eps;
+    float *stat_out;      // EPI_CAND: out -- per (sample, gate norm group) (mean, rstd) [B][2F/32][2] for the backward pass (block 0)
     float *ss_out;        // EPI_CAND: out -- gates' per-channel (scale, shift) [B][2F][2] for the blend kernel (written by block 0)
     int B;                // EPI_CAND: samples (size of the reset-gate scale/shift table kept in LDS)
     const float *wt;      // packed weights [NG][KT][NB][64] (group stride aFloats); lane l of row (kp, nb) holds
@@ -44,7 +45,7 @@ hipError_t urnn_launch_cand(ConvGemmParams p, int B, int PB, int map, hipStream_
 
 // ---- elementwise / reduction kernels (urnn_elem.hip) ----
 hipError_t urnn_launch_gn_finalize(const float *partial, int ntiles, double count, const float *gamma, const float *beta,
-                                   float eps, float *ss, int B, int C, hipStream_t st);
+                                   float eps, float *ss, float *stat, int B, int C, hipStream_t st);
 hipError_t urnn_launch_blend(const float *g1, const float *c, const float *h, const float *ss1, const float *ss2, float *out,
                              int B, int F, int P, hipStream_t st);
 
@@ -79,3 +80,21 @@ hipError_t urnn_launch_pack_conv(const float *w, const float *bias, float *packe
 hipError_t urnn_launch_pack_gru(const float *W1, const float *b1, const float *W2, const float *b2, float *packed, int I,
                                 int F, int skip, hipStream_t st);
 hipError_t urnn_launch_pack_deconv(const float *w, const float *bias, float *packed, int Cin, int Cout, hipStream_t st);
+
+// ---- training building blocks (urnn_train.hip) ----
+int urnn_train_nchunk(int P);
+hipError_t urnn_train_chan_sums(const float *a, long a_bs, const float *v, long v_bs, const float *stat, int B, int C, int P,
+                                float *partial, double *sums, hipStream_t st);
+hipError_t urnn_train_gn_backward(float *dy, const float *v, const float *stat, const float *gamma, int B, int C, int P, float *partial,
+                                  double *sums, float *coef, float *dgamma, float *dbeta, int accumulate, hipStream_t st);
+hipError_t urnn_train_blend_bwd(const float *dout, const float *g1, const float *c, const float *h, const float *ss1, const float *ss2,
+                                float *dy2, float *dy1, float *dh, int B, int F, int P, hipStream_t st);
+hipError_t urnn_train_reset_gate(const float *g1, const float *h, const float *ss1, float *rh, int B, int F, int P, hipStream_t st);
+hipError_t urnn_train_reset_gate_bwd(const float *drh, long drh_bs, const float *g1, const float *h, const float *ss1, float *dy1,
+                                     float *dh, int B, int F, int P, hipStream_t st);
+hipError_t urnn_train_add_slices(float *out, long out_bs, const float *a, long a_bs, const float *a2, long a2_bs, int B, int C, int P,
+                                 int accumulate, hipStream_t st);
+size_t urnn_train_wgrad_partial_floats(int B, int N, int K, int P);
+hipError_t urnn_train_wgrad(const float *dy, const float *const seg[3], const int segC[3], int B, int N, int K, int P, float *partial,
+                            float *dW, float *db, int accumulate, hipStream_t st);
+hipError_t urnn_train_transpose(const float *w, float *wt, int N, int K, hipStream_t st);

@@ -1,0 +1,376 @@
+// urnn_train.hip -- first building blocks of the training path: backward of the ConvGRU / Skip-ConvGRU
+// cell.  Straightforward first version: correctness against reference autograd first, one kernel per mathematical step,
+// deterministic reductions (per-chunk fp32 partials -> fixed-order double), fp32 MFMA for the two contraction shapes:
+//   dX = W^T . dY   -- the forward GEMM kernel (urnn_gemm.hip) on transposed packed weights, identity epilogue;
+//   dW = dY . X^T   -- wgrad_kernel below: contraction over PIXELS, operands transposed through LDS.
+#include "urnn_common.h"
+#include "urnn_kernels.h"
+
+// ------------------------------------------------------------------------------------------------------------------
+// Per-(sample, channel) sums  S1 = sum_p a,  S2 = sum_p a * xhat(v)  with xhat = (v - mean_g) * rstd_g  (v == nullptr: S2 = 0).
+// grid (chunks, B*C); partial[(b*C + c)][chunk][2]
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void chan_partial_kernel(const float *__restrict__ a, long a_bs, const float *__restrict__ v, long v_bs,
+                                                           const float *__restrict__ stat, int C, int P, int nchunk,
+                                                           float *__restrict__ partial)
+{
+    __shared__ float sh[2][4];
+    const int bc = blockIdx.y, b = bc / C, c = bc - b * C;
+    const float *ap = a + (size_t)b * a_bs + (size_t)c * P;
+    const float *vp = v ? v + (size_t)b * v_bs + (size_t)c * P : nullptr;
+    float mu = 0.f, rs = 0.f;
+    if (v) {
+        mu = stat[((size_t)b * (C / 32) + c / 32) * 2];
+        rs = stat[((size_t)b * (C / 32) + c / 32) * 2 + 1];
+    }
+    const int per = (P + nchunk - 1) / nchunk;
+    const int lo = blockIdx.x * per, hi = min(P, lo + per);
+    float s1 = 0.f, s2 = 0.f;
+    for (int p = lo + threadIdx.x; p < hi; p += 256) {
+        const float av = ap[p];
+        s1 += av;
+        if (vp) s2 += av * ((vp[p] - mu) * rs);
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { sh[0][wave] = s1; sh[1][wave] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float *pp = partial + ((size_t)bc * nchunk + blockIdx.x) * 2;
+        pp[0] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+        pp[1] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+    }
+}
+
+// one wave per (b, c): chunks summed in double, fixed order -> sums[(b*C + c)][2] (double)
+__global__ __launch_bounds__(64) void chan_finalize_kernel(const float *__restrict__ partial, int nchunk, double *__restrict__ sums)
+{
+    const int bc = blockIdx.x, lane = threadIdx.x;
+    const float *pp = partial + (size_t)bc * nchunk * 2;
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = lane; t < nchunk; t += 64) {
+        s1 += (double)pp[2 * t];
+        s2 += (double)pp[2 * t + 1];
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        s1 += __shfl_xor(s1, m, 64);
+        s2 += __shfl_xor(s2, m, 64);
+    }
+    if (lane == 0) {
+        sums[(size_t)bc * 2] = s1;
+        sums[(size_t)bc * 2 + 1] = s2;
+    }
+}
+
+// GroupNorm backward coefficients.  One thread per (b, group): m1 = mean(dxhat), m2 = mean(dxhat * xhat) over the group's
+// 32*P values (dxhat = dy * gamma); coef[(b*G + g)][2].  Threads with b == 0 also emit dgamma / dbeta (summed over samples).
+__global__ void gn_bwd_coef_kernel(const double *__restrict__ sums, const float *__restrict__ gamma, int B, int C, double count,
+                                   float *__restrict__ coef, float *__restrict__ dgamma, float *__restrict__ dbeta, int accumulate)
+{
+    const int G = C / 32;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < B * G) {
+        const int b = idx / G, g = idx - b * G;
+        double m1 = 0.0, m2 = 0.0;
+        for (int j = 0; j < 32; ++j) {
+            const int c = g * 32 + j;
+            m1 += (double)gamma[c] * sums[((size_t)b * C + c) * 2];
+            m2 += (double)gamma[c] * sums[((size_t)b * C + c) * 2 + 1];
+        }
+        coef[(size_t)idx * 2] = (float)(m1 / count);
+        coef[(size_t)idx * 2 + 1] = (float)(m2 / count);
+    }
+    if (idx < C) {
+        double d1 = 0.0, d2 = 0.0;
+        for (int b = 0; b < B; ++b) {
+            d1 += sums[((size_t)b * C + idx) * 2];
+            d2 += sums[((size_t)b * C + idx) * 2 + 1];
+        }
+        dbeta[idx] = (accumulate ? dbeta[idx] : 0.f) + (float)d1;
+        dgamma[idx] = (accumulate ? dgamma[idx] : 0.f) + (float)d2;
+    }
+}
+
+// dv = rstd * (gamma * dy - m1 - xhat * m2), in place over dy.  grid (chunks, B*C)
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(float *dy, const float *__restrict__ v, const float *__restrict__ stat,
+                                                           const float *__restrict__ coef, const float *__restrict__ gamma, int C, int P)
+{
+    const int bc = blockIdx.y, b = bc / C, c = bc - b * C;
+    const int G = C / 32, g = c / 32;
+    const float mu = stat[((size_t)b * G + g) * 2], rs = stat[((size_t)b * G + g) * 2 + 1];
+    const float m1 = coef[((size_t)b * G + g) * 2], m2 = coef[((size_t)b * G + g) * 2 + 1];
+    const float gm = gamma[c];
+    float *dp = dy + (size_t)bc * P;
+    const float *vp = v + (size_t)bc * P;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += gridDim.x * 256) {
+        const float xh = (vp[p] - mu) * rs;
+        dp[p] = rs * (gm * dp[p] - m1 - xh * m2);
+    }
+}
+
+// Blend backward (h' = (1 - z) h + z n,  z = sigmoid(GN(gz)),  n = tanh(GN(c))):
+//   dy2 = dout * z * (1 - n^2)          gradient w.r.t. the normalised candidate
+//   dyz = dout * (n - h) * z * (1 - z)  gradient w.r.t. the normalised update gate  -> dy1[:, :F]
+//   dh  = dout * (1 - z)
+__global__ __launch_bounds__(256) void blend_bwd_kernel(const float *__restrict__ dout, const float *__restrict__ g1, const float *__restrict__ c,
+                                                        const float *__restrict__ h, const float *__restrict__ ss1, const float *__restrict__ ss2,
+                                                        float *__restrict__ dy2, float *__restrict__ dy1, float *__restrict__ dh, int F, int P)
+{
+    const int bc = blockIdx.y, b = bc / F, f = bc - b * F;
+    const float s1 = ss1[((size_t)b * 2 * F + f) * 2], t1 = ss1[((size_t)b * 2 * F + f) * 2 + 1];
+    const float s2 = ss2[((size_t)b * F + f) * 2], t2 = ss2[((size_t)b * F + f) * 2 + 1];
+    const float *gz = g1 + ((size_t)b * 2 * F + f) * P, *cc = c + (size_t)bc * P, *hh = h + (size_t)bc * P, *dd = dout + (size_t)bc * P;
+    float *o2 = dy2 + (size_t)bc * P, *o1 = dy1 + ((size_t)b * 2 * F + f) * P, *oh = dh + (size_t)bc * P;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += gridDim.x * 256) {
+        const float z = 1.0f / (1.0f + expf(-(gz[p] * s1 + t1)));
+        const float n = tanhf(cc[p] * s2 + t2);
+        const float d = dd[p];
+        o2[p] = d * z * (1.0f - n * n);
+        o1[p] = d * (n - hh[p]) * z * (1.0f - z);
+        oh[p] = d * (1.0f - z);
+    }
+}
+
+// rh = sigmoid(GN(gr)) * h   (the candidate GEMM's gated rows, materialised for the weight gradient)
+__global__ __launch_bounds__(256) void reset_gate_kernel(const float *__restrict__ g1, const float *__restrict__ h, const float *__restrict__ ss1,
+                                                         float *__restrict__ rh, int F, int P)
+{
+    const int bc = blockIdx.y, b = bc / F, f = bc - b * F;
+    const float s = ss1[((size_t)b * 2 * F + F + f) * 2], t = ss1[((size_t)b * 2 * F + F + f) * 2 + 1];
+    const float *gr = g1 + ((size_t)b * 2 * F + F + f) * P, *hh = h + (size_t)bc * P;
+    float *o = rh + (size_t)bc * P;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += gridDim.x * 256) o[p] = hh[p] / (1.0f + expf(-(gr[p] * s + t)));
+}
+
+// From d(r*h) (rows K-F.. of dA2, batch stride K*P): dyr = drh * h * r (1 - r) -> dy1[:, F:];  dh += drh * r
+__global__ __launch_bounds__(256) void reset_gate_bwd_kernel(const float *__restrict__ drh, long drh_bs, const float *__restrict__ g1,
+                                                             const float *__restrict__ h, const float *__restrict__ ss1,
+                                                             float *__restrict__ dy1, float *__restrict__ dh, int F, int P)
+{
+    const int bc = blockIdx.y, b = bc / F, f = bc - b * F;
+    const float s = ss1[((size_t)b * 2 * F + F + f) * 2], t = ss1[((size_t)b * 2 * F + F + f) * 2 + 1];
+    const float *gr = g1 + ((size_t)b * 2 * F + F + f) * P, *hh = h + (size_t)bc * P;
+    const float *dd = drh + (size_t)b * drh_bs + (size_t)f * P;
+    float *o1 = dy1 + ((size_t)b * 2 * F + F + f) * P, *oh = dh + (size_t)bc * P;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += gridDim.x * 256) {
+        const float r = 1.0f / (1.0f + expf(-(gr[p] * s + t)));
+        const float d = dd[p];
+        o1[p] = d * hh[p] * r * (1.0f - r);
+        oh[p] += d * r;
+    }
+}
+
+// out[b][c][p] (+)= a[b][c][p] (+ a2[b][c][p]) with independent batch strides (channel slices of (B,K,P) buffers)
+__global__ __launch_bounds__(256) void add_slices_kernel(float *out, long out_bs, const float *__restrict__ a, long a_bs,
+                                                         const float *__restrict__ a2, long a2_bs, int C, int P, int accumulate)
+{
+    const int bc = blockIdx.y, b = bc / C, c = bc - b * C;
+    float *o = out + (size_t)b * out_bs + (size_t)c * P;
+    const float *pa = a + (size_t)b * a_bs + (size_t)c * P;
+    const float *pb = a2 ? a2 + (size_t)b * a2_bs + (size_t)c * P : nullptr;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += gridDim.x * 256) {
+        float v = pa[p] + (pb ? pb[p] : 0.f);
+        o[p] = accumulate ? o[p] + v : v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight gradient dW[n][k] = sum_{b,p} dY[b][n][p] * X[b][k][p]  (+ row sums of dY for the bias gradient).
+// Block = 4 waves, output tile 64 n x 64 k (wave w: n-block w >> 1, k-block w & 1), one pixel chunk; per step the block
+// stages dY[64][64 px] and X[64][64 px] in LDS (rows padded to 65 floats: the MFMA fragments read a COLUMN of the tile,
+// lane l -> row l & 31, and the pad makes those 32 rows hit 32 banks), then 32 v_mfma_f32_32x32x2_f32 per wave.
+// X rows come from up to three tensors (x | e | h-or-rh), k < K.  partial[chunk][N][K]; grid (K/64, N/64, chunks).
+// ------------------------------------------------------------------------------------------------------------------
+struct WgradParams {
+    const float *dy;          // (B,N,P)
+    const float *seg[3];      // X segments, (B,segC[i],P)
+    int segC[3];              // real channel counts (0 = unused)
+    int segK0[3];             // first k of each segment
+    int N, K, P, B;
+    int chunkPix;             // pixels per chunk (multiple of 64), chunks cover B*ceil(P/chunkPix)
+    int chunksPerSample;
+    float *partial;           // [chunks][N][K]
+    float *rowpart;           // [chunks][N] sums of dY (written by the blockIdx.x == 0 column), may be nullptr
+};
+
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams prm)
+{
+    __shared__ float tA[64 * 65], tB[64 * 65];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, half = lane >> 5;
+    const int n0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
+    const int chunk = blockIdx.z, b = chunk / prm.chunksPerSample;
+    const int p_lo = (chunk - b * prm.chunksPerSample) * prm.chunkPix;
+    const int p_hi = min(prm.P, p_lo + prm.chunkPix);
+    const int wn = wave >> 1, wk = wave & 1;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float rsum = 0.f;   // thread t < 64 of the k-column 0 blocks accumulates the row sum of dY row n0 + t
+
+    for (int p0 = p_lo; p0 < p_hi; p0 += 64) {
+        __syncthreads();
+        // stage: thread t loads column (t & 63) of rows (t >> 6) + 4*i
+        const int col = threadIdx.x & 63, p = p0 + col;
+        const bool pin = p < p_hi;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = (threadIdx.x >> 6) + 4 * i;
+            const int n = n0 + row;
+            tA[row * 65 + col] = (pin && n < prm.N) ? prm.dy[((size_t)b * prm.N + n) * prm.P + p] : 0.f;
+            const int k = k0 + row;
+            float xv = 0.f;
+            if (pin && k < prm.K) {
+                const int s = k >= prm.segK0[2] ? 2 : (k >= prm.segK0[1] ? 1 : 0);
+                const int ch = k - prm.segK0[s];
+                if (ch < prm.segC[s]) xv = prm.seg[s][((size_t)b * prm.segC[s] + ch) * prm.P + p];
+            }
+            tB[row * 65 + col] = xv;
+        }
+        __syncthreads();
+        if (prm.rowpart && blockIdx.x == 0 && threadIdx.x < 64) {
+            float s = 0.f;
+            for (int c = 0; c < 64; ++c) s += tA[threadIdx.x * 65 + c];
+            rsum += s;
+        }
+#pragma unroll 8
+        for (int s = 0; s < 32; ++s) {
+            const float a = tA[(wn * 32 + j) * 65 + 2 * s + half];
+            const float bv = tB[(wk * 32 + j) * 65 + 2 * s + half];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
+        }
+    }
+    float *out = prm.partial + (size_t)chunk * prm.N * prm.K;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 32 + mfma_row(r, half), k = k0 + wk * 32 + j;
+        if (n < prm.N && k < prm.K) out[(size_t)n * prm.K + k] = acc[r];
+    }
+    if (prm.rowpart && blockIdx.x == 0 && threadIdx.x < 64 && n0 + (int)threadIdx.x < prm.N)
+        prm.rowpart[(size_t)chunk * prm.N + n0 + threadIdx.x] = rsum;
+}
+
+// dW[i] (+)= sum over chunks (double, fixed order); the same for the bias row sums
+__global__ void wgrad_finalize_kernel(const float *__restrict__ partial, int nchunk, long count, float *__restrict__ out, int accumulate)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    double s = 0.0;
+    for (int c = 0; c < nchunk; ++c) s += (double)partial[(size_t)c * count + i];
+    out[i] = (accumulate ? out[i] : 0.f) + (float)s;
+}
+
+// weight (N,K) row-major -> transposed (K,N) row-major (the "weight" of the dX GEMM)
+__global__ void transpose_kernel(const float *__restrict__ w, float *__restrict__ wt, int N, int K)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N * K) {
+        const int n = i / K, k = i - n * K;
+        wt[(size_t)k * N + n] = w[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host-side launchers
+// ------------------------------------------------------------------------------------------------------------------
+static dim3 plane_grid(int P, int planes)
+{
+    int gx = (P + 1023) / 1024;
+    gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+    return dim3(gx, planes);
+}
+
+hipError_t urnn_train_chan_sums(const float *a, long a_bs, const float *v, long v_bs, const float *stat, int B, int C, int P,
+                                float *partial, double *sums, hipStream_t st)
+{
+    const int nchunk = urnn_train_nchunk(P);
+    hipLaunchKernelGGL(chan_partial_kernel, dim3(nchunk, B * C), dim3(256), 0, st, a, a_bs, v, v_bs, stat, C, P, nchunk, partial);
+    hipLaunchKernelGGL(chan_finalize_kernel, dim3(B * C), dim3(64), 0, st, partial, nchunk, sums);
+    return hipGetLastError();
+}
+
+int urnn_train_nchunk(int P)
+{
+    const int n = (P + 4095) / 4096;
+    return n < 1 ? 1 : (n > 64 ? 64 : n);
+}
+
+hipError_t urnn_train_gn_backward(float *dy, const float *v, const float *stat, const float *gamma, int B, int C, int P, float *partial,
+                                  double *sums, float *coef, float *dgamma, float *dbeta, int accumulate, hipStream_t st)
+{
+    hipError_t e = urnn_train_chan_sums(dy, (long)C * P, v, (long)C * P, stat, B, C, P, partial, sums, st);
+    if (e != hipSuccess) return e;
+    const int n = B * (C / 32) > C ? B * (C / 32) : C;
+    hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3((n + 127) / 128), dim3(128), 0, st, sums, gamma, B, C, 32.0 * (double)P, coef, dgamma,
+                       dbeta, accumulate);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, plane_grid(P, B * C), dim3(256), 0, st, dy, v, stat, coef, gamma, C, P);
+    return hipGetLastError();
+}
+
+hipError_t urnn_train_blend_bwd(const float *dout, const float *g1, const float *c, const float *h, const float *ss1, const float *ss2,
+                                float *dy2, float *dy1, float *dh, int B, int F, int P, hipStream_t st)
+{
+    hipLaunchKernelGGL(blend_bwd_kernel, plane_grid(P, B * F), dim3(256), 0, st, dout, g1, c, h, ss1, ss2, dy2, dy1, dh, F, P);
+    return hipGetLastError();
+}
+
+hipError_t urnn_train_reset_gate(const float *g1, const float *h, const float *ss1, float *rh, int B, int F, int P, hipStream_t st)
+{
+    hipLaunchKernelGGL(reset_gate_kernel, plane_grid(P, B * F), dim3(256), 0, st, g1, h, ss1, rh, F, P);
+    return hipGetLastError();
+}
+
+hipError_t urnn_train_reset_gate_bwd(const float *drh, long drh_bs, const float *g1, const float *h, const float *ss1, float *dy1,
+                                     float *dh, int B, int F, int P, hipStream_t st)
+{
+    hipLaunchKernelGGL(reset_gate_bwd_kernel, plane_grid(P, B * F), dim3(256), 0, st, drh, drh_bs, g1, h, ss1, dy1, dh, F, P);
+    return hipGetLastError();
+}
+
+hipError_t urnn_train_add_slices(float *out, long out_bs, const float *a, long a_bs, const float *a2, long a2_bs, int B, int C, int P,
+                                 int accumulate, hipStream_t st)
+{
+    if (C < 1) return hipSuccess;
+    hipLaunchKernelGGL(add_slices_kernel, plane_grid(P, B * C), dim3(256), 0, st, out, out_bs, a, a_bs, a2, a2_bs, C, P, accumulate);
+    return hipGetLastError();
+}
+
+size_t urnn_train_wgrad_partial_floats(int B, int N, int K, int P)
+{
+    const int cps = urnn_train_nchunk(P);
+    return (size_t)B * cps * ((size_t)N * K + N);
+}
+
+hipError_t urnn_train_wgrad(const float *dy, const float *const seg[3], const int segC[3], int B, int N, int K, int P, float *partial,
+                            float *dW, float *db, int accumulate, hipStream_t st)
+{
+    WgradParams w = {};
+    w.dy = dy;
+    int k0 = 0;
+    for (int i = 0; i < 3; ++i) {
+        w.seg[i] = seg[i];
+        w.segC[i] = seg[i] ? segC[i] : 0;
+        w.segK0[i] = k0;
+        k0 += segC[i];          // a missing segment (x == nullptr) still owns its weight columns: they get zero gradient
+    }
+    w.N = N; w.K = K; w.P = P; w.B = B;
+    w.chunksPerSample = urnn_train_nchunk(P);
+    w.chunkPix = ((P + w.chunksPerSample - 1) / w.chunksPerSample + 63) / 64 * 64;
+    const int chunks = B * w.chunksPerSample;
+    w.partial = partial;
+    w.rowpart = db ? partial + (size_t)chunks * N * K : nullptr;
+    hipLaunchKernelGGL(wgrad_kernel, dim3((K + 63) / 64, (N + 63) / 64, chunks), dim3(256), 0, st, w);
+    const long cnt = (long)N * K;
+    hipLaunchKernelGGL(wgrad_finalize_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, partial, chunks, cnt, dW, accumulate);
+    if (db)
+        hipLaunchKernelGGL(wgrad_finalize_kernel, dim3((N + 255) / 256), dim3(256), 0, st, w.rowpart, chunks, (long)N, db, accumulate);
+    return hipGetLastError();
+}
+
+hipError_t urnn_train_transpose(const float *w, float *wt, int N, int K, hipStream_t st)
+{
+    hipLaunchKernelGGL(transpose_kernel, dim3((N * K + 255) / 256), dim3(256), 0, st, w, wt, N, K);
+    return hipGetLastError();
+}

@@ -1,0 +1,44 @@
+"""ctypes wrappers of the training building blocks.  So far: the backward of one ConvGRU / Skip-ConvGRU
+step.  The training loop, the other layers' backward passes, the optimizer and the DDP all-reduce are not built yet."""
+import torch
+
+from . import ops
+from ._lib import check, lib
+
+_BWD_SLOT = 7   # workspace slot of the backward scratch (the forward's scratch must survive until the backward has run)
+
+
+def gru_cell_backward(x, e, h, W1, W2, gn1_w, gn2_w, dh_out, I, grads=None, accumulate=False):
+    """Gradients of one cell step.  Must directly follow ``ops.gru_cell(x, e, h, ...)`` on the same inputs (same workspace
+    slot, nothing in between): the forward leaves the raw gates / candidate and the GroupNorm statistics in its workspace.
+    W1 (2F,K[,1,1]) / W2 (F,K[,1,1]): conv weights in the reference layout.  Returns a dict with dx, de (when given), dh and
+    dW1, db1, dg1, dbe1, dW2, db2, dg2, dbe2; pass ``grads`` (the dict of a previous call) with ``accumulate=True`` to add
+    the parameter gradients of another timestep."""
+    ops._dev_check(x, e, h, W1, W2, gn1_w, gn2_w, dh_out)
+    B, F, H, W = h.shape
+    K = I + (F if e is not None else 0) + F
+    if W1.numel() != 2 * F * K or W2.numel() != F * K:
+        raise RuntimeError(f"gru_cell_backward: weights do not match I={I}, F={F}, skip={e is not None}")
+    L = lib()
+    dev = h.device
+    fwd = ops.WORKSPACE.get(L.urnn_gru_cell_workspace_bytes(B, F, H, W), dev)
+    slot = ops.WORKSPACE.slot
+    ops.WORKSPACE.use_slot(_BWD_SLOT)
+    nbytes = L.urnn_gru_cell_backward_workspace_bytes(B, I, F, int(e is not None), H, W)
+    ws = ops.WORKSPACE.get(nbytes, dev)
+    ops.WORKSPACE.use_slot(slot)
+    f32 = dict(dtype=torch.float32, device=dev)
+    g = grads if grads is not None else {}
+    if grads is None or not accumulate:
+        g.update(dW1=torch.empty(2 * F, K, **f32), db1=torch.empty(2 * F, **f32), dg1=torch.empty(2 * F, **f32),
+                 dbe1=torch.empty(2 * F, **f32), dW2=torch.empty(F, K, **f32), db2=torch.empty(F, **f32),
+                 dg2=torch.empty(F, **f32), dbe2=torch.empty(F, **f32))
+    g["dh"] = torch.empty_like(h)
+    g["dx"] = torch.empty_like(x) if x is not None else None
+    g["de"] = torch.empty_like(e) if e is not None else None
+    p = ops._ptr
+    check(L.urnn_gru_cell_backward_f32(p(x), p(e), p(h), p(W1), p(W2), p(gn1_w), p(gn2_w), p(fwd), p(dh_out), p(g["dx"]), p(g["de"]),
+                                       p(g["dh"]), p(g["dW1"]), p(g["db1"]), p(g["dg1"]), p(g["dbe1"]), p(g["dW2"]), p(g["db2"]),
+                                       p(g["dg2"]), p(g["dbe2"]), p(ws), ws.numel(), B, I, F, H, W, int(bool(accumulate)),
+                                       ops._stream()), "urnn_gru_cell_backward_f32")
+    return g
