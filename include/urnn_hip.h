@@ -147,6 +147,20 @@ int urnn_gru_cell_backward_f32(const float *x, const float *e, const float *h, c
                                float *dgn2_b, void *workspace, size_t workspace_bytes, int B, int I, int F, int H, int W,
                                int accumulate, void *stream);
 
+/* Backward of urnn_stage_conv_f32 (conv1x1 + LeakyReLU [+ AvgPool2d(2,2)]): weight (Cout,Cin), bias (Cout) in the reference
+ * layout; dout has the forward output's shape; din (B,Cin,H,W) is overwritten, dweight / dbias overwritten or accumulated. */
+size_t urnn_stage_conv_backward_workspace_bytes(int B, int Cin, int Cout, int H, int W);
+int urnn_stage_conv_backward_f32(const float *in, const float *weight, const float *bias, const float *dout, float *din, float *dweight,
+                                 float *dbias, void *workspace, size_t workspace_bytes, int B, int Cin, int Cout, int H, int W,
+                                 int pool, float slope, int accumulate, void *stream);
+
+/* Backward of urnn_deconv2x2_f32: weight (Cin,Cout,2,2); out = the forward output (B,Cout,2H,2W) (LeakyReLU keeps the sign
+ * of its input), dout the same shape; din (B,Cin,H,W) overwritten, dweight / dbias overwritten or accumulated. */
+size_t urnn_deconv2x2_backward_workspace_bytes(int B, int Cin, int Cout, int H, int W);
+int urnn_deconv2x2_backward_f32(const float *in, const float *weight, const float *out, const float *dout, float *din, float *dweight,
+                                float *dbias, void *workspace, size_t workspace_bytes, int B, int Cin, int Cout, int H, int W,
+                                float slope, int accumulate, void *stream);
+
 /* Device-side frame counter helper for graph-captured rollouts: *counter += delta. */
 int urnn_advance_counter(int *counter, int delta, void *stream);
 

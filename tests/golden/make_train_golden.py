@@ -121,6 +121,48 @@ def gen_cell_backward(out):
             out[f"cell_{tag}_d{name}"] = prm.grad.numpy()
 
 
+def gen_layers_backward(out, H=16, W=16, C=9, seed=31):
+    """Stage convs (conv1x1 + LeakyReLU [+ AvgPool]), a transposed conv stage and the head, each with a random upstream
+    gradient, from reference autograd (modules of a seeded reference ED)."""
+    net, sd = mg.ref_net(H, W, C, seed)
+    rs = np.random.RandomState(seed)
+    out.update({"lay_H": H, "lay_W": W, "lay_C": C, "lay_seed": seed})
+
+    def one(tag, module, x_shape, params):
+        for prm in module.parameters():
+            prm.grad = None
+        x = torch.from_numpy(rs.normal(0, 1, x_shape).astype(np.float32)).requires_grad_(True)
+        y = module(x)
+        dy = torch.from_numpy(rs.normal(0, 1, y.shape).astype(np.float32))
+        y.backward(dy)
+        out[f"lay_{tag}_x"], out[f"lay_{tag}_y"], out[f"lay_{tag}_dy"], out[f"lay_{tag}_dx"] = x.detach().numpy(), y.detach().numpy(), dy.numpy(), x.grad.numpy()
+        for name, prm in params.items():
+            out[f"lay_{tag}_{name}"] = prm.detach().numpy()
+            out[f"lay_{tag}_d{name}"] = prm.grad.numpy()
+
+    e, d = net.encoder, net.decoder
+    one("s1", e.stage1, (2, C, H, W), {"w": e.stage1[0].weight, "b": e.stage1[0].bias})
+    one("s2", e.stage2, (1, 64, H, W), {"w": e.stage2[0].weight, "b": e.stage2[0].bias})
+    one("s3", e.stage3, (2, 96, H // 2, W // 2), {"w": e.stage3[0].weight, "b": e.stage3[0].bias})
+    one("dc3", d.stage3, (1, 96, H // 4, W // 4), {"w": d.stage3[0].weight, "b": d.stage3[0].bias})
+    one("dc2", d.stage2, (2, 96, H // 2, W // 2), {"w": d.stage2[0].weight, "b": d.stage2[0].bias})
+    one("st1", d.stage1, (1, 64, H, W), {"w": d.stage1[0].weight, "b": d.stage1[0].bias})
+    # head: input (S=1, B=1, 16, H, W) as the decoder hands it over; the loss only sees channel 0 (masked reg)
+    hd = net.head
+    for prm in hd.parameters():
+        prm.grad = None
+    f = torch.from_numpy(rs.normal(0, 1, (1, 1, 16, H, W)).astype(np.float32)).requires_grad_(True)
+    o = hd(f)
+    dreg = torch.from_numpy(rs.normal(0, 1, o[:, :, 0].shape).astype(np.float32))
+    (o[:, :, 0] * dreg).sum().backward()
+    out["lay_head_f"], out["lay_head_out"], out["lay_head_dreg"], out["lay_head_df"] = f.detach().numpy(), o.detach().numpy(), dreg.numpy(), f.grad.numpy()
+    for name, prm in hd.named_parameters():
+        if "_wrapper" in name:
+            continue
+        out[f"lay_head_p_{name}"] = prm.detach().numpy()
+        out[f"lay_head_g_{name}"] = prm.grad.numpy() if prm.grad is not None else np.zeros_like(prm.detach().numpy())
+
+
 if __name__ == "__main__":
     sys.modules.setdefault("wandb", types.ModuleType("wandb"))
     out = {}
@@ -129,6 +171,9 @@ if __name__ == "__main__":
     cells = {}
     gen_cell_backward(cells)
     np.savez_compressed(os.path.join(HERE, "train_cell_backward.npz"), **cells)
+    layers = {}
+    gen_layers_backward(layers)
+    np.savez_compressed(os.path.join(HERE, "train_layers_backward.npz"), **layers)
     path = os.path.join(HERE, "train_window_16x16.npz")
     np.savez_compressed(path, **out)
     ng = sum(1 for k in out if k.startswith("win_grad_"))

@@ -98,3 +98,36 @@ def test_cell_backward_accumulates_parameter_gradients_and_is_deterministic(dev)
     for k in ("dW1", "db1", "dg1", "dbe1", "dW2", "db2", "dg2", "dbe2"):
         assert torch.allclose(c[k], 2 * a[k], rtol=1e-6, atol=0), k
     assert torch.equal(c["dh"], a["dh"]) and torch.equal(c["dx"], a["dx"])      # input gradients are overwritten
+
+
+@pytest.fixture(scope="module")
+def layers():
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "train_layers_backward.npz"))
+
+
+@pytest.mark.parametrize("tag,pool", [("s1", False), ("s2", True), ("s3", True), ("st1", False)])
+def test_stage_conv_backward_vs_reference_autograd(dev, layers, tag, pool):
+    from urnn_amd import ops, train_ops
+    k = lambda n: layers[f"lay_{tag}_{n}"]
+    x, w, b = T(k("x"), dev), T(k("w"), dev), T(k("b"), dev)
+    y = ops.stage_conv(x, ops.pack_conv(w, b), w.shape[0], pool)
+    assert_close(y.cpu().numpy(), k("y"), 1e-4, f"{tag}: forward")
+    dx, dw, db = train_ops.stage_conv_backward(x, w, b, T(k("dy"), dev), pool)
+    assert_close(dx.cpu().numpy(), k("dx"), GRAD_TOL, f"{tag}: dx")
+    assert_close(dw.cpu().numpy(), k("dw"), GRAD_TOL, f"{tag}: dw")
+    assert_close(db.cpu().numpy(), k("db"), GRAD_TOL, f"{tag}: db")
+    dx2, dw2, db2 = train_ops.stage_conv_backward(x, w, b, T(k("dy"), dev), pool, dweight=dw, dbias=db, accumulate=True)
+    assert torch.allclose(dw2, 2 * T(k("dw"), dev), rtol=5e-4, atol=1e-5 * float(np.abs(k("dw")).max()))
+
+
+@pytest.mark.parametrize("tag", ["dc3", "dc2"])
+def test_deconv_backward_vs_reference_autograd(dev, layers, tag):
+    from urnn_amd import ops, train_ops
+    k = lambda n: layers[f"lay_{tag}_{n}"]
+    x, w, b = T(k("x"), dev), T(k("w"), dev), T(k("b"), dev)
+    y = ops.deconv2x2(x, ops.pack_deconv(w, b), w.shape[1])
+    assert_close(y.cpu().numpy(), k("y"), 1e-4, f"{tag}: forward")
+    dx, dw, db = train_ops.deconv2x2_backward(x, w, y, T(k("dy"), dev))
+    assert_close(dx.cpu().numpy(), k("dx"), GRAD_TOL, f"{tag}: dx")
+    assert_close(dw.cpu().numpy(), k("dw"), GRAD_TOL, f"{tag}: dw")
+    assert_close(db.cpu().numpy(), k("db"), GRAD_TOL, f"{tag}: db")

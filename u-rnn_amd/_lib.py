@@ -36,6 +36,10 @@ SIGNATURES = {
     "urnn_stage1_scalar_rain_f32": (_i, [_p] * 6 + [_i, _p, _i, _i, _i, _i, _i, _i, _f, _f, _f, _p]),
     "urnn_gru_cell_backward_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "urnn_gru_cell_backward_f32": (_i, [_p] * 21 + [_sz, _i, _i, _i, _i, _i, _i, _p]),
+    "urnn_stage_conv_backward_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "urnn_stage_conv_backward_f32": (_i, [_p] * 8 + [_sz, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "urnn_deconv2x2_backward_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "urnn_deconv2x2_backward_f32": (_i, [_p] * 8 + [_sz, _i, _i, _i, _i, _i, _f, _i, _p]),
     "urnn_advance_counter": (_i, [_p, _i, _p]),
 }
 

@@ -401,6 +401,93 @@ extern "C" int urnn_gru_cell_backward_f32(const float *x, const float *e, const 
     return URNN_OK;
 }
 
+// ---- stage conv / deconv backward (training building blocks) ----------------------------------------------------------
+struct ConvBwdWs {
+    float *u, *pk, *wt, *pkt, *wpart, *rows, *drows, *dsum;
+    size_t bytes;
+};
+
+// N = output channels of the equivalent 1x1 conv (Cout, or 4*Cout for the transposed conv), planes of P pixels
+static ConvBwdWs carve_conv_bwd(void *base, int B, int Cin, int N, long P, int deconv)
+{
+    size_t off = 0;
+    auto takef = [&](size_t nfloats) {
+        float *p = base ? reinterpret_cast<float *>(reinterpret_cast<char *>(base) + off) : nullptr;
+        off += align_up(nfloats * sizeof(float), 256);
+        return p;
+    };
+    ConvBwdWs w;
+    w.u = takef((size_t)B * N * P);
+    w.pk = takef(urnn_packed_conv_floats(Cin, N));
+    w.wt = takef((size_t)N * Cin);
+    w.pkt = takef(urnn_packed_conv_floats(N, Cin));
+    w.wpart = takef(urnn_train_wgrad_partial_floats(B, N, Cin, (int)P));
+    w.rows = takef(deconv ? (size_t)N * Cin : 0);
+    w.drows = takef(deconv ? (size_t)N * Cin : 0);
+    w.dsum = takef(deconv ? (size_t)N : 0);
+    w.bytes = off;
+    return w;
+}
+
+extern "C" size_t urnn_stage_conv_backward_workspace_bytes(int B, int Cin, int Cout, int H, int W)
+{
+    if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return 0;
+    return carve_conv_bwd(nullptr, B, Cin, Cout, (long)H * W, 0).bytes;
+}
+
+extern "C" int urnn_stage_conv_backward_f32(const float *in, const float *weight, const float *bias, const float *dout, float *din,
+                                            float *dweight, float *dbias, void *workspace, size_t workspace_bytes, int B, int Cin,
+                                            int Cout, int H, int W, int pool, float slope, int accumulate, void *stream)
+{
+    if (!in || !weight || !bias || !dout || !din || !dweight || !dbias || !workspace)
+        return fail(URNN_ENULL, "urnn_stage_conv_backward_f32: NULL argument");
+    if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || (pool && (H < 2 || W < 2)))
+        return fail(URNN_EINVAL, "urnn_stage_conv_backward_f32: bad dims");
+    const long P = (long)H * W;
+    const ConvBwdWs ws = carve_conv_bwd(workspace, B, Cin, Cout, P, 0);
+    if (workspace_bytes < ws.bytes)
+        return fail(URNN_EWORKSPACE, "urnn_stage_conv_backward_f32: workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
+    hipStream_t st = (hipStream_t)stream;
+    // pre-activation u = W.x + b (the forward kernel with an identity epilogue), then du = (un-pooled) dout * lrelu'(u)
+    CHECK_HIP(urnn_launch_pack_conv(weight, bias, ws.pk, Cin, Cout, st), "pack");
+    int rc = urnn_stage_conv_f32(in, ws.pk, ws.u, B, Cin, Cout, H, W, 0, 1.0f, stream);
+    if (rc) return rc;
+    CHECK_HIP(urnn_train_lrelu_pool_bwd(ws.u, dout, B, Cout, H, W, pool, slope, st), "lrelu backward");
+    const float *seg[3] = {in, nullptr, nullptr};
+    const int segC[3] = {Cin, 0, 0};
+    CHECK_HIP(urnn_train_wgrad(ws.u, seg, segC, B, Cout, Cin, (int)P, ws.wpart, dweight, dbias, accumulate, st), "weight gradient");
+    return dx_gemm(ws.u, weight, ws.wt, ws.pkt, din, B, Cout, Cin, H, W, st, "input gradient");
+}
+
+extern "C" size_t urnn_deconv2x2_backward_workspace_bytes(int B, int Cin, int Cout, int H, int W)
+{
+    if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return 0;
+    return carve_conv_bwd(nullptr, B, Cin, 4 * Cout, (long)H * W, 1).bytes;
+}
+
+extern "C" int urnn_deconv2x2_backward_f32(const float *in, const float *weight, const float *out, const float *dout, float *din,
+                                           float *dweight, float *dbias, void *workspace, size_t workspace_bytes, int B, int Cin,
+                                           int Cout, int H, int W, float slope, int accumulate, void *stream)
+{
+    if (!in || !weight || !out || !dout || !din || !dweight || !dbias || !workspace)
+        return fail(URNN_ENULL, "urnn_deconv2x2_backward_f32: NULL argument");
+    if (B < 1 || Cin < 1 || Cout < 1 || Cout > 96 || H < 1 || W < 1) return fail(URNN_EINVAL, "urnn_deconv2x2_backward_f32: bad dims");
+    const long P = (long)H * W;
+    const int N = 4 * Cout;
+    const ConvBwdWs ws = carve_conv_bwd(workspace, B, Cin, N, P, 1);
+    if (workspace_bytes < ws.bytes)
+        return fail(URNN_EWORKSPACE, "urnn_deconv2x2_backward_f32: workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
+    hipStream_t st = (hipStream_t)stream;
+    // the transposed conv is a 1x1 conv to 4*Cout channels (one per output parity) followed by a pixel shuffle
+    CHECK_HIP(urnn_train_deconv_unshuffle(dout, out, ws.u, B, Cout, H, W, slope, st), "deconv un-shuffle");
+    CHECK_HIP(urnn_train_deconv_weight_rows(weight, ws.rows, Cin, Cout, st), "deconv weight rows");
+    const float *seg[3] = {in, nullptr, nullptr};
+    const int segC[3] = {Cin, 0, 0};
+    CHECK_HIP(urnn_train_wgrad(ws.u, seg, segC, B, N, Cin, (int)P, ws.wpart, ws.drows, ws.dsum, 0, st), "weight gradient");
+    CHECK_HIP(urnn_train_deconv_rows_weight(ws.drows, ws.dsum, dweight, dbias, Cin, Cout, accumulate, st), "weight gradient layout");
+    return dx_gemm(ws.u, ws.rows, ws.wt, ws.pkt, din, B, N, Cin, H, W, st, "input gradient");
+}
+
 // ---- deconv ----------------------------------------------------------------------------------------------------------
 extern "C" int urnn_deconv2x2_f32(const float *in, const float *packed, float *out, int B, int Cin, int Cout, int H, int W,
                                   float slope, void *stream)

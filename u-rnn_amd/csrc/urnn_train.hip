@@ -374,3 +374,98 @@ hipError_t urnn_train_transpose(const float *w, float *wt, int N, int K, hipStre
     hipLaunchKernelGGL(transpose_kernel, dim3((N * K + 255) / 256), dim3(256), 0, st, w, wt, N, K);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Stage conv / deconv backward helpers
+// ------------------------------------------------------------------------------------------------------------------
+// u holds the pre-activation W.x + b (B,C,P); du = dy_at(p) * lrelu'(u), written over u.  pool: dy is (B,C,P2) and every
+// input pixel receives a quarter of its 2x2 cell's gradient (AvgPool2d(2,2) backward).
+__global__ __launch_bounds__(256) void lrelu_pool_bwd_kernel(float *u, const float *__restrict__ dy, int P, int W, int P2, int W2, int pool,
+                                                             float slope)
+{
+    const int bc = blockIdx.y;
+    float *up = u + (size_t)bc * P;
+    const float *dp = dy + (size_t)bc * (pool ? P2 : P);
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += gridDim.x * 256) {
+        float d;
+        if (pool) {
+            const int y = p / W, x = p - y * W;
+            const int y2 = y >> 1, x2 = x >> 1;
+            d = (y2 * W2 + x2 < P2 && x2 < W2) ? 0.25f * dp[y2 * W2 + x2] : 0.f;   // odd last row / column: dropped by the floor pooling
+        } else {
+            d = dp[p];
+        }
+        up[p] = up[p] >= 0.f ? d : d * slope;
+    }
+}
+
+// Deconv: D4[b][(a*2+bb)*Cout + co][i*W + j] = dy[b][co][2i+a][2j+bb] * lrelu'(y[...])   (y = forward output, sign-preserving)
+__global__ __launch_bounds__(256) void deconv_unshuffle_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y, float *__restrict__ d4,
+                                                                   int Cout, int P, int W, float slope)
+{
+    const int bn = blockIdx.y;                 // b * 4*Cout + n
+    const int b = bn / (4 * Cout), n = bn - b * 4 * Cout;
+    const int ab = n / Cout, co = n - ab * Cout, a = ab >> 1, bb = ab & 1;
+    const float *dp = dy + ((size_t)b * Cout + co) * 4 * P, *yp = y + ((size_t)b * Cout + co) * 4 * P;
+    float *o = d4 + (size_t)bn * P;
+    const int W2 = 2 * W;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += gridDim.x * 256) {
+        const int i = p / W, j = p - i * W;
+        const size_t q = (size_t)(2 * i + a) * W2 + 2 * j + bb;
+        o[p] = yp[q] >= 0.f ? dp[q] : dp[q] * slope;
+    }
+}
+
+// w (Cin,Cout,2,2) -> rows[(ab*Cout + co)][ci]
+__global__ void deconv_weight_rows_kernel(const float *__restrict__ w, float *__restrict__ rows, int Cin, int Cout)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 4 * Cout * Cin) return;
+    const int n = i / Cin, ci = i - n * Cin;
+    const int ab = n / Cout, co = n - ab * Cout;
+    rows[i] = w[((size_t)ci * Cout + co) * 4 + ab];
+}
+
+// drows[(ab*Cout + co)][ci], drow_sum[(ab*Cout + co)] -> dw (Cin,Cout,2,2) (+)=, db[co] (+)= sum_ab
+__global__ void deconv_rows_weight_kernel(const float *__restrict__ drows, const float *__restrict__ dsum, float *__restrict__ dw,
+                                          float *__restrict__ db, int Cin, int Cout, int accumulate)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 4 * Cout * Cin) {
+        const int n = i / Cin, ci = i - n * Cin;
+        const int ab = n / Cout, co = n - ab * Cout;
+        float *o = dw + ((size_t)ci * Cout + co) * 4 + ab;
+        *o = (accumulate ? *o : 0.f) + drows[i];
+    }
+    if (i < Cout) {
+        const float s = (dsum[i] + dsum[Cout + i]) + (dsum[2 * Cout + i] + dsum[3 * Cout + i]);
+        db[i] = (accumulate ? db[i] : 0.f) + s;
+    }
+}
+
+hipError_t urnn_train_lrelu_pool_bwd(float *u, const float *dy, int B, int C, int H, int W, int pool, float slope, hipStream_t st)
+{
+    const int P = H * W, W2 = W / 2, P2 = (H / 2) * W2;
+    hipLaunchKernelGGL(lrelu_pool_bwd_kernel, plane_grid(P, B * C), dim3(256), 0, st, u, dy, P, W, P2, W2, pool, slope);
+    return hipGetLastError();
+}
+
+hipError_t urnn_train_deconv_unshuffle(const float *dy, const float *y, float *d4, int B, int Cout, int H, int W, float slope, hipStream_t st)
+{
+    const int P = H * W;
+    hipLaunchKernelGGL(deconv_unshuffle_bwd_kernel, plane_grid(P, B * 4 * Cout), dim3(256), 0, st, dy, y, d4, Cout, P, W, slope);
+    return hipGetLastError();
+}
+
+hipError_t urnn_train_deconv_weight_rows(const float *w, float *rows, int Cin, int Cout, hipStream_t st)
+{
+    hipLaunchKernelGGL(deconv_weight_rows_kernel, dim3((4 * Cout * Cin + 255) / 256), dim3(256), 0, st, w, rows, Cin, Cout);
+    return hipGetLastError();
+}
+
+hipError_t urnn_train_deconv_rows_weight(const float *drows, const float *dsum, float *dw, float *db, int Cin, int Cout, int accumulate,
+                                         hipStream_t st)
+{
+    hipLaunchKernelGGL(deconv_rows_weight_kernel, dim3((4 * Cout * Cin + 255) / 256), dim3(256), 0, st, drows, dsum, dw, db, Cin, Cout, accumulate);
+    return hipGetLastError();
+}

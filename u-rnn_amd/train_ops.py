@@ -42,3 +42,45 @@ def gru_cell_backward(x, e, h, W1, W2, gn1_w, gn2_w, dh_out, I, grads=None, accu
                                        p(g["dg2"]), p(g["dbe2"]), p(ws), ws.numel(), B, I, F, H, W, int(bool(accumulate)),
                                        ops._stream()), "urnn_gru_cell_backward_f32")
     return g
+
+
+def _bwd_workspace(nbytes, dev):
+    slot = ops.WORKSPACE.slot
+    ops.WORKSPACE.use_slot(_BWD_SLOT)
+    ws = ops.WORKSPACE.get(nbytes, dev)
+    ops.WORKSPACE.use_slot(slot)
+    return ws
+
+
+def stage_conv_backward(x, weight, bias, dout, pool, dweight=None, dbias=None, accumulate=False, slope=ops.LRELU_SLOPE):
+    """Backward of ``ops.stage_conv`` (conv1x1 + LeakyReLU [+ AvgPool2]).  weight (Cout,Cin[,1,1]), bias (Cout).
+    Returns (dx, dweight, dbias)."""
+    ops._dev_check(x, weight, bias, dout)
+    B, Cin, H, W = x.shape
+    Cout = weight.shape[0]
+    L = lib()
+    ws = _bwd_workspace(L.urnn_stage_conv_backward_workspace_bytes(B, Cin, Cout, H, W), x.device)
+    if dweight is None or not accumulate:
+        dweight, dbias = torch.empty_like(weight), torch.empty_like(bias)
+    dx = torch.empty_like(x)
+    p = ops._ptr
+    check(L.urnn_stage_conv_backward_f32(p(x), p(weight), p(bias), p(dout), p(dx), p(dweight), p(dbias), p(ws), ws.numel(), B, Cin,
+                                         Cout, H, W, int(bool(pool)), slope, int(bool(accumulate)), ops._stream()),
+          "urnn_stage_conv_backward_f32")
+    return dx, dweight, dbias
+
+
+def deconv2x2_backward(x, weight, out, dout, dweight=None, dbias=None, accumulate=False, slope=ops.LRELU_SLOPE):
+    """Backward of ``ops.deconv2x2``.  weight (Cin,Cout,2,2); ``out`` is the forward output.  Returns (dx, dweight, dbias)."""
+    ops._dev_check(x, weight, out, dout)
+    B, Cin, H, W = x.shape
+    Cout = weight.shape[1]
+    L = lib()
+    ws = _bwd_workspace(L.urnn_deconv2x2_backward_workspace_bytes(B, Cin, Cout, H, W), x.device)
+    if dweight is None or not accumulate:
+        dweight, dbias = torch.empty_like(weight), torch.empty(Cout, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    p = ops._ptr
+    check(L.urnn_deconv2x2_backward_f32(p(x), p(weight), p(out), p(dout), p(dx), p(dweight), p(dbias), p(ws), ws.numel(), B, Cin, Cout,
+                                        H, W, slope, int(bool(accumulate)), ops._stream()), "urnn_deconv2x2_backward_f32")
+    return dx, dweight, dbias
