@@ -161,6 +161,18 @@ int urnn_deconv2x2_backward_f32(const float *in, const float *weight, const floa
                                 float *dbias, void *workspace, size_t workspace_bytes, int B, int Cin, int Cout, int H, int W,
                                 float slope, int accumulate, void *stream);
 
+/* Backward of urnn_head_f32 w.r.t. its first output (the masked depth; the loss never sees the probability map).  Call it
+ * after the forward on the same feat with the forward's workspace untouched (fwd_workspace: the five LayerNorm statistics) and
+ * the forward's out_raw / out_cls.  Only the regression branch carries gradient: the wet/dry mask is a comparison
+ * (flood_head.py:179-202), so the classification blocks' gradients are zero.  dconv_w 5 x (C x C), dln_w / dln_b 5 x (C,H,W),
+ * dreg_w (C), dreg_b (1) in the forward's parameter order; overwritten, or added to when accumulate != 0. */
+size_t urnn_head_backward_workspace_bytes(int B, int H, int W);
+int urnn_head_backward_f32(const float *feat, const float *conv_w, const float *ln_w, const float *ln_b, const float *reg_w,
+                           const void *fwd_workspace, const float *out_raw, const float *out_cls, const float *dout, float *dfeat,
+                           float *dconv_w, float *dln_w, float *dln_b, float *dreg_w, float *dreg_b, void *workspace,
+                           size_t workspace_bytes, int B, int C, int H, int W, float cls_thred, float slope, int accumulate,
+                           void *stream);
+
 /* Device-side frame counter helper for graph-captured rollouts: *counter += delta. */
 int urnn_advance_counter(int *counter, int delta, void *stream);
 

@@ -131,3 +131,32 @@ def test_deconv_backward_vs_reference_autograd(dev, layers, tag):
     assert_close(dx.cpu().numpy(), k("dx"), GRAD_TOL, f"{tag}: dx")
     assert_close(dw.cpu().numpy(), k("dw"), GRAD_TOL, f"{tag}: dw")
     assert_close(db.cpu().numpy(), k("db"), GRAD_TOL, f"{tag}: db")
+
+
+def test_head_backward_vs_reference_autograd(dev, layers):
+    from urnn_amd import ops, train_ops
+    k = lambda n: layers[f"lay_head_{n}"]
+    names = ["stems", "cls_convs.0", "cls_convs.1", "reg_convs.0", "reg_convs.1"]
+    conv_w = T(np.stack([k(f"p_{n}.conv.weight").reshape(16, 16) for n in names]), dev)
+    ln_w = T(np.stack([k(f"p_{n}.ln.weight") for n in names]), dev)
+    ln_b = T(np.stack([k(f"p_{n}.ln.bias") for n in names]), dev)
+    cls_w, cls_b = T(k("p_cls_preds.conv.weight").reshape(-1), dev), T(k("p_cls_preds.conv.bias"), dev)
+    reg_w, reg_b = T(k("p_reg_preds.conv.weight").reshape(-1), dev), T(k("p_reg_preds.conv.bias"), dev)
+    feat = T(k("f")[0], dev)                                   # (B=1,16,H,W)
+    masked, cls, raw = ops.head(feat, conv_w, ln_w, ln_b, cls_w, cls_b, reg_w, reg_b, 0.5, want_raw=True)
+    ref_out = k("out")[0]                                      # (1,2,H,W)
+    assert_close(cls.cpu().numpy(), ref_out[:, 1], 1e-4, "head forward cls")
+    g = train_ops.head_backward(feat, conv_w, ln_w, ln_b, reg_w, raw, cls, T(k("dreg")[0], dev), 0.5)
+    assert_close(g["dfeat"].cpu().numpy(), k("df")[0], GRAD_TOL, "head: dfeat")
+    for i, n in enumerate(names):
+        if not n.startswith("cls"):
+            assert_close(g["dconv_w"][i].cpu().numpy(), k(f"g_{n}.conv.weight").reshape(16, 16), GRAD_TOL, f"head: d{n}.conv")
+        ref_w, ref_b = k(f"g_{n}.ln.weight"), k(f"g_{n}.ln.bias")
+        if n.startswith("cls"):
+            assert float(g["dconv_w"][i].abs().max()) == 0.0 and float(g["dln_w"][i].abs().max()) == 0.0
+            assert float(np.abs(ref_w).max()) == 0.0            # and so says the reference
+        else:
+            assert_close(g["dln_w"][i].cpu().numpy(), ref_w, GRAD_TOL, f"head: d{n}.ln.weight")
+            assert_close(g["dln_b"][i].cpu().numpy(), ref_b, GRAD_TOL, f"head: d{n}.ln.bias")
+    assert_close(g["dreg_w"].cpu().numpy(), k("g_reg_preds.conv.weight").reshape(-1), GRAD_TOL, "head: dreg_w")
+    assert_close(g["dreg_b"].cpu().numpy(), k("g_reg_preds.conv.bias"), GRAD_TOL, "head: dreg_b")

@@ -596,6 +596,90 @@ extern "C" int urnn_head_f32(const float *feat, const float *conv_w, const float
     return URNN_OK;
 }
 
+// ---- head backward (training building block) -----------------------------------------------------------------------------
+struct HeadBwdWs {
+    float *save, *ds, *draw, *partial, *coef, *wpart, *wt, *pkt;
+    size_t bytes;
+};
+
+static HeadBwdWs carve_head_bwd(void *base, int B, long P)
+{
+    size_t off = 0;
+    auto takef = [&](size_t nfloats) {
+        float *p = base ? reinterpret_cast<float *>(reinterpret_cast<char *>(base) + off) : nullptr;
+        off += align_up(nfloats * sizeof(float), 256);
+        return p;
+    };
+    HeadBwdWs w;
+    w.save = takef((size_t)6 * B * 16 * P);
+    w.ds = takef((size_t)B * 16 * P);
+    w.draw = takef((size_t)B * P);
+    w.partial = takef((size_t)B * ((P + 255) / 256) * 2);
+    w.coef = takef((size_t)B * 2);
+    w.wpart = takef(urnn_train_wgrad_partial_floats(B, 16, 16, (int)P));
+    w.wt = takef(256);
+    w.pkt = takef(urnn_packed_conv_floats(16, 16));
+    w.bytes = off;
+    return w;
+}
+
+extern "C" size_t urnn_head_backward_workspace_bytes(int B, int H, int W)
+{
+    if (B < 1 || H < 1 || W < 1) return 0;
+    return carve_head_bwd(nullptr, B, (long)H * W).bytes;
+}
+
+extern "C" int urnn_head_backward_f32(const float *feat, const float *conv_w, const float *ln_w, const float *ln_b, const float *reg_w,
+                                      const void *fwd_workspace, const float *out_raw, const float *out_cls, const float *dout,
+                                      float *dfeat, float *dconv_w, float *dln_w, float *dln_b, float *dreg_w, float *dreg_b,
+                                      void *workspace, size_t workspace_bytes, int B, int C, int H, int W, float cls_thred, float slope,
+                                      int accumulate, void *stream)
+{
+    if (!feat || !conv_w || !ln_w || !ln_b || !reg_w || !fwd_workspace || !out_raw || !out_cls || !dout || !dfeat || !dconv_w || !dln_w ||
+        !dln_b || !dreg_w || !dreg_b || !workspace)
+        return fail(URNN_ENULL, "urnn_head_backward_f32: NULL argument");
+    if (C != 16) return fail(URNN_EINVAL, "urnn_head_backward_f32: head width C=%d unsupported (kernels are built for 16)", C);
+    if (B < 1 || H < 1 || W < 1) return fail(URNN_EINVAL, "urnn_head_backward_f32: bad dims");
+    const long P = (long)H * W;
+    const HeadWs fw = carve_head(const_cast<void *>(fwd_workspace), B, C, P);
+    const HeadBwdWs ws = carve_head_bwd(workspace, B, P);
+    if (workspace_bytes < ws.bytes)
+        return fail(URNN_EWORKSPACE, "urnn_head_backward_f32: workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
+    hipStream_t st = (hipStream_t)stream;
+    const int Pi = (int)P;
+    const size_t CP = (size_t)16 * P, plane = (size_t)B * CP;
+    CHECK_HIP(urnn_train_head_save(feat, conv_w, ln_w, ln_b, fw.stats, B, Pi, ws.save, st), "head: recompute the regression branch");
+    CHECK_HIP(urnn_train_head_pred_bwd(dout, out_cls, out_raw, reg_w, cls_thred, slope, B, Pi, ws.draw, ws.ds, st), "head: prediction layer");
+    {   // d(reg_preds): w_r[c] += sum draw * q2[c], b_r += sum draw
+        const float *seg[3] = {ws.save + 5 * plane, nullptr, nullptr};
+        const int segC[3] = {16, 0, 0};
+        CHECK_HIP(urnn_train_wgrad(ws.draw, seg, segC, B, 1, 16, Pi, ws.wpart, dreg_w, dreg_b, accumulate, st), "head: prediction weights");
+    }
+    const int blk[3] = {4, 3, 0};            // reg_convs[1], reg_convs[0], stems
+    const int uslot[3] = {2, 1, 0};          // pre-norm activations v2, v1, u0
+    for (int l = 0; l < 3; ++l) {
+        const int k = blk[l];
+        CHECK_HIP(urnn_train_head_ln_bwd(ws.ds, ws.save + uslot[l] * plane, ln_w + k * CP, ln_b + k * CP, fw.stats + (size_t)k * B * 2, B, Pi,
+                                         dln_w + k * CP, dln_b + k * CP, accumulate, ws.partial, ws.coef, st), "head: LayerNorm backward");
+        const float *in = l == 2 ? feat : ws.save + (size_t)(3 + (1 - l)) * plane;      // layer input: q1, t, feat
+        const float *seg[3] = {in, nullptr, nullptr};
+        const int segC[3] = {16, 0, 0};
+        CHECK_HIP(urnn_train_wgrad(ws.ds, seg, segC, B, 16, 16, Pi, ws.wpart, dconv_w + k * 256, nullptr, accumulate, st), "head: conv weights");
+        // input gradient W^T . du: for the inner layers it becomes the next ds; it may not alias the GEMM input, so go through dfeat
+        int rc = dx_gemm(ws.ds, conv_w + k * 256, ws.wt, ws.pkt, dfeat, B, 16, 16, H, W, st, "head: input gradient");
+        if (rc) return rc;
+        if (l < 2) CHECK_HIP(hipMemcpyAsync(ws.ds, dfeat, plane * sizeof(float), hipMemcpyDeviceToDevice, st), "head: hand-over");
+    }
+    if (!accumulate) {   // the classification branch receives no gradient
+        for (int k = 1; k <= 2; ++k) {
+            CHECK_HIP(hipMemsetAsync(dconv_w + k * 256, 0, 256 * sizeof(float), st), "head: zero cls grads");
+            CHECK_HIP(hipMemsetAsync(dln_w + k * CP, 0, CP * sizeof(float), st), "head: zero cls grads");
+            CHECK_HIP(hipMemsetAsync(dln_b + k * CP, 0, CP * sizeof(float), st), "head: zero cls grads");
+        }
+    }
+    return URNN_OK;
+}
+
 // ---- input assembly --------------------------------------------------------------------------------------------------
 extern "C" int urnn_preprocess_f32(const float *rain, const float *cumsum, const float *dem, const float *imperv,
                                    const float *manhole, float dem_min, float dem_max, float *out, int t, const int *t_dev,

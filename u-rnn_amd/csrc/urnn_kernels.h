@@ -103,3 +103,9 @@ hipError_t urnn_train_deconv_unshuffle(const float *dy, const float *y, float *d
 hipError_t urnn_train_deconv_weight_rows(const float *w, float *rows, int Cin, int Cout, hipStream_t st);
 hipError_t urnn_train_deconv_rows_weight(const float *drows, const float *dsum, float *dw, float *db, int Cin, int Cout, int accumulate,
                                          hipStream_t st);
+hipError_t urnn_train_head_save(const float *feat, const float *conv_w, const float *ln_w, const float *ln_b, const float *stats, int B,
+                                int P, float *save, hipStream_t st);
+hipError_t urnn_train_head_pred_bwd(const float *dout, const float *cls, const float *reg, const float *reg_w, float thr, float slope,
+                                    int B, int P, float *draw, float *ds, hipStream_t st);
+hipError_t urnn_train_head_ln_bwd(float *ds, const float *u, const float *g, const float *bt, const float *stats, int B, int P, float *dg,
+                                  float *dbt, int accumulate, float *partial, float *coef, hipStream_t st);

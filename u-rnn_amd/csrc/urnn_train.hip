@@ -469,3 +469,191 @@ hipError_t urnn_train_deconv_rows_weight(const float *drows, const float *dsum, 
     hipLaunchKernelGGL(deconv_rows_weight_kernel, dim3((4 * Cout * Cin + 255) / 256), dim3(256), 0, st, drows, dsum, dw, db, Cin, Cout, accumulate);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Head backward (flood_head.py:131-202, regression branch: the classification branch only enters through the wet/dry mask,
+// a comparison, and receives no gradient).  C = 16 channels, one thread per pixel.
+//   stem:  u0 = Ws.f      t  = SiLU(LN0(u0))        block index 0
+//   reg0:  v1 = Wq1.t     q1 = SiLU(LN3(v1))        block index 3
+//   reg1:  v2 = Wq2.q1    q2 = SiLU(LN4(v2))        block index 4
+//   pred:  raw = w_r.q2 + b_r,  reg = lrelu(raw),  out = reg * [cls >= thr]
+// LayerNorm([16,H,W]): statistics over all 16*P values of a sample, element-wise affine (16,P).
+// ------------------------------------------------------------------------------------------------------------------
+#define HC 16
+
+__device__ __forceinline__ void hb_matvec(const float *__restrict__ w, const float (&x)[HC], float (&u)[HC])
+{
+#pragma unroll
+    for (int n = 0; n < HC; ++n) {
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < HC; ++c) s = fmaf(w[n * HC + c], x[c], s);
+        u[n] = s;
+    }
+}
+
+__device__ __forceinline__ void hb_ln_silu(const float (&u)[HC], const float *__restrict__ g, const float *__restrict__ bt, int P, int p,
+                                           float mean, float rstd, float (&s)[HC])
+{
+#pragma unroll
+    for (int c = 0; c < HC; ++c) {
+        const float y = (u[c] - mean) * rstd * g[(size_t)c * P + p] + bt[(size_t)c * P + p];
+        s[c] = y / (1.0f + expf(-y));
+    }
+}
+
+// recompute and store the regression branch: pre-norm u0, v1, v2 and layer inputs t, q1, q2 (each (B,16,P)); stats [5][B][2]
+__global__ __launch_bounds__(256) void head_train_save_kernel(const float *__restrict__ feat, const float *__restrict__ conv_w,
+                                                              const float *__restrict__ ln_w, const float *__restrict__ ln_b,
+                                                              const float *__restrict__ stats, int B, int P, float *__restrict__ save)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (p >= P) return;
+    const size_t CP = (size_t)HC * P, plane = (size_t)B * CP;
+    float f[HC], u[HC], s[HC];
+#pragma unroll
+    for (int c = 0; c < HC; ++c) f[c] = feat[b * CP + (size_t)c * P + p];
+    auto put = [&](int slot, const float (&v)[HC]) {
+#pragma unroll
+        for (int c = 0; c < HC; ++c) save[slot * plane + b * CP + (size_t)c * P + p] = v[c];
+    };
+    const int blk[3] = {0, 3, 4};
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+        hb_matvec(conv_w + blk[l] * HC * HC, f, u);
+        put(l, u);                                                            // slots 0..2: u0, v1, v2
+        hb_ln_silu(u, ln_w + blk[l] * CP, ln_b + blk[l] * CP, P, p, stats[(blk[l] * B + b) * 2], stats[(blk[l] * B + b) * 2 + 1], s);
+        put(3 + l, s);                                                        // slots 3..5: t, q1, q2
+#pragma unroll
+        for (int c = 0; c < HC; ++c) f[c] = s[c];
+    }
+}
+
+// prediction layer: draw = dout * mask * lrelu'(reg);  ds[c] = w_r[c] * draw
+__global__ __launch_bounds__(256) void head_pred_bwd_kernel(const float *__restrict__ dout, const float *__restrict__ cls,
+                                                            const float *__restrict__ reg, const float *__restrict__ reg_w, float thr,
+                                                            float slope, int P, float *__restrict__ draw, float *__restrict__ ds)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (p >= P) return;
+    const size_t i = (size_t)b * P + p;
+    const float d = (cls[i] >= thr ? dout[i] : 0.f) * (reg[i] >= 0.f ? 1.f : slope);
+    draw[i] = d;
+#pragma unroll
+    for (int c = 0; c < HC; ++c) ds[((size_t)b * HC + c) * P + p] = reg_w[c] * d;
+}
+
+// LayerNorm + SiLU backward, first half: dy = ds * SiLU'(y); dgamma/dbeta (element-wise, summed over samples);
+// dxhat = dy * gamma -> ds (in place); per-sample partial sums of dxhat and dxhat * xhat.  grid (chunks); loops over samples.
+__global__ __launch_bounds__(256) void head_ln_bwd_a_kernel(float *ds, const float *__restrict__ u, const float *__restrict__ g,
+                                                            const float *__restrict__ bt, const float *__restrict__ stats, int B, int P,
+                                                            float *dg, float *dbt, int accumulate, float *__restrict__ partial)
+{
+    __shared__ float sh[2][4];
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const bool in = p < P;
+    const size_t CP = (size_t)HC * P;
+    float ag[HC], ab[HC];
+#pragma unroll
+    for (int c = 0; c < HC; ++c) ag[c] = ab[c] = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float mean = stats[b * 2], rstd = stats[b * 2 + 1];
+        float s1 = 0.f, s2 = 0.f;
+        if (in) {
+#pragma unroll
+            for (int c = 0; c < HC; ++c) {
+                const size_t i = b * CP + (size_t)c * P + p;
+                const float xh = (u[i] - mean) * rstd;
+                const float gm = g[(size_t)c * P + p];
+                const float y = xh * gm + bt[(size_t)c * P + p];
+                const float sg = 1.0f / (1.0f + expf(-y));
+                const float dy = ds[i] * sg * (1.0f + y * (1.0f - sg));
+                ag[c] += dy * xh;
+                ab[c] += dy;
+                const float dxh = dy * gm;
+                ds[i] = dxh;
+                s1 += dxh;
+                s2 += dxh * xh;
+            }
+        }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        __syncthreads();
+        if (lane == 0) { sh[0][wave] = s1; sh[1][wave] = s2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float *pp = partial + ((size_t)b * gridDim.x + blockIdx.x) * 2;
+            pp[0] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+            pp[1] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+        }
+    }
+    if (in) {
+#pragma unroll
+        for (int c = 0; c < HC; ++c) {
+            const size_t i = (size_t)c * P + p;
+            dg[i] = (accumulate ? dg[i] : 0.f) + ag[c];
+            dbt[i] = (accumulate ? dbt[i] : 0.f) + ab[c];
+        }
+    }
+}
+
+// per sample: m1 = sum(dxhat) / (16 P), m2 = sum(dxhat * xhat) / (16 P); one wave per sample
+__global__ __launch_bounds__(64) void head_ln_coef_kernel(const float *__restrict__ partial, int nblk, double count, float *__restrict__ coef)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float *pp = partial + (size_t)b * nblk * 2;
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = lane; t < nblk; t += 64) {
+        s1 += (double)pp[2 * t];
+        s2 += (double)pp[2 * t + 1];
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        s1 += __shfl_xor(s1, m, 64);
+        s2 += __shfl_xor(s2, m, 64);
+    }
+    if (lane == 0) {
+        coef[b * 2] = (float)(s1 / count);
+        coef[b * 2 + 1] = (float)(s2 / count);
+    }
+}
+
+// second half: du = rstd * (dxhat - m1 - xhat * m2), in place
+__global__ __launch_bounds__(256) void head_ln_bwd_b_kernel(float *ds, const float *__restrict__ u, const float *__restrict__ stats,
+                                                            const float *__restrict__ coef, int P)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (p >= P) return;
+    const float mean = stats[b * 2], rstd = stats[b * 2 + 1], m1 = coef[b * 2], m2 = coef[b * 2 + 1];
+#pragma unroll
+    for (int c = 0; c < HC; ++c) {
+        const size_t i = ((size_t)b * HC + c) * P + p;
+        const float xh = (u[i] - mean) * rstd;
+        ds[i] = rstd * (ds[i] - m1 - xh * m2);
+    }
+}
+
+hipError_t urnn_train_head_save(const float *feat, const float *conv_w, const float *ln_w, const float *ln_b, const float *stats, int B,
+                                int P, float *save, hipStream_t st)
+{
+    hipLaunchKernelGGL(head_train_save_kernel, dim3((P + 255) / 256, B), dim3(256), 0, st, feat, conv_w, ln_w, ln_b, stats, B, P, save);
+    return hipGetLastError();
+}
+
+hipError_t urnn_train_head_pred_bwd(const float *dout, const float *cls, const float *reg, const float *reg_w, float thr, float slope,
+                                    int B, int P, float *draw, float *ds, hipStream_t st)
+{
+    hipLaunchKernelGGL(head_pred_bwd_kernel, dim3((P + 255) / 256, B), dim3(256), 0, st, dout, cls, reg, reg_w, thr, slope, P, draw, ds);
+    return hipGetLastError();
+}
+
+hipError_t urnn_train_head_ln_bwd(float *ds, const float *u, const float *g, const float *bt, const float *stats, int B, int P, float *dg,
+                                  float *dbt, int accumulate, float *partial, float *coef, hipStream_t st)
+{
+    const int nblk = (P + 255) / 256;
+    hipLaunchKernelGGL(head_ln_bwd_a_kernel, dim3(nblk), dim3(256), 0, st, ds, u, g, bt, stats, B, P, dg, dbt, accumulate, partial);
+    hipLaunchKernelGGL(head_ln_coef_kernel, dim3(B), dim3(64), 0, st, partial, nblk, (double)HC * (double)P, coef);
+    hipLaunchKernelGGL(head_ln_bwd_b_kernel, dim3(nblk, B), dim3(256), 0, st, ds, u, stats, coef, P);
+    return hipGetLastError();
+}

@@ -84,3 +84,26 @@ def deconv2x2_backward(x, weight, out, dout, dweight=None, dbias=None, accumulat
     check(L.urnn_deconv2x2_backward_f32(p(x), p(weight), p(out), p(dout), p(dx), p(dweight), p(dbias), p(ws), ws.numel(), B, Cin, Cout,
                                         H, W, slope, int(bool(accumulate)), ops._stream()), "urnn_deconv2x2_backward_f32")
     return dx, dweight, dbias
+
+
+def head_backward(feat, conv_w, ln_w, ln_b, reg_w, out_raw, out_cls, dout, cls_thred, grads=None, accumulate=False,
+                  slope=ops.LRELU_SLOPE):
+    """Backward of ``ops.head`` w.r.t. the masked depth.  Must directly follow the forward on the same ``feat`` (same
+    workspace slot; ``want_raw=True`` so that ``out_raw`` exists).  conv_w (5,C,C), ln_w / ln_b (5,C,H,W), reg_w (C).
+    Returns a dict: dfeat, dconv_w, dln_w, dln_b, dreg_w, dreg_b."""
+    ops._dev_check(feat, conv_w, ln_w, ln_b, reg_w, out_raw, out_cls, dout)
+    B, C, H, W = feat.shape
+    L = lib()
+    fwd = ops.WORKSPACE.get(L.urnn_head_workspace_bytes(B, C, H, W), feat.device)
+    ws = _bwd_workspace(L.urnn_head_backward_workspace_bytes(B, H, W), feat.device)
+    f32 = dict(dtype=torch.float32, device=feat.device)
+    g = grads if grads is not None else {}
+    if grads is None or not accumulate:
+        g.update(dconv_w=torch.empty_like(conv_w), dln_w=torch.empty_like(ln_w), dln_b=torch.empty_like(ln_b),
+                 dreg_w=torch.empty(C, **f32), dreg_b=torch.empty(1, **f32))
+    g["dfeat"] = torch.empty_like(feat)
+    p = ops._ptr
+    check(L.urnn_head_backward_f32(p(feat), p(conv_w), p(ln_w), p(ln_b), p(reg_w), p(fwd), p(out_raw), p(out_cls), p(dout), p(g["dfeat"]),
+                                   p(g["dconv_w"]), p(g["dln_w"]), p(g["dln_b"]), p(g["dreg_w"]), p(g["dreg_b"]), p(ws), ws.numel(),
+                                   B, C, H, W, float(cls_thred), slope, int(bool(accumulate)), ops._stream()), "urnn_head_backward_f32")
+    return g
