@@ -173,6 +173,13 @@ int urnn_head_backward_f32(const float *feat, const float *conv_w, const float *
                            size_t workspace_bytes, int B, int C, int H, int W, float cls_thred, float slope, int accumulate,
                            void *stream);
 
+/* Training loss FocalBCE_and_WMSE (losses.py:44-249) on a window's concatenated outputs reg / targets (n values each), as the SWP
+ * loop forms it (main.py:489-539: cls = [reg >= cls_thred], a comparison).  components (device, 5 floats): loss, loss_reg,
+ * wet-cell MSE, dry-cell MSE, loss_cls.  dreg (n, may be NULL): d loss / d reg.  Deterministic. */
+size_t urnn_loss_workspace_bytes(long n);
+int urnn_loss_f32(const float *reg, const float *target, float cls_thred, float *components, float *dreg, void *workspace,
+                  size_t workspace_bytes, long n, void *stream);
+
 /* Device-side frame counter helper for graph-captured rollouts: *counter += delta. */
 int urnn_advance_counter(int *counter, int delta, void *stream);
 

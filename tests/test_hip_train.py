@@ -160,3 +160,51 @@ def test_head_backward_vs_reference_autograd(dev, layers):
             assert_close(g["dln_b"][i].cpu().numpy(), ref_b, GRAD_TOL, f"head: d{n}.ln.bias")
     assert_close(g["dreg_w"].cpu().numpy(), k("g_reg_preds.conv.weight").reshape(-1), GRAD_TOL, "head: dreg_w")
     assert_close(g["dreg_b"].cpu().numpy(), k("g_reg_preds.conv.bias"), GRAD_TOL, "head: dreg_b")
+
+
+@pytest.mark.parametrize("thr", [0.0, 0.01])
+def test_loss_vs_reference(dev, thr):
+    from urnn_amd import train_ops
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_window_16x16.npz"))
+    comps, dreg = train_ops.loss(T(g["loss_reg"], dev), T(g["loss_tgt"], dev), cls_thred=thr)
+    names = ["loss", "loss_reg", "loss_reg_label", "loss_reg_pred", "loss_cls"]
+    for v, n in zip(comps.cpu().numpy(), names):
+        assert v == pytest.approx(float(g[f"loss_thr{thr}_{n}"]), rel=5e-6), n
+    ref = g[f"loss_thr{thr}_dreg"]
+    assert np.abs(dreg.cpu().numpy() - ref).max() <= 5e-6 * np.abs(ref).max()
+
+
+def test_window_gradients_vs_reference_autograd(dev):
+    """The whole backward: two timesteps of an SWP window from zero states, loss, BPTT through the six recurrent states --
+    loss components, both outputs and the gradient of all 79 parameter tensors against reference autograd."""
+    import urnn_amd.weights as uw
+    from urnn_amd.net_config import load_net_config
+    from urnn_amd.networks import ED, get_network_params
+    from urnn_amd.training import WindowGradients
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_window_16x16.npz"))
+    H, W, nums, steps = int(g["win_H"]), int(g["win_W"]), int(g["win_nums"]), int(g["win_steps"])
+    C = 2 * nums + 3
+    sd = uw.make_state_dict(H, W, C, seed=int(g["win_weights_seed"]))
+    ep, dp = get_network_params(False, H, W, C, load_net_config())
+    net = ED(False, ep, dp, 0.5, False, H, W)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net = net.to(dev).eval()
+    ev = uw.make_event(steps + 1, H, W, float(g["win_rain_max"]), seed=int(g["win_event_seed"]))
+    wg = WindowGradients(net, H, W, nums, float(g["win_rain_max"]), float(g["win_cumsum_max"]))
+    out = wg.run(ev, g["win_target"], 0, steps)
+    assert_close(out["reg"].cpu().numpy(), g["win_reg"], 1e-4, "window outputs")
+    for v, n in zip(out["loss"].cpu().numpy(), ["loss", "loss_reg", "loss_reg_label", "loss_reg_pred", "loss_cls"]):
+        assert v == pytest.approx(float(g[f"win_{n}"]), rel=2e-4), n
+    assert set(out["grads"]) == set(sd)
+    worst = ("", 0.0)
+    for name in sd:
+        ref = g[f"win_grad_{name}"]
+        got = out["grads"][name].cpu().numpy().reshape(ref.shape)
+        scale = np.abs(ref).max()
+        if scale == 0.0:
+            assert np.abs(got).max() == 0.0, name
+            continue
+        err = np.abs(got - ref).max() / scale
+        worst = max(worst, (name, err), key=lambda t: t[1])
+        assert err <= 1e-3, (name, err)
+    print("worst gradient:", worst)

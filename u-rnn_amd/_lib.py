@@ -42,6 +42,8 @@ SIGNATURES = {
     "urnn_deconv2x2_backward_f32": (_i, [_p] * 8 + [_sz, _i, _i, _i, _i, _i, _f, _i, _p]),
     "urnn_head_backward_workspace_bytes": (_sz, [_i, _i, _i]),
     "urnn_head_backward_f32": (_i, [_p] * 16 + [_sz, _i, _i, _i, _i, _f, _f, _i, _p]),
+    "urnn_loss_workspace_bytes": (_sz, [ctypes.c_long]),
+    "urnn_loss_f32": (_i, [_p, _p, _f, _p, _p, _p, _sz, ctypes.c_long, _p]),
     "urnn_advance_counter": (_i, [_p, _i, _p]),
 }
 

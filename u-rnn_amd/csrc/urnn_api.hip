@@ -680,6 +680,25 @@ extern "C" int urnn_head_backward_f32(const float *feat, const float *conv_w, co
     return URNN_OK;
 }
 
+// ---- training loss -----------------------------------------------------------------------------------------------------
+extern "C" size_t urnn_loss_workspace_bytes(long n)
+{
+    if (n < 1) return 0;
+    return align_up((size_t)urnn_train_loss_nblk(n) * 5 * sizeof(float), 256) + 256;
+}
+
+extern "C" int urnn_loss_f32(const float *reg, const float *target, float cls_thred, float *components, float *dreg, void *workspace,
+                             size_t workspace_bytes, long n, void *stream)
+{
+    if (!reg || !target || !components || !workspace) return fail(URNN_ENULL, "urnn_loss_f32: NULL argument");
+    if (n < 1) return fail(URNN_EINVAL, "urnn_loss_f32: n=%ld", n);
+    if (workspace_bytes < urnn_loss_workspace_bytes(n)) return fail(URNN_EWORKSPACE, "urnn_loss_f32: workspace too small");
+    float *partial = reinterpret_cast<float *>(workspace);
+    float *scales = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + align_up((size_t)urnn_train_loss_nblk(n) * 5 * sizeof(float), 256));
+    CHECK_HIP(urnn_train_loss(reg, target, cls_thred, n, partial, scales, components, dreg, (hipStream_t)stream), "loss");
+    return URNN_OK;
+}
+
 // ---- input assembly --------------------------------------------------------------------------------------------------
 extern "C" int urnn_preprocess_f32(const float *rain, const float *cumsum, const float *dem, const float *imperv,
                                    const float *manhole, float dem_min, float dem_max, float *out, int t, const int *t_dev,

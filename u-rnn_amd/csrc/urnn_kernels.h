@@ -109,3 +109,6 @@ hipError_t urnn_train_head_pred_bwd(const float *dout, const float *cls, const f
                                     int B, int P, float *draw, float *ds, hipStream_t st);
 hipError_t urnn_train_head_ln_bwd(float *ds, const float *u, const float *g, const float *bt, const float *stats, int B, int P, float *dg,
                                   float *dbt, int accumulate, float *partial, float *coef, hipStream_t st);
+int urnn_train_loss_nblk(long n);
+hipError_t urnn_train_loss(const float *reg, const float *tgt, float thr, long n, float *partial, float *scales, float *comps, float *dreg,
+                           hipStream_t st);

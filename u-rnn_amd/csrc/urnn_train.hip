@@ -657,3 +657,86 @@ hipError_t urnn_train_head_ln_bwd(float *ds, const float *u, const float *g, con
     hipLaunchKernelGGL(head_ln_bwd_b_kernel, dim3(nblk, B), dim3(256), 0, st, ds, u, stats, coef, P);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Training loss  FocalBCE_and_WMSE (losses.py:44-249) as the SWP loop applies it (main.py:489-539): reg = network output,
+// cls = [reg >= cls_thred] (non-differentiable), wet = target > 0:
+//   loss_reg = 20 * mean((reg - t)^2 | wet) + mean((reg - t)^2 | dry);   loss_cls = mean focal BCE of the 0/1 "probabilities";
+//   loss = loss_reg + 0.1 * loss_cls;   d loss / d reg = 40 (reg - t) / n_wet on wet cells, 2 (reg - t) / n_dry on dry ones.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void loss_partial_kernel(const float *__restrict__ reg, const float *__restrict__ tgt, float thr, long n,
+                                                           float *__restrict__ partial)
+{
+    __shared__ float sh[5][4];
+    float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};   // n_wet, sse_wet, sse_dry, n(p=0,y=1), n(p=1,y=0)
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float r = reg[i], t = tgt[i], e = r - t;
+        const bool wet = t > 0.f, pos = r >= thr;
+        if (wet) { v[0] += 1.f; v[1] += e * e; } else v[2] += e * e;
+        if (wet && !pos) v[3] += 1.f;
+        if (!wet && pos) v[4] += 1.f;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const float s = wave_sum(v[k]);
+        if (lane == 0) sh[k][wave] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) partial[(size_t)blockIdx.x * 5 + threadIdx.x] = (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+}
+
+// one wave: comps[5] = loss, loss_reg, wet MSE, dry MSE, loss_cls; scales[2] = 40 / n_wet, 2 / n_dry
+__global__ __launch_bounds__(64) void loss_finalize_kernel(const float *__restrict__ partial, int nblk, long n, float *__restrict__ comps,
+                                                           float *__restrict__ scales)
+{
+    const int lane = threadIdx.x;
+    double s[5] = {0, 0, 0, 0, 0};
+    for (int t = lane; t < nblk; t += 64)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) s[k] += (double)partial[(size_t)t * 5 + k];
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) s[k] += __shfl_xor(s[k], m, 64);
+    if (lane == 0) {
+        const double n_wet = s[0], n_dry = (double)n - s[0];
+        const double flood = s[1] / n_wet, dry = s[2] / n_dry;        // empty class -> nan, as torch's mse_loss of an empty tensor
+        const double L = -log(1e-9);
+        const double cls = (0.25 * L * s[3] + 0.75 * L * s[4]) / (double)n;
+        const double lreg = 20.0 * flood + dry;
+        comps[0] = (float)(lreg + 0.1 * cls);
+        comps[1] = (float)lreg;
+        comps[2] = (float)flood;
+        comps[3] = (float)dry;
+        comps[4] = (float)cls;
+        scales[0] = (float)(40.0 / n_wet);
+        scales[1] = (float)(2.0 / n_dry);
+    }
+}
+
+__global__ __launch_bounds__(256) void loss_grad_kernel(const float *__restrict__ reg, const float *__restrict__ tgt, const float *__restrict__ scales,
+                                                        long n, float *__restrict__ dreg)
+{
+    const float sw = scales[0], sd = scales[1];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float t = tgt[i];
+        dreg[i] = (t > 0.f ? sw : sd) * (reg[i] - t);
+    }
+}
+
+int urnn_train_loss_nblk(long n)
+{
+    const long b = (n + 4095) / 4096;
+    return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+
+hipError_t urnn_train_loss(const float *reg, const float *tgt, float thr, long n, float *partial, float *scales, float *comps, float *dreg,
+                           hipStream_t st)
+{
+    const int nblk = urnn_train_loss_nblk(n);
+    hipLaunchKernelGGL(loss_partial_kernel, dim3(nblk), dim3(256), 0, st, reg, tgt, thr, n, partial);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, partial, nblk, n, comps, scales);
+    if (dreg) hipLaunchKernelGGL(loss_grad_kernel, dim3(nblk), dim3(256), 0, st, reg, tgt, scales, n, dreg);
+    return hipGetLastError();
+}

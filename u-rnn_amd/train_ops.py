@@ -107,3 +107,19 @@ def head_backward(feat, conv_w, ln_w, ln_b, reg_w, out_raw, out_cls, dout, cls_t
                                    p(g["dconv_w"]), p(g["dln_w"]), p(g["dln_b"]), p(g["dreg_w"]), p(g["dreg_b"]), p(ws), ws.numel(),
                                    B, C, H, W, float(cls_thred), slope, int(bool(accumulate)), ops._stream()), "urnn_head_backward_f32")
     return g
+
+
+def loss(reg, target, cls_thred=0.0, want_grad=True):
+    """FocalBCE_and_WMSE on a window's outputs.  Returns (components: 5-float device tensor [loss, loss_reg, wet MSE, dry MSE,
+    loss_cls], dreg or None)."""
+    ops._dev_check(reg, target)
+    n = reg.numel()
+    if target.numel() != n:
+        raise RuntimeError("loss: reg and target differ in size")
+    L = lib()
+    ws = _bwd_workspace(L.urnn_loss_workspace_bytes(n), reg.device)
+    comps = torch.empty(5, dtype=torch.float32, device=reg.device)
+    dreg = torch.empty_like(reg) if want_grad else None
+    check(L.urnn_loss_f32(ops._ptr(reg), ops._ptr(target), float(cls_thred), ops._ptr(comps), ops._ptr(dreg), ops._ptr(ws), ws.numel(), n,
+                          ops._stream()), "urnn_loss_f32")
+    return comps, dreg

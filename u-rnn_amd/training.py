@@ -1,0 +1,156 @@
+"""One SWP training window on the HIP path (main.py:598-768 `process_window` + loss + backward):
+`seq_num` timesteps forward with every activation the backward needs kept, the loss on the concatenated outputs, then
+back-propagation through the steps and through the six recurrent states, giving the gradient of all 79 parameter tensors.
+
+What is NOT here yet: the optimizer (Adam + clipping), the epoch / window scheduler, pre-warming, DDP gradient all-reduce.
+The kernels are first versions (correct, deterministic, not tuned)."""
+import torch
+
+from . import ops, train_ops
+from .dataset import event_to_device
+
+_SLOT0 = 100   # workspace slots 100 + 16 * step + k hold the forward scratch of layer k of step `step` until its backward ran
+
+
+def _cell_params(cell):
+    c1, g1, c2, g2 = cell.conv1[0], cell.conv1[1], cell.conv2[0], cell.conv2[1]
+    return c1, g1, c2, g2
+
+
+class WindowGradients:
+    """gradients of one window:  wg = WindowGradients(net, H, W, nums, rain_max, cumsum_max);  out = wg.run(event, targets, t0,
+    steps, states)  ->  dict(loss=5 floats, grads={reference parameter name: tensor}, states=[6 tensors], reg=(B,steps,H,W))."""
+
+    def __init__(self, net, H, W, nums, rain_max, cumsum_max, cls_thred_train=0.0):
+        self.net, self.H, self.W, self.nums = net, H, W, int(nums)
+        self.rain_max, self.cumsum_max = float(rain_max), float(cumsum_max)
+        self.cls_thred_train = float(cls_thred_train)          # classify_outputs threshold of the loop (main.py:598: 0)
+        self.device = next(net.parameters()).device
+
+    # -- forward of one timestep, keeping what the backward reads ---------------------------------------------------
+    def _forward_step(self, ev, t, states, step):
+        net = self.net
+        enc, dec, head = net.encoder, net.decoder, net.head
+        e1, e2, e3, d1, d2, d3 = states
+        base = _SLOT0 + 16 * step
+        S = {"prev": list(states)}
+        x_in = ops.preprocess(ev["rain"], ev["cumsum"], ev["dem"], ev["imperv"], ev["manhole"], ev["dem_min"], ev["dem_max"], int(t),
+                              self.nums, self.rain_max, self.cumsum_max)
+
+        def cell(k, mod, x, e, h):
+            ops.WORKSPACE.use_slot(base + k)
+            return mod.step(x, e, h)
+        S["x_in"] = x_in
+        S["a1"] = enc.stage1(x_in)
+        S["e1"] = cell(0, enc.rnn1, S["a1"], None, e1)
+        S["a2"] = enc.stage2(S["e1"])
+        S["e2"] = cell(1, enc.rnn2, S["a2"], None, e2)
+        S["a3"] = enc.stage3(S["e2"])
+        S["e3"] = cell(2, enc.rnn3, S["a3"], None, e3)
+        S["d1"] = cell(3, dec.rnn3, None, S["e3"], d1)
+        S["u3"] = dec.stage3(S["d1"])
+        S["d2"] = cell(4, dec.rnn2, S["u3"], S["e2"], d2)
+        S["u2"] = dec.stage2(S["d2"])
+        S["d3"] = cell(5, dec.rnn1, S["u2"], S["e1"], d3)
+        S["feat"] = dec.stage1(S["d3"])
+        ops.WORKSPACE.use_slot(base + 6)
+        S["masked"], S["cls"], S["raw"] = head.run(S["feat"], want_raw=True)
+        ops.WORKSPACE.use_slot(0)
+        return S, [S["e1"], S["e2"], S["e3"], S["d1"], S["d2"], S["d3"]]
+
+    # -- backward of one timestep -----------------------------------------------------------------------------------------
+    def _backward_step(self, S, step, dout, dstate, G, acc):
+        """dout: d loss / d masked output of this step (B,H,W); dstate: gradients arriving at this step's six NEW states from
+        the following step (or None); returns the gradients w.r.t. the six states this step STARTED from."""
+        net = self.net
+        enc, dec, head = net.encoder, net.decoder, net.head
+        base = _SLOT0 + 16 * step
+        e1p, e2p, e3p, d1p, d2p, d3p = S["prev"]
+        dE1, dE2, dE3, dD1, dD2, dD3 = dstate if dstate is not None else [None] * 6
+        add = lambda a, b: a if b is None else (b if a is None else a + b)
+
+        def conv_bwd(name, mod, x, dy):
+            L = mod.layer
+            key = f"{name}.{mod._pname}"
+            dx, dw, db = train_ops.stage_conv_backward(x, L.weight.detach(), L.bias.detach(), dy, mod.pool, dweight=G.get(key + ".weight"),
+                                                       dbias=G.get(key + ".bias"), accumulate=acc)
+            G[key + ".weight"], G[key + ".bias"] = dw, db
+            return dx
+
+        def deconv_bwd(name, mod, x, out, dy):
+            L = mod.layer
+            key = f"{name}.{mod._pname}"
+            dx, dw, db = train_ops.deconv2x2_backward(x, L.weight.detach(), out, dy, dweight=G.get(key + ".weight"),
+                                                      dbias=G.get(key + ".bias"), accumulate=acc)
+            G[key + ".weight"], G[key + ".bias"] = dw, db
+            return dx
+
+        def cell_bwd(k, name, mod, x, e, h, dout_h):
+            c1, g1, c2, g2 = _cell_params(mod)
+            ops.WORKSPACE.use_slot(base + k)
+            names = {"dW1": "conv1.0.weight", "db1": "conv1.0.bias", "dg1": "conv1.1.weight", "dbe1": "conv1.1.bias",
+                     "dW2": "conv2.0.weight", "db2": "conv2.0.bias", "dg2": "conv2.1.weight", "dbe2": "conv2.1.bias"}
+            prev = {k_: G[f"{name}.{v}"].reshape(-1) if k_ in ("db1", "dg1", "dbe1", "db2", "dg2", "dbe2") else
+                    G[f"{name}.{v}"].reshape(G[f"{name}.{v}"].shape[0], -1) for k_, v in names.items()} if acc and f"{name}.conv1.0.weight" in G else None
+            g = train_ops.gru_cell_backward(x, e, h, c1.weight.detach(), c2.weight.detach(), g1.weight.detach(), g2.weight.detach(),
+                                            dout_h.contiguous(), mod.input_channels, grads=prev, accumulate=prev is not None)
+            for k_, v in names.items():
+                ref = dict(mod.named_parameters())[v]
+                G[f"{name}.{v}"] = g[k_].reshape(ref.shape)
+            ops.WORKSPACE.use_slot(0)
+            return g.get("dx"), g.get("de"), g["dh"]
+
+        # head
+        fp = head.flat_params()
+        ops.WORKSPACE.use_slot(base + 6)
+        hg_prev = G.get("_head") if acc else None
+        hg = train_ops.head_backward(S["feat"], fp["conv_w"], fp["ln_w"], fp["ln_b"], head.reg_preds.conv.weight.detach().reshape(-1),
+                                     S["raw"], S["cls"], dout.contiguous(), head.cls_thred, grads=hg_prev, accumulate=hg_prev is not None)
+        G["_head"] = hg
+        ops.WORKSPACE.use_slot(0)
+        # decoder
+        g_d3 = add(conv_bwd("decoder.stage1", dec.stage1, S["d3"], hg["dfeat"]), dD3)
+        du2, dE1_dec, dD3n = cell_bwd(5, "decoder.rnn1", dec.rnn1, S["u2"], S["e1"], d3p, g_d3)
+        g_d2 = add(deconv_bwd("decoder.stage2", dec.stage2, S["d2"], S["u2"], du2), dD2)
+        du3, dE2_dec, dD2n = cell_bwd(4, "decoder.rnn2", dec.rnn2, S["u3"], S["e2"], d2p, g_d2)
+        g_d1 = add(deconv_bwd("decoder.stage3", dec.stage3, S["d1"], S["u3"], du3), dD1)
+        _, dE3_dec, dD1n = cell_bwd(3, "decoder.rnn3", dec.rnn3, None, S["e3"], d1p, g_d1)
+        # encoder
+        g_e3 = add(dE3_dec, dE3)
+        da3, _, dE3n = cell_bwd(2, "encoder.rnn3", enc.rnn3, S["a3"], None, e3p, g_e3)
+        g_e2 = add(add(conv_bwd("encoder.stage3", enc.stage3, S["e2"], da3), dE2_dec), dE2)
+        da2, _, dE2n = cell_bwd(1, "encoder.rnn2", enc.rnn2, S["a2"], None, e2p, g_e2)
+        g_e1 = add(add(conv_bwd("encoder.stage2", enc.stage2, S["e1"], da2), dE1_dec), dE1)
+        da1, _, dE1n = cell_bwd(0, "encoder.rnn1", enc.rnn1, S["a1"], None, e1p, g_e1)
+        conv_bwd("encoder.stage1", enc.stage1, S["x_in"], da1)
+        return [dE1n, dE2n, dE3n, dD1n, dD2n, dD3n]
+
+    def run(self, event, targets, t0, steps, states=None):
+        """event: reference-layout event dict (or already on the device); targets (B,steps,H,W) normalised depths of frames
+        t0 .. t0+steps-1; states: six (B,C,h,w) tensors or None (zeros).  See the class docstring for the result."""
+        ev = event if "rain" in event else event_to_device(event, self.device)
+        B = ev["B"]
+        if states is None:
+            from .general import initialize_states
+            states = [s.to(self.device).repeat(B, 1, 1, 1) for s in initialize_states(self.device, self.H, self.W)]
+        targets = torch.as_tensor(targets, dtype=torch.float32, device=self.device).contiguous()
+        saved = []
+        for s in range(steps):
+            S, states = self._forward_step(ev, t0 + s, states, s)
+            saved.append(S)
+        reg = torch.stack([S["masked"] for S in saved], dim=1).contiguous()            # (B,steps,H,W) as main.py concatenates
+        comps, dreg = train_ops.loss(reg, targets, cls_thred=self.cls_thred_train)
+        G, dstate = {}, None
+        for s in reversed(range(steps)):
+            dstate = self._backward_step(saved[s], s, dreg[:, s], dstate, G, acc=(s != steps - 1))
+        grads = {k: v for k, v in G.items() if not k.startswith("_")}
+        hg, head = G["_head"], self.net.head
+        for i, blk in enumerate(["stems", "cls_convs.0", "cls_convs.1", "reg_convs.0", "reg_convs.1"]):
+            grads[f"head.{blk}.conv.weight"] = hg["dconv_w"][i].reshape(head.channels, head.channels, 1, 1)
+            grads[f"head.{blk}.ln.weight"] = hg["dln_w"][i]
+            grads[f"head.{blk}.ln.bias"] = hg["dln_b"][i]
+        grads["head.reg_preds.conv.weight"] = hg["dreg_w"].reshape(1, -1, 1, 1)
+        grads["head.reg_preds.conv.bias"] = hg["dreg_b"]
+        grads["head.cls_preds.conv.weight"] = torch.zeros_like(head.cls_preds.conv.weight)
+        grads["head.cls_preds.conv.bias"] = torch.zeros_like(head.cls_preds.conv.bias)
+        return {"loss": comps, "grads": grads, "states": [s.detach() for s in states], "reg": reg, "state_grads": dstate}
