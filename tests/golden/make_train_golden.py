@@ -163,6 +163,57 @@ def gen_layers_backward(out, H=16, W=16, C=9, seed=31):
         out[f"lay_head_g_{name}"] = prm.grad.numpy() if prm.grad is not None else np.zeros_like(prm.detach().numpy())
 
 
+def gen_training_loop(out, H=16, W=16, nums=3, seq_num=2, windows=3, wseed=21, eseed=8, lr=1e-3, grad_clip=1.0):
+    """The reference SWP loop in fast mode (main.py:700-768: per window zero_grad, seq_num steps from the previous window's
+    detached states, loss, backward, clip_grad_norm_, Adam step) on one seeded event: per-window losses and gradient norms,
+    a (sum, sum of squares) fingerprint of every parameter after every window, and the final value of the small tensors."""
+    C = 2 * nums + 3
+    net, sd = mg.ref_net(H, W, C, wseed)
+    net.train()
+    T = seq_num * windows
+    ev = uw.make_event(T, H, W, 60.0, seed=eseed)
+    tev = mg.event_to_torch(ev)
+    rs = np.random.RandomState(eseed + 1)
+    label = (rs.uniform(0, 1, (1, T, H, W)) ** 3).astype(np.float32)
+    label[label < 0.1] = 0.0
+    named = {}
+    for key in sd:
+        named[key] = next(v for k, v in net.state_dict(keep_vars=True).items()
+                          if k.replace("_wrapper.module.", ".").replace(".conv1_module.", ".conv1.").replace(".conv2_module.", ".conv2.") == key)
+    params = list({id(p): p for p in named.values()}.values())
+    opt = torch.optim.Adam(params, lr=lr)
+    lossf = FocalBCE_and_WMSE(gamma=2, alpha=0.25)
+    states = None
+    out.update({"loop_H": H, "loop_W": W, "loop_nums": nums, "loop_seq_num": seq_num, "loop_windows": windows, "loop_weights_seed": wseed,
+                "loop_event_seed": eseed, "loop_lr": lr, "loop_grad_clip": grad_clip, "loop_label": label, "loop_rain_max": 60.0,
+                "loop_cumsum_max": 250.0})
+    for wdx in range(windows):
+        ind = wdx * seq_num
+        opt.zero_grad()
+        st = states if states is not None else initialize_states(torch.device("cpu"), input_height=H, input_width=W, net_cfg=mg.CFG)
+        pred = None
+        for t in range(ind, ind + seq_num):
+            x = preprocess_inputs(t, tev, torch.device("cpu"), nums=nums, rain_max=60.0, cumsum_rain_max=250.0)
+            res = net(x, *st)
+            o, st = res[0], res[1:]
+            cls = torch.where(o >= 0, 1, 0)
+            pred = {"reg": o, "cls": cls} if pred is None else {"reg": torch.cat((pred["reg"], o), 1), "cls": torch.cat((pred["cls"], cls), 1)}
+        states = [s.detach() for s in st]
+        losses = lossf(pred, torch.from_numpy(label[:, ind:ind + seq_num]), epoch=0)
+        losses["loss"].backward()
+        norm = torch.nn.utils.clip_grad_norm_(params, grad_clip)
+        opt.step()
+        out[f"loop_w{wdx}_loss"] = np.float64(losses["loss"].item())
+        out[f"loop_w{wdx}_gradnorm"] = np.float64(norm.item())
+        out[f"loop_w{wdx}_fingerprint"] = np.array([[float(named[k].detach().double().sum()), float((named[k].detach().double() ** 2).sum())]
+                                                    for k in sd])
+    for k in sd:
+        if named[k].numel() <= 4096:
+            out[f"loop_final_{k}"] = named[k].detach().numpy()
+    for i, s_ in enumerate(states):
+        out[f"loop_state{i}"] = s_.numpy()
+
+
 if __name__ == "__main__":
     sys.modules.setdefault("wandb", types.ModuleType("wandb"))
     out = {}
@@ -174,6 +225,9 @@ if __name__ == "__main__":
     layers = {}
     gen_layers_backward(layers)
     np.savez_compressed(os.path.join(HERE, "train_layers_backward.npz"), **layers)
+    loop = {}
+    gen_training_loop(loop)
+    np.savez_compressed(os.path.join(HERE, "train_loop_16x16.npz"), **loop)
     path = os.path.join(HERE, "train_window_16x16.npz")
     np.savez_compressed(path, **out)
     ng = sum(1 for k in out if k.startswith("win_grad_"))

@@ -208,3 +208,49 @@ def test_window_gradients_vs_reference_autograd(dev):
         worst = max(worst, (name, err), key=lambda t: t[1])
         assert err <= 1e-3, (name, err)
     print("worst gradient:", worst)
+
+
+def _loop_net(g, dev):
+    import urnn_amd.weights as uw
+    from urnn_amd.net_config import load_net_config
+    from urnn_amd.networks import ED, get_network_params
+    H, W, nums = int(g["loop_H"]), int(g["loop_W"]), int(g["loop_nums"])
+    C = 2 * nums + 3
+    sd = uw.make_state_dict(H, W, C, seed=int(g["loop_weights_seed"]))
+    ep, dp = get_network_params(False, H, W, C, load_net_config())
+    net = ED(False, ep, dp, 0.5, False, H, W)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return net.to(dev).eval(), sd
+
+
+def test_swp_training_loop_vs_reference(dev):
+    """Three SWP windows (fast mode) with clipping and Adam: per-window loss and gradient norm, a fingerprint of every
+    parameter after every step, the small tensors and the carried states at the end -- against the reference loop."""
+    import urnn_amd.weights as uw
+    from urnn_amd.training import Trainer
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_loop_16x16.npz"))
+    net, sd = _loop_net(g, dev)
+    H, W, nums, seq, nwin = int(g["loop_H"]), int(g["loop_W"]), int(g["loop_nums"]), int(g["loop_seq_num"]), int(g["loop_windows"])
+    tr = Trainer(net, H, W, nums, float(g["loop_rain_max"]), float(g["loop_cumsum_max"]), lr=float(g["loop_lr"]),
+                 grad_clip=float(g["loop_grad_clip"]))
+    ev = uw.make_event(seq * nwin, H, W, float(g["loop_rain_max"]), seed=int(g["loop_event_seed"]))
+    label = torch.from_numpy(g["loop_label"]).to(dev)
+    states = None
+    params = dict(net.named_parameters())
+    for w in range(nwin):
+        loss, states = tr.train_window(ev, label[:, w * seq:(w + 1) * seq], w * seq, seq, states)
+        assert float(loss[0]) == pytest.approx(float(g[f"loop_w{w}_loss"]), rel=3e-4), w
+        assert float(tr.last["clip"][1]) == pytest.approx(float(g[f"loop_w{w}_gradnorm"]), rel=3e-4), w
+        fp = g[f"loop_w{w}_fingerprint"]
+        for i, name in enumerate(sd):
+            p = params[name].detach().double()
+            assert float(p.sum()) == pytest.approx(fp[i, 0], rel=1e-4, abs=2e-3), (w, name)
+            assert float((p * p).sum()) == pytest.approx(fp[i, 1], rel=1e-4, abs=1e-6), (w, name)
+    for name in sd:
+        key = f"loop_final_{name}"
+        if key in g.files:
+            ref = g[key]
+            got = params[name].detach().cpu().numpy()
+            assert np.abs(got - ref).max() <= 3e-4 * max(np.abs(ref).max(), 1e-3) + 3e-5, name      # Adam divides by sqrt(v): ~lr-sized steps
+    for i, s in enumerate(states):
+        assert_close(s.cpu().numpy(), g[f"loop_state{i}"], 2e-3, f"carried state {i}")

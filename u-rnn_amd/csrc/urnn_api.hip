@@ -699,6 +699,26 @@ extern "C" int urnn_loss_f32(const float *reg, const float *target, float cls_th
     return URNN_OK;
 }
 
+// ---- optimizer -------------------------------------------------------------------------------------------------------
+extern "C" size_t urnn_adam_workspace_bytes(long n)
+{
+    if (n < 1) return 0;
+    return align_up((size_t)urnn_train_loss_nblk(n) * sizeof(float), 256);
+}
+
+extern "C" int urnn_adam_step_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, long n, float lr, float beta1,
+                                  float beta2, float eps, int step, float max_grad_norm, float *clip_out, void *workspace,
+                                  size_t workspace_bytes, void *stream)
+{
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !clip_out || !workspace) return fail(URNN_ENULL, "urnn_adam_step_f32: NULL argument");
+    if (n < 1 || step < 1) return fail(URNN_EINVAL, "urnn_adam_step_f32: n=%ld step=%d", n, step);
+    if (workspace_bytes < urnn_adam_workspace_bytes(n)) return fail(URNN_EWORKSPACE, "urnn_adam_step_f32: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    CHECK_HIP(urnn_train_clip_coef(grads, n, max_grad_norm, reinterpret_cast<float *>(workspace), clip_out, st), "gradient norm");
+    CHECK_HIP(urnn_train_adam(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, clip_out, st), "adam");
+    return URNN_OK;
+}
+
 // ---- input assembly --------------------------------------------------------------------------------------------------
 extern "C" int urnn_preprocess_f32(const float *rain, const float *cumsum, const float *dem, const float *imperv,
                                    const float *manhole, float dem_min, float dem_max, float *out, int t, const int *t_dev,

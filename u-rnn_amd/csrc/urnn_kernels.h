@@ -112,3 +112,6 @@ hipError_t urnn_train_head_ln_bwd(float *ds, const float *u, const float *g, con
 int urnn_train_loss_nblk(long n);
 hipError_t urnn_train_loss(const float *reg, const float *tgt, float thr, long n, float *partial, float *scales, float *comps, float *dreg,
                            hipStream_t st);
+hipError_t urnn_train_clip_coef(const float *g, long n, float max_norm, float *partial, float *out, hipStream_t st);
+hipError_t urnn_train_adam(float *p, const float *g, float *m, float *v, long n, float lr, float b1, float b2, float eps, int step,
+                           const float *coef, hipStream_t st);

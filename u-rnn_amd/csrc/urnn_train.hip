@@ -740,3 +740,66 @@ hipError_t urnn_train_loss(const float *reg, const float *tgt, float thr, long n
     if (dreg) hipLaunchKernelGGL(loss_grad_kernel, dim3(nblk), dim3(256), 0, st, reg, tgt, scales, n, dreg);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Optimizer step on the flat parameter buffer: global gradient-norm clipping (torch.nn.utils.clip_grad_norm_, main.py:760-761)
+// and Adam (torch.optim.Adam defaults, main.py:306).  Deterministic (fixed-order double sum of the per-block partials).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float *__restrict__ g, long n, float *__restrict__ partial)
+{
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += g[i] * g[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// out[0] = clip coefficient min(1, max_norm / (norm + 1e-6)) (1 when max_norm <= 0), out[1] = the norm
+__global__ __launch_bounds__(64) void clip_coef_kernel(const float *__restrict__ partial, int nblk, float max_norm, float *__restrict__ out)
+{
+    double s = 0.0;
+    for (int t = threadIdx.x; t < nblk; t += 64) s += (double)partial[t];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (threadIdx.x == 0) {
+        const double norm = sqrt(s);
+        double c = max_norm > 0.f ? (double)max_norm / (norm + 1e-6) : 1.0;
+        out[0] = (float)(c < 1.0 ? c : 1.0);
+        out[1] = (float)norm;
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
+                                                   long n, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt,
+                                                   const float *__restrict__ coef)
+{
+    const float c = coef ? coef[0] : 1.f;
+    const float step = lr / bc1;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float gi = g[i] * c;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    }
+}
+
+hipError_t urnn_train_clip_coef(const float *g, long n, float max_norm, float *partial, float *out, hipStream_t st)
+{
+    const int nblk = urnn_train_loss_nblk(n);
+    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(nblk), dim3(256), 0, st, g, n, partial);
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, st, partial, nblk, max_norm, out);
+    return hipGetLastError();
+}
+
+hipError_t urnn_train_adam(float *p, const float *g, float *m, float *v, long n, float lr, float b1, float b2, float eps, int step,
+                           const float *coef, hipStream_t st)
+{
+    const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
+    const int nblk = urnn_train_loss_nblk(n);
+    hipLaunchKernelGGL(adam_kernel, dim3(nblk), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, bc1, sqrtf(bc2), coef);
+    return hipGetLastError();
+}

@@ -123,3 +123,17 @@ def loss(reg, target, cls_thred=0.0, want_grad=True):
     check(L.urnn_loss_f32(ops._ptr(reg), ops._ptr(target), float(cls_thred), ops._ptr(comps), ops._ptr(dreg), ops._ptr(ws), ws.numel(), n,
                           ops._stream()), "urnn_loss_f32")
     return comps, dreg
+
+
+def adam_step(params, grads, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=0.0):
+    """In-place Adam step on flat float32 buffers (with optional global-norm clipping).  Returns a 2-float device tensor:
+    (clip coefficient, gradient norm)."""
+    ops._dev_check(params, grads, exp_avg, exp_avg_sq)
+    n = params.numel()
+    L = lib()
+    ws = _bwd_workspace(L.urnn_adam_workspace_bytes(n), params.device)
+    out = torch.empty(2, dtype=torch.float32, device=params.device)
+    p = ops._ptr
+    check(L.urnn_adam_step_f32(p(params), p(grads), p(exp_avg), p(exp_avg_sq), n, float(lr), float(betas[0]), float(betas[1]), float(eps),
+                               int(step), float(max_grad_norm), p(out), p(ws), ws.numel(), ops._stream()), "urnn_adam_step_f32")
+    return out

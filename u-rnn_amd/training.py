@@ -154,3 +154,81 @@ class WindowGradients:
         grads["head.cls_preds.conv.weight"] = torch.zeros_like(head.cls_preds.conv.weight)
         grads["head.cls_preds.conv.bias"] = torch.zeros_like(head.cls_preds.conv.bias)
         return {"loss": comps, "grads": grads, "states": [s.detach() for s in states], "reg": reg, "state_grads": dstate}
+
+
+def window_starts(loc, seq_num, window_size):
+    """Start indices of the SWP windows of one sample (split_iter_index, main.py:439): loc, loc + seq_num, ... over window_size."""
+    return list(range(int(loc), int(loc) + int(window_size) - int(seq_num) + 1, int(seq_num)))
+
+
+class Trainer:
+    """SWP training on the HIP path: the loop of ``model_forward`` (main.py:700-768) in fast mode -- per window: zero the
+    gradients, ``seq_num`` timesteps from the previous window's (detached) states, loss, backward, global-norm clipping, Adam.
+
+    The 79 parameter tensors are re-homed as views of ONE flat float32 buffer (same for the gradients and Adam's moments), so
+    the optimizer is a single kernel over 40 M floats at 500x500 and the DDP exchange a single all-reduce of that buffer
+    (``torch.distributed``, RCCL over xGMI with the nccl backend) -- mean over ranks, as DistributedDataParallel does
+    (main.py:384-387)."""
+
+    def __init__(self, net, H, W, nums, rain_max, cumsum_max, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_clip=0.0,
+                 cls_thred_train=0.0, process_group=None, distributed=False):
+        self.net = net
+        self.wg = WindowGradients(net, H, W, nums, rain_max, cumsum_max, cls_thred_train)
+        self.lr, self.betas, self.eps, self.grad_clip = float(lr), tuple(betas), float(eps), float(grad_clip)
+        self.distributed, self.pg = bool(distributed), process_group
+        self.names = [n for n, _ in net.named_parameters()]
+        params = dict(net.named_parameters())
+        total = sum(p.numel() for p in params.values())
+        dev = next(net.parameters()).device
+        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
+        self.gflat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.m = torch.zeros_like(self.flat)
+        self.v = torch.zeros_like(self.flat)
+        self.views, off = {}, 0
+        for n in self.names:
+            p = params[n]
+            k = p.numel()
+            self.flat[off:off + k].copy_(p.detach().reshape(-1))
+            p.data = self.flat[off:off + k].view(p.shape)                 # parameters now live in the flat buffer
+            self.views[n] = (off, k, tuple(p.shape))
+            off += k
+        self.step_count = 0
+        self.last = None
+
+    def _invalidate_packed(self):
+        """The kernels read packed copies of the weights; an in-place optimizer step does not bump torch's version counters."""
+        for mod in self.net.modules():
+            cache = getattr(mod, "_cache", None)
+            if cache is not None and hasattr(cache, "clear"):
+                cache.clear()
+        self.net.head._stamp = None
+
+    def train_window(self, event, targets, t0, steps, states=None):
+        """One window: returns (loss components, final states); the parameters have been updated."""
+        out = self.wg.run(event, targets, t0, steps, states)
+        for n, g in out["grads"].items():
+            off, k, _ = self.views[n]
+            self.gflat[off:off + k].copy_(g.reshape(-1))
+        if self.distributed:
+            import torch.distributed as dist
+            dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM, group=self.pg)
+            self.gflat.div_(dist.get_world_size(self.pg))
+        self.step_count += 1
+        clip = train_ops.adam_step(self.flat, self.gflat, self.m, self.v, self.step_count, lr=self.lr, betas=self.betas, eps=self.eps,
+                                   max_grad_norm=self.grad_clip)
+        self._invalidate_packed()
+        self.last = {"loss": out["loss"], "clip": clip, "reg": out["reg"]}
+        return out["loss"], out["states"]
+
+    def train_event(self, event, label, seq_num, window_size=None, loc=0):
+        """All windows of one sample in order (fast mode: states carried between windows).  label (B,T,H,W) normalised depths.
+        Returns the list of per-window loss components (device tensors)."""
+        ev = event if "rain" in event else event_to_device(event, self.wg.device)
+        label = torch.as_tensor(label, dtype=torch.float32, device=self.wg.device)
+        T = label.shape[1]
+        window_size = T - loc if window_size is None else window_size
+        states, losses = None, []
+        for ind in window_starts(loc, seq_num, window_size):
+            loss, states = self.train_window(ev, label[:, ind:ind + seq_num], ind, seq_num, states)
+            losses.append(loss)
+        return losses, states
