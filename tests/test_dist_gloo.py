@@ -17,7 +17,7 @@ def _free_port():
 def _worker(rank, world, port, num_events, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     import torch.distributed as dist
-    from urnn_amd.distributed import env_ranks, gather_event_results, max_over_ranks, shard_events
+    from urnn_amd.distributed import allreduce_mean_, env_ranks, gather_event_results, max_over_ranks, shard_events
     dist.init_process_group("gloo", rank=rank, world_size=world)
     assert env_ranks() == (rank, rank, world)
     mine = shard_events(num_events, rank, world)
@@ -25,8 +25,12 @@ def _worker(rank, world, port, num_events, out_dir):
     results = [torch.full((3, 4, 5), float(idx)) for idx in mine]
     slowest = max_over_ranks(1.0 + rank)
     gathered = gather_event_results(results, num_events)
+    # the trainer's gradient exchange: bucketed in-place mean of a flat buffer (DDP semantics)
+    flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    allreduce_mean_(flat, bucket_floats=256)
+    mean_ok = torch.equal(flat, torch.arange(1000, dtype=torch.float32) * (sum(range(1, world + 1)) / world))
     dist.barrier()
-    ok = slowest == float(world) and len(gathered) == num_events and all(float(g[0, 0, 0]) == i for i, g in enumerate(gathered))
+    ok = mean_ok and slowest == float(world) and len(gathered) == num_events and all(float(g[0, 0, 0]) == i for i, g in enumerate(gathered))
     np.save(os.path.join(out_dir, f"rank{rank}.npy"), np.array([int(ok)] + mine))
     dist.destroy_process_group()
 

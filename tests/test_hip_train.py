@@ -254,3 +254,39 @@ def test_swp_training_loop_vs_reference(dev):
             assert np.abs(got - ref).max() <= 3e-4 * max(np.abs(ref).max(), 1e-3) + 3e-5, name      # Adam divides by sqrt(v): ~lr-sized steps
     for i, s in enumerate(states):
         assert_close(s.cpu().numpy(), g[f"loop_state{i}"], 2e-3, f"carried state {i}")
+
+
+def _ddp_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    import urnn_amd.weights as uw
+    from urnn_amd.training import Trainer
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # both ranks share the one GPU of the test box
+    dev = torch.device("cuda:0")
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_loop_16x16.npz"))
+    net, sd = _loop_net(g, dev)
+    H, W, nums = int(g["loop_H"]), int(g["loop_W"]), int(g["loop_nums"])
+    tr = Trainer(net, H, W, nums, 60.0, 250.0, lr=1e-3, grad_clip=1.0, distributed=True)
+    ev = uw.make_event(4, H, W, 60.0, seed=100 + rank)                # every rank trains on its own event
+    label = torch.from_numpy(g["loop_label"][:, :4]).to(dev) * (1.0 + 0.5 * rank)
+    tr.train_event(ev, label, seq_num=2)
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, f"flat{rank}.npy"), tr.flat.cpu().numpy())
+    np.save(os.path.join(out_dir, f"grad{rank}.npy"), tr.gflat.cpu().numpy())
+    dist.destroy_process_group()
+
+
+def test_two_rank_ddp_training_keeps_replicas_identical(dev, tmp_path):
+    """DDP semantics (main.py:384-387): per-rank events, gradients averaged over the ranks before the optimizer step -- the
+    replicas stay bit-identical.  Two processes on the one GPU, gloo as the control plane (RCCL on a multi-GPU node)."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    f0, f1 = np.load(tmp_path / "flat0.npy"), np.load(tmp_path / "flat1.npy")
+    g0, g1 = np.load(tmp_path / "grad0.npy"), np.load(tmp_path / "grad1.npy")
+    assert np.array_equal(g0, g1) and np.array_equal(f0, f1)
+    assert np.isfinite(f0).all() and np.abs(g0).max() > 0

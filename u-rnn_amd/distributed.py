@@ -39,6 +39,25 @@ def max_over_ranks(value, device=None):
     return float(t.item())
 
 
+def allreduce_mean_(flat, group=None, bucket_floats=1 << 24):
+    """DDP's gradient exchange (main.py:384-387) on the trainer's flat gradient buffer: in-place mean over the ranks, in
+    buckets of ``bucket_floats`` (64 MiB) so that the xGMI ring pipelines and a following optimizer kernel can start on the
+    first buckets.  With the nccl backend this is RCCL on the device buffer; gloo (CPU dry runs) stages through the host."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return flat
+    world = dist.get_world_size(group)
+    staged = dist.get_backend(group) == "gloo" and flat.is_cuda
+    buf = flat.cpu() if staged else flat
+    for lo in range(0, buf.numel(), bucket_floats):
+        piece = buf[lo:lo + bucket_floats]
+        dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=group)
+        piece.div_(world)
+    if staged:
+        flat.copy_(buf)
+    return flat
+
+
 def gather_event_results(local_results, num_events, device=None):
     """Gather per-event tensors (same shape on every rank) onto every rank in GLOBAL event order.
 

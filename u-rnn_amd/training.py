@@ -210,9 +210,8 @@ class Trainer:
             off, k, _ = self.views[n]
             self.gflat[off:off + k].copy_(g.reshape(-1))
         if self.distributed:
-            import torch.distributed as dist
-            dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM, group=self.pg)
-            self.gflat.div_(dist.get_world_size(self.pg))
+            from .distributed import allreduce_mean_
+            allreduce_mean_(self.gflat, group=self.pg)
         self.step_count += 1
         clip = train_ops.adam_step(self.flat, self.gflat, self.m, self.v, self.step_count, lr=self.lr, betas=self.betas, eps=self.eps,
                                    max_grad_norm=self.grad_clip)
