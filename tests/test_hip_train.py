@@ -290,3 +290,23 @@ def test_two_rank_ddp_training_keeps_replicas_identical(dev, tmp_path):
     g0, g1 = np.load(tmp_path / "grad0.npy"), np.load(tmp_path / "grad1.npy")
     assert np.array_equal(g0, g1) and np.array_equal(f0, f1)
     assert np.isfinite(f0).all() and np.abs(g0).max() > 0
+
+
+def test_prewarming_states_equal_the_inference_rollout(dev):
+    import urnn_amd.weights as uw
+    from urnn_amd.rollout import RolloutEngine
+    from urnn_amd.training import Trainer
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_loop_16x16.npz"))
+    net, _ = _loop_net(g, dev)
+    H, W, nums = int(g["loop_H"]), int(g["loop_W"]), int(g["loop_nums"])
+    ev = uw.make_event(5, H, W, 60.0, seed=5)
+    eng = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=5, use_graph=False, overlap=False)
+    eng.load_event(ev); eng.reset(); eng.run(3)
+    want = [s.clone() for s in eng.final_states()]
+    tr = Trainer(net, H, W, nums, 60.0, 250.0)
+    got = tr.prewarm(ev, 3)
+    for i, (a, b) in enumerate(zip(got, want)):      # (the engine folds the input assembly into its first stage: not bit-equal)
+        assert_close(a.cpu().numpy(), b.cpu().numpy(), 1e-4, f"pre-warmed state {i}")
+    label = torch.from_numpy(g["loop_label"][:, :4]).to(dev)
+    losses, _ = tr.train_event(ev, label, seq_num=2, prewarming=True)
+    assert len(losses) == 2 and all(torch.isfinite(l).all() for l in losses)

@@ -219,15 +219,27 @@ class Trainer:
         self.last = {"loss": out["loss"], "clip": clip, "reg": out["reg"]}
         return out["loss"], out["states"]
 
-    def train_event(self, event, label, seq_num, window_size=None, loc=0):
-        """All windows of one sample in order (fast mode: states carried between windows).  label (B,T,H,W) normalised depths.
-        Returns the list of per-window loss components (device tensors)."""
+    def prewarm(self, event, ind):
+        """SWP pre-warming (main.py:540-595): the six states after a gradient-free rollout of frames 0 .. ind-1 from zeros."""
+        ev = event if "rain" in event else event_to_device(event, self.wg.device)
+        from .general import initialize_states
+        states = [s.to(self.wg.device).repeat(ev["B"], 1, 1, 1) for s in initialize_states(self.wg.device, self.wg.H, self.wg.W)]
+        for t in range(int(ind)):
+            _, states = self.wg._forward_step(ev, t, states, 0)
+        return states
+
+    def train_event(self, event, label, seq_num, window_size=None, loc=0, prewarming=False):
+        """All windows of one sample in order.  Fast mode (default): states carried between windows; ``prewarming=True``: the
+        paper's schedule, every window starts from a gradient-free rollout from frame 0 (main.py:655-672).  label (B,T,H,W)
+        normalised depths.  Returns (per-window loss components, final states)."""
         ev = event if "rain" in event else event_to_device(event, self.wg.device)
         label = torch.as_tensor(label, dtype=torch.float32, device=self.wg.device)
         T = label.shape[1]
         window_size = T - loc if window_size is None else window_size
         states, losses = None, []
         for ind in window_starts(loc, seq_num, window_size):
+            if prewarming:
+                states = self.prewarm(ev, ind) if ind > 0 else None
             loss, states = self.train_window(ev, label[:, ind:ind + seq_num], ind, seq_num, states)
             losses.append(loss)
         return losses, states
