@@ -131,7 +131,7 @@ int urnn_stage1_scalar_rain_f32(const float *S, const float *rain, const float *
                                 float *out, int t, const int *t_dev, int B, int T, int nums, int Cout, int H, int W,
                                 float rain_max, float cumsum_max, float slope, void *stream);
 
-/* ---- training building blocks (the training loop itself is not built yet) ------------------- */
+/* ---- training: backward of every layer, loss, optimizer step; first version --------------------- */
 
 /* Backward of urnn_gru_cell_f32: gradients of every input and parameter of one ConvGRU / Skip-ConvGRU step
  * (autograd of CGRU_cell.forward -- ConvRNN.py:111-194) given dL/dh' (dh_out).

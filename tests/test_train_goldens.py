@@ -1,6 +1,6 @@
-"""Training rows: what exists so far is the reference-autograd golden of one SWP window (loss, the gradient of
-all 79 parameter tensors through two recurrent timesteps) and the CPU restatement of the loss.  The HIP backward is not
-built yet; these tests pin the oracle side and the facts the backward design relies on."""
+"""Training rows, CPU side: the reference-autograd goldens (loss, one ConvGRU cell, one SWP window with the
+gradient of all 79 parameter tensors) pin the numpy oracles of oracle/train_oracle.py and the facts the HIP backward relies
+on; the HIP path itself is checked against the same goldens in tests/test_hip_train.py."""
 import os
 
 import numpy as np

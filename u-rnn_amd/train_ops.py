@@ -1,5 +1,6 @@
-"""ctypes wrappers of the training building blocks.  So far: the backward of one ConvGRU / Skip-ConvGRU
-step.  The training loop, the other layers' backward passes, the optimizer and the DDP all-reduce are not built yet."""
+"""ctypes wrappers of the training entry points of the C ABI: backward of the ConvGRU / Skip-ConvGRU cell, the
+stage convs, the transposed convs and the head; the loss; the clipped Adam step.  ``urnn_amd.training`` assembles them into SWP
+windows and the training loop.  Every backward call must directly follow its forward on the same workspace slot."""
 import torch
 
 from . import ops
