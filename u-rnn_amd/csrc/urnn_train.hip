@@ -195,60 +195,109 @@ struct WgradParams {
     float *rowpart;           // [chunks][N] sums of dY (written by the blockIdx.x == 0 column), may be nullptr
 };
 
+// Second version: 128 n x 128 k per block (wave w: the 64 x 64 quadrant (w >> 1, w & 1) = 2 x 2 MFMA tiles), 16-byte global
+// loads of the NEXT 64-pixel stage into registers while the current one is multiplied out of LDS, row bases (incl. the K
+// segment lookup) resolved once per block.  LDS rows are padded to 65 floats: an MFMA fragment reads one COLUMN of the
+// tile (lane l -> row l & 31), the odd stride spreads it over 32 banks.
+constexpr int WG_T = 128, WG_LD = 65;
+
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams prm)
 {
-    __shared__ float tA[64 * 65], tB[64 * 65];
+    extern __shared__ __attribute__((aligned(16))) float wg_smem[];
+    float *tA = wg_smem, *tB = wg_smem + WG_T * WG_LD;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, half = lane >> 5;
-    const int n0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
+    const int n0 = blockIdx.y * WG_T, k0 = blockIdx.x * WG_T;
     const int chunk = blockIdx.z, b = chunk / prm.chunksPerSample;
     const int p_lo = (chunk - b * prm.chunksPerSample) * prm.chunkPix;
     const int p_hi = min(prm.P, p_lo + prm.chunkPix);
     const int wn = wave >> 1, wk = wave & 1;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    float rsum = 0.f;   // thread t < 64 of the k-column 0 blocks accumulates the row sum of dY row n0 + t
+    const bool vec = (prm.P & 3) == 0;                     // rows 16-byte aligned
 
-    for (int p0 = p_lo; p0 < p_hi; p0 += 64) {
-        __syncthreads();
-        // stage: thread t loads column (t & 63) of rows (t >> 6) + 4*i
-        const int col = threadIdx.x & 63, p = p0 + col;
-        const bool pin = p < p_hi;
+    // this thread stages rows r0 + 16*i (i < 8) of both operands, 4 consecutive pixels at column c4
+    const int r0 = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;
+    const float *rowA[8], *rowB[8];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = (threadIdx.x >> 6) + 4 * i;
-            const int n = n0 + row;
-            tA[row * 65 + col] = (pin && n < prm.N) ? prm.dy[((size_t)b * prm.N + n) * prm.P + p] : 0.f;
-            const int k = k0 + row;
-            float xv = 0.f;
-            if (pin && k < prm.K) {
-                const int s = k >= prm.segK0[2] ? 2 : (k >= prm.segK0[1] ? 1 : 0);
-                const int ch = k - prm.segK0[s];
-                if (ch < prm.segC[s]) xv = prm.seg[s][((size_t)b * prm.segC[s] + ch) * prm.P + p];
+    for (int i = 0; i < 8; ++i) {
+        const int n = n0 + r0 + 16 * i;
+        rowA[i] = n < prm.N ? prm.dy + ((size_t)b * prm.N + n) * prm.P : nullptr;
+        const int k = k0 + r0 + 16 * i;
+        rowB[i] = nullptr;
+        if (k < prm.K) {
+            const int sg = k >= prm.segK0[2] ? 2 : (k >= prm.segK0[1] ? 1 : 0);
+            const int ch = k - prm.segK0[sg];
+            if (ch < prm.segC[sg]) rowB[i] = prm.seg[sg] + ((size_t)b * prm.segC[sg] + ch) * prm.P;
+        }
+    }
+    f32x4 ra[8], rb[8];
+    auto fetch = [&](const float *row, int p) -> f32x4 {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row) {
+            if (vec && p + 3 < p_hi) v = *reinterpret_cast<const f32x4 *>(row + p);
+            else {
+                if (p < p_hi) v.x = row[p];
+                if (p + 1 < p_hi) v.y = row[p + 1];
+                if (p + 2 < p_hi) v.z = row[p + 2];
+                if (p + 3 < p_hi) v.w = row[p + 3];
             }
-            tB[row * 65 + col] = xv;
+        }
+        return v;
+    };
+    auto load_stage = [&](int p0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            ra[i] = fetch(rowA[i], p0 + c4);
+            rb[i] = fetch(rowB[i], p0 + c4);
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+    float rsum = 0.f;   // threads < 128 of the k-column 0 blocks: row sum of dY row n0 + threadIdx.x
+
+    load_stage(p_lo);
+    for (int p0 = p_lo; p0 < p_hi; p0 += 64) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float *da = tA + (r0 + 16 * i) * WG_LD + c4, *db = tB + (r0 + 16 * i) * WG_LD + c4;
+            da[0] = ra[i].x; da[1] = ra[i].y; da[2] = ra[i].z; da[3] = ra[i].w;
+            db[0] = rb[i].x; db[1] = rb[i].y; db[2] = rb[i].z; db[3] = rb[i].w;
         }
         __syncthreads();
-        if (prm.rowpart && blockIdx.x == 0 && threadIdx.x < 64) {
-            float s = 0.f;
-            for (int c = 0; c < 64; ++c) s += tA[threadIdx.x * 65 + c];
-            rsum += s;
+        if (p0 + 64 < p_hi) load_stage(p0 + 64);          // in flight while this stage is multiplied
+        if (prm.rowpart && blockIdx.x == 0 && threadIdx.x < WG_T) {
+            float s_ = 0.f;
+#pragma unroll 16
+            for (int c = 0; c < 64; ++c) s_ += tA[threadIdx.x * WG_LD + c];
+            rsum += s_;
         }
-#pragma unroll 8
-        for (int s = 0; s < 32; ++s) {
-            const float a = tA[(wn * 32 + j) * 65 + 2 * s + half];
-            const float bv = tB[(wk * 32 + j) * 65 + 2 * s + half];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
+#pragma unroll 4
+        for (int s_ = 0; s_ < 32; ++s_) {
+            const int col = 2 * s_ + half;
+            const float a0 = tA[(wn * 64 + j) * WG_LD + col], a1 = tA[(wn * 64 + 32 + j) * WG_LD + col];
+            const float b0 = tB[(wk * 64 + j) * WG_LD + col], b1 = tB[(wk * 64 + 32 + j) * WG_LD + col];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
+        __syncthreads();
     }
     float *out = prm.partial + (size_t)chunk * prm.N * prm.K;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wn * 32 + mfma_row(r, half), k = k0 + wk * 32 + j;
-        if (n < prm.N && k < prm.K) out[(size_t)n * prm.K + k] = acc[r];
-    }
-    if (prm.rowpart && blockIdx.x == 0 && threadIdx.x < 64 && n0 + (int)threadIdx.x < prm.N)
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wn * 64 + a * 32 + mfma_row(r, half), k = k0 + wk * 64 + c * 32 + j;
+                if (n < prm.N && k < prm.K) out[(size_t)n * prm.K + k] = acc[a][c][r];
+            }
+    if (prm.rowpart && blockIdx.x == 0 && threadIdx.x < WG_T && n0 + (int)threadIdx.x < prm.N)
         prm.rowpart[(size_t)chunk * prm.N + n0 + threadIdx.x] = rsum;
 }
 
@@ -337,10 +386,18 @@ hipError_t urnn_train_add_slices(float *out, long out_bs, const float *a, long a
     return hipGetLastError();
 }
 
+int urnn_train_wgrad_chunks(int P);
+
 size_t urnn_train_wgrad_partial_floats(int B, int N, int K, int P)
 {
-    const int cps = urnn_train_nchunk(P);
-    return (size_t)B * cps * ((size_t)N * K + N);
+    return (size_t)B * urnn_train_wgrad_chunks(P) * ((size_t)N * K + N);
+}
+
+// pixel chunks per sample of the weight-gradient GEMM: ~1024 pixels each (enough blocks for the chip on small N x K), <= 256
+int urnn_train_wgrad_chunks(int P)
+{
+    const int n = (P + 1023) / 1024;
+    return n < 1 ? 1 : (n > 256 ? 256 : n);
 }
 
 hipError_t urnn_train_wgrad(const float *dy, const float *const seg[3], const int segC[3], int B, int N, int K, int P, float *partial,
@@ -356,12 +413,19 @@ hipError_t urnn_train_wgrad(const float *dy, const float *const seg[3], const in
         k0 += segC[i];          // a missing segment (x == nullptr) still owns its weight columns: they get zero gradient
     }
     w.N = N; w.K = K; w.P = P; w.B = B;
-    w.chunksPerSample = urnn_train_nchunk(P);
+    w.chunksPerSample = urnn_train_wgrad_chunks(P);
     w.chunkPix = ((P + w.chunksPerSample - 1) / w.chunksPerSample + 63) / 64 * 64;
     const int chunks = B * w.chunksPerSample;
     w.partial = partial;
     w.rowpart = db ? partial + (size_t)chunks * N * K : nullptr;
-    hipLaunchKernelGGL(wgrad_kernel, dim3((K + 63) / 64, (N + 63) / 64, chunks), dim3(256), 0, st, w);
+    const size_t lds = (size_t)2 * WG_T * WG_LD * sizeof(float);
+    static bool big = false;
+    if (!big) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        big = true;
+    }
+    hipLaunchKernelGGL(wgrad_kernel, dim3((K + WG_T - 1) / WG_T, (N + WG_T - 1) / WG_T, chunks), dim3(256), lds, st, w);
     const long cnt = (long)N * K;
     hipLaunchKernelGGL(wgrad_finalize_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, partial, chunks, cnt, dW, accumulate);
     if (db)
