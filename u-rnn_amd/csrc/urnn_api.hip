@@ -68,7 +68,7 @@ static void pick_tile(long pixels_total, int waves_per_tile, long P, int *pb_out
 // ---- packing ---------------------------------------------------------------------------------------------------------
 extern "C" size_t urnn_packed_conv_floats(int Cin, int Cout)
 {
-    const size_t NB = urnn_conv_nb(Cout), NG = ((Cout + 31) / 32) / NB, KT = (Cin + 1) / 2;
+    const size_t NB = urnn_conv_nb(Cout), NG = urnn_conv_ng(Cout), KT = (Cin + 1) / 2;
     return NG * slab_floats(KT, NB) + NG * NB * 32;
 }
 
@@ -123,7 +123,7 @@ extern "C" int urnn_stage_conv_f32(const float *in, const float *packed, float *
     if (!aligned16(in) || !aligned16(out) || !aligned16(packed)) return fail(URNN_EALIGN, "urnn_stage_conv_f32: pointers must be 16-byte aligned");
     const long P = (long)H * W;
     if (!plane_fits(P, Cin > Cout ? Cin : Cout)) return fail(URNN_EINVAL, "urnn_stage_conv_f32: %d x %d plane with %d channels exceeds the 4-GiB segment limit", H, W, Cin > Cout ? Cin : Cout);
-    const int NB = urnn_conv_nb(Cout), NG = ((Cout + 31) / 32) / NB;
+    const int NB = urnn_conv_nb(Cout), NG = urnn_conv_ng(Cout);
     ConvGemmParams p = {};
     p.seg[0] = p.seg[1] = p.seg[2] = in;
     p.segC[0] = p.segC[1] = p.segC[2] = Cin;

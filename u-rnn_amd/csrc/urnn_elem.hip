@@ -559,7 +559,7 @@ __global__ void pack_conv_kernel(const float *__restrict__ w, const float *__res
 
 hipError_t urnn_launch_pack_conv(const float *w, const float *bias, float *packed, int Cin, int Cout, hipStream_t st)
 {
-    const int NB = urnn_conv_nb(Cout), NG = ((Cout + 31) / 32) / NB, KT = (Cin + 1) / 2;
+    const int NB = urnn_conv_nb(Cout), NG = urnn_conv_ng(Cout), KT = (Cin + 1) / 2;
     const int total = NG * slab_floats(KT, NB) + NG * NB * 32;
     hipLaunchKernelGGL(pack_conv_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, bias, packed, Cin, Cout, NB, NG, KT);
     return hipGetLastError();

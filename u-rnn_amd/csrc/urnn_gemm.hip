@@ -767,8 +767,16 @@ static hipError_t launch_flat(const ConvGemmParams &p, int pb, int map, hipStrea
 
 int urnn_conv_nb(int Cout)
 {
+    // n-blocks per group: all of them up to three; else 3 or 2 when that divides the count; else 3 with the last group
+    // padded by zero columns (7 blocks -> 3 groups instead of 7 groups of one block that would each re-read the input)
     const int nblk = (Cout + 31) / 32;
-    return nblk <= 3 ? nblk : (nblk % 3 == 0 ? 3 : (nblk % 2 == 0 ? 2 : 1));
+    return nblk <= 3 ? nblk : (nblk % 3 == 0 ? 3 : (nblk % 2 == 0 ? 2 : 3));
+}
+
+int urnn_conv_ng(int Cout)
+{
+    const int nblk = (Cout + 31) / 32, NB = urnn_conv_nb(Cout);
+    return (nblk + NB - 1) / NB;
 }
 
 // Flat 1x1 conv + LeakyReLU.  NB n-blocks per group chosen from Cout; NG groups cover all columns.

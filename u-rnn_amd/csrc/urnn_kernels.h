@@ -36,6 +36,7 @@ struct ConvGemmParams {
 };
 
 int urnn_conv_nb(int Cout);   // n-blocks per wave for a Cout-wide 1x1 conv (packing and launch must agree)
+int urnn_conv_ng(int Cout);   // number of n-groups (the last one may be padded with zero columns)
 hipError_t urnn_launch_conv_flat(ConvGemmParams p, int B, int PB, int map, hipStream_t st);
 hipError_t urnn_launch_conv_pool(ConvGemmParams p, int B, hipStream_t st);
 hipError_t urnn_launch_deconv(ConvGemmParams p, int B, int PB, int map, hipStream_t st);
