@@ -110,6 +110,61 @@ def cpu_baseline(sd, cfgname, budget_s=15.0, max_frames=8):
                       f"C oracle with OpenMP on {orc.num_threads()} threads of {os.cpu_count()} logical CPUs"}
 
 
+def bench_train(args, dev, dist, world, rank):
+    """SWP training throughput (BASELINE configs 3-4 shape of work, fp32): a step = one training timestep of one event per GPU
+    (forward with kept activations, backward through the window, loss; per window one gradient mean over the ranks and one
+    clipped Adam step).  First-version kernels -- see DESIGN.md section 6a."""
+    import urnn_amd.weights as uw
+    from urnn_amd.training import Trainer
+    name = args.config if args.config != "mixed" else "futian"
+    H, W, nums, T, rain_max, cum_max, spatial = CONFIGS[name]
+    S = args.seq_num
+    net, sd, cfg = build_net(H, W, 2 * nums + 3, dev)
+    tr = Trainer(net, H, W, nums, rain_max, cum_max, lr=1e-4, grad_clip=1.0, distributed=world > 1)
+    nwin_w, nwin = max(1, (args.warmup + S - 1) // S), max(1, (args.steps + S - 1) // S)
+    frames = S * (nwin_w + nwin)
+    ev = uw.make_event(frames, H, W, rain_max, seed=42 + rank, spatial_rain=spatial)
+    g = torch.Generator(device=dev).manual_seed(7 + rank)
+    label = torch.rand(1, frames, H, W, device=dev, generator=g) ** 3
+    label[label < 0.1] = 0
+
+    def run(w0, n, states):
+        for w in range(w0, w0 + n):
+            loss, states = tr.train_window(ev, label[:, w * S:(w + 1) * S], w * S, S, states)
+        return loss, states
+    loss, states = run(0, nwin_w, None)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    loss, states = run(nwin_w, nwin, states)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    from urnn_amd.distributed import max_over_ranks
+    elapsed = max_over_ranks(elapsed, device=dev if args.dist_backend == "nccl" else None)
+    steps = nwin * S
+    if rank == 0:
+        gflop = algorithmic_work(H, W, 2 * nums + 3) * 3.0          # forward + dX + dW
+        print(json.dumps({
+            "metric": "SWP training timesteps/s (forward + backward + clipped Adam), whole job", "value": steps * world / elapsed,
+            "unit": "steps/s", "n_gpus": world, "steps": steps, "warmup": nwin_w * S, "ms_per_step": elapsed / steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"train {name}: {H}x{W} grid, historical_nums={nums}, SWP windows of seq_num={S} (fast mode), "
+                                   f"1 event per GPU, Adam lr 1e-4, grad clip 1.0", "parallelism": f"DDP x{world} (flat-buffer mean all-reduce)"
+                       if world > 1 else "single GPU"},
+            "gflop_per_step": gflop, "step_mfma_frac": steps / elapsed * gflop / 1e3 / PEAK_MFMA_F32_TFLOPS,
+            "loss": float(loss[0]), "grad_norm": float(tr.last["clip"][1]),
+            "roofline": None, "cpu_baseline": None,
+            "note": "first-version training kernels (DESIGN.md 6a); the BASELINE metric is the default --mode infer"}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,6 +179,10 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="dry run: every rank uses cuda:0 (needs --dist-backend gloo)")
     ap.add_argument("--overlap", type=int, default=1,
                     help="1 (default): encoder(t+1) || decoder+head(t) as two concurrent kernel chains; 0: one chain")
+    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
+                    help="infer (default, the BASELINE metric): rollout frames/s.  train: SWP training timesteps/s (forward + backward + "
+                         "clipped Adam, windows of --seq-num steps; N>1: DDP mean all-reduce of the flat gradient buffer over RCCL)")
+    ap.add_argument("--seq-num", type=int, default=4, help="train mode: timesteps per SWP window")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -145,6 +204,9 @@ def main():
 
     import urnn_amd.weights as uw
     from urnn_amd.rollout import RolloutEngine
+
+    if args.mode == "train":
+        return bench_train(args, dev, dist, world, rank)
 
     # "mixed" = BASELINE configs[4]: Futian + UKEA events alternating on every rank, one engine (and one captured hipGraph)
     # per grid shape; every other config is a single shape
