@@ -310,3 +310,25 @@ def test_prewarming_states_equal_the_inference_rollout(dev):
     label = torch.from_numpy(g["loop_label"][:, :4]).to(dev)
     losses, _ = tr.train_event(ev, label, seq_num=2, prewarming=True)
     assert len(losses) == 2 and all(torch.isfinite(l).all() for l in losses)
+
+
+def test_window_gradients_batched_events(dev):
+    """Two copies of one event in a batch: the loss is a mean over all cells, so every parameter gradient equals the
+    single-event one; two different events: finite, and the per-sample state gradients are independent."""
+    import urnn_amd.weights as uw
+    from urnn_amd.training import WindowGradients
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_loop_16x16.npz"))
+    net, sd = _loop_net(g, dev)
+    H, W, nums = int(g["loop_H"]), int(g["loop_W"]), int(g["loop_nums"])
+    wg = WindowGradients(net, H, W, nums, 60.0, 250.0)
+    ev1 = uw.make_event(3, H, W, 60.0, seed=9)
+    ev2 = {k: (np.concatenate([v, v], 0) if isinstance(v, np.ndarray) and v.ndim > 0 else v) for k, v in ev1.items()}
+    tgt = g["loop_label"][:, :2]
+    one = wg.run(ev1, tgt, 0, 2)
+    two = wg.run(ev2, np.concatenate([tgt, tgt], 0), 0, 2)
+    assert float(two["loss"][0]) == pytest.approx(float(one["loss"][0]), rel=1e-5)
+    for name in sd:
+        a, b = one["grads"][name].cpu().numpy(), two["grads"][name].cpu().numpy().reshape(one["grads"][name].shape)
+        scale = max(np.abs(a).max(), 1e-12)
+        assert np.abs(a - b).max() <= 2e-5 * scale + 1e-9, name
+    assert_close(two["reg"][1].cpu().numpy(), one["reg"][0].cpu().numpy(), 1e-6, "batched outputs")
