@@ -120,12 +120,14 @@ def bench_train(args, dev, dist, world, rank):
     H, W, nums, T, rain_max, cum_max, spatial = CONFIGS[name]
     S = args.seq_num
     net, sd, cfg = build_net(H, W, 2 * nums + 3, dev)
-    tr = Trainer(net, H, W, nums, rain_max, cum_max, lr=1e-4, grad_clip=1.0, distributed=world > 1)
+    tr = Trainer(net, H, W, nums, rain_max, cum_max, lr=1e-4, grad_clip=1.0, distributed=world > 1,
+                 use_graph=(world == 1 and not args.no_graph))
     nwin_w, nwin = max(1, (args.warmup + S - 1) // S), max(1, (args.steps + S - 1) // S)
     frames = S * (nwin_w + nwin)
-    ev = uw.make_event(frames, H, W, rain_max, seed=42 + rank, spatial_rain=spatial)
+    B = args.batch
+    ev = uw.make_event(frames, H, W, rain_max, seed=42 + rank, spatial_rain=spatial, batch=B)
     g = torch.Generator(device=dev).manual_seed(7 + rank)
-    label = torch.rand(1, frames, H, W, device=dev, generator=g) ** 3
+    label = torch.rand(B, frames, H, W, device=dev, generator=g) ** 3
     label[label < 0.1] = 0
 
     def run(w0, n, states):
@@ -146,7 +148,7 @@ def bench_train(args, dev, dist, world, rank):
     elapsed = time.perf_counter() - t0
     from urnn_amd.distributed import max_over_ranks
     elapsed = max_over_ranks(elapsed, device=dev if args.dist_backend == "nccl" else None)
-    steps = nwin * S
+    steps = nwin * S * B                                            # one step = one training timestep of one event
     if rank == 0:
         gflop = algorithmic_work(H, W, 2 * nums + 3) * 3.0          # forward + dX + dW
         print(json.dumps({
@@ -154,7 +156,7 @@ def bench_train(args, dev, dist, world, rank):
             "unit": "steps/s", "n_gpus": world, "steps": steps, "warmup": nwin_w * S, "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"train {name}: {H}x{W} grid, historical_nums={nums}, SWP windows of seq_num={S} (fast mode), "
-                                   f"1 event per GPU, Adam lr 1e-4, grad clip 1.0", "parallelism": f"DDP x{world} (flat-buffer mean all-reduce)"
+                                   f"{B} event(s) per GPU, Adam lr 1e-4, grad clip 1.0", "parallelism": f"DDP x{world} (flat-buffer mean all-reduce)"
                        if world > 1 else "single GPU"},
             "gflop_per_step": gflop, "step_mfma_frac": steps / elapsed * gflop / 1e3 / PEAK_MFMA_F32_TFLOPS,
             "loss": float(loss[0]), "grad_norm": float(tr.last["clip"][1]),

@@ -182,10 +182,12 @@ int urnn_loss_f32(const float *reg, const float *target, float cls_thred, float 
 
 /* One optimizer step on flat buffers of n floats: gradients are scaled by min(1, max_grad_norm / (||g||_2 + 1e-6))
  * (torch.nn.utils.clip_grad_norm_, main.py:760-761; max_grad_norm <= 0: no clipping), then Adam with torch.optim.Adam's
- * defaults' arithmetic (main.py:306).  step counts from 1.  clip_out (device, 2 floats): the coefficient and the norm. */
+ * defaults' arithmetic (main.py:306).  step counts from 1; step_dev (device int, may be NULL) overrides it for hipGraph replay.
+ * clip_out (device, 2 floats): the coefficient and the norm. */
 size_t urnn_adam_workspace_bytes(long n);
 int urnn_adam_step_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, long n, float lr, float beta1, float beta2,
-                       float eps, int step, float max_grad_norm, float *clip_out, void *workspace, size_t workspace_bytes, void *stream);
+                       float eps, int step, const int *step_dev, float max_grad_norm, float *clip_out, void *workspace,
+                       size_t workspace_bytes, void *stream);
 
 /* Device-side frame counter helper for graph-captured rollouts: *counter += delta. */
 int urnn_advance_counter(int *counter, int delta, void *stream);

@@ -332,3 +332,30 @@ def test_window_gradients_batched_events(dev):
         scale = max(np.abs(a).max(), 1e-12)
         assert np.abs(a - b).max() <= 2e-5 * scale + 1e-9, name
     assert_close(two["reg"][1].cpu().numpy(), one["reg"][0].cpu().numpy(), 1e-6, "batched outputs")
+
+
+def test_graph_captured_training_windows_match_eager(dev):
+    """The hipGraph path of the trainer (device-side frame indices and Adam step counter, static buffers) gives the same
+    parameters, losses and states as the eager path, bit for bit, over several windows and a change of event."""
+    import urnn_amd.weights as uw
+    from urnn_amd.training import Trainer
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_loop_16x16.npz"))
+    H, W, nums = int(g["loop_H"]), int(g["loop_W"]), int(g["loop_nums"])
+    label = torch.from_numpy(g["loop_label"]).to(dev)
+    results = []
+    for use_graph in (False, True):
+        net, _ = _loop_net(g, dev)
+        tr = Trainer(net, H, W, nums, 60.0, 250.0, lr=1e-3, grad_clip=1.0, use_graph=use_graph)
+        losses = []
+        for seed in (8, 11):                                      # two events of one catchment (same DEM): one capture
+            ev = uw.make_event(6, H, W, 60.0, seed=seed)
+            ev["absolute_DEM"] = uw.make_event(6, H, W, 60.0, seed=8)["absolute_DEM"]
+            ev["max_DEM"], ev["min_DEM"] = ev["absolute_DEM"].reshape(1, -1).max(1), ev["absolute_DEM"].reshape(1, -1).min(1)
+            ls, states = tr.train_event(ev, label, seq_num=2)
+            losses += [float(l[0]) for l in ls]
+        results.append((tr.flat.clone(), losses, [s.clone() for s in states], tr.step_count))
+    (fa, la, sa, na), (fb, lb, sb, nb) = results
+    assert na == nb == 6 and la == lb
+    assert torch.equal(fa, fb)
+    for a, b in zip(sa, sb):
+        assert torch.equal(a, b)

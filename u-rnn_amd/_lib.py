@@ -45,7 +45,7 @@ SIGNATURES = {
     "urnn_loss_workspace_bytes": (_sz, [ctypes.c_long]),
     "urnn_loss_f32": (_i, [_p, _p, _f, _p, _p, _p, _sz, ctypes.c_long, _p]),
     "urnn_adam_workspace_bytes": (_sz, [ctypes.c_long]),
-    "urnn_adam_step_f32": (_i, [_p, _p, _p, _p, ctypes.c_long, _f, _f, _f, _f, _i, _f, _p, _p, _sz, _p]),
+    "urnn_adam_step_f32": (_i, [_p, _p, _p, _p, ctypes.c_long, _f, _f, _f, _f, _i, _p, _f, _p, _p, _sz, _p]),
     "urnn_advance_counter": (_i, [_p, _i, _p]),
 }
 

@@ -707,15 +707,15 @@ extern "C" size_t urnn_adam_workspace_bytes(long n)
 }
 
 extern "C" int urnn_adam_step_f32(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, long n, float lr, float beta1,
-                                  float beta2, float eps, int step, float max_grad_norm, float *clip_out, void *workspace,
-                                  size_t workspace_bytes, void *stream)
+                                  float beta2, float eps, int step, const int *step_dev, float max_grad_norm, float *clip_out,
+                                  void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!params || !grads || !exp_avg || !exp_avg_sq || !clip_out || !workspace) return fail(URNN_ENULL, "urnn_adam_step_f32: NULL argument");
-    if (n < 1 || step < 1) return fail(URNN_EINVAL, "urnn_adam_step_f32: n=%ld step=%d", n, step);
+    if (n < 1 || (!step_dev && step < 1)) return fail(URNN_EINVAL, "urnn_adam_step_f32: n=%ld step=%d", n, step);
     if (workspace_bytes < urnn_adam_workspace_bytes(n)) return fail(URNN_EWORKSPACE, "urnn_adam_step_f32: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     CHECK_HIP(urnn_train_clip_coef(grads, n, max_grad_norm, reinterpret_cast<float *>(workspace), clip_out, st), "gradient norm");
-    CHECK_HIP(urnn_train_adam(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, clip_out, st), "adam");
+    CHECK_HIP(urnn_train_adam(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, step_dev, clip_out, st), "adam");
     return URNN_OK;
 }
 

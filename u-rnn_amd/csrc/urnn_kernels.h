@@ -115,4 +115,4 @@ hipError_t urnn_train_loss(const float *reg, const float *tgt, float thr, long n
                            hipStream_t st);
 hipError_t urnn_train_clip_coef(const float *g, long n, float max_norm, float *partial, float *out, hipStream_t st);
 hipError_t urnn_train_adam(float *p, const float *g, float *m, float *v, long n, float lr, float b1, float b2, float eps, int step,
-                           const float *coef, hipStream_t st);
+                           const int *step_dev, const float *coef, hipStream_t st);

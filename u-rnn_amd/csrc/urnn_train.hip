@@ -841,18 +841,21 @@ __global__ __launch_bounds__(64) void clip_coef_kernel(const float *__restrict__
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
-                                                   long n, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt,
+                                                   long n, float lr, float b1, float b2, float eps, int step_host, const int *__restrict__ step_dev,
                                                    const float *__restrict__ coef)
 {
+    // step_dev (device counter, for hipGraph replay) overrides step_host; every thread derives the same bias corrections
+    const int step = step_dev ? *step_dev : step_host;
+    const float bc1 = 1.f - powf(b1, (float)step), bc2_sqrt = sqrtf(1.f - powf(b2, (float)step));
     const float c = coef ? coef[0] : 1.f;
-    const float step = lr / bc1;
+    const float stepsz = lr / bc1;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const float gi = g[i] * c;
         const float mi = b1 * m[i] + (1.f - b1) * gi;
         const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
         m[i] = mi;
         v[i] = vi;
-        p[i] -= step * mi / (sqrtf(vi) / bc2_sqrt + eps);
+        p[i] -= stepsz * mi / (sqrtf(vi) / bc2_sqrt + eps);
     }
 }
 
@@ -865,10 +868,9 @@ hipError_t urnn_train_clip_coef(const float *g, long n, float max_norm, float *p
 }
 
 hipError_t urnn_train_adam(float *p, const float *g, float *m, float *v, long n, float lr, float b1, float b2, float eps, int step,
-                           const float *coef, hipStream_t st)
+                           const int *step_dev, const float *coef, hipStream_t st)
 {
-    const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
     const int nblk = urnn_train_loss_nblk(n);
-    hipLaunchKernelGGL(adam_kernel, dim3(nblk), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, bc1, sqrtf(bc2), coef);
+    hipLaunchKernelGGL(adam_kernel, dim3(nblk), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, step, step_dev, coef);
     return hipGetLastError();
 }

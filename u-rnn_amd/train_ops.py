@@ -126,15 +126,17 @@ def loss(reg, target, cls_thred=0.0, want_grad=True):
     return comps, dreg
 
 
-def adam_step(params, grads, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=0.0):
-    """In-place Adam step on flat float32 buffers (with optional global-norm clipping).  Returns a 2-float device tensor:
-    (clip coefficient, gradient norm)."""
+def adam_step(params, grads, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=0.0, step_dev=None):
+    """In-place Adam step on flat float32 buffers (with optional global-norm clipping).  ``step_dev`` (int32 device scalar)
+    overrides ``step`` for graph replay.  Returns a 2-float device tensor: (clip coefficient, gradient norm)."""
     ops._dev_check(params, grads, exp_avg, exp_avg_sq)
+    if step_dev is not None and (not step_dev.is_cuda or step_dev.dtype != torch.int32):
+        raise RuntimeError("adam_step: step_dev must be an int32 device scalar")
     n = params.numel()
     L = lib()
     ws = _bwd_workspace(L.urnn_adam_workspace_bytes(n), params.device)
     out = torch.empty(2, dtype=torch.float32, device=params.device)
     p = ops._ptr
     check(L.urnn_adam_step_f32(p(params), p(grads), p(exp_avg), p(exp_avg_sq), n, float(lr), float(betas[0]), float(betas[1]), float(eps),
-                               int(step), float(max_grad_norm), p(out), p(ws), ws.numel(), ops._stream()), "urnn_adam_step_f32")
+                               int(step), p(step_dev), float(max_grad_norm), p(out), p(ws), ws.numel(), ops._stream()), "urnn_adam_step_f32")
     return out

@@ -28,14 +28,14 @@ class WindowGradients:
         self.device = next(net.parameters()).device
 
     # -- forward of one timestep, keeping what the backward reads ---------------------------------------------------
-    def _forward_step(self, ev, t, states, step):
+    def _forward_step(self, ev, t, states, step, t_dev=None):
         net = self.net
         enc, dec, head = net.encoder, net.decoder, net.head
         e1, e2, e3, d1, d2, d3 = states
         base = _SLOT0 + 16 * step
         S = {"prev": list(states)}
         x_in = ops.preprocess(ev["rain"], ev["cumsum"], ev["dem"], ev["imperv"], ev["manhole"], ev["dem_min"], ev["dem_max"], int(t),
-                              self.nums, self.rain_max, self.cumsum_max)
+                              self.nums, self.rain_max, self.cumsum_max, t_dev=t_dev)
 
         def cell(k, mod, x, e, h):
             ops.WORKSPACE.use_slot(base + k)
@@ -125,9 +125,10 @@ class WindowGradients:
         conv_bwd("encoder.stage1", enc.stage1, S["x_in"], da1)
         return [dE1n, dE2n, dE3n, dD1n, dD2n, dD3n]
 
-    def run(self, event, targets, t0, steps, states=None):
+    def run(self, event, targets, t0, steps, states=None, t_devs=None):
         """event: reference-layout event dict (or already on the device); targets (B,steps,H,W) normalised depths of frames
-        t0 .. t0+steps-1; states: six (B,C,h,w) tensors or None (zeros).  See the class docstring for the result."""
+        t0 .. t0+steps-1; states: six (B,C,h,w) tensors or None (zeros); t_devs: optional list of int32 device scalars holding
+        the frame index of every step (hipGraph replay).  See the class docstring for the result."""
         ev = event if "rain" in event else event_to_device(event, self.device)
         B = ev["B"]
         if states is None:
@@ -136,7 +137,7 @@ class WindowGradients:
         targets = torch.as_tensor(targets, dtype=torch.float32, device=self.device).contiguous()
         saved = []
         for s in range(steps):
-            S, states = self._forward_step(ev, t0 + s, states, s)
+            S, states = self._forward_step(ev, t0 + s, states, s, None if t_devs is None else t_devs[s])
             saved.append(S)
         reg = torch.stack([S["masked"] for S in saved], dim=1).contiguous()            # (B,steps,H,W) as main.py concatenates
         comps, dreg = train_ops.loss(reg, targets, cls_thred=self.cls_thred_train)
@@ -171,8 +172,10 @@ class Trainer:
     (main.py:384-387)."""
 
     def __init__(self, net, H, W, nums, rain_max, cumsum_max, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_clip=0.0,
-                 cls_thred_train=0.0, process_group=None, distributed=False):
+                 cls_thred_train=0.0, process_group=None, distributed=False, use_graph=False):
         self.net = net
+        self.use_graph = bool(use_graph)        # capture one window (forward, loss, backward, clip + Adam) as a hipGraph
+        self._graph = None
         self.wg = WindowGradients(net, H, W, nums, rain_max, cumsum_max, cls_thred_train)
         self.lr, self.betas, self.eps, self.grad_clip = float(lr), tuple(betas), float(eps), float(grad_clip)
         self.distributed, self.pg = bool(distributed), process_group
@@ -203,19 +206,79 @@ class Trainer:
                 cache.clear()
         self.net.head._stamp = None
 
-    def train_window(self, event, targets, t0, steps, states=None):
-        """One window: returns (loss components, final states); the parameters have been updated."""
-        out = self.wg.run(event, targets, t0, steps, states)
+    def _window_body(self, ev, targets, t0, steps, states, t_devs=None, step_dev=None):
+        out = self.wg.run(ev, targets, t0, steps, states, t_devs=t_devs)
         for n, g in out["grads"].items():
             off, k, _ = self.views[n]
             self.gflat[off:off + k].copy_(g.reshape(-1))
         if self.distributed:
             from .distributed import allreduce_mean_
             allreduce_mean_(self.gflat, group=self.pg)
-        self.step_count += 1
-        clip = train_ops.adam_step(self.flat, self.gflat, self.m, self.v, self.step_count, lr=self.lr, betas=self.betas, eps=self.eps,
-                                   max_grad_norm=self.grad_clip)
+        clip = train_ops.adam_step(self.flat, self.gflat, self.m, self.v, max(self.step_count, 1), lr=self.lr, betas=self.betas,
+                                   eps=self.eps, max_grad_norm=self.grad_clip, step_dev=step_dev)
         self._invalidate_packed()
+        return out, clip
+
+    def _train_window_graph(self, ev, targets, t0, steps, states):
+        """hipGraph path: static input buffers (targets, the six states, the per-step frame indices, the Adam step counter) are
+        refreshed on the stream, then the captured window -- ~250 launches per timestep -- replays as one graph."""
+        dev = self.wg.device
+        B = ev["B"]
+        # the DEM normalisation bounds are kernel ARGUMENTS (frozen into the graph): one capture per (shape, bounds), i.e. per
+        # catchment; the event's tensors are copied into static buffers before every replay
+        key = (steps, B, ev["T"], tuple(ev["rain"].shape), ev["dem_min"], ev["dem_max"])
+        if self._graph is None or self._graph["key"] != key:
+            from .general import initialize_states
+            zero = [s.to(dev).repeat(B, 1, 1, 1) for s in initialize_states(dev, self.wg.H, self.wg.W)]
+            sev = dict(ev)
+            for k in ("rain", "cumsum", "dem", "imperv", "manhole"):
+                sev[k] = ev[k].clone()
+            G = {"key": key, "ev": sev, "tgt": torch.zeros((B, steps, self.wg.H, self.wg.W), device=dev),
+                 "states": [torch.zeros_like(z) for z in zero], "zero": zero,
+                 "t_devs": [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(steps)],
+                 "step_dev": torch.zeros(1, dtype=torch.int32, device=dev)}
+            keep = (self.flat.clone(), self.m.clone(), self.v.clone())
+            G["step_dev"].fill_(1)
+            self._invalidate_packed()
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):                       # eager warm-up: sizes every workspace, packs every weight
+                self._window_body(sev, G["tgt"], 0, steps, G["states"], t_devs=G["t_devs"], step_dev=G["step_dev"])
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            for dst, src in zip((self.flat, self.m, self.v), keep):
+                dst.copy_(src)
+            self._invalidate_packed()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out, clip = self._window_body(sev, G["tgt"], 0, steps, G["states"], t_devs=G["t_devs"], step_dev=G["step_dev"])
+            G.update(graph=g, out=out, clip=clip)
+            self._graph = G
+        G = self._graph
+        if ev is not G["ev"]:
+            for k in ("rain", "cumsum", "dem", "imperv", "manhole"):
+                if G["ev"][k].data_ptr() != ev[k].data_ptr():
+                    G["ev"][k].copy_(ev[k])
+        G["tgt"].copy_(targets)
+        for dst, src in zip(G["states"], states if states is not None else G["zero"]):
+            dst.copy_(src)
+        for s, td in enumerate(G["t_devs"]):
+            td.fill_(int(t0) + s)
+        G["step_dev"].fill_(self.step_count)
+        G["graph"].replay()
+        self._invalidate_packed()       # host-side caches of packed weights now describe the previous parameters
+        return G["out"], G["clip"]
+
+    def train_window(self, event, targets, t0, steps, states=None):
+        """One window: returns (loss components, final states); the parameters have been updated."""
+        ev = event if "rain" in event else event_to_device(event, self.wg.device)
+        self.step_count += 1
+        if self.use_graph and not self.distributed:
+            targets = torch.as_tensor(targets, dtype=torch.float32, device=self.wg.device)
+            out, clip = self._train_window_graph(ev, targets, t0, steps, states)
+            self.last = {"loss": out["loss"], "clip": clip, "reg": out["reg"]}        # static buffers: valid until the next window
+            return out["loss"].clone(), [s.clone() for s in out["states"]]
+        out, clip = self._window_body(ev, targets, t0, steps, states)
         self.last = {"loss": out["loss"], "clip": clip, "reg": out["reg"]}
         return out["loss"], out["states"]
 
