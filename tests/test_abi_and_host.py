@@ -123,3 +123,13 @@ def test_shard_events_is_distributed_sampler():
         for rank in range(world):
             ref = list(DistributedSampler(range(n), num_replicas=world, rank=rank, shuffle=False))
             assert shard_events(n, rank, world) == ref
+
+
+def test_swp_window_schedule():
+    """split_iter_index of the reference (main.py:162-178): consecutive windows of seq_num steps; a remainder moves the last
+    window back so that it ends with the training window."""
+    from urnn_amd.training import window_starts
+    assert window_starts(0, 12, 36) == [0, 12, 24]
+    assert window_starts(5, 4, 12) == [5, 9, 13]
+    assert window_starts(0, 4, 10) == [0, 4, 6]
+    assert window_starts(0, 8, 8) == [0]

@@ -158,8 +158,13 @@ class WindowGradients:
 
 
 def window_starts(loc, seq_num, window_size):
-    """Start indices of the SWP windows of one sample (split_iter_index, main.py:439): loc, loc + seq_num, ... over window_size."""
-    return list(range(int(loc), int(loc) + int(window_size) - int(seq_num) + 1, int(seq_num)))
+    """Start indices of the SWP windows of one sample (split_iter_index, main.py:162-178): loc, loc + seq_num, ...; when
+    window_size is not a multiple of seq_num the last window is shifted back to end exactly at loc + window_size."""
+    loc, seq_num, window_size = int(loc), int(seq_num), int(window_size)
+    idx = list(range(loc, loc + window_size, seq_num))
+    if window_size % seq_num > 0:
+        idx[-1] = loc + window_size - seq_num
+    return idx
 
 
 class Trainer:
