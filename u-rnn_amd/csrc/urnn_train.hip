@@ -197,9 +197,10 @@ struct WgradParams {
 
 // Second version: 128 n x 128 k per block (wave w: the 64 x 64 quadrant (w >> 1, w & 1) = 2 x 2 MFMA tiles), 16-byte global
 // loads of the NEXT 64-pixel stage into registers while the current one is multiplied out of LDS, row bases (incl. the K
-// segment lookup) resolved once per block.  LDS rows are padded to 65 floats: an MFMA fragment reads one COLUMN of the
-// tile (lane l -> row l & 31), the odd stride spreads it over 32 banks.
-constexpr int WG_T = 128, WG_LD = 65;
+// segment lookup) resolved once per block.  An MFMA fragment reads one COLUMN of the LDS tile (lane l -> row l & 31).
+// (A third version with one 8-wave block per CU on 128 x 256 / 64 x 512 / 256 x 128 tiles -- fewer staged bytes per MFMA --
+// measured slower, 8.9 vs 8.2 ms per training step: two independent 4-wave blocks hide each other's barriers.)
+constexpr int WG_T = 128, WG_LD = 68;   // 68: rows stay 16-byte aligned (one ds_write_b128 per staged float4); column reads are 2-way conflicted, cheap next to the MFMAs
 
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams prm)
 {
@@ -263,9 +264,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams prm)
     for (int p0 = p_lo; p0 < p_hi; p0 += 64) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            float *da = tA + (r0 + 16 * i) * WG_LD + c4, *db = tB + (r0 + 16 * i) * WG_LD + c4;
-            da[0] = ra[i].x; da[1] = ra[i].y; da[2] = ra[i].z; da[3] = ra[i].w;
-            db[0] = rb[i].x; db[1] = rb[i].y; db[2] = rb[i].z; db[3] = rb[i].w;
+            *reinterpret_cast<f32x4 *>(tA + (r0 + 16 * i) * WG_LD + c4) = ra[i];
+            *reinterpret_cast<f32x4 *>(tB + (r0 + 16 * i) * WG_LD + c4) = rb[i];
         }
         __syncthreads();
         if (p0 + 64 < p_hi) load_stage(p0 + 64);          // in flight while this stage is multiplied
