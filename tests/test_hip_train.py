@@ -359,3 +359,33 @@ def test_graph_captured_training_windows_match_eager(dev):
     assert torch.equal(fa, fb)
     for a, b in zip(sa, sb):
         assert torch.equal(a, b)
+
+
+def test_training_reduces_the_loss_and_weights_round_trip(dev, tmp_path):
+    """Behavioural check: repeated SWP passes over one event drive the loss down; the trained parameters leave through
+    state_dict() / load_state_dict() like any torch module and reproduce the same forward."""
+    import urnn_amd.weights as uw
+    from urnn_amd.training import Trainer
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_loop_16x16.npz"))
+    net, sd = _loop_net(g, dev)
+    H, W, nums = int(g["loop_H"]), int(g["loop_W"]), int(g["loop_nums"])
+    ev = uw.make_event(6, H, W, 60.0, seed=3)
+    label = torch.from_numpy(g["loop_label"]).to(dev)
+    tr = Trainer(net, H, W, nums, 60.0, 250.0, lr=2e-3, grad_clip=1.0)
+    first = last = None
+    for epoch in range(12):
+        losses, _ = tr.train_event(ev, label, seq_num=3)
+        mean = float(torch.stack([l[0] for l in losses]).mean())
+        first = mean if first is None else first
+        last = mean
+    assert np.isfinite(last) and last < 0.7 * first, (first, last)
+    path = str(tmp_path / "ckpt.pth.tar")
+    torch.save({"state_dict": net.state_dict()}, path)
+    net2, _ = _loop_net(g, dev)
+    net2.load_state_dict(torch.load(path, map_location="cpu")["state_dict"])
+    x = torch.randn(1, 1, 2 * nums + 3, H, W, device=dev)
+    from urnn_amd.general import initialize_states
+    st = [s.to(dev) for s in initialize_states(dev, H, W)]
+    a, b = net(x, *st), net2.to(dev)(x, *st)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
