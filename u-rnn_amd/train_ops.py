@@ -30,10 +30,11 @@ def gru_cell_backward(x, e, h, W1, W2, gn1_w, gn2_w, dh_out, I, grads=None, accu
     ops.WORKSPACE.use_slot(slot)
     f32 = dict(dtype=torch.float32, device=dev)
     g = grads if grads is not None else {}
-    if grads is None or not accumulate:
+    if "dW1" not in g:          # caller-provided buffers (e.g. views of a flat gradient buffer) are written in place
         g.update(dW1=torch.empty(2 * F, K, **f32), db1=torch.empty(2 * F, **f32), dg1=torch.empty(2 * F, **f32),
                  dbe1=torch.empty(2 * F, **f32), dW2=torch.empty(F, K, **f32), db2=torch.empty(F, **f32),
                  dg2=torch.empty(F, **f32), dbe2=torch.empty(F, **f32))
+        accumulate = False
     g["dh"] = torch.empty_like(h)
     g["dx"] = torch.empty_like(x) if x is not None else None
     g["de"] = torch.empty_like(e) if e is not None else None
@@ -61,8 +62,8 @@ def stage_conv_backward(x, weight, bias, dout, pool, dweight=None, dbias=None, a
     Cout = weight.shape[0]
     L = lib()
     ws = _bwd_workspace(L.urnn_stage_conv_backward_workspace_bytes(B, Cin, Cout, H, W), x.device)
-    if dweight is None or not accumulate:
-        dweight, dbias = torch.empty_like(weight), torch.empty_like(bias)
+    if dweight is None:
+        dweight, dbias, accumulate = torch.empty_like(weight), torch.empty_like(bias), False
     dx = torch.empty_like(x)
     p = ops._ptr
     check(L.urnn_stage_conv_backward_f32(p(x), p(weight), p(bias), p(dout), p(dx), p(dweight), p(dbias), p(ws), ws.numel(), B, Cin,
@@ -78,8 +79,8 @@ def deconv2x2_backward(x, weight, out, dout, dweight=None, dbias=None, accumulat
     Cout = weight.shape[1]
     L = lib()
     ws = _bwd_workspace(L.urnn_deconv2x2_backward_workspace_bytes(B, Cin, Cout, H, W), x.device)
-    if dweight is None or not accumulate:
-        dweight, dbias = torch.empty_like(weight), torch.empty(Cout, dtype=torch.float32, device=x.device)
+    if dweight is None:
+        dweight, dbias, accumulate = torch.empty_like(weight), torch.empty(Cout, dtype=torch.float32, device=x.device), False
     dx = torch.empty_like(x)
     p = ops._ptr
     check(L.urnn_deconv2x2_backward_f32(p(x), p(weight), p(out), p(dout), p(dx), p(dweight), p(dbias), p(ws), ws.numel(), B, Cin, Cout,

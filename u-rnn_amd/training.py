@@ -73,7 +73,7 @@ class WindowGradients:
             L = mod.layer
             key = f"{name}.{mod._pname}"
             dx, dw, db = train_ops.stage_conv_backward(x, L.weight.detach(), L.bias.detach(), dy, mod.pool, dweight=G.get(key + ".weight"),
-                                                       dbias=G.get(key + ".bias"), accumulate=acc)
+                                                       dbias=G.get(key + ".bias"), accumulate=acc and (key + ".weight") in G)
             G[key + ".weight"], G[key + ".bias"] = dw, db
             return dx
 
@@ -81,7 +81,7 @@ class WindowGradients:
             L = mod.layer
             key = f"{name}.{mod._pname}"
             dx, dw, db = train_ops.deconv2x2_backward(x, L.weight.detach(), out, dy, dweight=G.get(key + ".weight"),
-                                                      dbias=G.get(key + ".bias"), accumulate=acc)
+                                                      dbias=G.get(key + ".bias"), accumulate=acc and (key + ".weight") in G)
             G[key + ".weight"], G[key + ".bias"] = dw, db
             return dx
 
@@ -90,10 +90,11 @@ class WindowGradients:
             ops.WORKSPACE.use_slot(base + k)
             names = {"dW1": "conv1.0.weight", "db1": "conv1.0.bias", "dg1": "conv1.1.weight", "dbe1": "conv1.1.bias",
                      "dW2": "conv2.0.weight", "db2": "conv2.0.bias", "dg2": "conv2.1.weight", "dbe2": "conv2.1.bias"}
-            prev = {k_: G[f"{name}.{v}"].reshape(-1) if k_ in ("db1", "dg1", "dbe1", "db2", "dg2", "dbe2") else
-                    G[f"{name}.{v}"].reshape(G[f"{name}.{v}"].shape[0], -1) for k_, v in names.items()} if acc and f"{name}.conv1.0.weight" in G else None
+            have = f"{name}.conv1.0.weight" in G
+            prev = {k_: (G[f"{name}.{v}"].reshape(-1) if k_ in ("db1", "dg1", "dbe1", "db2", "dg2", "dbe2") else
+                         G[f"{name}.{v}"].reshape(G[f"{name}.{v}"].shape[0], -1)) for k_, v in names.items()} if have else None
             g = train_ops.gru_cell_backward(x, e, h, c1.weight.detach(), c2.weight.detach(), g1.weight.detach(), g2.weight.detach(),
-                                            dout_h.contiguous(), mod.input_channels, grads=prev, accumulate=prev is not None)
+                                            dout_h.contiguous(), mod.input_channels, grads=prev, accumulate=acc and have)
             for k_, v in names.items():
                 ref = dict(mod.named_parameters())[v]
                 G[f"{name}.{v}"] = g[k_].reshape(ref.shape)
@@ -125,10 +126,11 @@ class WindowGradients:
         conv_bwd("encoder.stage1", enc.stage1, S["x_in"], da1)
         return [dE1n, dE2n, dE3n, dD1n, dD2n, dD3n]
 
-    def run(self, event, targets, t0, steps, states=None, t_devs=None):
+    def run(self, event, targets, t0, steps, states=None, t_devs=None, grad_buffers=None):
         """event: reference-layout event dict (or already on the device); targets (B,steps,H,W) normalised depths of frames
         t0 .. t0+steps-1; states: six (B,C,h,w) tensors or None (zeros); t_devs: optional list of int32 device scalars holding
-        the frame index of every step (hipGraph replay).  See the class docstring for the result."""
+        the frame index of every step (hipGraph replay); grad_buffers: optional {parameter name: tensor} the encoder / decoder
+        gradients are written into directly (views of a flat gradient buffer).  See the class docstring for the result."""
         ev = event if "rain" in event else event_to_device(event, self.device)
         B = ev["B"]
         if states is None:
@@ -141,7 +143,7 @@ class WindowGradients:
             saved.append(S)
         reg = torch.stack([S["masked"] for S in saved], dim=1).contiguous()            # (B,steps,H,W) as main.py concatenates
         comps, dreg = train_ops.loss(reg, targets, cls_thred=self.cls_thred_train)
-        G, dstate = {}, None
+        G, dstate = ({k: v for k, v in grad_buffers.items() if not k.startswith("head.")} if grad_buffers else {}), None
         for s in reversed(range(steps)):
             dstate = self._backward_step(saved[s], s, dreg[:, s], dstate, G, acc=(s != steps - 1))
         grads = {k: v for k, v in G.items() if not k.startswith("_")}
@@ -200,6 +202,7 @@ class Trainer:
             p.data = self.flat[off:off + k].view(p.shape)                 # parameters now live in the flat buffer
             self.views[n] = (off, k, tuple(p.shape))
             off += k
+        self.grad_views = {n: self.gflat[off:off + k].view(shape) for n, (off, k, shape) in self.views.items()}
         self.step_count = 0
         self.last = None
 
@@ -212,10 +215,11 @@ class Trainer:
         self.net.head._stamp = None
 
     def _window_body(self, ev, targets, t0, steps, states, t_devs=None, step_dev=None):
-        out = self.wg.run(ev, targets, t0, steps, states, t_devs=t_devs)
+        out = self.wg.run(ev, targets, t0, steps, states, t_devs=t_devs, grad_buffers=self.grad_views)
         for n, g in out["grads"].items():
             off, k, _ = self.views[n]
-            self.gflat[off:off + k].copy_(g.reshape(-1))
+            if g.data_ptr() != self.grad_views[n].data_ptr():      # the head's stacked buffers; the rest was written in place
+                self.gflat[off:off + k].copy_(g.reshape(-1))
         if self.distributed:
             from .distributed import allreduce_mean_
             allreduce_mean_(self.gflat, group=self.pg)
