@@ -302,18 +302,25 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams prm)
 }
 
 // dW[i] (+)= sum over chunks (double, fixed order); the same for the bias row sums
-__global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float *__restrict__ partial, int nchunk, long count, float *__restrict__ out,
-                                                             int accumulate)
+__global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float *__restrict__ partial, const float *__restrict__ rowpart, int nchunk,
+                                                             long cntW, long cntB, float *__restrict__ dW, float *__restrict__ db, int accumulate)
 {
-    // four lanes per output: lane q sums chunks q, q+4, ... in double, then the four sub-sums are added in a fixed order
+    // outputs 0 .. cntW-1: weight gradient, cntW .. cntW+cntB-1: bias gradient (row sums).  Four lanes per output: lane q sums
+    // chunks q, q+4, ... in double, then the four sub-sums are added in a fixed order
     const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
     const int q = threadIdx.x & 3;
+    const bool isW = i < cntW, live = i < cntW + cntB;
+    const float *src = isW ? partial + i : rowpart + (i - cntW);
+    const long stride = isW ? cntW : cntB;
     double s = 0.0;
-    if (i < count)
-        for (int c = q; c < nchunk; c += 4) s += (double)partial[(size_t)c * count + i];
+    if (live)
+        for (int c = q; c < nchunk; c += 4) s += (double)src[(size_t)c * stride];
     const double s1 = s + __shfl_xor(s, 1, 64);
     const double s2 = s1 + __shfl_xor(s1, 2, 64);
-    if (i < count && q == 0) out[i] = (accumulate ? out[i] : 0.f) + (float)s2;
+    if (live && q == 0) {
+        float *o = isW ? dW + i : db + (i - cntW);
+        *o = (accumulate ? *o : 0.f) + (float)s2;
+    }
 }
 
 // weight (N,K) row-major -> transposed (K,N) row-major (the "weight" of the dX GEMM)
@@ -431,10 +438,9 @@ hipError_t urnn_train_wgrad(const float *dy, const float *const seg[3], const in
         big = true;
     }
     hipLaunchKernelGGL(wgrad_kernel, dim3((K + WG_T - 1) / WG_T, (N + WG_T - 1) / WG_T, chunks), dim3(256), lds, st, w);
-    const long cnt = (long)N * K;
-    hipLaunchKernelGGL(wgrad_finalize_kernel, dim3((unsigned)((cnt * 4 + 255) / 256)), dim3(256), 0, st, partial, chunks, cnt, dW, accumulate);
-    if (db)
-        hipLaunchKernelGGL(wgrad_finalize_kernel, dim3((N * 4 + 255) / 256), dim3(256), 0, st, w.rowpart, chunks, (long)N, db, accumulate);
+    const long cntW = (long)N * K, cntB = db ? N : 0;
+    hipLaunchKernelGGL(wgrad_finalize_kernel, dim3((unsigned)(((cntW + cntB) * 4 + 255) / 256)), dim3(256), 0, st, partial, w.rowpart, chunks,
+                       cntW, cntB, dW, db, accumulate);
     return hipGetLastError();
 }
 
