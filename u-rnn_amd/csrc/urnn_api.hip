@@ -320,7 +320,10 @@ static GruBwdWs carve_gru_bwd(void *base, int B, int I, int F, int skip, long P)
     w.pk2 = takef(urnn_packed_conv_floats(F, K));
     w.chpart = takef((size_t)B * 2 * F * urnn_train_nchunk((int)P) * 2);
     w.coef = takef((size_t)B * (2 * F / 32) * 2);
-    w.wpart = takef(urnn_train_wgrad_partial_floats(B, 2 * F, K, (int)P));
+    {
+        const size_t a = urnn_train_wgrad_partial_floats(B, 2 * F, K, (int)P), b = urnn_train_wgrad_partial_floats(B, F, K, (int)P);
+        w.wpart = takef(a > b ? a : b);
+    }
     w.sums = reinterpret_cast<double *>(take((size_t)B * 2 * F * 2 * sizeof(double)));
     w.bytes = off;
     return w;
@@ -616,7 +619,10 @@ static HeadBwdWs carve_head_bwd(void *base, int B, long P)
     w.draw = takef((size_t)B * P);
     w.partial = takef((size_t)B * ((P + 255) / 256) * 2);
     w.coef = takef((size_t)B * 2);
-    w.wpart = takef(urnn_train_wgrad_partial_floats(B, 16, 16, (int)P));
+    {
+        const size_t a = urnn_train_wgrad_partial_floats(B, 16, 16, (int)P), b = urnn_train_wgrad_partial_floats(B, 1, 16, (int)P);
+        w.wpart = takef(a > b ? a : b);
+    }
     w.wt = takef(256);
     w.pkt = takef(urnn_packed_conv_floats(16, 16));
     w.bytes = off;

@@ -398,18 +398,23 @@ hipError_t urnn_train_add_slices(float *out, long out_bs, const float *a, long a
     return hipGetLastError();
 }
 
-int urnn_train_wgrad_chunks(int P);
+int urnn_train_wgrad_chunks(int B, int N, int K, int P);
 
 size_t urnn_train_wgrad_partial_floats(int B, int N, int K, int P)
 {
-    return (size_t)B * urnn_train_wgrad_chunks(P) * ((size_t)N * K + N);
+    return (size_t)B * urnn_train_wgrad_chunks(B, N, K, P) * ((size_t)N * K + N);
 }
 
-// pixel chunks per sample of the weight-gradient GEMM: ~1024 pixels each (enough blocks for the chip on small N x K), <= 256
-int urnn_train_wgrad_chunks(int P)
+// pixel chunks per sample of the weight-gradient GEMM: enough blocks (~768) to fill the chip whatever the plane and the
+// N x K tile count, at least one 64-pixel stage per chunk, at most 256 chunks (their partial tiles are summed afterwards)
+int urnn_train_wgrad_chunks(int B, int N, int K, int P)
 {
-    const int n = (P + 1023) / 1024;
-    return n < 1 ? 1 : (n > 256 ? 256 : n);
+    const int tiles = ((N + WG_T - 1) / WG_T) * ((K + WG_T - 1) / WG_T) * B;
+    int n = (768 + tiles - 1) / tiles;
+    const int most = (P + 63) / 64;
+    n = n > most ? most : n;
+    n = n > 256 ? 256 : n;
+    return n < 1 ? 1 : n;
 }
 
 hipError_t urnn_train_wgrad(const float *dy, const float *const seg[3], const int segC[3], int B, int N, int K, int P, float *partial,
@@ -425,7 +430,7 @@ hipError_t urnn_train_wgrad(const float *dy, const float *const seg[3], const in
         k0 += segC[i];          // a missing segment (x == nullptr) still owns its weight columns: they get zero gradient
     }
     w.N = N; w.K = K; w.P = P; w.B = B;
-    w.chunksPerSample = urnn_train_wgrad_chunks(P);
+    w.chunksPerSample = urnn_train_wgrad_chunks(B, N, K, P);
     w.chunkPix = ((P + w.chunksPerSample - 1) / w.chunksPerSample + 63) / 64 * 64;
     const int chunks = B * w.chunksPerSample;
     w.partial = partial;
