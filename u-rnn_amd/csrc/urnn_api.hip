@@ -293,7 +293,7 @@ extern "C" int urnn_gru_cell_f32(const float *x, const float *e, const float *h,
 
 // ---- GRU cell backward (training building block) ----------------------------------------------------------------------
 struct GruBwdWs {
-    float *dy1, *dy2, *rh, *dA2, *dA, *wt1, *wt2, *pk1, *pk2, *chpart, *coef, *wpart;
+    float *dy1, *dy2, *rh, *dA2, *dA, *wt1, *wt2, *pk1, *pk2, *chpart, *chpart2, *coef, *wpart;
     double *sums;
     size_t bytes;
 };
@@ -318,7 +318,8 @@ static GruBwdWs carve_gru_bwd(void *base, int B, int I, int F, int skip, long P)
     w.wt2 = takef((size_t)F * K);
     w.pk1 = takef(urnn_packed_conv_floats(2 * F, K));
     w.pk2 = takef(urnn_packed_conv_floats(F, K));
-    w.chpart = takef((size_t)B * 2 * F * urnn_train_nchunk((int)P) * 2);
+    w.chpart = takef((size_t)B * 2 * F * 64 * 2);      // per-plane partial sums: at most 64 blocks per plane
+    w.chpart2 = takef((size_t)B * F * 64 * 2);
     w.coef = takef((size_t)B * (2 * F / 32) * 2);
     {
         const size_t a = urnn_train_wgrad_partial_floats(B, 2 * F, K, (int)P), b = urnn_train_wgrad_partial_floats(B, F, K, (int)P);
@@ -369,9 +370,10 @@ extern "C" int urnn_gru_cell_backward_f32(const float *x, const float *e, const 
     const int Pi = (int)P;
 
     // 1. blend: dy2 (normalised candidate), dy1[:, :F] (normalised update gate), dh = dout * (1 - z)
-    CHECK_HIP(urnn_train_blend_bwd(dh_out, fw.g1, fw.cx, h, fw.ss1, fw.ss2, ws.dy2, ws.dy1, dh, B, F, Pi, st), "blend backward");
+    CHECK_HIP(urnn_train_blend_bwd(dh_out, fw.g1, fw.cx, h, fw.ss1, fw.ss2, fw.st1, fw.st2, ws.dy2, ws.dy1, dh, ws.chpart, ws.chpart2, B, F,
+                                   Pi, st), "blend backward");
     // 2. GroupNorm of the candidate: dy2 -> dc (in place), dgamma2 / dbeta2
-    CHECK_HIP(urnn_train_gn_backward(ws.dy2, fw.cx, fw.st2, gn2_w, B, F, Pi, ws.chpart, ws.sums, ws.coef, dgn2_w, dgn2_b, accumulate, st),
+    CHECK_HIP(urnn_train_gn_backward(ws.dy2, fw.cx, fw.st2, gn2_w, B, F, Pi, ws.chpart2, ws.sums, ws.coef, dgn2_w, dgn2_b, accumulate, 1, st),
               "GroupNorm 2 backward");
     // 3. conv2: dW2 / db2 = dc . [x; e; r*h]^T,  dA2 = W2^T . dc
     CHECK_HIP(urnn_train_reset_gate(fw.g1, h, fw.ss1, ws.rh, B, F, Pi, st), "reset gate");
@@ -383,10 +385,10 @@ extern "C" int urnn_gru_cell_backward_f32(const float *x, const float *e, const 
     int rc = dx_gemm(ws.dy2, W2, ws.wt2, ws.pk2, ws.dA2, B, F, K, H, W, st, "conv2 input gradient");
     if (rc) return rc;
     // 4. reset gate: d(r*h) -> dy1[:, F:], dh += d(r*h) * r
-    CHECK_HIP(urnn_train_reset_gate_bwd(ws.dA2 + (size_t)(K - F) * P, (long)K * P, fw.g1, h, fw.ss1, ws.dy1, dh, B, F, Pi, st),
+    CHECK_HIP(urnn_train_reset_gate_bwd(ws.dA2 + (size_t)(K - F) * P, (long)K * P, fw.g1, h, fw.ss1, fw.st1, ws.dy1, dh, ws.chpart, B, F, Pi, st),
               "reset gate backward");
     // 5. GroupNorm of the gates: dy1 -> dg (in place), dgamma1 / dbeta1
-    CHECK_HIP(urnn_train_gn_backward(ws.dy1, fw.g1, fw.st1, gn1_w, B, 2 * F, Pi, ws.chpart, ws.sums, ws.coef, dgn1_w, dgn1_b, accumulate, st),
+    CHECK_HIP(urnn_train_gn_backward(ws.dy1, fw.g1, fw.st1, gn1_w, B, 2 * F, Pi, ws.chpart, ws.sums, ws.coef, dgn1_w, dgn1_b, accumulate, 1, st),
               "GroupNorm 1 backward");
     // 6. conv1: dW1 / db1 = dg . [x; e; h]^T,  dA = W1^T . dg
     {

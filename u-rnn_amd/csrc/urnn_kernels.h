@@ -87,12 +87,13 @@ int urnn_train_nchunk(int P);
 hipError_t urnn_train_chan_sums(const float *a, long a_bs, const float *v, long v_bs, const float *stat, int B, int C, int P,
                                 float *partial, double *sums, hipStream_t st);
 hipError_t urnn_train_gn_backward(float *dy, const float *v, const float *stat, const float *gamma, int B, int C, int P, float *partial,
-                                  double *sums, float *coef, float *dgamma, float *dbeta, int accumulate, hipStream_t st);
+                                  double *sums, float *coef, float *dgamma, float *dbeta, int accumulate, int have_partials, hipStream_t st);
 hipError_t urnn_train_blend_bwd(const float *dout, const float *g1, const float *c, const float *h, const float *ss1, const float *ss2,
-                                float *dy2, float *dy1, float *dh, int B, int F, int P, hipStream_t st);
+                                const float *st1, const float *st2, float *dy2, float *dy1, float *dh, float *part1, float *part2, int B,
+                                int F, int P, hipStream_t st);
 hipError_t urnn_train_reset_gate(const float *g1, const float *h, const float *ss1, float *rh, int B, int F, int P, hipStream_t st);
-hipError_t urnn_train_reset_gate_bwd(const float *drh, long drh_bs, const float *g1, const float *h, const float *ss1, float *dy1,
-                                     float *dh, int B, int F, int P, hipStream_t st);
+hipError_t urnn_train_reset_gate_bwd(const float *drh, long drh_bs, const float *g1, const float *h, const float *ss1, const float *st1,
+                                     float *dy1, float *dh, float *part1, int B, int F, int P, hipStream_t st);
 hipError_t urnn_train_add_slices(float *out, long out_bs, const float *a, long a_bs, const float *a2, long a2_bs, int B, int C, int P,
                                  int accumulate, hipStream_t st);
 size_t urnn_train_wgrad_partial_floats(int B, int N, int K, int P);

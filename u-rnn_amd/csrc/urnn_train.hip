@@ -114,23 +114,58 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(float *dy, const floa
 //   dy2 = dout * z * (1 - n^2)          gradient w.r.t. the normalised candidate
 //   dyz = dout * (n - h) * z * (1 - z)  gradient w.r.t. the normalised update gate  -> dy1[:, :F]
 //   dh  = dout * (1 - z)
+__device__ __forceinline__ void block_partials(float (&v)[4], int n, float *dst0, float *dst1)
+{
+    // n = 2: (v0, v1) -> dst0;  n = 4: also (v2, v3) -> dst1.  256-thread blocks, fixed order.
+    __shared__ float sh[4][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = 0; k < n; ++k) {
+        const float s = wave_sum(v[k]);
+        if (lane == 0) sh[k][wave] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        dst0[0] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+        dst0[1] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+        if (n == 4) {
+            dst1[0] = (sh[2][0] + sh[2][1]) + (sh[2][2] + sh[2][3]);
+            dst1[1] = (sh[3][0] + sh[3][1]) + (sh[3][2] + sh[3][3]);
+        }
+    }
+}
+
+// Also emits, per (plane, blockIdx.x), the partial sums the two GroupNorm backward passes need (sum dy, sum dy * xhat):
+// part2[(b*F + f)][gx][2] for the candidate, part1[(b*2F + f)][gx][2] for the update-gate half of the gates.
 __global__ __launch_bounds__(256) void blend_bwd_kernel(const float *__restrict__ dout, const float *__restrict__ g1, const float *__restrict__ c,
                                                         const float *__restrict__ h, const float *__restrict__ ss1, const float *__restrict__ ss2,
-                                                        float *__restrict__ dy2, float *__restrict__ dy1, float *__restrict__ dh, int F, int P)
+                                                        const float *__restrict__ st1, const float *__restrict__ st2, float *__restrict__ dy2,
+                                                        float *__restrict__ dy1, float *__restrict__ dh, float *__restrict__ part1,
+                                                        float *__restrict__ part2, int F, int P)
 {
     const int bc = blockIdx.y, b = bc / F, f = bc - b * F;
     const float s1 = ss1[((size_t)b * 2 * F + f) * 2], t1 = ss1[((size_t)b * 2 * F + f) * 2 + 1];
     const float s2 = ss2[((size_t)b * F + f) * 2], t2 = ss2[((size_t)b * F + f) * 2 + 1];
+    const float mu1 = st1[((size_t)b * (2 * F / 32) + f / 32) * 2], rs1 = st1[((size_t)b * (2 * F / 32) + f / 32) * 2 + 1];
+    const float mu2 = st2[((size_t)b * (F / 32) + f / 32) * 2], rs2 = st2[((size_t)b * (F / 32) + f / 32) * 2 + 1];
     const float *gz = g1 + ((size_t)b * 2 * F + f) * P, *cc = c + (size_t)bc * P, *hh = h + (size_t)bc * P, *dd = dout + (size_t)bc * P;
     float *o2 = dy2 + (size_t)bc * P, *o1 = dy1 + ((size_t)b * 2 * F + f) * P, *oh = dh + (size_t)bc * P;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};       // sum dyz, sum dyz * xhat1, sum dy2, sum dy2 * xhat2
     for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += gridDim.x * 256) {
-        const float z = 1.0f / (1.0f + expf(-(gz[p] * s1 + t1)));
-        const float n = tanhf(cc[p] * s2 + t2);
+        const float gv = gz[p], cv = cc[p];
+        const float z = 1.0f / (1.0f + expf(-(gv * s1 + t1)));
+        const float n = tanhf(cv * s2 + t2);
         const float d = dd[p];
-        o2[p] = d * z * (1.0f - n * n);
-        o1[p] = d * (n - hh[p]) * z * (1.0f - z);
+        const float a2 = d * z * (1.0f - n * n);
+        const float a1 = d * (n - hh[p]) * z * (1.0f - z);
+        o2[p] = a2;
+        o1[p] = a1;
         oh[p] = d * (1.0f - z);
+        acc[0] += a1;
+        acc[1] += a1 * ((gv - mu1) * rs1);
+        acc[2] += a2;
+        acc[3] += a2 * ((cv - mu2) * rs2);
     }
+    block_partials(acc, 4, part1 + (((size_t)b * 2 * F + f) * gridDim.x + blockIdx.x) * 2, part2 + ((size_t)bc * gridDim.x + blockIdx.x) * 2);
 }
 
 // rh = sigmoid(GN(gr)) * h   (the candidate GEMM's gated rows, materialised for the weight gradient)
@@ -147,19 +182,28 @@ __global__ __launch_bounds__(256) void reset_gate_kernel(const float *__restrict
 // From d(r*h) (rows K-F.. of dA2, batch stride K*P): dyr = drh * h * r (1 - r) -> dy1[:, F:];  dh += drh * r
 __global__ __launch_bounds__(256) void reset_gate_bwd_kernel(const float *__restrict__ drh, long drh_bs, const float *__restrict__ g1,
                                                              const float *__restrict__ h, const float *__restrict__ ss1,
-                                                             float *__restrict__ dy1, float *__restrict__ dh, int F, int P)
+                                                             const float *__restrict__ st1, float *__restrict__ dy1, float *__restrict__ dh,
+                                                             float *__restrict__ part1, int F, int P)
 {
     const int bc = blockIdx.y, b = bc / F, f = bc - b * F;
     const float s = ss1[((size_t)b * 2 * F + F + f) * 2], t = ss1[((size_t)b * 2 * F + F + f) * 2 + 1];
+    const int grp = F / 32 + f / 32;
+    const float mu = st1[((size_t)b * (2 * F / 32) + grp) * 2], rs = st1[((size_t)b * (2 * F / 32) + grp) * 2 + 1];
     const float *gr = g1 + ((size_t)b * 2 * F + F + f) * P, *hh = h + (size_t)bc * P;
     const float *dd = drh + (size_t)b * drh_bs + (size_t)f * P;
     float *o1 = dy1 + ((size_t)b * 2 * F + F + f) * P, *oh = dh + (size_t)bc * P;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += gridDim.x * 256) {
-        const float r = 1.0f / (1.0f + expf(-(gr[p] * s + t)));
+        const float gv = gr[p];
+        const float r = 1.0f / (1.0f + expf(-(gv * s + t)));
         const float d = dd[p];
-        o1[p] = d * hh[p] * r * (1.0f - r);
+        const float a = d * hh[p] * r * (1.0f - r);
+        o1[p] = a;
         oh[p] += d * r;
+        acc[0] += a;
+        acc[1] += a * ((gv - mu) * rs);
     }
+    block_partials(acc, 2, part1 + (((size_t)b * 2 * F + F + f) * gridDim.x + blockIdx.x) * 2, nullptr);
 }
 
 // out[b][c][p] (+)= a[b][c][p] (+ a2[b][c][p]) with independent batch strides (channel slices of (B,K,P) buffers)
@@ -358,11 +402,16 @@ int urnn_train_nchunk(int P)
     return n < 1 ? 1 : (n > 64 ? 64 : n);
 }
 
+// have_partials: the producers of dy (blend / reset-gate backward) already wrote partial[(b*C + c)][plane_grid x][2]
 hipError_t urnn_train_gn_backward(float *dy, const float *v, const float *stat, const float *gamma, int B, int C, int P, float *partial,
-                                  double *sums, float *coef, float *dgamma, float *dbeta, int accumulate, hipStream_t st)
+                                  double *sums, float *coef, float *dgamma, float *dbeta, int accumulate, int have_partials, hipStream_t st)
 {
-    hipError_t e = urnn_train_chan_sums(dy, (long)C * P, v, (long)C * P, stat, B, C, P, partial, sums, st);
-    if (e != hipSuccess) return e;
+    if (have_partials) {
+        hipLaunchKernelGGL(chan_finalize_kernel, dim3(B * C), dim3(64), 0, st, partial, (int)plane_grid(P, 1).x, sums);
+    } else {
+        hipError_t e = urnn_train_chan_sums(dy, (long)C * P, v, (long)C * P, stat, B, C, P, partial, sums, st);
+        if (e != hipSuccess) return e;
+    }
     const int n = B * (C / 32) > C ? B * (C / 32) : C;
     hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3((n + 127) / 128), dim3(128), 0, st, sums, gamma, B, C, 32.0 * (double)P, coef, dgamma,
                        dbeta, accumulate);
@@ -371,9 +420,11 @@ hipError_t urnn_train_gn_backward(float *dy, const float *v, const float *stat, 
 }
 
 hipError_t urnn_train_blend_bwd(const float *dout, const float *g1, const float *c, const float *h, const float *ss1, const float *ss2,
-                                float *dy2, float *dy1, float *dh, int B, int F, int P, hipStream_t st)
+                                const float *st1, const float *st2, float *dy2, float *dy1, float *dh, float *part1, float *part2, int B,
+                                int F, int P, hipStream_t st)
 {
-    hipLaunchKernelGGL(blend_bwd_kernel, plane_grid(P, B * F), dim3(256), 0, st, dout, g1, c, h, ss1, ss2, dy2, dy1, dh, F, P);
+    hipLaunchKernelGGL(blend_bwd_kernel, plane_grid(P, B * F), dim3(256), 0, st, dout, g1, c, h, ss1, ss2, st1, st2, dy2, dy1, dh, part1, part2,
+                       F, P);
     return hipGetLastError();
 }
 
@@ -383,10 +434,10 @@ hipError_t urnn_train_reset_gate(const float *g1, const float *h, const float *s
     return hipGetLastError();
 }
 
-hipError_t urnn_train_reset_gate_bwd(const float *drh, long drh_bs, const float *g1, const float *h, const float *ss1, float *dy1,
-                                     float *dh, int B, int F, int P, hipStream_t st)
+hipError_t urnn_train_reset_gate_bwd(const float *drh, long drh_bs, const float *g1, const float *h, const float *ss1, const float *st1,
+                                     float *dy1, float *dh, float *part1, int B, int F, int P, hipStream_t st)
 {
-    hipLaunchKernelGGL(reset_gate_bwd_kernel, plane_grid(P, B * F), dim3(256), 0, st, drh, drh_bs, g1, h, ss1, dy1, dh, F, P);
+    hipLaunchKernelGGL(reset_gate_bwd_kernel, plane_grid(P, B * F), dim3(256), 0, st, drh, drh_bs, g1, h, ss1, st1, dy1, dh, part1, F, P);
     return hipGetLastError();
 }
 
