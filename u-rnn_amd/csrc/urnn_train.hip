@@ -246,18 +246,49 @@ struct WgradParams {
 // measured slower, 8.9 vs 8.2 ms per training step: two independent 4-wave blocks hide each other's barriers.)
 constexpr int WG_T = 128, WG_LD = 68;   // 68: rows stay 16-byte aligned (one ds_write_b128 per staged float4); column reads are 2-way conflicted, cheap next to the MFMAs
 
+// one 64-pixel stage of a wave: AN x AK MFMA tiles, pixel pairs [sLo, sLo + sCnt) of the stage
+template <int AN, int AK>
+__device__ __forceinline__ void wgrad_stage(const float *__restrict__ pa, const float *__restrict__ pb, int sLo, int sCnt, f32x16 (&acc)[2][2])
+{
+    for (int s4 = sLo; s4 < sLo + sCnt; s4 += 4) {         // sCnt is 8, 16 or 32
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int s_ = s4 + u;
+            const float a0 = pa[2 * s_], b0 = pb[2 * s_];
+            const float a1 = AN > 1 ? pa[32 * WG_LD + 2 * s_] : 0.f, b1 = AK > 1 ? pb[32 * WG_LD + 2 * s_] : 0.f;
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            if (AK > 1) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            if (AN > 1) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            if (AN > 1 && AK > 1) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams prm)
 {
     extern __shared__ __attribute__((aligned(16))) float wg_smem[];
     float *tA = wg_smem, *tB = wg_smem + WG_T * WG_LD;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, half = lane >> 5;
     const int n0 = blockIdx.y * WG_T, k0 = blockIdx.x * WG_T;
     const int chunk = blockIdx.z, b = chunk / prm.chunksPerSample;
     const int p_lo = (chunk - b * prm.chunksPerSample) * prm.chunkPix;
     const int p_hi = min(prm.P, p_lo + prm.chunkPix);
-    const int wn = wave >> 1, wk = wave & 1;
     const bool vec = (prm.P & 3) == 0;                     // rows 16-byte aligned
+
+    // Only the 32 x 32 tiles that hold real outputs are multiplied (the layers run from 16 x 16 to 384 x 96, 192 x 288: a
+    // fixed 128 x 128 grid of MFMAs would mostly multiply padding).  The four waves share what is there: a block with at
+    // most 2 x 2 valid tiles gives every wave ALL its tiles on a quarter of each stage's pixels, one with at most two valid
+    // tile rows (or columns) pairs the waves on halves of the pixels, a full block gives each wave a 2 x 2 quadrant.  Waves
+    // that share tiles add their accumulators in wave order through LDS at the end.
+    const int rowsV = min(4, (prm.N - n0 + 31) >> 5), colsV = min(4, (prm.K - k0 + 31) >> 5);
+    int row0, col0, sLo, sCnt;
+    if (rowsV <= 2 && colsV <= 2) { row0 = 0; col0 = 0; sLo = 8 * wave; sCnt = 8; }
+    else if (rowsV <= 2) { row0 = 0; col0 = 2 * (wave & 1); sLo = 16 * (wave >> 1); sCnt = 16; }
+    else if (colsV <= 2) { row0 = 2 * (wave & 1); col0 = 0; sLo = 16 * (wave >> 1); sCnt = 16; }
+    else { row0 = 2 * (wave >> 1); col0 = 2 * (wave & 1); sLo = 0; sCnt = 32; }
+    const int owners = sCnt / 8;                           // 4, 2 or 1 ... waves 0 .. owners-1 own a distinct tile set each
+    const int an = min(2, rowsV - row0), ak = min(2, colsV - col0);
 
     // this thread stages rows r0 + 16*i (i < 8) of both operands, 4 consecutive pixels at column c4
     const int r0 = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;
@@ -274,6 +305,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams prm)
             if (ch < prm.segC[sg]) rowB[i] = prm.seg[sg] + ((size_t)b * prm.segC[sg] + ch) * prm.P;
         }
     }
+    // rows of a missing segment (x == nullptr) are inside K: they are staged as zeros; rows beyond N / K are never staged --
+    // an output only depends on ITS row of dY and ITS row of X, and the outputs beyond N / K are not stored
+    bool zeroB[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) zeroB[i] = rowB[i] == nullptr && k0 + r0 + 16 * i < prm.K;
     f32x4 ra[8], rb[8];
     auto fetch = [&](const float *row, int p) -> f32x4 {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -303,46 +339,66 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams prm)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
     float rsum = 0.f;   // threads < 128 of the k-column 0 blocks: row sum of dY row n0 + threadIdx.x
+    const bool sums = prm.rowpart && blockIdx.x == 0 && threadIdx.x < WG_T && n0 + (int)threadIdx.x < prm.N;
+    const float *pa = tA + (row0 * 32 + j) * WG_LD + half, *pb = tB + (col0 * 32 + j) * WG_LD + half;
 
     load_stage(p_lo);
     for (int p0 = p_lo; p0 < p_hi; p0 += 64) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            *reinterpret_cast<f32x4 *>(tA + (r0 + 16 * i) * WG_LD + c4) = ra[i];
-            *reinterpret_cast<f32x4 *>(tB + (r0 + 16 * i) * WG_LD + c4) = rb[i];
+            if (rowA[i]) *reinterpret_cast<f32x4 *>(tA + (r0 + 16 * i) * WG_LD + c4) = ra[i];
+            if (rowB[i] || zeroB[i]) *reinterpret_cast<f32x4 *>(tB + (r0 + 16 * i) * WG_LD + c4) = rb[i];
         }
         __syncthreads();
         if (p0 + 64 < p_hi) load_stage(p0 + 64);          // in flight while this stage is multiplied
-        if (prm.rowpart && blockIdx.x == 0 && threadIdx.x < WG_T) {
+        if (sums) {
             float s_ = 0.f;
 #pragma unroll 16
             for (int c = 0; c < 64; ++c) s_ += tA[threadIdx.x * WG_LD + c];
             rsum += s_;
         }
-#pragma unroll 4
-        for (int s_ = 0; s_ < 32; ++s_) {
-            const int col = 2 * s_ + half;
-            const float a0 = tA[(wn * 64 + j) * WG_LD + col], a1 = tA[(wn * 64 + 32 + j) * WG_LD + col];
-            const float b0 = tB[(wk * 64 + j) * WG_LD + col], b1 = tB[(wk * 64 + 32 + j) * WG_LD + col];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        }
+        if (an == 2 && ak == 2) wgrad_stage<2, 2>(pa, pb, sLo, sCnt, acc);
+        else if (an == 2) wgrad_stage<2, 1>(pa, pb, sLo, sCnt, acc);
+        else if (ak == 2) wgrad_stage<1, 2>(pa, pb, sLo, sCnt, acc);
+        else wgrad_stage<1, 1>(pa, pb, sLo, sCnt, acc);
         __syncthreads();
     }
+    if (owners < 4) {                                      // waves owners .. 3 hand their accumulators to the owning waves
+        float *red = wg_smem;                              // [wave][2][2][16][64] = 64 KiB of the 68 KiB staging area
+        if (wave >= owners) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    if (a < an && c < ak)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) red[(((wave * 2 + a) * 2 + c) * 16 + r) * 64 + lane] = acc[a][c][r];
+        }
+        __syncthreads();
+        if (wave < owners)
+            for (int o = wave + owners; o < 4; o += owners)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+                        if (a < an && c < ak)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[a][c][r] += red[(((o * 2 + a) * 2 + c) * 16 + r) * 64 + lane];
+    }
     float *out = prm.partial + (size_t)chunk * prm.N * prm.K;
+    if (wave < owners) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+            for (int c = 0; c < 2; ++c)
+                if (a < an && c < ak)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = n0 + wn * 64 + a * 32 + mfma_row(r, half), k = k0 + wk * 64 + c * 32 + j;
-                if (n < prm.N && k < prm.K) out[(size_t)n * prm.K + k] = acc[a][c][r];
-            }
-    if (prm.rowpart && blockIdx.x == 0 && threadIdx.x < WG_T && n0 + (int)threadIdx.x < prm.N)
-        prm.rowpart[(size_t)chunk * prm.N + n0 + threadIdx.x] = rsum;
+                    for (int r = 0; r < 16; ++r) {
+                        const int n = n0 + (row0 + a) * 32 + mfma_row(r, half), k = k0 + (col0 + c) * 32 + j;
+                        if (n < prm.N && k < prm.K) out[(size_t)n * prm.K + k] = acc[a][c][r];
+                    }
+    }
+    if (sums) prm.rowpart[(size_t)chunk * prm.N + n0 + threadIdx.x] = rsum;
 }
 
 // dW[i] (+)= sum over chunks (double, fixed order); the same for the bias row sums
