@@ -405,21 +405,33 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams prm)
 __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float *__restrict__ partial, const float *__restrict__ rowpart, int nchunk,
                                                              long cntW, long cntB, float *__restrict__ dW, float *__restrict__ db, int accumulate)
 {
-    // outputs 0 .. cntW-1: weight gradient, cntW .. cntW+cntB-1: bias gradient (row sums).  Four lanes per output: lane q sums
-    // chunks q, q+4, ... in double, then the four sub-sums are added in a fixed order
-    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
-    const int q = threadIdx.x & 3;
+    // outputs 0 .. cntW-1: weight gradient, cntW .. cntW+cntB-1: bias gradient (row sums).  A block finishes 16 outputs:
+    // thread (q, io) sums chunks q, q+16, ... of output io in double (independent loads, 16 lanes on consecutive outputs),
+    // then the 16 sub-sums of an output are added in a fixed order
+    __shared__ double sub[16][17];
+    const int io = threadIdx.x & 15, q = threadIdx.x >> 4;
+    const long i = (long)blockIdx.x * 16 + io;
     const bool isW = i < cntW, live = i < cntW + cntB;
     const float *src = isW ? partial + i : rowpart + (i - cntW);
     const long stride = isW ? cntW : cntB;
     double s = 0.0;
-    if (live)
-        for (int c = q; c < nchunk; c += 4) s += (double)src[(size_t)c * stride];
-    const double s1 = s + __shfl_xor(s, 1, 64);
-    const double s2 = s1 + __shfl_xor(s1, 2, 64);
-    if (live && q == 0) {
+    if (live) {
+        int c = q;
+        for (; c + 48 < nchunk; c += 64) {
+            const float v0 = src[(size_t)c * stride], v1 = src[(size_t)(c + 16) * stride], v2 = src[(size_t)(c + 32) * stride],
+                        v3 = src[(size_t)(c + 48) * stride];
+            s += (double)v0; s += (double)v1; s += (double)v2; s += (double)v3;
+        }
+        for (; c < nchunk; c += 16) s += (double)src[(size_t)c * stride];
+    }
+    sub[q][io] = s;
+    __syncthreads();
+    if (threadIdx.x < 16 && live) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sub[k][io];
         float *o = isW ? dW + i : db + (i - cntW);
-        *o = (accumulate ? *o : 0.f) + (float)s2;
+        *o = (accumulate ? *o : 0.f) + (float)t;
     }
 }
 
@@ -551,7 +563,7 @@ hipError_t urnn_train_wgrad(const float *dy, const float *const seg[3], const in
     }
     hipLaunchKernelGGL(wgrad_kernel, dim3((K + WG_T - 1) / WG_T, (N + WG_T - 1) / WG_T, chunks), dim3(256), lds, st, w);
     const long cntW = (long)N * K, cntB = db ? N : 0;
-    hipLaunchKernelGGL(wgrad_finalize_kernel, dim3((unsigned)(((cntW + cntB) * 4 + 255) / 256)), dim3(256), 0, st, partial, w.rowpart, chunks,
+    hipLaunchKernelGGL(wgrad_finalize_kernel, dim3((unsigned)((cntW + cntB + 15) / 16)), dim3(256), 0, st, partial, w.rowpart, chunks,
                        cntW, cntB, dW, db, accumulate);
     return hipGetLastError();
 }
