@@ -214,6 +214,57 @@ class Trainer:
                 cache.clear()
         self.net.head._stamp = None
 
+    def set_lr(self, lr):
+        """Learning rate of the following windows (the epoch loop calls this once per epoch; the captured window is re-captured)."""
+        self.lr = float(lr)
+
+    # -- checkpoints: the reference's file content (earlystopping.py:40-44) ----------------------------------------------------
+    def state_dict(self):
+        """The network's state dict (reference key names), detached copies on the host."""
+        return {k: v.detach().cpu().clone() for k, v in self.net.state_dict().items()}
+
+    def load_state_dict(self, sd):
+        """Copy a reference-layout state dict into the flat parameter buffer (missing / unexpected keys raise as in torch)."""
+        own = self.net.state_dict()
+        missing, unexpected = [k for k in own if k not in sd], [k for k in sd if k not in own]
+        if missing or unexpected:
+            raise KeyError(f"load_state_dict: missing {missing[:3]}{'...' if len(missing) > 3 else ''}, unexpected {unexpected[:3]}")
+        with torch.no_grad():
+            for k, v in own.items():
+                v.copy_(torch.as_tensor(sd[k]).to(device=v.device, dtype=v.dtype).reshape(v.shape))
+        self._invalidate_packed()
+
+    def optimizer_state_dict(self):
+        """torch.optim.Adam.state_dict() of the equivalent optimizer: parameters numbered in ``net.parameters()`` order."""
+        state = {}
+        if self.step_count > 0:
+            for i, n in enumerate(self.names):
+                off, k, shape = self.views[n]
+                state[i] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": self.m[off:off + k].view(shape).detach().cpu().clone(),
+                            "exp_avg_sq": self.v[off:off + k].view(shape).detach().cpu().clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(self.names)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, osd):
+        group = osd["param_groups"][0]
+        if len(group["params"]) != len(self.names):
+            raise ValueError(f"optimizer state has {len(group['params'])} parameters, the network {len(self.names)}")
+        self.lr, self.betas, self.eps = float(group["lr"]), tuple(group["betas"]), float(group["eps"])
+        self.m.zero_()
+        self.v.zero_()
+        steps = 0
+        for i, pid in enumerate(group["params"]):
+            st = osd["state"].get(pid)
+            if st is None:
+                continue
+            off, k, _ = self.views[self.names[i]]
+            self.m[off:off + k].copy_(torch.as_tensor(st["exp_avg"]).reshape(-1))
+            self.v[off:off + k].copy_(torch.as_tensor(st["exp_avg_sq"]).reshape(-1))
+            steps = max(steps, int(float(st["step"])))
+        self.step_count = steps
+
     def _window_body(self, ev, targets, t0, steps, states, t_devs=None, step_dev=None):
         out = self.wg.run(ev, targets, t0, steps, states, t_devs=t_devs, grad_buffers=self.grad_views)
         for n, g in out["grads"].items():
@@ -235,7 +286,7 @@ class Trainer:
         B = ev["B"]
         # the DEM normalisation bounds are kernel ARGUMENTS (frozen into the graph): one capture per (shape, bounds), i.e. per
         # catchment; the event's tensors are copied into static buffers before every replay
-        key = (steps, B, ev["T"], tuple(ev["rain"].shape), ev["dem_min"], ev["dem_max"])
+        key = (steps, B, ev["T"], tuple(ev["rain"].shape), ev["dem_min"], ev["dem_max"], self.lr)   # lr: one re-capture per epoch
         if self._graph is None or self._graph["key"] != key:
             from .general import initialize_states
             zero = [s.to(dev).repeat(B, 1, 1, 1) for s in initialize_states(dev, self.wg.H, self.wg.W)]
@@ -300,8 +351,8 @@ class Trainer:
             _, states = self.wg._forward_step(ev, t, states, 0)
         return states
 
-    def train_event(self, event, label, seq_num, window_size=None, loc=0, prewarming=False):
-        """All windows of one sample in order.  Fast mode (default): states carried between windows; ``prewarming=True``: the
+    def train_event(self, event, label, seq_num, window_size=None, loc=0, prewarming=False, starts=None):
+        """All windows of one sample in order (or in the order of ``starts``, e.g. the shuffled plan of ``fit.plan_windows``).  Fast mode (default): states carried between windows; ``prewarming=True``: the
         paper's schedule, every window starts from a gradient-free rollout from frame 0 (main.py:655-672).  label (B,T,H,W)
         normalised depths.  Returns (per-window loss components, final states)."""
         ev = event if "rain" in event else event_to_device(event, self.wg.device)
@@ -309,7 +360,7 @@ class Trainer:
         T = label.shape[1]
         window_size = T - loc if window_size is None else window_size
         states, losses = None, []
-        for ind in window_starts(loc, seq_num, window_size):
+        for ind in (window_starts(loc, seq_num, window_size) if starts is None else starts):
             if prewarming:
                 states = self.prewarm(ev, ind) if ind > 0 else None
             loss, states = self.train_window(ev, label[:, ind:ind + seq_num], ind, seq_num, states)
