@@ -167,6 +167,48 @@ def bench_train(args, dev, dist, world, rank):
         dist.destroy_process_group()
 
 
+def bench_strips(args, dev, dist, world, rank):
+    """Single-event latency mode: ONE event's grid split over the ranks in horizontal strips; per timestep
+    15 all-reduces of a few doubles (GroupNorm / LayerNorm statistics) are the only exchange.  Strong scaling: the total work is
+    fixed.  Eager launches (the exchanges sit inside the cells)."""
+    import urnn_amd.weights as uw
+    from urnn_amd.strips import StripRollout, strip_rows
+    name = args.config if args.config != "mixed" else "futian"
+    H, W, nums, T, rain_max, cum_max, spatial = CONFIGS[name]
+    net, sd, cfg = build_net(H, W, 2 * nums + 3, dev)
+    frames = args.warmup + args.steps
+    ev = uw.make_event(frames, H, W, rain_max, seed=42, spatial_rain=spatial, batch=args.batch)     # the same event on every rank
+    sr = StripRollout(net, H, W, nums, rain_max, cum_max, rank=rank, world=world)
+    sr.load_event(ev)
+    sr.run(args.warmup)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    strip = sr.run(args.steps, t0=args.warmup)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    from urnn_amd.distributed import max_over_ranks
+    elapsed = max_over_ranks(elapsed, device=dev if args.dist_backend == "nccl" else None)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "flood-map frames/s of ONE event split into spatial strips", "value": args.steps * args.batch / elapsed,
+            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{name}: {H}x{W} grid split into {world} strip(s) of rows {[strip_rows(H, r, world) for r in range(world)]}, "
+                                   f"historical_nums={nums}, {args.batch} event(s)", "parallelism": f"spatial strips x{world}, "
+                       f"{sr.exchanges // max(1, frames)} statistics all-reduces per timestep", "graph": False},
+            "roofline": None, "cpu_baseline": None,
+            "note": "latency mode, eager; the BASELINE metric is the default --mode infer (event-parallel)"}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,9 +223,10 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="dry run: every rank uses cuda:0 (needs --dist-backend gloo)")
     ap.add_argument("--overlap", type=int, default=1,
                     help="1 (default): encoder(t+1) || decoder+head(t) as two concurrent kernel chains; 0: one chain")
-    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
+    ap.add_argument("--mode", default="infer", choices=["infer", "train", "strips"],
                     help="infer (default, the BASELINE metric): rollout frames/s.  train: SWP training timesteps/s (forward + backward + "
-                         "clipped Adam, windows of --seq-num steps; N>1: DDP mean all-reduce of the flat gradient buffer over RCCL)")
+                         "clipped Adam, windows of --seq-num steps; N>1: DDP mean all-reduce of the flat gradient buffer over RCCL).  "
+                         "strips: ONE event split into horizontal strips over the ranks (single-event latency, strong scaling)")
     ap.add_argument("--seq-num", type=int, default=4, help="train mode: timesteps per SWP window")
     args = ap.parse_args()
 
@@ -209,6 +252,8 @@ def main():
 
     if args.mode == "train":
         return bench_train(args, dev, dist, world, rank)
+    if args.mode == "strips":
+        return bench_strips(args, dev, dist, world, rank)
 
     # "mixed" = BASELINE configs[4]: Futian + UKEA events alternating on every rank, one engine (and one captured hipGraph)
     # per grid shape; every other config is a single shape

@@ -189,6 +189,38 @@ int urnn_adam_step_f32(float *params, const float *grads, float *exp_avg, float 
                        float eps, int step, const int *step_dev, float max_grad_norm, float *clip_out, void *workspace,
                        size_t workspace_bytes, void *stream);
 
+/* ---- Spatial strips (one event's plane split over ranks, single-event latency) ------------------------------
+ * Every conv of the network is 1x1 and the pool / transposed-conv blocks are 2x2, so a horizontal strip whose height is a multiple
+ * of 4 needs no halo: the only cross-strip quantities are the GroupNorm (ConvRNN.py:85,99) and LayerNorm (network_blocks.py:93)
+ * statistics.  A strip run is the phase-split cell / head with an exchange between the phase that accumulates a norm's partial
+ * sums and the one that finalizes it:
+ *     urnn_gru_cell_strip_f32(GATES)  -> stats(which 1, direction 0) -> all-reduce(sum) -> stats(which 1, direction 1)
+ *     urnn_gru_cell_strip_f32(CAND)   -> stats(which 2, 0)           -> all-reduce      -> stats(which 2, 1)
+ *     urnn_gru_cell_strip_f32(GN2 | BLEND)
+ * and likewise K1 | F1 | K2 | F2 | K3 | F3 | K4 for the head (levels 0..2).  H, W are the STRIP's; global_pixels the whole plane's
+ * pixel count at this stage's resolution.  sums: device doubles, (sum, sum of squares) per (sample, norm group) [B][groups][2]
+ * (cell) or per (norm of the level, sample) [norms][B][2] (head); the caller all-reduces them (RCCL) between direction 0 and 1.
+ * With one rank the result equals the unsplit call up to the double -> float pair round trip of the sums (~1e-14 relative). */
+int urnn_gru_cell_strip_f32(const float *x, const float *e, const float *h, const float *packed, const float *gn1_w, const float *gn1_b,
+                            const float *gn2_w, const float *gn2_b, float *h_out, void *workspace, size_t workspace_bytes, int B, int I,
+                            int F, int H, int W, float eps, int phase_mask, long global_pixels, void *stream);
+int urnn_gru_cell_strip_stats_f32(void *workspace, size_t workspace_bytes, int B, int F, int H, int W, int which, int direction,
+                                  double *sums, void *stream);
+#define URNN_HEAD_K1 1   /* stems conv, LayerNorm partial sums (level 0)                 */
+#define URNN_HEAD_F1 2   /* finalize level 0                                             */
+#define URNN_HEAD_K2 4   /* stems norm + SiLU, cls_convs.0 / reg_convs.0 convs (level 1) */
+#define URNN_HEAD_F2 8
+#define URNN_HEAD_K3 16  /* cls_convs.1 / reg_convs.1 (level 2)                          */
+#define URNN_HEAD_F3 32
+#define URNN_HEAD_K4 64  /* prediction layers, mask                                      */
+#define URNN_HEAD_ALL 127
+int urnn_head_strip_f32(const float *feat, const float *conv_w, const float *ln_w, const float *ln_b, const float *cls_w,
+                        const float *cls_b, const float *reg_w, const float *reg_b, float *out_masked, float *out_cls, float *out_raw,
+                        const int *frame_index, void *workspace, size_t workspace_bytes, int B, int C, int H, int W, float cls_thred,
+                        float eps, float slope, int phase_mask, long global_pixels, void *stream);
+int urnn_head_strip_stats_f32(void *workspace, size_t workspace_bytes, int B, int C, int H, int W, int level, int direction, double *sums,
+                              void *stream);
+
 /* Device-side frame counter helper for graph-captured rollouts: *counter += delta. */
 int urnn_advance_counter(int *counter, int delta, void *stream);
 

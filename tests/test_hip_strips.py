@@ -1,0 +1,133 @@
+"""Spatial-strip rollout: one event's grid split over ranks, exchanging only norm statistics.  The strips
+must reproduce the unsplit rollout (itself pinned to the reference goldens in test_hip_rollout.py) within the 1e-4 parity bar --
+observed ~1e-6: the statistics are the same double sums, only their summation order changes."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+H, W, NUMS, T = 32, 48, 3, 4
+RAIN_MAX, CUM_MAX = 60.0, 250.0
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _net(dev, seed=12):
+    import urnn_amd.weights as uw
+    from urnn_amd.net_config import load_net_config
+    from urnn_amd.networks.model import ED
+    from urnn_amd.networks.net_params import get_network_params
+    C = 2 * NUMS + 3
+    ep, dp = get_network_params(False, H, W, C, load_net_config())
+    net = ED(False, ep, dp, 0.5, False, input_height=H, input_width=W)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in uw.make_state_dict(H, W, C, seed=seed).items()})
+    return net.to(dev)
+
+
+def _reference_rollout(net, ev, dev):
+    from urnn_amd.rollout import RolloutEngine
+    eng = RolloutEngine(net, H, W, NUMS, RAIN_MAX, CUM_MAX, max_frames=T, use_graph=False, overlap=False, spatial_rain=ev["rainfall"].shape[-1] > 1)
+    want = eng.rollout(ev).clone()                              # (T,B,H,W)
+    return want, [s.clone() for s in eng.final_states()]
+
+
+def _close(a, b, what, rel=1e-4):
+    from conftest import assert_close                         # the suite's parity metric (floor = 0.1 * max-abs, conftest.py)
+    assert_close(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rel, what)
+
+
+def test_strip_rows_cover_the_grid():
+    from urnn_amd.strips import strip_rows
+    for Hh, world in ((500, 8), (32, 3), (400, 7), (52, 13)):
+        rows = [strip_rows(Hh, r, world) for r in range(world)]
+        assert rows[0][0] == 0 and rows[-1][1] == Hh
+        assert all(a % 4 == 0 and b > a for a, b in rows) and all(rows[i][1] == rows[i + 1][0] for i in range(world - 1))
+    with pytest.raises(ValueError):
+        strip_rows(30, 0, 2)
+    with pytest.raises(ValueError):
+        strip_rows(8, 0, 3)
+
+
+@pytest.mark.parametrize("spatial", [False, True])
+def test_one_strip_equals_the_unsplit_rollout(dev, spatial):
+    """world = 1: the phase-split cell / head with the statistics round trip (double sums -> hi + lo float pseudo-tiles)."""
+    import urnn_amd.weights as uw
+    from urnn_amd.strips import StripRollout
+    net = _net(dev)
+    ev = uw.make_event(T, H, W, RAIN_MAX, seed=9, spatial_rain=spatial)
+    want, want_states = _reference_rollout(net, ev, dev)
+    sr = StripRollout(net, H, W, NUMS, RAIN_MAX, CUM_MAX)
+    sr.load_event(ev)
+    got = sr.run(T)
+    assert sr.exchanges == T * 15                               # 6 cells x 2 norms + 3 head levels per timestep
+    _close(got.reshape(want.shape), want, "masked depth", rel=1e-4)
+    for i, (a, b) in enumerate(zip(sr.states, want_states)):
+        _close(a, b, f"state {i}", rel=1e-4)
+
+
+def _strip_worker(rank, world, port, out_dir, spatial):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    import urnn_amd.weights as uw
+    from urnn_amd.strips import StripRollout
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # the ranks share the one GPU of the test box
+    dev = torch.device("cuda:0")
+    net = _net(dev)
+    ev = uw.make_event(T, H, W, RAIN_MAX, seed=9, spatial_rain=spatial)
+    sr = StripRollout(net, H, W, NUMS, RAIN_MAX, CUM_MAX, rank=rank, world=world)
+    sr.load_event(ev)
+    strip = sr.run(T)
+    full = sr.gather(strip)
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, f"full{rank}.npy"), full.cpu().numpy())
+    np.save(os.path.join(out_dir, f"d3_{rank}.npy"), sr.states[5].cpu().numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,spatial", [(2, False), (3, True)])
+def test_strips_over_ranks_reproduce_the_unsplit_rollout(dev, tmp_path, world, spatial):
+    """2 and 3 (uneven: 12 + 12 + 8 rows) strips in separate processes, statistics all-reduced through gloo; every rank gathers
+    the same full maps, equal to the unsplit rollout within the parity bar."""
+    import torch.multiprocessing as mp
+    import urnn_amd.weights as uw
+    from urnn_amd.strips import strip_rows
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_strip_worker, args=(world, port, str(tmp_path), spatial), nprocs=world, join=True)
+    net = _net(dev)
+    ev = uw.make_event(T, H, W, RAIN_MAX, seed=9, spatial_rain=spatial)
+    want, want_states = _reference_rollout(net, ev, dev)
+    fulls = [np.load(tmp_path / f"full{r}.npy") for r in range(world)]
+    for r in range(1, world):
+        assert np.array_equal(fulls[0], fulls[r])
+    _close(torch.from_numpy(fulls[0]).reshape(want.shape), want, "gathered masked depth", rel=1e-4)
+    d3 = np.concatenate([np.load(tmp_path / f"d3_{r}.npy") for r in range(world)], axis=2)
+    assert [np.load(tmp_path / f"d3_{r}.npy").shape[2] for r in range(world)] == [b - a for a, b in (strip_rows(H, r, world) for r in range(world))]
+    _close(torch.from_numpy(d3), want_states[5], "final decoder state", rel=1e-4)
+
+
+def test_strip_calls_reject_fused_phases(dev):
+    from urnn_amd import ops
+    from urnn_amd._lib import lib
+    L = lib()
+    B, F, Hs, Ws = 1, 32, 8, 8
+    h = torch.zeros(B, F, Hs, Ws, device=dev)
+    ws = torch.empty(L.urnn_gru_cell_workspace_bytes(B, F, Hs, Ws), dtype=torch.uint8, device=dev)
+    packed = torch.zeros(L.urnn_packed_gru_floats(16, F, 0), device=dev)
+    gn = torch.ones(2 * F, device=dev)
+    p = ops._ptr
+    args = (p(h), None, p(h), p(packed), p(gn), p(gn), p(gn), p(gn), p(h), p(ws), ws.numel(), B, 16, F, Hs, Ws, 1e-5)
+    assert L.urnn_gru_cell_strip_f32(*args, ops.PHASE_GATES | ops.PHASE_CAND, 4 * Hs * Ws, None) != 0
+    assert "exchanged" in L.urnn_last_error().decode()
+    assert L.urnn_gru_cell_strip_f32(*args, ops.PHASE_GATES, Hs * Ws - 1, None) != 0

@@ -164,7 +164,7 @@ struct GruWs {
 static GruWs carve_gru(void *base, int B, int F, long P)
 {
     // partial buffers are sized for the smallest tile (32 pixels) so any PB choice fits
-    const size_t tiles = (size_t)((P + 31) / 32);
+    const size_t tiles = (size_t)((P + 31) / 32) < 2 ? 2 : (size_t)((P + 31) / 32);   // >= 2: the strip mode's two pseudo-tiles
     size_t off = 0;
     auto take = [&](size_t nfloats) {
         float *p = base ? reinterpret_cast<float *>(reinterpret_cast<char *>(base) + off) : nullptr;
@@ -190,10 +190,24 @@ extern "C" size_t urnn_gru_cell_workspace_bytes(int B, int F, int H, int W)
     return carve_gru(nullptr, B, F, (long)H * W).bytes;
 }
 
-extern "C" int urnn_gru_cell_phases_f32(const float *x, const float *e, const float *h, const float *packed, const float *gn1_w,
-                                        const float *gn1_b, const float *gn2_w, const float *gn2_b, float *h_out, void *workspace,
-                                        size_t workspace_bytes, int B, int I, int F, int H, int W, float eps, int phase_mask,
-                                        void *stream)
+// tiles per sample of the gate GEMM (which = 1) / the candidate GEMM (which = 2): the layout of their GroupNorm partials
+static int gru_tiles(int B, int F, long P, int which, int *pb_out = nullptr, int *map_out = nullptr)
+{
+    int pb, map;
+    if (which == 1) pick_tile((long)B * P, F / 32, P, &pb, &map, "URNN_TUNE_PB_GATES", 1024);
+    else pick_tile((long)B * P, (F / 32) / urnn_cand_nb(F), P, &pb, &map, "URNN_TUNE_PB_CAND", 1024);
+    if (pb_out) *pb_out = pb;
+    if (map_out) *map_out = map;
+    return (int)((P + 32 * pb - 1) / (32 * pb));
+}
+
+// global_pixels > 0: this call computes one horizontal STRIP of a plane of global_pixels pixels that is split over ranks
+// (SURVEY 8e); the GroupNorm partials have been replaced by the all-reduced totals (two pseudo-tiles: hi + lo floats of
+// the double sums, urnn_gru_cell_strip_stats_f32) and the statistics are over the whole plane
+static int gru_cell_impl(const float *x, const float *e, const float *h, const float *packed, const float *gn1_w,
+                         const float *gn1_b, const float *gn2_w, const float *gn2_b, float *h_out, void *workspace,
+                         size_t workspace_bytes, int B, int I, int F, int H, int W, float eps, int phase_mask, long global_pixels,
+                         void *stream)
 {
     if (!h || !packed || !gn1_w || !gn1_b || !gn2_w || !gn2_b || !h_out || !workspace)
         return fail(URNN_ENULL, "urnn_gru_cell_f32: NULL argument");
@@ -240,13 +254,14 @@ extern "C" int urnn_gru_cell_phases_f32(const float *x, const float *e, const fl
     p.partial = ws.part1;
     int pb1, map1;
     // the gate GEMM prefers 128-pixel tiles (one 1-KiB DMA per 8 MFMAs) even when they only fill half the wave slots
-    pick_tile((long)B * P, NW, P, &pb1, &map1, "URNN_TUNE_PB_GATES", 1024);
-    const int tiles1 = (int)((P + 32 * pb1 - 1) / (32 * pb1));
+    const int tiles1 = gru_tiles(B, F, P, 1, &pb1, &map1);
+    const int ftiles1 = global_pixels > 0 ? 2 : tiles1;                              // tiles the finalizes read
+    const double count = 32.0 * (double)(global_pixels > 0 ? global_pixels : P);     // values per (sample, norm group)
     if (phase_mask & URNN_PHASE_GATES) CHECK_HIP(urnn_launch_gru1(p, B, pb1, map1, st), "gru gates");
     // GroupNorm finalise of the gates: folded into the candidate GEMM's prologue; launched on its own only when asked for
     // without the candidate phase (profiling)
     if ((phase_mask & URNN_PHASE_GN1) && !(phase_mask & URNN_PHASE_CAND))
-        CHECK_HIP(urnn_launch_gn_finalize(ws.part1, tiles1, 32.0 * (double)P, gn1_w, gn1_b, eps, ws.ss1, ws.st1, B, 2 * F, st), "gn finalize 1");
+        CHECK_HIP(urnn_launch_gn_finalize(ws.part1, ftiles1, count, gn1_w, gn1_b, eps, ws.ss1, ws.st1, B, 2 * F, st), "gn finalize 1");
 
     // K2: candidate (pre-norm) = W2 . [x; e; sigmoid(GN(r)) * h] + b2, GroupNorm partials.  The hidden-state rows are gated
     // on the fly from the raw reset gate and K1's folded (scale, shift).
@@ -257,8 +272,8 @@ extern "C" int urnn_gru_cell_phases_f32(const float *x, const float *e, const fl
     c.hKp0 = Ie / 2 + (skip ? F / 2 : 0);
     c.gate = ws.g1;
     c.gpart = ws.part1;
-    c.gtiles = tiles1;
-    c.gcount = 32.0 * (double)P;
+    c.gtiles = ftiles1;
+    c.gcount = count;
     c.gn_w = gn1_w;
     c.gn_b = gn1_b;
     c.eps = eps;
@@ -272,14 +287,54 @@ extern "C" int urnn_gru_cell_phases_f32(const float *x, const float *e, const fl
     c.out0 = ws.cx;
     c.partial = ws.part2;
     int pb2, map2;
-    pick_tile((long)B * P, NG2, P, &pb2, &map2, "URNN_TUNE_PB_CAND", 1024);
-    const int tiles2 = (int)((P + 32 * pb2 - 1) / (32 * pb2));
+    const int tiles2 = gru_tiles(B, F, P, 2, &pb2, &map2);
     if (phase_mask & URNN_PHASE_CAND) CHECK_HIP(urnn_launch_cand(c, B, pb2, map2, st), "gru candidate");
     if (phase_mask & URNN_PHASE_GN2)
-        CHECK_HIP(urnn_launch_gn_finalize(ws.part2, tiles2, 32.0 * (double)P, gn2_w, gn2_b, eps, ws.ss2, ws.st2, B, F, st), "gn finalize 2");
+        CHECK_HIP(urnn_launch_gn_finalize(ws.part2, global_pixels > 0 ? 2 : tiles2, count, gn2_w, gn2_b, eps, ws.ss2, ws.st2, B, F, st), "gn finalize 2");
 
     // K3: blend
     if (phase_mask & URNN_PHASE_BLEND) CHECK_HIP(urnn_launch_blend(ws.g1, ws.cx, h, ws.ss1, ws.ss2, h_out, B, F, (int)P, st), "gru blend");
+    return URNN_OK;
+}
+
+extern "C" int urnn_gru_cell_phases_f32(const float *x, const float *e, const float *h, const float *packed, const float *gn1_w,
+                                        const float *gn1_b, const float *gn2_w, const float *gn2_b, float *h_out, void *workspace,
+                                        size_t workspace_bytes, int B, int I, int F, int H, int W, float eps, int phase_mask,
+                                        void *stream)
+{
+    return gru_cell_impl(x, e, h, packed, gn1_w, gn1_b, gn2_w, gn2_b, h_out, workspace, workspace_bytes, B, I, F, H, W, eps, phase_mask, 0,
+                         stream);
+}
+
+extern "C" int urnn_gru_cell_strip_f32(const float *x, const float *e, const float *h, const float *packed, const float *gn1_w,
+                                       const float *gn1_b, const float *gn2_w, const float *gn2_b, float *h_out, void *workspace,
+                                       size_t workspace_bytes, int B, int I, int F, int H, int W, float eps, int phase_mask,
+                                       long global_pixels, void *stream)
+{
+    if (global_pixels < (long)H * W) return fail(URNN_EINVAL, "urnn_gru_cell_strip_f32: global_pixels %ld < the strip's %ld", global_pixels, (long)H * W);
+    if ((phase_mask & URNN_PHASE_GATES) && (phase_mask & (URNN_PHASE_CAND | URNN_PHASE_GN1)))
+        return fail(URNN_EINVAL, "urnn_gru_cell_strip_f32: the gates' statistics must be exchanged between the gate and the candidate phase");
+    if ((phase_mask & URNN_PHASE_CAND) && (phase_mask & URNN_PHASE_GN2))
+        return fail(URNN_EINVAL, "urnn_gru_cell_strip_f32: the candidate's statistics must be exchanged before its finalize");
+    return gru_cell_impl(x, e, h, packed, gn1_w, gn1_b, gn2_w, gn2_b, h_out, workspace, workspace_bytes, B, I, F, H, W, eps, phase_mask,
+                         global_pixels, stream);
+}
+
+// direction 0: local tile partials -> sums[B][groups][2] (double: sum, sum of squares; fixed order);
+// direction 1: (all-reduced) sums -> the two pseudo-tiles the strip finalizes read
+extern "C" int urnn_gru_cell_strip_stats_f32(void *workspace, size_t workspace_bytes, int B, int F, int H, int W, int which, int direction,
+                                             double *sums, void *stream)
+{
+    if (!workspace || !sums) return fail(URNN_ENULL, "urnn_gru_cell_strip_stats_f32: NULL argument");
+    if (B < 1 || H < 1 || W < 1 || F < 32 || F % 32 != 0 || F > 128 || (which != 1 && which != 2))
+        return fail(URNN_EINVAL, "urnn_gru_cell_strip_stats_f32: bad arguments");
+    const long P = (long)H * W;
+    const GruWs ws = carve_gru(workspace, B, F, P);
+    if (workspace_bytes < ws.bytes) return fail(URNN_EWORKSPACE, "urnn_gru_cell_strip_stats_f32: workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
+    const int rows = B * (which == 1 ? 2 * F / 32 : F / 32);
+    float *part = which == 1 ? ws.part1 : ws.part2;
+    if (direction == 0) CHECK_HIP(urnn_launch_stats_reduce(part, rows, gru_tiles(B, F, P, which), gru_tiles(B, F, P, which), sums, (hipStream_t)stream), "strip stats");
+    else CHECK_HIP(urnn_launch_stats_scatter(sums, rows, 2, part, (hipStream_t)stream), "strip stats");
     return URNN_OK;
 }
 
@@ -559,10 +614,10 @@ extern "C" size_t urnn_head_workspace_bytes(int B, int C, int H, int W)
     return carve_head(nullptr, B, C, (long)H * W).bytes;
 }
 
-extern "C" int urnn_head_f32(const float *feat, const float *conv_w, const float *ln_w, const float *ln_b, const float *cls_w,
-                             const float *cls_b, const float *reg_w, const float *reg_b, float *out_masked, float *out_cls,
-                             float *out_raw, const int *frame_index, void *workspace, size_t workspace_bytes, int B, int C,
-                             int H, int W, float cls_thred, float eps, float slope, void *stream)
+static int head_impl(const float *feat, const float *conv_w, const float *ln_w, const float *ln_b, const float *cls_w,
+                     const float *cls_b, const float *reg_w, const float *reg_b, float *out_masked, float *out_cls,
+                     float *out_raw, const int *frame_index, void *workspace, size_t workspace_bytes, int B, int C,
+                     int H, int W, float cls_thred, float eps, float slope, int phase_mask, long global_pixels, void *stream)
 {
     if (!feat || !conv_w || !ln_w || !ln_b || !cls_w || !cls_b || !reg_w || !reg_b || !out_masked || !out_cls || !workspace)
         return fail(URNN_ENULL, "urnn_head_f32: NULL argument");
@@ -597,7 +652,51 @@ extern "C" int urnn_head_f32(const float *feat, const float *conv_w, const float
     p.cls_thred = cls_thred;
     p.eps = eps;
     p.slope = slope;
-    CHECK_HIP(urnn_launch_head(p, (hipStream_t)stream), "head");
+    p.Pglobal = global_pixels;
+    CHECK_HIP(urnn_launch_head(p, phase_mask, (hipStream_t)stream), "head");
+    return URNN_OK;
+}
+
+extern "C" int urnn_head_f32(const float *feat, const float *conv_w, const float *ln_w, const float *ln_b, const float *cls_w,
+                             const float *cls_b, const float *reg_w, const float *reg_b, float *out_masked, float *out_cls,
+                             float *out_raw, const int *frame_index, void *workspace, size_t workspace_bytes, int B, int C,
+                             int H, int W, float cls_thred, float eps, float slope, void *stream)
+{
+    return head_impl(feat, conv_w, ln_w, ln_b, cls_w, cls_b, reg_w, reg_b, out_masked, out_cls, out_raw, frame_index, workspace,
+                     workspace_bytes, B, C, H, W, cls_thred, eps, slope, URNN_HEAD_ALL, 0, stream);
+}
+
+extern "C" int urnn_head_strip_f32(const float *feat, const float *conv_w, const float *ln_w, const float *ln_b, const float *cls_w,
+                                   const float *cls_b, const float *reg_w, const float *reg_b, float *out_masked, float *out_cls,
+                                   float *out_raw, const int *frame_index, void *workspace, size_t workspace_bytes, int B, int C,
+                                   int H, int W, float cls_thred, float eps, float slope, int phase_mask, long global_pixels,
+                                   void *stream)
+{
+    if (global_pixels < (long)H * W) return fail(URNN_EINVAL, "urnn_head_strip_f32: global_pixels %ld < the strip's %ld", global_pixels, (long)H * W);
+    for (int l = 0; l < 3; ++l)
+        if ((phase_mask & (URNN_HEAD_K1 << (2 * l))) && (phase_mask & (URNN_HEAD_F1 << (2 * l))))
+            return fail(URNN_EINVAL, "urnn_head_strip_f32: the LayerNorm statistics of level %d must be exchanged before their finalize", l);
+    return head_impl(feat, conv_w, ln_w, ln_b, cls_w, cls_b, reg_w, reg_b, out_masked, out_cls, out_raw, frame_index, workspace,
+                     workspace_bytes, B, C, H, W, cls_thred, eps, slope, phase_mask, global_pixels, stream);
+}
+
+// LayerNorm statistics of level 0 (stems: 1 norm), 1 (cls_convs.0 + reg_convs.0), 2 (cls_convs.1 + reg_convs.1):
+// sums[norms of the level][B][2] doubles; directions as in urnn_gru_cell_strip_stats_f32
+extern "C" int urnn_head_strip_stats_f32(void *workspace, size_t workspace_bytes, int B, int C, int H, int W, int level, int direction,
+                                         double *sums, void *stream)
+{
+    if (!workspace || !sums) return fail(URNN_ENULL, "urnn_head_strip_stats_f32: NULL argument");
+    if (B < 1 || C != 16 || H < 1 || W < 1 || level < 0 || level > 2) return fail(URNN_EINVAL, "urnn_head_strip_stats_f32: bad arguments");
+    const long P = (long)H * W;
+    const HeadWs ws = carve_head(workspace, B, C, P);
+    if (workspace_bytes < ws.bytes) return fail(URNN_EWORKSPACE, "urnn_head_strip_stats_f32: workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
+    const int nblk = urnn_head_nblk((int)P), used = urnn_head_nblk_used((int)P);
+    const int first = level == 0 ? 0 : level, n = level == 0 ? 1 : 2;      // norm indices first, first + 2
+    for (int i = 0; i < n; ++i) {
+        float *part = ws.partial + (size_t)(first + 2 * i) * B * nblk * 2;
+        if (direction == 0) CHECK_HIP(urnn_launch_stats_reduce(part, B, nblk, used, sums + (size_t)i * B * 2, (hipStream_t)stream), "strip stats");
+        else CHECK_HIP(urnn_launch_stats_scatter(sums + (size_t)i * B * 2, B, nblk, part, (hipStream_t)stream), "strip stats");
+    }
     return URNN_OK;
 }
 

@@ -344,7 +344,7 @@ __global__ __launch_bounds__(64) void ln_finalize_kernel(const HeadParams prm, i
         s2 += __shfl_xor(s2, m, 64);
     }
     if (lane == 0) {
-        const double count = (double)HEAD_C * (double)prm.P;
+        const double count = (double)HEAD_C * (double)(prm.Pglobal > 0 ? prm.Pglobal : (long)prm.P);
         const double mean = s1 / count;
         double var = s2 / count - mean * mean;
         var = var > 0.0 ? var : 0.0;
@@ -353,27 +353,79 @@ __global__ __launch_bounds__(64) void ln_finalize_kernel(const HeadParams prm, i
     }
 }
 
-int urnn_head_nblk(int P) { return (P + 255) / 256; }
+int urnn_head_nblk(int P) { const int n = (P + 255) / 256; return n < 2 ? 2 : n; }   // >= 2: the strip mode's two pseudo-blocks
+int urnn_head_nblk_used(int P) { const int v = P % 2 == 0 ? 2 : 1; return (P + 256 * v - 1) / (256 * v); }
 
 template <int V>
-static hipError_t launch_head_v(const HeadParams &p, hipStream_t st)
+static hipError_t launch_head_v(const HeadParams &p, int mask, hipStream_t st)
 {
     const int nb = (p.P + 256 * V - 1) / (256 * V);
+    const int fin = p.Pglobal > 0 ? 2 : nb;          // strip mode: the partials hold the all-reduced totals as two pseudo-blocks
     dim3 grid(nb, p.B), blk(256);
-    hipLaunchKernelGGL(head_k1<V>, grid, blk, 0, st, p);
-    hipLaunchKernelGGL(ln_finalize_kernel, dim3(p.B, 1), dim3(64), 0, st, p, 0, 1, nb);
-    hipLaunchKernelGGL(head_k2<V>, grid, blk, 0, st, p);
-    hipLaunchKernelGGL(ln_finalize_kernel, dim3(p.B, 2), dim3(64), 0, st, p, 1, 2, nb);
-    hipLaunchKernelGGL(head_k3<V>, grid, blk, 0, st, p);
-    hipLaunchKernelGGL(ln_finalize_kernel, dim3(p.B, 2), dim3(64), 0, st, p, 2, 2, nb);
-    hipLaunchKernelGGL(head_k4<V>, grid, blk, 0, st, p);
+    if (mask & URNN_HEAD_K1) hipLaunchKernelGGL(head_k1<V>, grid, blk, 0, st, p);
+    if (mask & URNN_HEAD_F1) hipLaunchKernelGGL(ln_finalize_kernel, dim3(p.B, 1), dim3(64), 0, st, p, 0, 1, fin);
+    if (mask & URNN_HEAD_K2) hipLaunchKernelGGL(head_k2<V>, grid, blk, 0, st, p);
+    if (mask & URNN_HEAD_F2) hipLaunchKernelGGL(ln_finalize_kernel, dim3(p.B, 2), dim3(64), 0, st, p, 1, 2, fin);
+    if (mask & URNN_HEAD_K3) hipLaunchKernelGGL(head_k3<V>, grid, blk, 0, st, p);
+    if (mask & URNN_HEAD_F3) hipLaunchKernelGGL(ln_finalize_kernel, dim3(p.B, 2), dim3(64), 0, st, p, 2, 2, fin);
+    if (mask & URNN_HEAD_K4) hipLaunchKernelGGL(head_k4<V>, grid, blk, 0, st, p);
     return hipGetLastError();
 }
 
-hipError_t urnn_launch_head(const HeadParams &p, hipStream_t st)
+hipError_t urnn_launch_head(const HeadParams &p, int mask, hipStream_t st)
 {
-    if (p.P % 2 == 0) return launch_head_v<2>(p, st);
-    return launch_head_v<1>(p, st);
+    if (p.P % 2 == 0) return launch_head_v<2>(p, mask, st);
+    return launch_head_v<1>(p, mask, st);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Strip mode (a plane split over ranks in horizontal strips): norm statistics leave as double sums and come
+// back, all-reduced, as two pseudo-tiles (hi + lo floats) that the unchanged finalizes add up in double.
+// partial[row][stride][2]; one wave per row.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void stats_reduce_kernel(const float *__restrict__ partial, int stride, int ntiles, double *__restrict__ sums)
+{
+    const int row = blockIdx.x, lane = threadIdx.x;
+    const float *pp = partial + (size_t)row * stride * 2;
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = lane; t < ntiles; t += 64) {
+        const f32x2 v = *reinterpret_cast<const f32x2 *>(pp + 2 * t);
+        s1 += (double)v.x;
+        s2 += (double)v.y;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        s1 += __shfl_xor(s1, m, 64);
+        s2 += __shfl_xor(s2, m, 64);
+    }
+    if (lane == 0) {
+        sums[2 * row] = s1;
+        sums[2 * row + 1] = s2;
+    }
+}
+
+__global__ void stats_scatter_kernel(const double *__restrict__ sums, int rows, int stride, float *__restrict__ partial)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // (row, component)
+    if (i >= rows * 2) return;
+    const int row = i >> 1, comp = i & 1;
+    const double v = sums[i];
+    const float hi = (float)v, lo = (float)(v - (double)hi);
+    float *pp = partial + (size_t)row * stride * 2;
+    pp[comp] = hi;
+    pp[2 + comp] = lo;
+}
+
+hipError_t urnn_launch_stats_reduce(const float *partial, int rows, int stride, int ntiles, double *sums, hipStream_t st)
+{
+    hipLaunchKernelGGL(stats_reduce_kernel, dim3(rows), dim3(64), 0, st, partial, stride, ntiles, sums);
+    return hipGetLastError();
+}
+
+hipError_t urnn_launch_stats_scatter(const double *sums, int rows, int stride, float *partial, hipStream_t st)
+{
+    hipLaunchKernelGGL(stats_scatter_kernel, dim3((rows * 2 + 255) / 256), dim3(256), 0, st, sums, rows, stride, partial);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include "../../include/urnn_hip.h"
 
 enum { MAP_VEC = 0, MAP_PAIR = 1, MAP_STRIDED = 2, MAP_POOL = 3, MAP_PAIR16 = 4 };   // pixel geometry of a wave tile (urnn_gemm.hip)
 enum { EPI_LRELU = 0, EPI_POOL = 1, EPI_DECONV = 2, EPI_GRU1 = 3, EPI_CAND = 4 };   // epilogue of conv_gemm_kernel
@@ -61,10 +62,14 @@ struct HeadParams {
     float *partial;             // [5][B][nblk][2]
     float *stats;               // [5][B][2] mean, rstd
     int B, C, P, nblk;
+    long Pglobal;               // > 0: strip mode, LayerNorm statistics over Pglobal pixels from two pseudo-blocks of partials
     float cls_thred, eps, slope;
 };
-hipError_t urnn_launch_head(const HeadParams &p, hipStream_t st);
-int urnn_head_nblk(int P);
+hipError_t urnn_launch_head(const HeadParams &p, int phase_mask, hipStream_t st);
+int urnn_head_nblk(int P);        // blocks allocated per (norm, sample) in the partial buffer
+int urnn_head_nblk_used(int P);   // blocks the head kernels write
+hipError_t urnn_launch_stats_reduce(const float *partial, int rows, int stride, int ntiles, double *sums, hipStream_t st);
+hipError_t urnn_launch_stats_scatter(const double *sums, int rows, int stride, float *partial, hipStream_t st);
 
 hipError_t urnn_launch_preprocess(const float *rain, const float *cumsum, const float *dem, const float *imperv,
                                   const float *manhole, float dem_min, float dem_max, float *out, int t, const int *t_dev,

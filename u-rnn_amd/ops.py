@@ -124,6 +124,66 @@ def gru_cell(x, e, h, packed, gn1_w, gn1_b, gn2_w, gn2_b, I, out=None, eps=NORM_
     return out
 
 
+def gru_cell_strip(x, e, h, packed, gn1_w, gn1_b, gn2_w, gn2_b, I, global_pixels, exchange, out=None, eps=NORM_EPS):
+    """One horizontal strip of a cell step whose plane of ``global_pixels`` pixels is split over ranks (include/urnn_hip.h,
+    "Spatial strips").  ``exchange(sums)`` must all-reduce (sum) the float64 device tensor in place; it is called twice."""
+    _dev_check(x, e, h, packed, gn1_w, gn1_b, gn2_w, gn2_b, out)
+    B, F, H, W = h.shape
+    L = lib()
+    ws = WORKSPACE.get(L.urnn_gru_cell_workspace_bytes(B, F, H, W), h.device)
+    if out is None:
+        out = torch.empty_like(h)
+
+    def phase(mask):
+        check(L.urnn_gru_cell_strip_f32(_ptr(x), _ptr(e), _ptr(h), _ptr(packed), _ptr(gn1_w), _ptr(gn1_b), _ptr(gn2_w), _ptr(gn2_b),
+                                        _ptr(out), _ptr(ws), ws.numel(), B, I, F, H, W, eps, mask, int(global_pixels), _stream()),
+              "urnn_gru_cell_strip_f32")
+
+    def swap(which, groups):
+        sums = torch.empty((B, groups, 2), dtype=torch.float64, device=h.device)
+        for direction in (0, 1):
+            check(L.urnn_gru_cell_strip_stats_f32(_ptr(ws), ws.numel(), B, F, H, W, which, direction, _ptr(sums), _stream()),
+                  "urnn_gru_cell_strip_stats_f32")
+            if direction == 0:
+                exchange(sums)
+
+    phase(PHASE_GATES)
+    swap(1, 2 * F // 32)
+    phase(PHASE_CAND)
+    swap(2, F // 32)
+    phase(PHASE_GN2 | PHASE_BLEND)
+    return out
+
+
+def head_strip(feat, conv_w, ln_w, ln_b, cls_w, cls_b, reg_w, reg_b, cls_thred, global_pixels, exchange, want_raw=False, eps=NORM_EPS,
+               slope=LRELU_SLOPE):
+    """One strip of the head: ln_w / ln_b are the strip's rows (5,C,H,W); three statistics exchanges (LayerNorm levels)."""
+    _dev_check(feat, conv_w, ln_w, ln_b, cls_w, cls_b, reg_w, reg_b)
+    B, C, H, W = feat.shape
+    L = lib()
+    ws = WORKSPACE.get(L.urnn_head_workspace_bytes(B, C, H, W), feat.device)
+    f32 = dict(dtype=torch.float32, device=feat.device)
+    masked, cls = torch.empty((B, H, W), **f32), torch.empty((B, H, W), **f32)
+    raw = torch.empty((B, H, W), **f32) if want_raw else None
+
+    def phase(mask):
+        check(L.urnn_head_strip_f32(_ptr(feat), _ptr(conv_w), _ptr(ln_w), _ptr(ln_b), _ptr(cls_w), _ptr(cls_b), _ptr(reg_w), _ptr(reg_b),
+                                    _ptr(masked), _ptr(cls), _ptr(raw), None, _ptr(ws), ws.numel(), B, C, H, W, float(cls_thred), eps,
+                                    slope, mask, int(global_pixels), _stream()), "urnn_head_strip_f32")
+
+    for level in range(3):
+        phase(1 << (2 * level))                                   # K1 / K2 / K3: convs + partial sums of the level's norms
+        sums = torch.empty((1 if level == 0 else 2, B, 2), dtype=torch.float64, device=feat.device)
+        for direction in (0, 1):
+            check(L.urnn_head_strip_stats_f32(_ptr(ws), ws.numel(), B, C, H, W, level, direction, _ptr(sums), _stream()),
+                  "urnn_head_strip_stats_f32")
+            if direction == 0:
+                exchange(sums)
+        phase(2 << (2 * level))                                   # F1 / F2 / F3
+    phase(64)                                                     # K4
+    return masked, cls, raw
+
+
 def deconv2x2(x, packed, Cout, out=None, slope=LRELU_SLOPE):
     """LeakyReLU(ConvTranspose2d(k=2,s=2)(x)): (B,Cin,H,W) -> (B,Cout,2H,2W)."""
     _dev_check(x, packed, out)
