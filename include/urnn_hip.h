@@ -141,11 +141,16 @@ int urnn_stage1_scalar_rain_f32(const float *S, const float *rain, const float *
  * (B,*,H,W) are overwritten; the parameter gradients (shapes of the parameters) are overwritten, or added to when
  * accumulate != 0 (BPTT over the steps of an SWP window).  Deterministic: reductions use fixed-order partial sums. */
 size_t urnn_gru_cell_backward_workspace_bytes(int B, int I, int F, int skip, int H, int W);
+/* bwd_packed (urnn_gru_cell_backward_packed_floats floats, caller-owned, one per cell): the packed weights of the three
+ * input-gradient GEMMs.  They depend on W1 / W2 only: pass repack != 0 on the first backward call after the weights changed
+ * (once per SWP window) and 0 afterwards.  When dx and de are one contiguous block (de == dx + I*H*W, B == 1) they are written
+ * in place by a single GEMM over the contraction [dgates; dcandidate]. */
+size_t urnn_gru_cell_backward_packed_floats(int I, int F, int skip);
 int urnn_gru_cell_backward_f32(const float *x, const float *e, const float *h, const float *W1, const float *W2, const float *gn1_w,
                                const float *gn2_w, const void *fwd_workspace, const float *dh_out, float *dx, float *de, float *dh,
                                float *dW1, float *db1, float *dgn1_w, float *dgn1_b, float *dW2, float *db2, float *dgn2_w,
-                               float *dgn2_b, void *workspace, size_t workspace_bytes, int B, int I, int F, int H, int W,
-                               int accumulate, void *stream);
+                               float *dgn2_b, float *bwd_packed, int repack, void *workspace, size_t workspace_bytes, int B, int I,
+                               int F, int H, int W, int accumulate, void *stream);
 
 /* Backward of urnn_stage_conv_f32 (conv1x1 + LeakyReLU [+ AvgPool2d(2,2)]): weight (Cout,Cin), bias (Cout) in the reference
  * layout; dout has the forward output's shape; din (B,Cin,H,W) is overwritten, dweight / dbias overwritten or accumulated. */

@@ -348,10 +348,31 @@ extern "C" int urnn_gru_cell_f32(const float *x, const float *e, const float *h,
 
 // ---- GRU cell backward (training building block) ----------------------------------------------------------------------
 struct GruBwdWs {
-    float *dy1, *dy2, *rh, *dA2, *dA, *wt1, *wt2, *pk1, *pk2, *chpart, *chpart2, *coef, *wpart;
+    float *dy1, *dy2, *rh, *tmpF, *dxe, *wv, *chpart, *chpart2, *coef, *wpart;
     double *sums;
     size_t bytes;
 };
+
+// packed "weights" of the three input-gradient GEMMs (cell_bwd_weights_kernel): they only change with the optimizer step,
+// so the caller keeps them per cell and asks for a re-pack once per window
+struct GruBwdPacks {
+    size_t h2, xe, h1, total;     // float offsets
+};
+static GruBwdPacks gru_bwd_packs(int I, int F, int skip)
+{
+    GruBwdPacks p;
+    p.h2 = 0;
+    p.xe = p.h2 + urnn_packed_conv_floats(F, F);
+    p.h1 = p.xe + urnn_packed_conv_floats(3 * F, I + (skip ? F : 0));
+    p.total = p.h1 + urnn_packed_conv_floats(2 * F, F);
+    return p;
+}
+
+extern "C" size_t urnn_gru_cell_backward_packed_floats(int I, int F, int skip)
+{
+    if (I < 1 || F < 32 || F % 32 != 0 || F > 128) return 0;
+    return gru_bwd_packs(I, F, skip ? 1 : 0).total;
+}
 
 static GruBwdWs carve_gru_bwd(void *base, int B, int I, int F, int skip, long P)
 {
@@ -367,12 +388,9 @@ static GruBwdWs carve_gru_bwd(void *base, int B, int I, int F, int skip, long P)
     w.dy1 = takef((size_t)B * 2 * F * P);
     w.dy2 = takef((size_t)B * F * P);
     w.rh = takef((size_t)B * F * P);
-    w.dA2 = takef((size_t)B * K * P);
-    w.dA = takef((size_t)B * K * P);
-    w.wt1 = takef((size_t)2 * F * K);
-    w.wt2 = takef((size_t)F * K);
-    w.pk1 = takef(urnn_packed_conv_floats(2 * F, K));
-    w.pk2 = takef(urnn_packed_conv_floats(F, K));
+    w.tmpF = takef((size_t)B * F * P);
+    w.dxe = takef((size_t)B * (K - F) * P);
+    w.wv = takef((size_t)3 * F * (K - F > F ? K - F : F));
     w.chpart = takef((size_t)B * 2 * F * 64 * 2);      // per-plane partial sums: at most 64 blocks per plane
     w.chpart2 = takef((size_t)B * F * 64 * 2);
     w.coef = takef((size_t)B * (2 * F / 32) * 2);
@@ -391,6 +409,35 @@ extern "C" size_t urnn_gru_cell_backward_workspace_bytes(int B, int I, int F, in
     return carve_gru_bwd(nullptr, B, I, F, skip ? 1 : 0, (long)H * W).bytes;
 }
 
+// out (B,Cout,P) = packed 1x1 conv (no bias, identity) of the channel concatenation [in0 (C0) ; in1 (C1)], C0 even
+static int conv_2seg(const float *in0, int C0, const float *in1, int C1, const float *packed, float *out, int B, int Cout, int H, int W,
+                     hipStream_t st, const char *what)
+{
+    const long P = (long)H * W;
+    const int Cin = C0 + C1;
+    const int NB = urnn_conv_nb(Cout), NG = urnn_conv_ng(Cout);
+    ConvGemmParams p = {};
+    p.seg[0] = in0; p.segC[0] = C0; p.segKp0[0] = 0;
+    p.seg[1] = in1 ? in1 : in0; p.segC[1] = in1 ? C1 : C0; p.segKp0[1] = in1 ? C0 / 2 : INT_MAX;
+    p.seg[2] = in0; p.segC[2] = C0; p.segKp0[2] = INT_MAX;
+    p.kpBegin = 0;
+    p.KT = (Cin + 1) / 2;
+    p.hKp0 = INT_MAX;
+    p.wt = packed;
+    p.aFloats = (int)slab_floats(p.KT, NB);
+    p.NG = NG;
+    p.bias = packed + (size_t)NG * p.aFloats;
+    p.P = (int)P;
+    p.W = W;
+    p.Cout = Cout;
+    p.slope = 1.0f;
+    p.out0 = out;
+    int pb, map;
+    pick_tile((long)B * P, NG, P, &pb, &map, "URNN_TUNE_PB_CONV", 1024);
+    CHECK_HIP(urnn_launch_conv_flat(p, B, pb, map, st), what);
+    return URNN_OK;
+}
+
 // dX = W^T . dY through the forward GEMM kernel: "weight" = W^T (K x N), identity epilogue, no bias.  out (B,K,P).
 static int dx_gemm(const float *dy, const float *w, float *wt, float *packed, float *out, int B, int N, int K, int H, int W, hipStream_t st,
                    const char *what)
@@ -403,26 +450,41 @@ static int dx_gemm(const float *dy, const float *w, float *wt, float *packed, fl
 extern "C" int urnn_gru_cell_backward_f32(const float *x, const float *e, const float *h, const float *W1, const float *W2,
                                           const float *gn1_w, const float *gn2_w, const void *fwd_workspace, const float *dh_out,
                                           float *dx, float *de, float *dh, float *dW1, float *db1, float *dgn1_w, float *dgn1_b,
-                                          float *dW2, float *db2, float *dgn2_w, float *dgn2_b, void *workspace, size_t workspace_bytes,
-                                          int B, int I, int F, int H, int W, int accumulate, void *stream)
+                                          float *dW2, float *db2, float *dgn2_w, float *dgn2_b, float *bwd_packed, int repack,
+                                          void *workspace, size_t workspace_bytes, int B, int I, int F, int H, int W, int accumulate,
+                                          void *stream)
 {
     if (!h || !W1 || !W2 || !gn1_w || !gn2_w || !fwd_workspace || !dh_out || !dh || !dW1 || !db1 || !dgn1_w || !dgn1_b || !dW2 || !db2 ||
-        !dgn2_w || !dgn2_b || !workspace)
+        !dgn2_w || !dgn2_b || !bwd_packed || !workspace)
         return fail(URNN_ENULL, "urnn_gru_cell_backward_f32: NULL argument");
     if ((x != nullptr) != (dx != nullptr) || (e != nullptr) != (de != nullptr))
         return fail(URNN_EINVAL, "urnn_gru_cell_backward_f32: dx / de must be given exactly when x / e are");
     if (B < 1 || I < 1 || H < 1 || W < 1 || F < 32 || F % 32 != 0 || F > 128)
         return fail(URNN_EINVAL, "urnn_gru_cell_backward_f32: bad dims (F=%d must be a multiple of 32 in [32,128])", F);
     const long P = (long)H * W;
-    if (!plane_fits(P, 2 * F > I ? 2 * F : I)) return fail(URNN_EINVAL, "urnn_gru_cell_backward_f32: plane exceeds the 4-GiB segment limit");
+    if (!plane_fits(P, 3 * F > I + F ? 3 * F : I + F)) return fail(URNN_EINVAL, "urnn_gru_cell_backward_f32: plane exceeds the 4-GiB segment limit");
     const int skip = e != nullptr;
     const int K = I + (skip ? F : 0) + F;
     const GruWs fw = carve_gru(const_cast<void *>(fwd_workspace), B, F, P);
     const GruBwdWs ws = carve_gru_bwd(workspace, B, I, F, skip, P);
     if (workspace_bytes < ws.bytes)
         return fail(URNN_EWORKSPACE, "urnn_gru_cell_backward_f32: workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
+    if (!aligned16(bwd_packed)) return fail(URNN_EALIGN, "urnn_gru_cell_backward_f32: bwd_packed must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const int Pi = (int)P;
+    // rows of [x; e] that need a gradient: a missing x (decoder stage 3) still owns columns of W1 / W2 but gets none
+    const int rlo = x ? 0 : I, nrows = (x ? I : 0) + (skip ? F : 0);
+    const GruBwdPacks pk = gru_bwd_packs(I, F, skip);
+    if (repack) {
+        CHECK_HIP(urnn_train_cell_bwd_weights(W1, W2, ws.wv, F, K, 0, 0, 0, st), "input-gradient weights");
+        CHECK_HIP(urnn_launch_pack_conv(ws.wv, nullptr, bwd_packed + pk.h2, F, F, st), "input-gradient weights");
+        if (nrows > 0) {
+            CHECK_HIP(urnn_train_cell_bwd_weights(W1, W2, ws.wv, F, K, rlo, nrows, 1, st), "input-gradient weights");
+            CHECK_HIP(urnn_launch_pack_conv(ws.wv, nullptr, bwd_packed + pk.xe, 3 * F, nrows, st), "input-gradient weights");
+        }
+        CHECK_HIP(urnn_train_cell_bwd_weights(W1, W2, ws.wv, F, K, 0, 0, 2, st), "input-gradient weights");
+        CHECK_HIP(urnn_launch_pack_conv(ws.wv, nullptr, bwd_packed + pk.h1, 2 * F, F, st), "input-gradient weights");
+    }
 
     // 1. blend: dy2 (normalised candidate), dy1[:, :F] (normalised update gate), dh = dout * (1 - z)
     CHECK_HIP(urnn_train_blend_bwd(dh_out, fw.g1, fw.cx, h, fw.ss1, fw.ss2, fw.st1, fw.st2, ws.dy2, ws.dy1, dh, ws.chpart, ws.chpart2, B, F,
@@ -430,34 +492,44 @@ extern "C" int urnn_gru_cell_backward_f32(const float *x, const float *e, const 
     // 2. GroupNorm of the candidate: dy2 -> dc (in place), dgamma2 / dbeta2
     CHECK_HIP(urnn_train_gn_backward(ws.dy2, fw.cx, fw.st2, gn2_w, B, F, Pi, ws.chpart2, ws.sums, ws.coef, dgn2_w, dgn2_b, accumulate, 1, st),
               "GroupNorm 2 backward");
-    // 3. conv2: dW2 / db2 = dc . [x; e; r*h]^T,  dA2 = W2^T . dc
+    // 3. conv2: dW2 / db2 = dc . [x; e; r*h]^T;  d(r*h) = W2[:, h]^T . dc  (the x / e rows of W2^T . dc join conv1's in step 7)
     CHECK_HIP(urnn_train_reset_gate(fw.g1, h, fw.ss1, ws.rh, B, F, Pi, st), "reset gate");
     {
         const float *seg[3] = {x, e, ws.rh};
         const int segC[3] = {I, skip ? F : 0, F};
         CHECK_HIP(urnn_train_wgrad(ws.dy2, seg, segC, B, F, K, Pi, ws.wpart, dW2, db2, accumulate, st), "conv2 weight gradient");
     }
-    int rc = dx_gemm(ws.dy2, W2, ws.wt2, ws.pk2, ws.dA2, B, F, K, H, W, st, "conv2 input gradient");
+    int rc = conv_2seg(ws.dy2, F, nullptr, 0, bwd_packed + pk.h2, ws.tmpF, B, F, H, W, st, "conv2 hidden-state gradient");
     if (rc) return rc;
     // 4. reset gate: d(r*h) -> dy1[:, F:], dh += d(r*h) * r
-    CHECK_HIP(urnn_train_reset_gate_bwd(ws.dA2 + (size_t)(K - F) * P, (long)K * P, fw.g1, h, fw.ss1, fw.st1, ws.dy1, dh, ws.chpart, B, F, Pi, st),
+    CHECK_HIP(urnn_train_reset_gate_bwd(ws.tmpF, (long)F * P, fw.g1, h, fw.ss1, fw.st1, ws.dy1, dh, ws.chpart, B, F, Pi, st),
               "reset gate backward");
     // 5. GroupNorm of the gates: dy1 -> dg (in place), dgamma1 / dbeta1
     CHECK_HIP(urnn_train_gn_backward(ws.dy1, fw.g1, fw.st1, gn1_w, B, 2 * F, Pi, ws.chpart, ws.sums, ws.coef, dgn1_w, dgn1_b, accumulate, 1, st),
               "GroupNorm 1 backward");
-    // 6. conv1: dW1 / db1 = dg . [x; e; h]^T,  dA = W1^T . dg
+    // 6. conv1: dW1 / db1 = dg . [x; e; h]^T
     {
         const float *seg[3] = {x, e, h};
         const int segC[3] = {I, skip ? F : 0, F};
         CHECK_HIP(urnn_train_wgrad(ws.dy1, seg, segC, B, 2 * F, K, Pi, ws.wpart, dW1, db1, accumulate, st), "conv1 weight gradient");
     }
-    rc = dx_gemm(ws.dy1, W1, ws.wt1, ws.pk1, ws.dA, B, 2 * F, K, H, W, st, "conv1 input gradient");
+    // 7. d[x; e] = [W1^T | W2^T][xe rows] . [dg; dc] in ONE GEMM (contraction over 3F), written straight into dx | de when they
+    //    are one contiguous (B, rows, P) block (always the case for B = 1 when the caller allocates them together)
+    if (nrows > 0) {
+        float *first = dx ? dx : de;
+        const bool direct = !(dx && de) || (B == 1 && de == dx + (size_t)I * P);
+        rc = conv_2seg(ws.dy1, 2 * F, ws.dy2, F, bwd_packed + pk.xe, direct ? first : ws.dxe, B, nrows, H, W, st, "input gradient");
+        if (rc) return rc;
+        if (!direct) {
+            const long bs = (long)nrows * P;
+            CHECK_HIP(urnn_train_add_slices(dx, (long)I * P, ws.dxe, bs, nullptr, 0, B, I, Pi, 0, st), "dx");
+            CHECK_HIP(urnn_train_add_slices(de, (long)F * P, ws.dxe + (size_t)I * P, bs, nullptr, 0, B, F, Pi, 0, st), "de");
+        }
+    }
+    // 8. dh += W1[:, h]^T . dg
+    rc = conv_2seg(ws.dy1, 2 * F, nullptr, 0, bwd_packed + pk.h1, ws.tmpF, B, F, H, W, st, "conv1 hidden-state gradient");
     if (rc) return rc;
-    // 7. gather the input gradients: dx = dA[:, :I] + dA2[:, :I], de likewise, dh += dA[:, K-F:]
-    const long kbs = (long)K * P;
-    if (dx) CHECK_HIP(urnn_train_add_slices(dx, (long)I * P, ws.dA, kbs, ws.dA2, kbs, B, I, Pi, 0, st), "dx");
-    if (de) CHECK_HIP(urnn_train_add_slices(de, (long)F * P, ws.dA + (size_t)I * P, kbs, ws.dA2 + (size_t)I * P, kbs, B, F, Pi, 0, st), "de");
-    CHECK_HIP(urnn_train_add_slices(dh, (long)F * P, ws.dA + (size_t)(K - F) * P, kbs, nullptr, 0, B, F, Pi, 1, st), "dh");
+    CHECK_HIP(urnn_train_add_slices(dh, (long)F * P, ws.tmpF, (long)F * P, nullptr, 0, B, F, Pi, 1, st), "dh");
     return URNN_OK;
 }
 

@@ -105,6 +105,7 @@ size_t urnn_train_wgrad_partial_floats(int B, int N, int K, int P);
 hipError_t urnn_train_wgrad(const float *dy, const float *const seg[3], const int segC[3], int B, int N, int K, int P, float *partial,
                             float *dW, float *db, int accumulate, hipStream_t st);
 hipError_t urnn_train_transpose(const float *w, float *wt, int N, int K, hipStream_t st);
+hipError_t urnn_train_cell_bwd_weights(const float *W1, const float *W2, float *out, int F, int K, int rlo, int nrows, int mode, hipStream_t st);
 hipError_t urnn_train_lrelu_pool_bwd(float *u, const float *dy, int B, int C, int H, int W, int pool, float slope, hipStream_t st);
 hipError_t urnn_train_deconv_unshuffle(const float *dy, const float *y, float *d4, int B, int Cout, int H, int W, float slope, hipStream_t st);
 hipError_t urnn_train_deconv_weight_rows(const float *w, float *rows, int Cin, int Cout, hipStream_t st);

@@ -435,6 +435,36 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float *__rest
     }
 }
 
+// "Weights" (Cout x Cin, row-major, the layout pack_conv takes) of the three input-gradient GEMMs of a cell, gathered from
+// W1 (2F x K) and W2 (F x K), K ordered x | e | h, kh = K - F:
+//   mode 0: d(r*h) = W2[:, h]^T . dc              out[j][n] = W2[n][kh + j]                           (F x F)
+//   mode 1: d[x;e] = W1[:, xe]^T . dg + W2[:, xe]^T . dc   out[r][n] = n < 2F ? W1[n][rlo + r] : W2[n - 2F][rlo + r]   (nrows x 3F)
+//   mode 2: dh    += W1[:, h]^T . dg              out[j][n] = W1[n][kh + j]                           (F x 2F)
+__global__ void cell_bwd_weights_kernel(const float *__restrict__ W1, const float *__restrict__ W2, float *__restrict__ out, int F, int K,
+                                        int rlo, int nrows, int mode)
+{
+    const int cin = mode == 0 ? F : (mode == 1 ? 3 * F : 2 * F);
+    const int rows = mode == 1 ? nrows : F;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cin) return;
+    const int r = i / cin, n = i - r * cin;
+    const int col = mode == 1 ? rlo + r : K - F + r;
+    float v;
+    if (mode == 0) v = W2[(size_t)n * K + col];
+    else if (mode == 2) v = W1[(size_t)n * K + col];
+    else v = n < 2 * F ? W1[(size_t)n * K + col] : W2[(size_t)(n - 2 * F) * K + col];
+    out[i] = v;
+}
+
+hipError_t urnn_train_cell_bwd_weights(const float *W1, const float *W2, float *out, int F, int K, int rlo, int nrows, int mode, hipStream_t st)
+{
+    const int cin = mode == 0 ? F : (mode == 1 ? 3 * F : 2 * F);
+    const int total = (mode == 1 ? nrows : F) * cin;
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(cell_bwd_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, st, W1, W2, out, F, K, rlo, nrows, mode);
+    return hipGetLastError();
+}
+
 // weight (N,K) row-major -> transposed (K,N) row-major (the "weight" of the dX GEMM)
 __global__ void transpose_kernel(const float *__restrict__ w, float *__restrict__ wt, int N, int K)
 {

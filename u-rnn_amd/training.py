@@ -26,6 +26,7 @@ class WindowGradients:
         self.rain_max, self.cumsum_max = float(rain_max), float(cumsum_max)
         self.cls_thred_train = float(cls_thred_train)          # classify_outputs threshold of the loop (main.py:598: 0)
         self.device = next(net.parameters()).device
+        self._bwd_packed = {}      # per cell: packed weights of the input-gradient GEMMs, valid until the parameters change
 
     # -- forward of one timestep, keeping what the backward reads ---------------------------------------------------
     def _forward_step(self, ev, t, states, step, t_dev=None):
@@ -94,7 +95,8 @@ class WindowGradients:
             prev = {k_: (G[f"{name}.{v}"].reshape(-1) if k_ in ("db1", "dg1", "dbe1", "db2", "dg2", "dbe2") else
                          G[f"{name}.{v}"].reshape(G[f"{name}.{v}"].shape[0], -1)) for k_, v in names.items()} if have else None
             g = train_ops.gru_cell_backward(x, e, h, c1.weight.detach(), c2.weight.detach(), g1.weight.detach(), g2.weight.detach(),
-                                            dout_h.contiguous(), mod.input_channels, grads=prev, accumulate=acc and have)
+                                            dout_h.contiguous(), mod.input_channels, grads=prev, accumulate=acc and have,
+                                            packed=self._bwd_packed.setdefault(name, []))
             for k_, v in names.items():
                 ref = dict(mod.named_parameters())[v]
                 G[f"{name}.{v}"] = g[k_].reshape(ref.shape)
@@ -137,6 +139,8 @@ class WindowGradients:
             from .general import initialize_states
             states = [s.to(self.device).repeat(B, 1, 1, 1) for s in initialize_states(self.device, self.H, self.W)]
         targets = torch.as_tensor(targets, dtype=torch.float32, device=self.device).contiguous()
+        for v in self._bwd_packed.values():      # the parameters may have changed since the last window: re-pack once per window
+            v.clear()
         saved = []
         for s in range(steps):
             S, states = self._forward_step(ev, t0 + s, states, s, None if t_devs is None else t_devs[s])
@@ -213,6 +217,7 @@ class Trainer:
             if cache is not None and hasattr(cache, "clear"):
                 cache.clear()
         self.net.head._stamp = None
+
 
     def set_lr(self, lr):
         """Learning rate of the following windows (the epoch loop calls this once per epoch; the captured window is re-captured)."""
