@@ -113,7 +113,7 @@ def cpu_baseline(sd, cfgname, budget_s=15.0, max_frames=8):
 def bench_train(args, dev, dist, world, rank):
     """SWP training throughput (BASELINE configs 3-4 shape of work, fp32): a step = one training timestep of one event per GPU
     (forward with kept activations, backward through the window, loss; per window one gradient mean over the ranks and one
-    clipped Adam step).  First-version kernels -- see DESIGN.md section 6a."""
+    clipped Adam step).  See DESIGN.md section 6a."""
     import urnn_amd.weights as uw
     from urnn_amd.training import Trainer
     name = args.config if args.config != "mixed" else "futian"
@@ -161,7 +161,7 @@ def bench_train(args, dev, dist, world, rank):
             "gflop_per_step": gflop, "step_mfma_frac": steps / elapsed * gflop / 1e3 / PEAK_MFMA_F32_TFLOPS,
             "loss": float(loss[0]), "grad_norm": float(tr.last["clip"][1]),
             "roofline": None, "cpu_baseline": None,
-            "note": "first-version training kernels (DESIGN.md 6a); the BASELINE metric is the default --mode infer"}))
+            "note": "training path (DESIGN.md 6a); the BASELINE metric is the default --mode infer"}))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
