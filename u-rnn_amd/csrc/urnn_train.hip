@@ -1,7 +1,7 @@
-// urnn_train.hip -- first building blocks of the training path: backward of the ConvGRU / Skip-ConvGRU
-// cell.  Straightforward first version: correctness against reference autograd first, one kernel per mathematical step,
-// deterministic reductions (per-chunk fp32 partials -> fixed-order double), fp32 MFMA for the two contraction shapes:
-//   dX = W^T . dY   -- the forward GEMM kernel (urnn_gemm.hip) on transposed packed weights, identity epilogue;
+// urnn_train.hip -- kernels of the training path: backward of the ConvGRU / Skip-ConvGRU cell, the
+// stage convs, the transposed convs and the head; loss; clipped Adam.  Deterministic reductions (per-chunk fp32 partials ->
+// fixed-order double); fp32 MFMA for the two contraction shapes:
+//   dX = W^T . dY   -- the forward GEMM kernel (urnn_gemm.hip) on gathered / transposed packed weights, identity epilogue;
 //   dW = dY . X^T   -- wgrad_kernel below: contraction over PIXELS, operands transposed through LDS.
 #include "urnn_common.h"
 #include "urnn_kernels.h"
@@ -222,10 +222,10 @@ __global__ __launch_bounds__(256) void add_slices_kernel(float *out, long out_bs
 
 // ------------------------------------------------------------------------------------------------------------------
 // Weight gradient dW[n][k] = sum_{b,p} dY[b][n][p] * X[b][k][p]  (+ row sums of dY for the bias gradient).
-// Block = 4 waves, output tile 64 n x 64 k (wave w: n-block w >> 1, k-block w & 1), one pixel chunk; per step the block
-// stages dY[64][64 px] and X[64][64 px] in LDS (rows padded to 65 floats: the MFMA fragments read a COLUMN of the tile,
-// lane l -> row l & 31, and the pad makes those 32 rows hit 32 banks), then 32 v_mfma_f32_32x32x2_f32 per wave.
-// X rows come from up to three tensors (x | e | h-or-rh), k < K.  partial[chunk][N][K]; grid (K/64, N/64, chunks).
+// Block = 4 waves on a 128 n x 128 k output tile and one pixel chunk; per 64-pixel stage the block stages dY[128][64 px]
+// and X[128][64 px] in LDS (rows padded to 68 floats), each wave multiplies its share of the VALID 32 x 32 tiles with
+// v_mfma_f32_32x32x2_f32 (an MFMA fragment reads a COLUMN of the LDS tile: lane l -> row l & 31).
+// X rows come from up to three tensors (x | e | h-or-rh), k < K.  partial[chunk][N][K]; grid (K/128, N/128, chunks).
 // ------------------------------------------------------------------------------------------------------------------
 struct WgradParams {
     const float *dy;          // (B,N,P)
@@ -239,11 +239,10 @@ struct WgradParams {
     float *rowpart;           // [chunks][N] sums of dY (written by the blockIdx.x == 0 column), may be nullptr
 };
 
-// Second version: 128 n x 128 k per block (wave w: the 64 x 64 quadrant (w >> 1, w & 1) = 2 x 2 MFMA tiles), 16-byte global
-// loads of the NEXT 64-pixel stage into registers while the current one is multiplied out of LDS, row bases (incl. the K
-// segment lookup) resolved once per block.  An MFMA fragment reads one COLUMN of the LDS tile (lane l -> row l & 31).
-// (A third version with one 8-wave block per CU on 128 x 256 / 64 x 512 / 256 x 128 tiles -- fewer staged bytes per MFMA --
-// measured slower, 8.9 vs 8.2 ms per training step: two independent 4-wave blocks hide each other's barriers.)
+// 16-byte global loads of the NEXT 64-pixel stage go into registers while the current one is multiplied out of LDS; row bases
+// (incl. the K segment lookup) are resolved once per block.  (The first version -- 64 x 64 tiles, scalar staging -- was 5x
+// slower; one 8-wave block per CU on 128 x 256 / 64 x 512 / 256 x 128 tiles -- fewer staged bytes per MFMA -- measured slower
+// too, 8.9 vs 8.2 ms per training step: two independent 4-wave blocks hide each other's barriers.)
 constexpr int WG_T = 128, WG_LD = 68;   // 68: rows stay 16-byte aligned (one ds_write_b128 per staged float4); column reads are 2-way conflicted, cheap next to the MFMAs
 
 // one 64-pixel stage of a wave: AN x AK MFMA tiles, pixel pairs [sLo, sLo + sCnt) of the stage
