@@ -1,0 +1,166 @@
+"""Training building blocks at BASELINE's full grid (500x500 and its 250x250 / 125x125 levels -- the last one an odd plane of
+15 625 pixels, i.e. the unaligned load paths), where the numpy oracle is too slow: the reference of each test is the same
+mathematics written with plain torch ops in FLOAT64 on the GPU (F.conv2d / F.group_norm / F.avg_pool2d / F.conv_transpose2d,
+the modules the reference network is made of: ConvRNN.py:73-194, utils.py:73-125) and differentiated by autograd."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as Fn
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+GRAD_TOL = 2e-4     # same bar as tests/test_hip_train.py: relative to each tensor's max (floor 0.1 * max, conftest.rel_err)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _off_kink(dy, u64, pool=False):
+    """LeakyReLU'(u) jumps at u = 0: where the float64 pre-activation is within fp32 rounding of zero the fp32 path may
+    legitimately take the other slope (a handful of values in 10^7, but each moves a weight gradient by O(1)).  The upstream
+    gradient is zeroed there, so neither path depends on the branch (cf. the threshold flips of conftest.masked_parity)."""
+    near = (u64.detach().abs() < 1e-5).double()
+    near = Fn.max_pool2d(near, 2) if pool else near
+    assert float(near.mean()) < 1e-3
+    return (dy * (1.0 - near).to(dy.dtype)).contiguous()
+
+
+def _rand(gen, *shape, scale=1.0, dev=None):
+    return (torch.randn(*shape, generator=gen, device=dev) * scale).contiguous()
+
+
+def _cell64(x, e, h, W1, b1, g1, be1, W2, b2, g2, be2, dout, eps=1e-5):
+    """CGRU_cell step (ConvRNN.py:150-189) in float64 with autograd; returns (h', {gradients})."""
+    d = lambda t: None if t is None else t.double().clone().requires_grad_(True)
+    xs, es, hs = d(x), d(e), d(h)
+    P = {k: d(v) for k, v in dict(W1=W1, b1=b1, g1=g1, be1=be1, W2=W2, b2=b2, g2=g2, be2=be2).items()}
+    F = h.shape[1]
+    I = W1.shape[1] - F - (F if e is not None else 0)
+    # a missing input (decoder stage 3) is a block of zeros (ConvRNN.py:136)
+    x_in = xs if xs is not None else torch.zeros((h.shape[0], I) + tuple(h.shape[2:]), dtype=torch.float64, device=h.device)
+    cat = lambda *t: torch.cat([u for u in t if u is not None], dim=1)
+    gates = Fn.group_norm(Fn.conv2d(cat(x_in, es, hs), P["W1"], P["b1"]), 2 * F // 32, P["g1"], P["be1"], eps)
+    z, r = torch.sigmoid(gates[:, :F]), torch.sigmoid(gates[:, F:])
+    n = torch.tanh(Fn.group_norm(Fn.conv2d(cat(x_in, es, r * hs), P["W2"], P["b2"]), F // 32, P["g2"], P["be2"], eps))
+    out = (1 - z) * hs + z * n
+    (out * dout.double()).sum().backward()
+    g = {"dh": hs.grad, "dW1": P["W1"].grad, "db1": P["b1"].grad, "dg1": P["g1"].grad, "dbe1": P["be1"].grad,
+         "dW2": P["W2"].grad, "db2": P["b2"].grad, "dg2": P["g2"].grad, "dbe2": P["be2"].grad}
+    if xs is not None:
+        g["dx"] = xs.grad
+    if es is not None:
+        g["de"] = es.grad
+    return out.detach(), g
+
+
+@pytest.mark.parametrize("name,I,F,skip,with_x,H,W", [
+    ("decoder.rnn1", 96, 64, 1, 1, 500, 500),        # K = 224: the largest GEMMs of the network
+    ("encoder.rnn1", 16, 64, 0, 1, 500, 500),
+    ("decoder.rnn2", 96, 96, 1, 1, 250, 250),        # 192 x 288 weight gradient
+    ("decoder.rnn3", 96, 96, 1, 0, 125, 125),        # x = None, odd plane
+    ("encoder.rnn3", 96, 96, 0, 1, 125, 125),
+])
+def test_cell_backward_full_size(dev, name, I, F, skip, with_x, H, W):
+    from urnn_amd import ops, train_ops
+    gen = torch.Generator(device=dev).manual_seed(1000 + I + F + H)
+    K = I + (2 * F if skip else F)
+    W1, W2 = _rand(gen, 2 * F, K, 1, 1, scale=K ** -0.5, dev=dev), _rand(gen, F, K, 1, 1, scale=K ** -0.5, dev=dev)
+    b1, b2, be1, be2 = (_rand(gen, n, scale=0.1, dev=dev) for n in (2 * F, F, 2 * F, F))
+    g1 = (torch.rand(2 * F, generator=gen, device=dev) + 0.5).contiguous()
+    g2 = (torch.rand(F, generator=gen, device=dev) + 0.5).contiguous()
+    x = _rand(gen, 1, I, H, W, dev=dev) if with_x else None
+    e = _rand(gen, 1, F, H, W, scale=0.5, dev=dev) if skip else None
+    h = _rand(gen, 1, F, H, W, scale=0.5, dev=dev)
+    dout = _rand(gen, 1, F, H, W, dev=dev)
+    packed = ops.pack_gru(W1, b1, W2, b2, I, F, bool(skip))
+    out = ops.gru_cell(x, e, h, packed, g1, be1, g2, be2, I)
+    got = train_ops.gru_cell_backward(x, e, h, W1, W2, g1, g2, dout, I)
+    want_out, want = _cell64(x, e, h, W1, b1, g1, be1, W2, b2, g2, be2, dout)
+    assert_close(out.cpu().numpy(), want_out.cpu().numpy(), 1e-4, f"{name}: forward")
+    for k, ref in want.items():
+        assert_close(got[k].reshape(ref.shape).cpu().numpy(), ref.cpu().numpy(), GRAD_TOL, f"{name} {H}x{W}: {k}")
+
+
+@pytest.mark.parametrize("name,Cin,Cout,pool,H,W", [("encoder.stage1", 63, 16, 0, 500, 500), ("encoder.stage2", 64, 64, 1, 500, 500),
+                                                    ("encoder.stage3", 96, 96, 1, 250, 250), ("decoder.stage1", 64, 16, 0, 500, 500)])
+def test_stage_conv_backward_full_size(dev, name, Cin, Cout, pool, H, W):
+    from urnn_amd import ops, train_ops
+    gen = torch.Generator(device=dev).manual_seed(2000 + Cin + Cout + H)
+    w, b = _rand(gen, Cout, Cin, 1, 1, scale=Cin ** -0.5, dev=dev), _rand(gen, Cout, scale=0.1, dev=dev)
+    x = _rand(gen, 1, Cin, H, W, dev=dev)
+    y = ops.stage_conv(x, ops.pack_conv(w, b), Cout, bool(pool))
+    xs, ws, bs = (t.double().clone().requires_grad_(True) for t in (x, w, b))
+    u = Fn.conv2d(xs, ws, bs)
+    ref = Fn.leaky_relu(u, 0.2)
+    ref = Fn.avg_pool2d(ref, 2) if pool else ref
+    dy = _off_kink(_rand(gen, *y.shape, dev=dev), u, bool(pool))
+    dx, dw, db = train_ops.stage_conv_backward(x, w, b, dy, bool(pool))
+    (ref * dy.double()).sum().backward()
+    assert_close(y.cpu().numpy(), ref.detach().cpu().numpy(), 1e-4, f"{name}: forward")
+    for k, a, r in (("dx", dx, xs.grad), ("dw", dw, ws.grad), ("db", db, bs.grad)):
+        assert_close(a.cpu().numpy(), r.cpu().numpy(), GRAD_TOL, f"{name} {H}x{W}: {k}")
+
+
+@pytest.mark.parametrize("name,Cin,Cout,H,W", [("decoder.stage2", 96, 96, 250, 250), ("decoder.stage3", 96, 96, 125, 125)])
+def test_deconv_backward_full_size(dev, name, Cin, Cout, H, W):
+    from urnn_amd import ops, train_ops
+    gen = torch.Generator(device=dev).manual_seed(3000 + Cin + H)
+    w, b = _rand(gen, Cin, Cout, 2, 2, scale=Cin ** -0.5, dev=dev), _rand(gen, Cout, scale=0.1, dev=dev)
+    x = _rand(gen, 1, Cin, H, W, dev=dev)
+    y = ops.deconv2x2(x, ops.pack_deconv(w, b), Cout)
+    xs, ws, bs = (t.double().clone().requires_grad_(True) for t in (x, w, b))
+    u = Fn.conv_transpose2d(xs, ws, bs, stride=2)
+    ref = Fn.leaky_relu(u, 0.2)
+    dy = _off_kink(_rand(gen, *y.shape, dev=dev), u)
+    dx, dw, db = train_ops.deconv2x2_backward(x, w, y, dy)
+    (ref * dy.double()).sum().backward()
+    assert_close(y.cpu().numpy(), ref.detach().cpu().numpy(), 1e-4, f"{name}: forward")
+    for k, a, r in (("dx", dx, xs.grad), ("dw", dw, ws.grad), ("db", db, bs.grad)):
+        assert_close(a.cpu().numpy(), r.cpu().numpy(), GRAD_TOL, f"{name} {H}x{W}: {k}")
+
+
+def test_head_backward_full_size(dev):
+    """YOLOXHead (flood_head.py:131-202) at 500x500: BaseConv = conv1x1 (no bias) + LayerNorm([16,H,W]) + SiLU; the gradient
+    flows through the regression branch only (the mask and classify_outputs are comparisons).  The float64 restatement uses
+    the HIP forward's own wet/dry mask and LeakyReLU branch of the prediction layer, so that threshold / kink flips of single
+    pixels (conftest.masked_parity) cannot enter the comparison."""
+    from urnn_amd import ops, train_ops
+    H = W = 500
+    C = 16
+    gen = torch.Generator(device=dev).manual_seed(4242)
+    conv_w = _rand(gen, 5, C, C, scale=0.4, dev=dev)
+    ln_w = (torch.rand(5, C, H, W, generator=gen, device=dev) + 0.5).contiguous()
+    ln_b = _rand(gen, 5, C, H, W, scale=0.1, dev=dev)
+    cls_w, cls_b, reg_w, reg_b = _rand(gen, C, scale=0.3, dev=dev), _rand(gen, 1, scale=0.1, dev=dev), _rand(gen, C, scale=0.3, dev=dev), \
+        _rand(gen, 1, scale=0.1, dev=dev)
+    feat = _rand(gen, 1, C, H, W, dev=dev)
+    dout = _rand(gen, 1, H, W, dev=dev)
+    masked, cls, raw = ops.head(feat, conv_w, ln_w, ln_b, cls_w, cls_b, reg_w, reg_b, 0.5, want_raw=True)
+    g = train_ops.head_backward(feat, conv_w, ln_w, ln_b, reg_w, raw, cls, dout, 0.5)
+
+    d = lambda t: t.double().clone().requires_grad_(True)
+    f64, cw, lw, lb, rw, rb = d(feat), d(conv_w), d(ln_w), d(ln_b), d(reg_w), d(reg_b)
+
+    def base(x, i):
+        u = Fn.conv2d(x, cw[i].reshape(C, C, 1, 1))
+        return Fn.silu(Fn.layer_norm(u, (C, H, W), lw[i], lb[i], 1e-5))
+    q = base(base(base(f64, 0), 3), 4)
+    pre = Fn.conv2d(q, rw.reshape(1, C, 1, 1), rb)[:, 0]
+    slope = torch.where(raw > 0, 1.0, 0.2).double()            # the branch the fp32 forward took
+    reg = pre * slope
+    wet = (cls >= 0.5).double()
+    assert_close((reg * wet).detach().cpu().numpy(), masked.cpu().numpy(), 1e-4, "head forward")
+    (reg * wet * dout.double()).sum().backward()
+    assert_close(g["dfeat"].cpu().numpy(), f64.grad.cpu().numpy(), GRAD_TOL, "head 500x500: dfeat")
+    for i, n in ((0, "stems"), (3, "reg_convs.0"), (4, "reg_convs.1")):
+        assert_close(g["dconv_w"][i].cpu().numpy(), cw.grad[i].cpu().numpy(), GRAD_TOL, f"head 500x500: d{n}.conv")
+        assert_close(g["dln_w"][i].cpu().numpy(), lw.grad[i].cpu().numpy(), GRAD_TOL, f"head 500x500: d{n}.ln.weight")
+        assert_close(g["dln_b"][i].cpu().numpy(), lb.grad[i].cpu().numpy(), GRAD_TOL, f"head 500x500: d{n}.ln.bias")
+    for i in (1, 2):
+        assert float(g["dconv_w"][i].abs().max()) == 0.0 and float(g["dln_w"][i].abs().max()) == 0.0
+    assert_close(g["dreg_w"].cpu().numpy(), rw.grad.cpu().numpy(), GRAD_TOL, "head 500x500: dreg_w")
+    assert_close(g["dreg_b"].cpu().numpy(), rb.grad.cpu().numpy(), GRAD_TOL, "head 500x500: dreg_b")
