@@ -165,6 +165,30 @@ def test_full_size_cell_vs_oracle(dev):
     assert_close(got, ref, 1e-4, "dec1 cell at 500x500")
 
 
+def test_full_size_rollout_vs_oracle(dev):
+    """BASELINE config 2 (500x500, C = 63) end to end: three frames of the product's default schedule (hipGraph, two
+    overlapped chains, input assembly folded into the first stage) against the CPU oracle -- every state, cls, the pre-mask
+    regression, and the masked depth where the oracle is not within 1e-5 of the threshold."""
+    import urnn_amd.weights as uw
+    from oracle import oracle as orc
+    from urnn_amd.rollout import RolloutEngine
+    H = W = 500
+    nums, T = 30, 3
+    net, sd = make_net(H, W, 2 * nums + 3, 0, dev)
+    ev = uw.make_event(T, H, W, 6.0, seed=42)
+    eng = RolloutEngine(net, H, W, nums, 6.0, 250.0, max_frames=T, keep_raw=True)
+    frames = eng.rollout(ev).cpu().numpy()
+    ref_frames, ref_states, aux = orc.rollout(orc.OracleNet(sd), ev, T, nums, 6.0, 250.0, want_aux=True)
+    ref_raw = np.stack([a["reg_raw"] for a in aux])
+    ref_cls = np.stack([a["cls"] for a in aux])
+    assert_close(eng.out_raw[:T].cpu().numpy(), ref_raw, 1e-4, "pre-mask reg at 500x500")
+    assert_close(eng.out_cls[:T].cpu().numpy(), ref_cls, 1e-4, "cls at 500x500")
+    for k, (got, ref) in enumerate(zip(eng.final_states(), ref_states)):
+        assert_close(got.cpu().numpy(), ref, 1e-4, f"final state {k} at 500x500")
+    excluded = masked_parity(frames, ref_frames, ref_cls, ref_raw, 1e-4)
+    assert excluded < 1e-4 * frames.size
+
+
 def test_batched_spatial_rollout_vs_oracle(dev):
     """Two events with spatial rainfall, ragged (non-square, tail tiles) grid, against the CPU oracle over T=5 frames."""
     import urnn_amd.weights as uw
