@@ -449,7 +449,7 @@ static int dx_gemm(const float *dy, const float *w, float *wt, float *packed, fl
 
 extern "C" int urnn_gru_cell_backward_f32(const float *x, const float *e, const float *h, const float *W1, const float *W2,
                                           const float *gn1_w, const float *gn2_w, const void *fwd_workspace, const float *dh_out,
-                                          float *dx, float *de, float *dh, float *dW1, float *db1, float *dgn1_w, float *dgn1_b,
+                                          const float *dh_out2, float *dx, float *de, float *dh, float *dW1, float *db1, float *dgn1_w, float *dgn1_b,
                                           float *dW2, float *db2, float *dgn2_w, float *dgn2_b, float *bwd_packed, int repack,
                                           void *workspace, size_t workspace_bytes, int B, int I, int F, int H, int W, int accumulate,
                                           void *stream)
@@ -487,7 +487,7 @@ extern "C" int urnn_gru_cell_backward_f32(const float *x, const float *e, const 
     }
 
     // 1. blend: dy2 (normalised candidate), dy1[:, :F] (normalised update gate), dh = dout * (1 - z)
-    CHECK_HIP(urnn_train_blend_bwd(dh_out, fw.g1, fw.cx, h, fw.ss1, fw.ss2, fw.st1, fw.st2, ws.dy2, ws.dy1, dh, ws.chpart, ws.chpart2, B, F,
+    CHECK_HIP(urnn_train_blend_bwd(dh_out, dh_out2, fw.g1, fw.cx, h, fw.ss1, fw.ss2, fw.st1, fw.st2, ws.dy2, ws.dy1, dh, ws.chpart, ws.chpart2, B, F,
                                    Pi, st), "blend backward");
     // 2. GroupNorm of the candidate: dy2 -> dc (in place), dgamma2 / dbeta2
     CHECK_HIP(urnn_train_gn_backward(ws.dy2, fw.cx, fw.st2, gn2_w, B, F, Pi, ws.chpart2, ws.sums, ws.coef, dgn2_w, dgn2_b, accumulate, 1, st),
@@ -836,18 +836,22 @@ extern "C" int urnn_head_backward_f32(const float *feat, const float *conv_w, co
     }
     const int blk[3] = {4, 3, 0};            // reg_convs[1], reg_convs[0], stems
     const int uslot[3] = {2, 1, 0};          // pre-norm activations v2, v1, u0
+    // The gradient ping-pongs between ws.ds and dfeat (a GEMM's output may not alias its input): ds -> dfeat -> ds -> dfeat,
+    // so the third layer's input gradient lands in dfeat, where the caller wants it.
+    float *cur = ws.ds, *other = dfeat;
     for (int l = 0; l < 3; ++l) {
         const int k = blk[l];
-        CHECK_HIP(urnn_train_head_ln_bwd(ws.ds, ws.save + uslot[l] * plane, ln_w + k * CP, ln_b + k * CP, fw.stats + (size_t)k * B * 2, B, Pi,
+        CHECK_HIP(urnn_train_head_ln_bwd(cur, ws.save + uslot[l] * plane, ln_w + k * CP, ln_b + k * CP, fw.stats + (size_t)k * B * 2, B, Pi,
                                          dln_w + k * CP, dln_b + k * CP, accumulate, ws.partial, ws.coef, st), "head: LayerNorm backward");
         const float *in = l == 2 ? feat : ws.save + (size_t)(3 + (1 - l)) * plane;      // layer input: q1, t, feat
         const float *seg[3] = {in, nullptr, nullptr};
         const int segC[3] = {16, 0, 0};
-        CHECK_HIP(urnn_train_wgrad(ws.ds, seg, segC, B, 16, 16, Pi, ws.wpart, dconv_w + k * 256, nullptr, accumulate, st), "head: conv weights");
-        // input gradient W^T . du: for the inner layers it becomes the next ds; it may not alias the GEMM input, so go through dfeat
-        int rc = dx_gemm(ws.ds, conv_w + k * 256, ws.wt, ws.pkt, dfeat, B, 16, 16, H, W, st, "head: input gradient");
+        CHECK_HIP(urnn_train_wgrad(cur, seg, segC, B, 16, 16, Pi, ws.wpart, dconv_w + k * 256, nullptr, accumulate, st), "head: conv weights");
+        int rc = dx_gemm(cur, conv_w + k * 256, ws.wt, ws.pkt, other, B, 16, 16, H, W, st, "head: input gradient");
         if (rc) return rc;
-        if (l < 2) CHECK_HIP(hipMemcpyAsync(ws.ds, dfeat, plane * sizeof(float), hipMemcpyDeviceToDevice, st), "head: hand-over");
+        float *t = cur;
+        cur = other;
+        other = t;
     }
     if (!accumulate) {   // the classification branch receives no gradient
         for (int k = 1; k <= 2; ++k) {

@@ -93,6 +93,46 @@ __global__ void gn_bwd_coef_kernel(const double *__restrict__ sums, const float 
     }
 }
 
+// The two kernels above in one launch, for partials that the producer of dy already wrote (blend / reset-gate backward): one
+// wave per 32-channel group; lane (j, half) adds every second chunk of channel g*32 + j in double, the halves are joined, the
+// group coefficients come from an xor butterfly over the 32 channels (fixed order: bit-reproducible).
+__global__ __launch_bounds__(64) void gn_bwd_sums_coef_kernel(const float *__restrict__ partial, int nchunk, const float *__restrict__ gamma,
+                                                              int B, int C, double count, float *__restrict__ coef,
+                                                              float *__restrict__ dgamma, float *__restrict__ dbeta, int accumulate)
+{
+    const int g = blockIdx.x, lane = threadIdx.x, j = lane & 31, hf = lane >> 5, G = C / 32;
+    const int c = g * 32 + j;
+    const double gm = (double)gamma[c];
+    double d1 = 0.0, d2 = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const float *pp = partial + ((size_t)b * C + c) * nchunk * 2;
+        double s1 = 0.0, s2 = 0.0;
+        for (int t = hf; t < nchunk; t += 2) {
+            const f32x2 v = *reinterpret_cast<const f32x2 *>(pp + 2 * t);
+            s1 += (double)v.x;
+            s2 += (double)v.y;
+        }
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        d1 += s1;
+        d2 += s2;
+        double m1 = gm * s1, m2 = gm * s2;
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) {
+            m1 += __shfl_xor(m1, m, 64);
+            m2 += __shfl_xor(m2, m, 64);
+        }
+        if (lane == 0) {
+            coef[((size_t)b * G + g) * 2] = (float)(m1 / count);
+            coef[((size_t)b * G + g) * 2 + 1] = (float)(m2 / count);
+        }
+    }
+    if (hf == 0) {
+        dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)d1;
+        dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)d2;
+    }
+}
+
 // dv = rstd * (gamma * dy - m1 - xhat * m2), in place over dy.  grid (chunks, B*C)
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(float *dy, const float *__restrict__ v, const float *__restrict__ stat,
                                                            const float *__restrict__ coef, const float *__restrict__ gamma, int C, int P)
@@ -136,7 +176,7 @@ __device__ __forceinline__ void block_partials(float (&v)[4], int n, float *dst0
 
 // Also emits, per (plane, blockIdx.x), the partial sums the two GroupNorm backward passes need (sum dy, sum dy * xhat):
 // part2[(b*F + f)][gx][2] for the candidate, part1[(b*2F + f)][gx][2] for the update-gate half of the gates.
-__global__ __launch_bounds__(256) void blend_bwd_kernel(const float *__restrict__ dout, const float *__restrict__ g1, const float *__restrict__ c,
+__global__ __launch_bounds__(256) void blend_bwd_kernel(const float *__restrict__ dout, const float *__restrict__ dout2, const float *__restrict__ g1, const float *__restrict__ c,
                                                         const float *__restrict__ h, const float *__restrict__ ss1, const float *__restrict__ ss2,
                                                         const float *__restrict__ st1, const float *__restrict__ st2, float *__restrict__ dy2,
                                                         float *__restrict__ dy1, float *__restrict__ dh, float *__restrict__ part1,
@@ -148,13 +188,14 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(const float *__restrict_
     const float mu1 = st1[((size_t)b * (2 * F / 32) + f / 32) * 2], rs1 = st1[((size_t)b * (2 * F / 32) + f / 32) * 2 + 1];
     const float mu2 = st2[((size_t)b * (F / 32) + f / 32) * 2], rs2 = st2[((size_t)b * (F / 32) + f / 32) * 2 + 1];
     const float *gz = g1 + ((size_t)b * 2 * F + f) * P, *cc = c + (size_t)bc * P, *hh = h + (size_t)bc * P, *dd = dout + (size_t)bc * P;
+    const float *dd2 = dout2 ? dout2 + (size_t)bc * P : nullptr;      // dL/dh' may arrive as two terms (layer above + next timestep)
     float *o2 = dy2 + (size_t)bc * P, *o1 = dy1 + ((size_t)b * 2 * F + f) * P, *oh = dh + (size_t)bc * P;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};       // sum dyz, sum dyz * xhat1, sum dy2, sum dy2 * xhat2
     for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += gridDim.x * 256) {
         const float gv = gz[p], cv = cc[p];
         const float z = 1.0f / (1.0f + expf(-(gv * s1 + t1)));
         const float n = tanhf(cv * s2 + t2);
-        const float d = dd[p];
+        const float d = dd2 ? dd[p] + dd2[p] : dd[p];
         const float a2 = d * z * (1.0f - n * n);
         const float a1 = d * (n - hh[p]) * z * (1.0f - z);
         o2[p] = a2;
@@ -504,23 +545,24 @@ hipError_t urnn_train_gn_backward(float *dy, const float *v, const float *stat, 
                                   double *sums, float *coef, float *dgamma, float *dbeta, int accumulate, int have_partials, hipStream_t st)
 {
     if (have_partials) {
-        hipLaunchKernelGGL(chan_finalize_kernel, dim3(B * C), dim3(64), 0, st, partial, (int)plane_grid(P, 1).x, sums);
+        hipLaunchKernelGGL(gn_bwd_sums_coef_kernel, dim3(C / 32), dim3(64), 0, st, partial, (int)plane_grid(P, 1).x, gamma, B, C,
+                           32.0 * (double)P, coef, dgamma, dbeta, accumulate);
     } else {
         hipError_t e = urnn_train_chan_sums(dy, (long)C * P, v, (long)C * P, stat, B, C, P, partial, sums, st);
         if (e != hipSuccess) return e;
+        const int n = B * (C / 32) > C ? B * (C / 32) : C;
+        hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3((n + 127) / 128), dim3(128), 0, st, sums, gamma, B, C, 32.0 * (double)P, coef, dgamma,
+                           dbeta, accumulate);
     }
-    const int n = B * (C / 32) > C ? B * (C / 32) : C;
-    hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3((n + 127) / 128), dim3(128), 0, st, sums, gamma, B, C, 32.0 * (double)P, coef, dgamma,
-                       dbeta, accumulate);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, plane_grid(P, B * C), dim3(256), 0, st, dy, v, stat, coef, gamma, C, P);
     return hipGetLastError();
 }
 
-hipError_t urnn_train_blend_bwd(const float *dout, const float *g1, const float *c, const float *h, const float *ss1, const float *ss2,
+hipError_t urnn_train_blend_bwd(const float *dout, const float *dout2, const float *g1, const float *c, const float *h, const float *ss1, const float *ss2,
                                 const float *st1, const float *st2, float *dy2, float *dy1, float *dh, float *part1, float *part2, int B,
                                 int F, int P, hipStream_t st)
 {
-    hipLaunchKernelGGL(blend_bwd_kernel, plane_grid(P, B * F), dim3(256), 0, st, dout, g1, c, h, ss1, ss2, st1, st2, dy2, dy1, dh, part1, part2,
+    hipLaunchKernelGGL(blend_bwd_kernel, plane_grid(P, B * F), dim3(256), 0, st, dout, dout2, g1, c, h, ss1, ss2, st1, st2, dy2, dy1, dh, part1, part2,
                        F, P);
     return hipGetLastError();
 }

@@ -9,15 +9,15 @@ from ._lib import check, lib
 _BWD_SLOT = 7   # workspace slot of the backward scratch (the forward's scratch must survive until the backward has run)
 
 
-def gru_cell_backward(x, e, h, W1, W2, gn1_w, gn2_w, dh_out, I, grads=None, accumulate=False, packed=None):
+def gru_cell_backward(x, e, h, W1, W2, gn1_w, gn2_w, dh_out, I, grads=None, accumulate=False, packed=None, dh_out2=None):
     """Gradients of one cell step.  Must directly follow ``ops.gru_cell(x, e, h, ...)`` on the same inputs (same workspace
     slot, nothing in between): the forward leaves the raw gates / candidate and the GroupNorm statistics in its workspace.
     W1 (2F,K[,1,1]) / W2 (F,K[,1,1]): conv weights in the reference layout.  Returns a dict with dx, de (when given), dh and
     dW1, db1, dg1, dbe1, dW2, db2, dg2, dbe2; pass ``grads`` (the dict of a previous call) with ``accumulate=True`` to add
     the parameter gradients of another timestep.  ``packed``: a one-element list the caller keeps per cell for the packed
     weights of the input-gradient GEMMs -- filled on the first call, reused until the caller empties it (after an optimizer
-    step); None: packed on every call."""
-    ops._dev_check(x, e, h, W1, W2, gn1_w, gn2_w, dh_out)
+    step); None: packed on every call.  ``dh_out2``: an optional second term of dL/dh' (added on the fly)."""
+    ops._dev_check(x, e, h, W1, W2, gn1_w, gn2_w, dh_out, dh_out2)
     B, F, H, W = h.shape
     K = I + (F if e is not None else 0) + F
     if W1.numel() != 2 * F * K or W2.numel() != F * K:
@@ -52,7 +52,8 @@ def gru_cell_backward(x, e, h, W1, W2, gn1_w, gn2_w, dh_out, I, grads=None, accu
     else:
         pk = packed[0]
     p = ops._ptr
-    check(L.urnn_gru_cell_backward_f32(p(x), p(e), p(h), p(W1), p(W2), p(gn1_w), p(gn2_w), p(fwd), p(dh_out), p(g["dx"]), p(g["de"]),
+    check(L.urnn_gru_cell_backward_f32(p(x), p(e), p(h), p(W1), p(W2), p(gn1_w), p(gn2_w), p(fwd), p(dh_out), p(dh_out2), p(g["dx"]),
+                                       p(g["de"]),
                                        p(g["dh"]), p(g["dW1"]), p(g["db1"]), p(g["dg1"]), p(g["dbe1"]), p(g["dW2"]), p(g["db2"]),
                                        p(g["dg2"]), p(g["dbe2"]), p(pk), int(repack), p(ws), ws.numel(), B, I, F, H, W,
                                        int(bool(accumulate)), ops._stream()), "urnn_gru_cell_backward_f32")

@@ -86,7 +86,9 @@ class WindowGradients:
             G[key + ".weight"], G[key + ".bias"] = dw, db
             return dx
 
-        def cell_bwd(k, name, mod, x, e, h, dout_h):
+        def cell_bwd(k, name, mod, x, e, h, dout_h, dout_h2=None):
+            if dout_h is None:
+                dout_h, dout_h2 = dout_h2, None
             c1, g1, c2, g2 = _cell_params(mod)
             ops.WORKSPACE.use_slot(base + k)
             names = {"dW1": "conv1.0.weight", "db1": "conv1.0.bias", "dg1": "conv1.1.weight", "dbe1": "conv1.1.bias",
@@ -96,7 +98,8 @@ class WindowGradients:
                          G[f"{name}.{v}"].reshape(G[f"{name}.{v}"].shape[0], -1)) for k_, v in names.items()} if have else None
             g = train_ops.gru_cell_backward(x, e, h, c1.weight.detach(), c2.weight.detach(), g1.weight.detach(), g2.weight.detach(),
                                             dout_h.contiguous(), mod.input_channels, grads=prev, accumulate=acc and have,
-                                            packed=self._bwd_packed.setdefault(name, []))
+                                            packed=self._bwd_packed.setdefault(name, []),
+                                            dh_out2=None if dout_h2 is None else dout_h2.contiguous())
             for k_, v in names.items():
                 ref = dict(mod.named_parameters())[v]
                 G[f"{name}.{v}"] = g[k_].reshape(ref.shape)
@@ -111,20 +114,15 @@ class WindowGradients:
                                      S["raw"], S["cls"], dout.contiguous(), head.cls_thred, grads=hg_prev, accumulate=hg_prev is not None)
         G["_head"] = hg
         ops.WORKSPACE.use_slot(0)
-        # decoder
-        g_d3 = add(conv_bwd("decoder.stage1", dec.stage1, S["d3"], hg["dfeat"]), dD3)
-        du2, dE1_dec, dD3n = cell_bwd(5, "decoder.rnn1", dec.rnn1, S["u2"], S["e1"], d3p, g_d3)
-        g_d2 = add(deconv_bwd("decoder.stage2", dec.stage2, S["d2"], S["u2"], du2), dD2)
-        du3, dE2_dec, dD2n = cell_bwd(4, "decoder.rnn2", dec.rnn2, S["u3"], S["e2"], d2p, g_d2)
-        g_d1 = add(deconv_bwd("decoder.stage3", dec.stage3, S["d1"], S["u3"], du3), dD1)
-        _, dE3_dec, dD1n = cell_bwd(3, "decoder.rnn3", dec.rnn3, None, S["e3"], d1p, g_d1)
+        # decoder.  A state's gradient has two sources -- the layer above in this timestep and the same cell in the next
+        # timestep; the cell backward takes them as two terms and adds on the fly (three terms: one torch add)
+        du2, dE1_dec, dD3n = cell_bwd(5, "decoder.rnn1", dec.rnn1, S["u2"], S["e1"], d3p, conv_bwd("decoder.stage1", dec.stage1, S["d3"], hg["dfeat"]), dD3)
+        du3, dE2_dec, dD2n = cell_bwd(4, "decoder.rnn2", dec.rnn2, S["u3"], S["e2"], d2p, deconv_bwd("decoder.stage2", dec.stage2, S["d2"], S["u2"], du2), dD2)
+        _, dE3_dec, dD1n = cell_bwd(3, "decoder.rnn3", dec.rnn3, None, S["e3"], d1p, deconv_bwd("decoder.stage3", dec.stage3, S["d1"], S["u3"], du3), dD1)
         # encoder
-        g_e3 = add(dE3_dec, dE3)
-        da3, _, dE3n = cell_bwd(2, "encoder.rnn3", enc.rnn3, S["a3"], None, e3p, g_e3)
-        g_e2 = add(add(conv_bwd("encoder.stage3", enc.stage3, S["e2"], da3), dE2_dec), dE2)
-        da2, _, dE2n = cell_bwd(1, "encoder.rnn2", enc.rnn2, S["a2"], None, e2p, g_e2)
-        g_e1 = add(add(conv_bwd("encoder.stage2", enc.stage2, S["e1"], da2), dE1_dec), dE1)
-        da1, _, dE1n = cell_bwd(0, "encoder.rnn1", enc.rnn1, S["a1"], None, e1p, g_e1)
+        da3, _, dE3n = cell_bwd(2, "encoder.rnn3", enc.rnn3, S["a3"], None, e3p, dE3_dec, dE3)
+        da2, _, dE2n = cell_bwd(1, "encoder.rnn2", enc.rnn2, S["a2"], None, e2p, add(conv_bwd("encoder.stage3", enc.stage3, S["e2"], da3), dE2_dec), dE2)
+        da1, _, dE1n = cell_bwd(0, "encoder.rnn1", enc.rnn1, S["a1"], None, e1p, add(conv_bwd("encoder.stage2", enc.stage2, S["e1"], da2), dE1_dec), dE1)
         conv_bwd("encoder.stage1", enc.stage1, S["x_in"], da1)
         return [dE1n, dE2n, dE3n, dD1n, dD2n, dD3n]
 
