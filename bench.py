@@ -149,6 +149,9 @@ def bench_train(args, dev, dist, world, rank):
     from urnn_amd.distributed import max_over_ranks
     elapsed = max_over_ranks(elapsed, device=dev if args.dist_backend == "nccl" else None)
     steps = nwin * S * B                                            # one step = one training timestep of one event
+    gnorm = float(tr.last["clip"][1])
+    if not (np.isfinite(gnorm) and np.isfinite(float(loss[0]))):
+        sys.exit(f"bench.py --mode train: non-finite loss / gradient norm ({float(loss[0])}, {gnorm})")
     if rank == 0:
         gflop = algorithmic_work(H, W, 2 * nums + 3) * 3.0          # forward + dX + dW
         print(json.dumps({
@@ -159,7 +162,7 @@ def bench_train(args, dev, dist, world, rank):
                                    f"{B} event(s) per GPU, Adam lr 1e-4, grad clip 1.0", "parallelism": f"DDP x{world} (flat-buffer mean all-reduce)"
                        if world > 1 else "single GPU"},
             "gflop_per_step": gflop, "step_mfma_frac": steps / elapsed * gflop / 1e3 / PEAK_MFMA_F32_TFLOPS,
-            "loss": float(loss[0]), "grad_norm": float(tr.last["clip"][1]),
+            "loss": float(loss[0]), "grad_norm": gnorm,
             "roofline": None, "cpu_baseline": None,
             "note": "training path (DESIGN.md 6a); the BASELINE metric is the default --mode infer"}))
     if dist is not None:
@@ -209,6 +212,25 @@ def bench_strips(args, dev, dist, world, rank):
         dist.destroy_process_group()
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-run this command as N ranks, one per GPU, the way the reference is
+    started (`torchrun --nproc_per_node=N`, README.md:415-422).  Fails loudly when the node has fewer than N GPUs."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    share = "--share-gpu" in sys.argv
+    if have < n and not share:
+        sys.exit(f"bench.py: --gpus {n} needs {n} GPUs, this node shows {have}")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: launching " + " ".join(cmd), file=sys.stderr)
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -230,22 +252,32 @@ def main():
     ap.add_argument("--seq-num", type=int, default=4, help="train mode: timesteps per SWP window")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)                      # plain `python bench.py --gpus N`: become N ranks (one per GPU)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    if world > 1 and not args.share_gpu and torch.cuda.device_count() < world:
+        sys.exit(f"bench.py: {world} ranks need {world} GPUs, this node shows {torch.cuda.device_count()} "
+                 "(one process per GPU; --share-gpu --dist-backend gloo is the single-GPU dry run)")
     dev = torch.device("cuda", 0 if args.share_gpu else local_rank)
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    if "WORLD_SIZE" in os.environ:                         # launched by torchrun (also with one rank: RCCL is exercised either way)
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI; used for the barrier + max-reduce only
+            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI; data path has no collective: barrier + max-reduce only
         else:
             dist.init_process_group("gloo")
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        # n_gpus in the result line is the size of a world the backend has CONFIRMED: every rank contributes a one
+        ones = torch.ones(1, device=dev if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        if int(ones.item()) != world or dist.get_world_size() != world:
+            sys.exit(f"bench.py: all_reduce over the {args.dist_backend} world returned {ones.item()} for WORLD_SIZE={world}")
+    if args.gpus != world and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
 
     import urnn_amd.weights as uw
     from urnn_amd.rollout import RolloutEngine

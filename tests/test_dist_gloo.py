@@ -46,3 +46,30 @@ def test_two_rank_event_sharding(tmp_path):
         seen += list(data[1:])
     assert set(seen) == set(range(num_events))          # every event processed
     assert len(seen) == 6                               # padded to a multiple of world, as DistributedSampler does
+
+
+def test_bench_self_launch_builds_torchrun_command(monkeypatch):
+    """`python bench.py --gpus N` (no launcher environment) re-runs itself as N ranks, one per GPU, like the reference's
+    `torchrun --nproc_per_node=N` (README.md:415-422); with fewer GPUs than ranks it refuses instead of printing n_gpus: 1."""
+    import subprocess
+    import sys
+
+    import pytest
+
+    import bench
+    calls = []
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: calls.append((cmd, env)) or 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2"])
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as exc:
+        bench.main()
+    assert exc.value.code == 0 and len(calls) == 1
+    cmd, env = calls[0]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    assert os.path.basename(cmd[cmd.index("--master-port") + 2]) == "bench.py" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(SystemExit) as exc:
+        bench.main()
+    assert "needs 4 GPUs" in str(exc.value.code) and len(calls) == 1

@@ -99,6 +99,41 @@ def test_gru_cell_shapes_vs_oracle(dev, I, F, skip, H, W, B, with_x):
     assert_close(got.cpu().numpy(), want, TOL, f"gru cell I={I} F={F} skip={skip} {H}x{W} B={B}")
 
 
+def test_norm_statistics_with_large_means(dev):
+    """GroupNorm (ConvRNN.py:94-104) / LayerNorm (network_blocks.py:93) statistics when the pre-norm activations sit far from
+    zero -- |mean| / std = 30, as a trained checkpoint's biases can make them -- against the oracle's two-pass double
+    statistics.  Raw fp32 (sum, sum of squares) partials lose the variance to cancellation here (rstd off by ~5e-4); the
+    kernels' partials are centred per tile (urnn_common.h tile_x2)."""
+    from oracle import oracle as orc
+    from urnn_amd import ops
+    rs = np.random.RandomState(77)
+    I, F, H, W, B = 16, 64, 96, 104, 2                    # 9984 pixels: 78 tiles of 128 pixels per (sample, group)
+    K = I + F
+    p = {"W1": rs.normal(0, 1 / np.sqrt(K), (2 * F, K)).astype(np.float32), "b1": (30.0 + rs.normal(0, 0.1, 2 * F)).astype(np.float32),
+         "g1": rs.uniform(0.5, 1.5, 2 * F).astype(np.float32), "be1": rs.normal(0, 0.1, 2 * F).astype(np.float32),
+         "W2": rs.normal(0, 1 / np.sqrt(K), (F, K)).astype(np.float32), "b2": (-30.0 + rs.normal(0, 0.1, F)).astype(np.float32),
+         "g2": rs.uniform(0.5, 1.5, F).astype(np.float32), "be2": rs.normal(0, 0.1, F).astype(np.float32)}
+    x = rs.normal(0, 1, (B, I, H, W)).astype(np.float32)
+    h = rs.normal(0, 0.5, (B, F, H, W)).astype(np.float32)
+    want = orc.gru_cell(x, None, h, p)
+    packed = ops.pack_gru(T(p["W1"].reshape(2 * F, K, 1, 1), dev), T(p["b1"], dev), T(p["W2"].reshape(F, K, 1, 1), dev), T(p["b2"], dev),
+                          I, F, False)
+    got = ops.gru_cell(T(x, dev), None, T(h, dev), packed, T(p["g1"], dev), T(p["be1"], dev), T(p["g2"], dev), T(p["be2"], dev), I)
+    assert_close(got.cpu().numpy(), want, TOL, "cell with pre-norm |mean|/std = 30")
+
+    C = 16
+    conv_w = (0.5 * np.eye(C)[None].repeat(5, 0) + rs.normal(0, 0.02, (5, C, C))).astype(np.float32)
+    hp = {"conv_w": conv_w, "ln_w": rs.uniform(0.5, 1.5, (5, C, H, W)).astype(np.float32), "ln_b": rs.normal(0, 0.1, (5, C, H, W)).astype(np.float32),
+          "cls_w": rs.normal(0, 0.3, (1, C)).astype(np.float32), "cls_b": rs.normal(0, 0.1, 1).astype(np.float32),
+          "reg_w": rs.normal(0, 0.3, (1, C)).astype(np.float32), "reg_b": rs.normal(0, 0.1, 1).astype(np.float32)}
+    feat = (30.0 + rs.normal(0, 0.5, (B, C, H, W))).astype(np.float32)       # stems conv output: mean ~15, std ~0.5
+    masked, cls, raw = orc.head(feat, hp)
+    gm, gc, gr = ops.head(T(feat, dev), T(hp["conv_w"], dev), T(hp["ln_w"], dev), T(hp["ln_b"], dev), T(hp["cls_w"].reshape(-1), dev),
+                          T(hp["cls_b"], dev), T(hp["reg_w"].reshape(-1), dev), T(hp["reg_b"], dev), 0.5, want_raw=True)
+    assert_close(gc.cpu().numpy(), cls, TOL, "head cls with pre-norm |mean|/std = 30")
+    assert_close(gr.cpu().numpy(), raw, TOL, "head raw with pre-norm |mean|/std = 30")
+
+
 def test_gru_cell_in_place(gnet, dev):
     g, net, _ = gnet
     x, h = T(g["enc1_x_B1"], dev), T(g["enc1_h_B1"], dev)

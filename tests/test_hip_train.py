@@ -30,8 +30,9 @@ def run_cell(dev, x, e, h, p, dout):
     W1, W2 = T(p["W1"].reshape(2 * F, K, 1, 1), dev), T(p["W2"].reshape(F, K, 1, 1), dev)
     packed = ops.pack_gru(W1, T(p["b1"], dev), W2, T(p["b2"], dev), I, F, e is not None)
     xs, es, hs = T(x, dev), T(e, dev), T(h, dev)
-    out = ops.gru_cell(xs, es, hs, packed, T(p["g1"], dev), T(p["be1"], dev), T(p["g2"], dev), T(p["be2"], dev), I)
-    g = train_ops.gru_cell_backward(xs, es, hs, W1, W2, T(p["g1"], dev), T(p["g2"], dev), T(dout, dev), I)
+    ws = ops.workspace(ops.gru_cell_workspace_bytes(hs.shape[0], F, hs.shape[2], hs.shape[3]), dev)     # forward scratch, read by the backward
+    out = ops.gru_cell(xs, es, hs, packed, T(p["g1"], dev), T(p["be1"], dev), T(p["g2"], dev), T(p["be2"], dev), I, ws=ws)
+    g = train_ops.gru_cell_backward(xs, es, hs, W1, W2, T(p["g1"], dev), T(p["g2"], dev), T(dout, dev), I, ws)
     return out.cpu().numpy(), {k: v.cpu().numpy() for k, v in g.items() if v is not None}
 
 
@@ -87,9 +88,11 @@ def test_cell_backward_accumulates_parameter_gradients_and_is_deterministic(dev)
     packed = ops.pack_gru(W1, b1, W2, b2, I, F, False)
     x, h, dout = mk(B, I, H, W), mk(B, F, H, W), mk(B, F, H, W)
 
+    ws = ops.workspace(ops.gru_cell_workspace_bytes(B, F, H, W), dev)
+
     def once(grads=None, acc=False):
-        ops.gru_cell(x, None, h, packed, g1, be1, g2, be2, I)
-        return train_ops.gru_cell_backward(x, None, h, W1, W2, g1, g2, dout, I, grads=grads, accumulate=acc)
+        ops.gru_cell(x, None, h, packed, g1, be1, g2, be2, I, ws=ws)
+        return train_ops.gru_cell_backward(x, None, h, W1, W2, g1, g2, dout, I, ws, grads=grads, accumulate=acc)
     a = {k: v.clone() for k, v in once().items() if v is not None}
     b = once()
     for k in a:
@@ -143,10 +146,11 @@ def test_head_backward_vs_reference_autograd(dev, layers):
     cls_w, cls_b = T(k("p_cls_preds.conv.weight").reshape(-1), dev), T(k("p_cls_preds.conv.bias"), dev)
     reg_w, reg_b = T(k("p_reg_preds.conv.weight").reshape(-1), dev), T(k("p_reg_preds.conv.bias"), dev)
     feat = T(k("f")[0], dev)                                   # (B=1,16,H,W)
-    masked, cls, raw = ops.head(feat, conv_w, ln_w, ln_b, cls_w, cls_b, reg_w, reg_b, 0.5, want_raw=True)
+    ws = ops.workspace(ops.head_workspace_bytes(*feat.shape), dev)
+    masked, cls, raw = ops.head(feat, conv_w, ln_w, ln_b, cls_w, cls_b, reg_w, reg_b, 0.5, want_raw=True, ws=ws)
     ref_out = k("out")[0]                                      # (1,2,H,W)
     assert_close(cls.cpu().numpy(), ref_out[:, 1], 1e-4, "head forward cls")
-    g = train_ops.head_backward(feat, conv_w, ln_w, ln_b, reg_w, raw, cls, T(k("dreg")[0], dev), 0.5)
+    g = train_ops.head_backward(feat, conv_w, ln_w, ln_b, reg_w, raw, cls, T(k("dreg")[0], dev), 0.5, ws)
     assert_close(g["dfeat"].cpu().numpy(), k("df")[0], GRAD_TOL, "head: dfeat")
     for i, n in enumerate(names):
         if not n.startswith("cls"):

@@ -77,8 +77,9 @@ def test_cell_backward_full_size(dev, name, I, F, skip, with_x, H, W):
     h = _rand(gen, 1, F, H, W, scale=0.5, dev=dev)
     dout = _rand(gen, 1, F, H, W, dev=dev)
     packed = ops.pack_gru(W1, b1, W2, b2, I, F, bool(skip))
-    out = ops.gru_cell(x, e, h, packed, g1, be1, g2, be2, I)
-    got = train_ops.gru_cell_backward(x, e, h, W1, W2, g1, g2, dout, I)
+    ws = ops.workspace(ops.gru_cell_workspace_bytes(1, F, H, W), dev)
+    out = ops.gru_cell(x, e, h, packed, g1, be1, g2, be2, I, ws=ws)
+    got = train_ops.gru_cell_backward(x, e, h, W1, W2, g1, g2, dout, I, ws)
     want_out, want = _cell64(x, e, h, W1, b1, g1, be1, W2, b2, g2, be2, dout)
     assert_close(out.cpu().numpy(), want_out.cpu().numpy(), 1e-4, f"{name}: forward")
     for k, ref in want.items():
@@ -139,8 +140,9 @@ def test_head_backward_full_size(dev):
         _rand(gen, 1, scale=0.1, dev=dev)
     feat = _rand(gen, 1, C, H, W, dev=dev)
     dout = _rand(gen, 1, H, W, dev=dev)
-    masked, cls, raw = ops.head(feat, conv_w, ln_w, ln_b, cls_w, cls_b, reg_w, reg_b, 0.5, want_raw=True)
-    g = train_ops.head_backward(feat, conv_w, ln_w, ln_b, reg_w, raw, cls, dout, 0.5)
+    ws = ops.workspace(ops.head_workspace_bytes(1, C, H, W), dev)
+    masked, cls, raw = ops.head(feat, conv_w, ln_w, ln_b, cls_w, cls_b, reg_w, reg_b, 0.5, want_raw=True, ws=ws)
+    g = train_ops.head_backward(feat, conv_w, ln_w, ln_b, reg_w, raw, cls, dout, 0.5, ws)
 
     d = lambda t: t.double().clone().requires_grad_(True)
     f64, cw, lw, lb, rw, rb = d(feat), d(conv_w), d(ln_w), d(ln_b), d(reg_w), d(reg_b)
@@ -164,3 +166,102 @@ def test_head_backward_full_size(dev):
         assert float(g["dconv_w"][i].abs().max()) == 0.0 and float(g["dln_w"][i].abs().max()) == 0.0
     assert_close(g["dreg_w"].cpu().numpy(), rw.grad.cpu().numpy(), GRAD_TOL, "head 500x500: dreg_w")
     assert_close(g["dreg_b"].cpu().numpy(), rb.grad.cpu().numpy(), GRAD_TOL, "head 500x500: dreg_b")
+
+
+def _bench_net(dev, H, W, C, seed=0):
+    import urnn_amd.weights as uw
+    from urnn_amd.net_config import load_net_config
+    from urnn_amd.networks import ED, get_network_params
+    sd = uw.make_state_dict(H, W, C, seed=seed)
+    ep, dp = get_network_params(False, H, W, C, load_net_config())
+    net = ED(False, ep, dp, 0.5, False, H, W)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return net.to(dev).eval(), sd
+
+
+def _train_inputs(dev, H, W, rain_max, frames, seed=7):
+    import urnn_amd.weights as uw
+    ev = uw.make_event(frames, H, W, rain_max, seed=42)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    label = torch.rand(1, frames, H, W, device=dev, generator=g) ** 3
+    label[label < 0.1] = 0
+    return ev, label
+
+
+def test_window_full_size(dev):
+    """One SWP window at BASELINE configs[3]'s grid (location1: 500x500, historical_nums 30 -> C = 63; main.py:598-768): four
+    timesteps from non-zero states through `WindowGradients.run`, every one of the 79 parameter gradients against float64
+    torch autograd of tests/torch_ref.py on the GPU (the restatement takes the fp32 path's LeakyReLU / wet-dry branches where
+    that path materialises the activation, so threshold pixels cannot enter), and everything finite."""
+    import torch_ref
+    from urnn_amd.dataset import event_to_device
+    from urnn_amd.training import WindowGradients
+    H = W = 500
+    nums, rain_max, cum_max, steps, t0 = 30, 6.0, 250.0, 4, 2
+    net, sd = _bench_net(dev, H, W, 2 * nums + 3)
+    ev_np, label = _train_inputs(dev, H, W, rain_max, t0 + steps)
+    ev = event_to_device(ev_np, dev)
+    wg = WindowGradients(net, H, W, nums, rain_max, cum_max)
+    states = None
+    from urnn_amd.general import initialize_states
+    states = [s.to(dev) for s in initialize_states(dev, H, W)]
+    for t in range(t0):                                   # gradient-free pre-roll: the window starts from real states
+        _, states = wg._forward_step(ev, t, states, 0)
+    start = [s.clone() for s in states]
+    out = wg.run(ev, label[:, t0:t0 + steps], t0, steps, states=[s.clone() for s in start])
+    torch.cuda.synchronize()
+    for name, gr in out["grads"].items():
+        assert bool(torch.isfinite(gr).all()), f"non-finite gradient in {name}"
+
+    # float64 autograd of the same window; branch decisions from the fp32 forward of each step
+    p = {k: torch.from_numpy(v).to(dev).double().requires_grad_(True) for k, v in sd.items()}
+    st64 = [s.double() for s in start]
+    regs, st_hip = [], [s.clone() for s in start]
+    for s in range(steps):
+        S, st_hip = wg._forward_step(ev, t0 + s, st_hip, 0)
+        hip = {k: S[k].double() for k in ("a1", "u3", "u2", "feat", "raw", "cls")}
+        masked, _, _, st64 = torch_ref.step(p, S["x_in"].double(), st64, H, W, hip=hip)
+        assert_close(masked.detach().cpu().numpy(), S["masked"].cpu().numpy(), 1e-4, f"step {s}: forward output")
+        regs.append(masked)
+    loss = torch_ref.wmse(torch.stack(regs, dim=1), label[:, t0:t0 + steps].double())
+    loss.backward()
+    assert float(out["loss"][1]) == pytest.approx(float(loss), rel=2e-4)
+    worst = ("", 0.0)
+    for name in sd:
+        ref = p[name].grad
+        got = out["grads"][name].double().reshape(p[name].shape)
+        if ref is None:                                   # classification branch: cut off by the wet/dry comparison
+            assert float(got.abs().max()) == 0.0, name
+            continue
+        scale = float(ref.abs().max())
+        err = float((got - ref).abs().max()) / max(scale, 1e-30)
+        worst = max(worst, (name, err), key=lambda t: t[1])
+        assert err <= 1e-3, (name, err, scale)            # the bar of the 16x16 window test (test_hip_train.py)
+    print("worst gradient at 500x500:", worst)
+
+
+def test_trainer_graph_equals_eager_full_size(dev):
+    """Three SWP windows of the training bench at 500x500 through `Trainer` with and without hipGraph capture: the clip
+    coefficient / gradient norm of every window is finite and the two paths agree bit for bit (round 1 printed
+    grad_norm = Infinity from the captured path: its memset nodes did not run on replay)."""
+    from urnn_amd.training import Trainer
+    H = W = 500
+    nums, rain_max, cum_max, S, nwin = 30, 6.0, 250.0, 4, 3
+    ev, label = _train_inputs(dev, H, W, rain_max, S * nwin)
+    res = {}
+    for graph in (False, True):
+        net, _ = _bench_net(dev, H, W, 2 * nums + 3)
+        tr = Trainer(net, H, W, nums, rain_max, cum_max, lr=1e-4, grad_clip=1.0, use_graph=graph)
+        states, clips = None, []
+        for w in range(nwin):
+            loss, states = tr.train_window(ev, label[:, w * S:(w + 1) * S], w * S, S, states)
+            torch.cuda.synchronize()
+            clip = tr.last["clip"].cpu()
+            assert bool(torch.isfinite(clip).all()) and 0.0 < float(clip[1]) < 1e3, (graph, w, clip)
+            assert bool(torch.isfinite(tr.gflat).all()), (graph, w)
+            clips.append(clip.clone())
+        res[graph] = (clips, tr.flat.clone())
+        del tr, net
+    for a, b in zip(res[False][0], res[True][0]):
+        assert torch.equal(a, b), (a, b)
+    assert torch.equal(res[False][1], res[True][1])

@@ -106,3 +106,60 @@ def test_rollout(golden, name):
         assert_close(states[k], g[f"final_state{k}"], tol, f"final state {k}")
     nflip = masked_parity(frames[::every, 0], g["reg"], g["cls"], g["raw"], tol)
     assert nflip < 0.001 * g["reg"].size
+
+
+# ---- tests/torch_ref.py (the autograd / float64 restatement used by the full-size GPU tests) pinned to the same goldens ----------
+def _torch_params(sd, dtype):
+    import torch
+    return {k: torch.from_numpy(v).to(dtype) for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_torch_ref_vs_reference(kern, B):
+    import torch
+    import torch_ref
+    g, sd, _ = kern
+    t = f"B{B}"
+    H, W = int(g["H"]), int(g["W"])
+    p = _torch_params(sd, torch.float64)
+    st = [torch.from_numpy(g[f"step_state{k}_{t}"]).double() for k in range(6)]
+    with torch.no_grad():
+        masked, cls, raw, new = torch_ref.step(p, torch.from_numpy(g[f"step_x_{t}"][:, 0]).double(), st, H, W)
+    for k in range(6):
+        assert_close(new[k].numpy(), g[f"step_newstate{k}_{t}"], TOL, f"torch_ref state {k}")
+    ref = g[f"step_reg_{t}"][:, 0]
+    assert (np.abs(masked.numpy() - ref) > 1e-4 * max(1e-3, np.abs(ref).max())).mean() < 0.01
+
+
+def test_torch_ref_window_gradients_vs_reference_autograd(golden):
+    """Two timesteps from zero states, the loss, one backward through both steps: every parameter gradient of the restatement
+    equals the reference's own autograd (tests/golden/make_train_golden.py)."""
+    import torch
+    import torch_ref
+    g = golden("train_window_16x16.npz")
+    H, W, nums, steps = int(g["win_H"]), int(g["win_W"]), int(g["win_nums"]), int(g["win_steps"])
+    sd = uw.make_state_dict(H, W, 2 * nums + 3, seed=int(g["win_weights_seed"]))
+    p = {k: v.requires_grad_(True) for k, v in _torch_params(sd, torch.float64).items()}
+    ev = uw.make_event(steps + 1, H, W, float(g["win_rain_max"]), seed=int(g["win_event_seed"]))
+    states = [torch.from_numpy(s).double() for s in orc.zero_states(1, H, W)]
+    outs = []
+    for t in range(steps):
+        x = torch.from_numpy(orc.preprocess_inputs(t, ev, nums, float(g["win_rain_max"]), float(g["win_cumsum_max"]))[:, 0]).double()
+        masked, _, _, states = torch_ref.step(p, x, states, H, W)
+        outs.append(masked)
+    reg = torch.stack(outs, dim=1)
+    assert_close(reg.detach().numpy(), g["win_reg"], TOL, "window outputs")
+    loss = torch_ref.wmse(reg, torch.from_numpy(g["win_target"]).double())
+    assert float(loss) == pytest.approx(float(g["win_loss_reg"]), rel=1e-4)
+    loss.backward()
+    for name in sd:
+        if not int(g[f"win_hasgrad_{name}"]):
+            continue
+        ref = g[f"win_grad_{name}"]
+        grad = p[name].grad            # None: cut off by the wet/dry comparison (the reference stores zeros there)
+        got = np.zeros(ref.shape) if grad is None else grad.numpy().reshape(ref.shape)
+        scale = np.abs(ref).max()
+        if scale == 0.0:
+            assert np.abs(got).max() == 0.0, name
+        else:
+            assert np.abs(got - ref).max() / scale <= 1e-3, name

@@ -261,7 +261,8 @@ static int gru_cell_impl(const float *x, const float *e, const float *h, const f
     // GroupNorm finalise of the gates: folded into the candidate GEMM's prologue; launched on its own only when asked for
     // without the candidate phase (profiling)
     if ((phase_mask & URNN_PHASE_GN1) && !(phase_mask & URNN_PHASE_CAND))
-        CHECK_HIP(urnn_launch_gn_finalize(ws.part1, ftiles1, count, gn1_w, gn1_b, eps, ws.ss1, ws.st1, B, 2 * F, st), "gn finalize 1");
+        CHECK_HIP(urnn_launch_gn_finalize(ws.part1, ftiles1, global_pixels > 0 ? 0 : 32 * pb1, (int)P, count, gn1_w, gn1_b, eps, ws.ss1, ws.st1, B,
+                                          2 * F, st), "gn finalize 1");
 
     // K2: candidate (pre-norm) = W2 . [x; e; sigmoid(GN(r)) * h] + b2, GroupNorm partials.  The hidden-state rows are gated
     // on the fly from the raw reset gate and K1's folded (scale, shift).
@@ -273,6 +274,7 @@ static int gru_cell_impl(const float *x, const float *e, const float *h, const f
     c.gate = ws.g1;
     c.gpart = ws.part1;
     c.gtiles = ftiles1;
+    c.gtilePix = global_pixels > 0 ? 0 : 32 * pb1;     // strip mode: raw all-reduced totals
     c.gcount = count;
     c.gn_w = gn1_w;
     c.gn_b = gn1_b;
@@ -290,7 +292,8 @@ static int gru_cell_impl(const float *x, const float *e, const float *h, const f
     const int tiles2 = gru_tiles(B, F, P, 2, &pb2, &map2);
     if (phase_mask & URNN_PHASE_CAND) CHECK_HIP(urnn_launch_cand(c, B, pb2, map2, st), "gru candidate");
     if (phase_mask & URNN_PHASE_GN2)
-        CHECK_HIP(urnn_launch_gn_finalize(ws.part2, global_pixels > 0 ? 2 : tiles2, count, gn2_w, gn2_b, eps, ws.ss2, ws.st2, B, F, st), "gn finalize 2");
+        CHECK_HIP(urnn_launch_gn_finalize(ws.part2, global_pixels > 0 ? 2 : tiles2, global_pixels > 0 ? 0 : 32 * pb2, (int)P, count, gn2_w, gn2_b,
+                                          eps, ws.ss2, ws.st2, B, F, st), "gn finalize 2");
 
     // K3: blend
     if (phase_mask & URNN_PHASE_BLEND) CHECK_HIP(urnn_launch_blend(ws.g1, ws.cx, h, ws.ss1, ws.ss2, h_out, B, F, (int)P, st), "gru blend");
@@ -333,7 +336,9 @@ extern "C" int urnn_gru_cell_strip_stats_f32(void *workspace, size_t workspace_b
     if (workspace_bytes < ws.bytes) return fail(URNN_EWORKSPACE, "urnn_gru_cell_strip_stats_f32: workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
     const int rows = B * (which == 1 ? 2 * F / 32 : F / 32);
     float *part = which == 1 ? ws.part1 : ws.part2;
-    if (direction == 0) CHECK_HIP(urnn_launch_stats_reduce(part, rows, gru_tiles(B, F, P, which), gru_tiles(B, F, P, which), sums, (hipStream_t)stream), "strip stats");
+    int pb;
+    const int tiles = gru_tiles(B, F, P, which, &pb);
+    if (direction == 0) CHECK_HIP(urnn_launch_stats_reduce(part, rows, tiles, tiles, 32 * pb, (int)P, 32, sums, (hipStream_t)stream), "strip stats");
     else CHECK_HIP(urnn_launch_stats_scatter(sums, rows, 2, part, (hipStream_t)stream), "strip stats");
     return URNN_OK;
 }
@@ -766,7 +771,9 @@ extern "C" int urnn_head_strip_stats_f32(void *workspace, size_t workspace_bytes
     const int first = level == 0 ? 0 : level, n = level == 0 ? 1 : 2;      // norm indices first, first + 2
     for (int i = 0; i < n; ++i) {
         float *part = ws.partial + (size_t)(first + 2 * i) * B * nblk * 2;
-        if (direction == 0) CHECK_HIP(urnn_launch_stats_reduce(part, B, nblk, used, sums + (size_t)i * B * 2, (hipStream_t)stream), "strip stats");
+        if (direction == 0)
+            CHECK_HIP(urnn_launch_stats_reduce(part, B, nblk, used, urnn_head_block_pix((int)P), (int)P, 16, sums + (size_t)i * B * 2, (hipStream_t)stream),
+                      "strip stats");
         else CHECK_HIP(urnn_launch_stats_scatter(sums + (size_t)i * B * 2, B, nblk, part, (hipStream_t)stream), "strip stats");
     }
     return URNN_OK;
@@ -855,9 +862,9 @@ extern "C" int urnn_head_backward_f32(const float *feat, const float *conv_w, co
     }
     if (!accumulate) {   // the classification branch receives no gradient
         for (int k = 1; k <= 2; ++k) {
-            CHECK_HIP(hipMemsetAsync(dconv_w + k * 256, 0, 256 * sizeof(float), st), "head: zero cls grads");
-            CHECK_HIP(hipMemsetAsync(dln_w + k * CP, 0, CP * sizeof(float), st), "head: zero cls grads");
-            CHECK_HIP(hipMemsetAsync(dln_b + k * CP, 0, CP * sizeof(float), st), "head: zero cls grads");
+            CHECK_HIP(urnn_train_zero(dconv_w + k * 256, 256, st), "head: zero cls grads");
+            CHECK_HIP(urnn_train_zero(dln_w + k * CP, CP, st), "head: zero cls grads");
+            CHECK_HIP(urnn_train_zero(dln_b + k * CP, CP, st), "head: zero cls grads");
         }
     }
     return URNN_OK;

@@ -28,6 +28,21 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+// GroupNorm / LayerNorm partial statistics.  A tile (or block) of n values leaves (s1, m2) = (sum, sum of squared deviations
+// from the tile's OWN mean s1 / n) in fp32; the finalizes rebuild the raw second moment in double, x2 = m2 + s1^2 / n, and
+// combine in double.  Raw fp32 (sum, sum of squares) partials lose the variance to cancellation once |mean| >> std (a
+// trained network's pre-norm activations: |mean| / std = 30 cost 5e-4 of rstd); centred ones keep ~2 (|mean|/std) eps.
+// n == 0 marks a RAW partial (strip mode's all-reduced totals): y already is the second moment.
+__device__ __forceinline__ int tile_valid(int t, int tile_pix, int P)
+{
+    const int left = P - t * tile_pix;
+    return left < 0 ? 0 : (left > tile_pix ? tile_pix : left);
+}
+__device__ __forceinline__ double tile_x2(float s1, float y, int n)
+{
+    return n > 0 ? (double)y + (double)s1 * (double)s1 / (double)n : (double)y;
+}
+
 __device__ __forceinline__ float sigmoidf_fast(float v) { return __frcp_rn(1.0f + __expf(-v)); }
 
 __device__ __forceinline__ float tanhf_fast(float v)

@@ -4,13 +4,13 @@
 #include "urnn_kernels.h"
 
 // ------------------------------------------------------------------------------------------------------------------
-// GroupNorm finalise: partial (sum, sumsq) per tile -> per-channel (scale, shift) with
+// GroupNorm finalise: partial (sum, centred second moment) per tile (urnn_common.h tile_x2) -> per-channel (scale, shift) with
 //   y = (v - mean) * rstd * gamma + beta = v * scale + shift.   One wavefront per (sample, 32-channel group).
 // Partials are fp32 sums over <= 4096 values; they are combined in double in a fixed order (deterministic).
 // ------------------------------------------------------------------------------------------------------------------
 // One wave per (sample, group): 32 independent partial loads in flight per lane, lane-strided double sums, xor butterfly
 // (the same fixed order as the fold in the candidate GEMM's prologue).
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float *__restrict__ partial, int ntiles, double count,
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float *__restrict__ partial, int ntiles, int tile_pix, int P, double count,
                                                          const float *__restrict__ gamma, const float *__restrict__ beta,
                                                          float eps, float *__restrict__ ss, float *__restrict__ stat, int C)
 {
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float *__restrict
 #pragma unroll
         for (int u = 0; u < 32; ++u) {
             s1 += (double)v[u].x;
-            s2 += (double)v[u].y;
+            s2 += tile_x2(v[u].x, v[u].y, 32 * tile_valid(t0 + u * 64 + lane, tile_pix, P));
         }
     }
 #pragma unroll
@@ -53,10 +53,11 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float *__restrict
     }
 }
 
-hipError_t urnn_launch_gn_finalize(const float *partial, int ntiles, double count, const float *gamma, const float *beta,
+hipError_t urnn_launch_gn_finalize(const float *partial, int ntiles, int tile_pix, int P, double count, const float *gamma, const float *beta,
                                    float eps, float *ss, float *stat, int B, int C, hipStream_t st)
 {
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * (C / 32)), dim3(64), 0, st, partial, ntiles, count, gamma, beta, eps, ss, stat, C);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * (C / 32)), dim3(64), 0, st, partial, ntiles, tile_pix, P, count, gamma, beta, eps, ss,
+                       stat, C);
     return hipGetLastError();
 }
 
@@ -183,32 +184,65 @@ __device__ __forceinline__ void head_ln_silu(float (&x)[HEAD_C][V], const float 
 }
 
 template <int V>
-__device__ __forceinline__ void head_sums(const float (&u)[HEAD_C][V], float &s1, float &s2)
+__device__ __forceinline__ float head_sum(const float (&u)[HEAD_C][V])
 {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < HEAD_C; ++c)
+#pragma unroll
+        for (int k = 0; k < V; ++k) s += u[c][k];
+    return s;
+}
+
+template <int V>
+__device__ __forceinline__ float head_sumsq_about(const float (&u)[HEAD_C][V], float m)
+{
+    float s = 0.f;
 #pragma unroll
     for (int c = 0; c < HEAD_C; ++c)
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            s1 += u[c][k];
-            s2 += u[c][k] * u[c][k];
+            const float d = u[c][k] - m;
+            s = fmaf(d, d, s);
         }
+    return s;
 }
 
-__device__ __forceinline__ void head_block_partial(float s1, float s2, float *dst)
+// Block-wide sums of two values, returned to every thread (fixed order: xor butterfly per wave, then waves 0..3).
+__device__ __forceinline__ void head_block_sum2(float &a, float &b)
 {
     __shared__ float sh[2][4];
-    s1 = wave_sum(s1);
-    s2 = wave_sum(s2);
+    a = wave_sum(a);
+    b = wave_sum(b);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();
     if (lane == 0) {
-        sh[0][wave] = s1;
-        sh[1][wave] = s2;
+        sh[0][wave] = a;
+        sh[1][wave] = b;
     }
     __syncthreads();
+    a = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+    b = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+}
+
+// LayerNorm partial statistics of up to two tensors held in registers by the block: (sum, second moment about the block's own
+// mean) each (urnn_common.h tile_x2).  Threads outside the plane pass live = false (their registers are not read).
+template <int V>
+__device__ __forceinline__ void head_block_stats2(const float (&ua)[HEAD_C][V], const float (&ub)[HEAD_C][V], bool live, bool two, int nvalid,
+                                                  float *dst_a, float *dst_b)
+{
+    float sa = live ? head_sum<V>(ua) : 0.f, sb = (live && two) ? head_sum<V>(ub) : 0.f;
+    head_block_sum2(sa, sb);
+    const float inv = 1.f / (float)nvalid;
+    float qa = live ? head_sumsq_about<V>(ua, sa * inv) : 0.f, qb = (live && two) ? head_sumsq_about<V>(ub, sb * inv) : 0.f;
+    head_block_sum2(qa, qb);
     if (threadIdx.x == 0) {
-        dst[0] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
-        dst[1] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+        dst_a[0] = sa;
+        dst_a[1] = qa;
+        if (two) {
+            dst_b[0] = sb;
+            dst_b[1] = qb;
+        }
     }
 }
 
@@ -223,14 +257,13 @@ __global__ __launch_bounds__(256) void head_k1(const HeadParams prm)
 {
     const int b = blockIdx.y;
     const int p = (blockIdx.x * 256 + threadIdx.x) * V;
-    float s1 = 0.f, s2 = 0.f;
-    if (p < prm.P) {
-        float f[HEAD_C][V], u[HEAD_C][V];
+    const bool live = p < prm.P;
+    float f[HEAD_C][V], u[HEAD_C][V];
+    if (live) {
         head_load<V>(prm.feat + (size_t)b * HEAD_C * prm.P, prm.P, p, f);
         head_conv<V>(prm.conv_w, f, u);
-        head_sums<V>(u, s1, s2);
     }
-    head_block_partial(s1, s2, head_partial(prm, 0, b, blockIdx.x));
+    head_block_stats2<V>(u, u, live, false, HEAD_C * tile_valid(blockIdx.x, 256 * V, prm.P), head_partial(prm, 0, b, blockIdx.x), nullptr);
 }
 
 template <int V>
@@ -238,22 +271,21 @@ __global__ __launch_bounds__(256) void head_k2(const HeadParams prm)
 {
     const int b = blockIdx.y;
     const int p = (blockIdx.x * 256 + threadIdx.x) * V;
-    float c1 = 0.f, c2 = 0.f, q1 = 0.f, q2 = 0.f;
-    if (p < prm.P) {
+    const bool live = p < prm.P;
+    float uc[HEAD_C][V], uq[HEAD_C][V];
+    if (live) {
         const size_t CP = (size_t)HEAD_C * prm.P;
         float f[HEAD_C][V], t[HEAD_C][V];
         head_load<V>(prm.feat + b * CP, prm.P, p, f);
         head_conv<V>(prm.conv_w, f, t);
         head_ln_silu<V>(t, prm.ln_w, prm.ln_b, prm.P, p, prm.stats[(0 * prm.B + b) * 2], prm.stats[(0 * prm.B + b) * 2 + 1]);
-        head_conv<V>(prm.conv_w + 1 * HEAD_C * HEAD_C, t, f);
-        head_sums<V>(f, c1, c2);
-        head_store<V>(prm.u1 + b * CP, prm.P, p, f);
-        head_conv<V>(prm.conv_w + 3 * HEAD_C * HEAD_C, t, f);
-        head_sums<V>(f, q1, q2);
-        head_store<V>(prm.u2 + b * CP, prm.P, p, f);
+        head_conv<V>(prm.conv_w + 1 * HEAD_C * HEAD_C, t, uc);
+        head_store<V>(prm.u1 + b * CP, prm.P, p, uc);
+        head_conv<V>(prm.conv_w + 3 * HEAD_C * HEAD_C, t, uq);
+        head_store<V>(prm.u2 + b * CP, prm.P, p, uq);
     }
-    head_block_partial(c1, c2, head_partial(prm, 1, b, blockIdx.x));
-    head_block_partial(q1, q2, head_partial(prm, 3, b, blockIdx.x));
+    head_block_stats2<V>(uc, uq, live, true, HEAD_C * tile_valid(blockIdx.x, 256 * V, prm.P), head_partial(prm, 1, b, blockIdx.x),
+                         head_partial(prm, 3, b, blockIdx.x));
 }
 
 template <int V>
@@ -261,23 +293,22 @@ __global__ __launch_bounds__(256) void head_k3(const HeadParams prm)
 {
     const int b = blockIdx.y;
     const int p = (blockIdx.x * 256 + threadIdx.x) * V;
-    float c1 = 0.f, c2 = 0.f, q1 = 0.f, q2 = 0.f;
-    if (p < prm.P) {
+    const bool live = p < prm.P;
+    float uc[HEAD_C][V], uq[HEAD_C][V];
+    if (live) {
         const size_t CP = (size_t)HEAD_C * prm.P;
-        float x[HEAD_C][V], u[HEAD_C][V];
+        float x[HEAD_C][V];
         head_load<V>(prm.u1 + b * CP, prm.P, p, x);
         head_ln_silu<V>(x, prm.ln_w + 1 * CP, prm.ln_b + 1 * CP, prm.P, p, prm.stats[(1 * prm.B + b) * 2], prm.stats[(1 * prm.B + b) * 2 + 1]);
-        head_conv<V>(prm.conv_w + 2 * HEAD_C * HEAD_C, x, u);
-        head_sums<V>(u, c1, c2);
-        head_store<V>(prm.u1 + b * CP, prm.P, p, u);
+        head_conv<V>(prm.conv_w + 2 * HEAD_C * HEAD_C, x, uc);
+        head_store<V>(prm.u1 + b * CP, prm.P, p, uc);
         head_load<V>(prm.u2 + b * CP, prm.P, p, x);
         head_ln_silu<V>(x, prm.ln_w + 3 * CP, prm.ln_b + 3 * CP, prm.P, p, prm.stats[(3 * prm.B + b) * 2], prm.stats[(3 * prm.B + b) * 2 + 1]);
-        head_conv<V>(prm.conv_w + 4 * HEAD_C * HEAD_C, x, u);
-        head_sums<V>(u, q1, q2);
-        head_store<V>(prm.u2 + b * CP, prm.P, p, u);
+        head_conv<V>(prm.conv_w + 4 * HEAD_C * HEAD_C, x, uq);
+        head_store<V>(prm.u2 + b * CP, prm.P, p, uq);
     }
-    head_block_partial(c1, c2, head_partial(prm, 2, b, blockIdx.x));
-    head_block_partial(q1, q2, head_partial(prm, 4, b, blockIdx.x));
+    head_block_stats2<V>(uc, uq, live, true, HEAD_C * tile_valid(blockIdx.x, 256 * V, prm.P), head_partial(prm, 2, b, blockIdx.x),
+                         head_partial(prm, 4, b, blockIdx.x));
 }
 
 template <int V>
@@ -318,7 +349,7 @@ __global__ __launch_bounds__(256) void head_k4(const HeadParams prm)
 }
 
 // LayerNorm finalise: one block per (which, sample); which = first + i * stride for i < n (blockIdx.y).
-__global__ __launch_bounds__(64) void ln_finalize_kernel(const HeadParams prm, int first, int stride, int nblk_used)
+__global__ __launch_bounds__(64) void ln_finalize_kernel(const HeadParams prm, int first, int stride, int nblk_used, int block_pix)
 {
     const int which = first + blockIdx.y * stride;
     const int b = blockIdx.x;
@@ -335,7 +366,7 @@ __global__ __launch_bounds__(64) void ln_finalize_kernel(const HeadParams prm, i
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             s1 += (double)v[u].x;
-            s2 += (double)v[u].y;
+            s2 += tile_x2(v[u].x, v[u].y, HEAD_C * tile_valid(t0 + u * 64 + lane, block_pix, prm.P));   // block_pix 0: raw (strip mode)
         }
     }
 #pragma unroll
@@ -355,19 +386,21 @@ __global__ __launch_bounds__(64) void ln_finalize_kernel(const HeadParams prm, i
 
 int urnn_head_nblk(int P) { const int n = (P + 255) / 256; return n < 2 ? 2 : n; }   // >= 2: the strip mode's two pseudo-blocks
 int urnn_head_nblk_used(int P) { const int v = P % 2 == 0 ? 2 : 1; return (P + 256 * v - 1) / (256 * v); }
+int urnn_head_block_pix(int P) { return 256 * (P % 2 == 0 ? 2 : 1); }
 
 template <int V>
 static hipError_t launch_head_v(const HeadParams &p, int mask, hipStream_t st)
 {
     const int nb = (p.P + 256 * V - 1) / (256 * V);
     const int fin = p.Pglobal > 0 ? 2 : nb;          // strip mode: the partials hold the all-reduced totals as two pseudo-blocks
+    const int bpix = p.Pglobal > 0 ? 0 : 256 * V;    //             ... which are raw (sum, sum of squares)
     dim3 grid(nb, p.B), blk(256);
     if (mask & URNN_HEAD_K1) hipLaunchKernelGGL(head_k1<V>, grid, blk, 0, st, p);
-    if (mask & URNN_HEAD_F1) hipLaunchKernelGGL(ln_finalize_kernel, dim3(p.B, 1), dim3(64), 0, st, p, 0, 1, fin);
+    if (mask & URNN_HEAD_F1) hipLaunchKernelGGL(ln_finalize_kernel, dim3(p.B, 1), dim3(64), 0, st, p, 0, 1, fin, bpix);
     if (mask & URNN_HEAD_K2) hipLaunchKernelGGL(head_k2<V>, grid, blk, 0, st, p);
-    if (mask & URNN_HEAD_F2) hipLaunchKernelGGL(ln_finalize_kernel, dim3(p.B, 2), dim3(64), 0, st, p, 1, 2, fin);
+    if (mask & URNN_HEAD_F2) hipLaunchKernelGGL(ln_finalize_kernel, dim3(p.B, 2), dim3(64), 0, st, p, 1, 2, fin, bpix);
     if (mask & URNN_HEAD_K3) hipLaunchKernelGGL(head_k3<V>, grid, blk, 0, st, p);
-    if (mask & URNN_HEAD_F3) hipLaunchKernelGGL(ln_finalize_kernel, dim3(p.B, 2), dim3(64), 0, st, p, 2, 2, fin);
+    if (mask & URNN_HEAD_F3) hipLaunchKernelGGL(ln_finalize_kernel, dim3(p.B, 2), dim3(64), 0, st, p, 2, 2, fin, bpix);
     if (mask & URNN_HEAD_K4) hipLaunchKernelGGL(head_k4<V>, grid, blk, 0, st, p);
     return hipGetLastError();
 }
@@ -379,11 +412,12 @@ hipError_t urnn_launch_head(const HeadParams &p, int mask, hipStream_t st)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Strip mode (a plane split over ranks in horizontal strips): norm statistics leave as double sums and come
-// back, all-reduced, as two pseudo-tiles (hi + lo floats) that the unchanged finalizes add up in double.
+// Strip mode (a plane split over ranks in horizontal strips): norm statistics leave as double (sum, sum of squares)
+// and come back, all-reduced, as two RAW pseudo-tiles (hi + lo floats) that the finalizes add up in double (tile_pix = 0).
 // partial[row][stride][2]; one wave per row.
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void stats_reduce_kernel(const float *__restrict__ partial, int stride, int ntiles, double *__restrict__ sums)
+__global__ __launch_bounds__(64) void stats_reduce_kernel(const float *__restrict__ partial, int stride, int ntiles, int tile_pix, int P, int chans,
+                                                          double *__restrict__ sums)
 {
     const int row = blockIdx.x, lane = threadIdx.x;
     const float *pp = partial + (size_t)row * stride * 2;
@@ -391,7 +425,7 @@ __global__ __launch_bounds__(64) void stats_reduce_kernel(const float *__restric
     for (int t = lane; t < ntiles; t += 64) {
         const f32x2 v = *reinterpret_cast<const f32x2 *>(pp + 2 * t);
         s1 += (double)v.x;
-        s2 += (double)v.y;
+        s2 += tile_x2(v.x, v.y, chans * tile_valid(t, tile_pix, P));      // centred tile partials -> raw second moment, in double
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
@@ -416,9 +450,10 @@ __global__ void stats_scatter_kernel(const double *__restrict__ sums, int rows, 
     pp[2 + comp] = lo;
 }
 
-hipError_t urnn_launch_stats_reduce(const float *partial, int rows, int stride, int ntiles, double *sums, hipStream_t st)
+hipError_t urnn_launch_stats_reduce(const float *partial, int rows, int stride, int ntiles, int tile_pix, int P, int chans, double *sums,
+                                    hipStream_t st)
 {
-    hipLaunchKernelGGL(stats_reduce_kernel, dim3(rows), dim3(64), 0, st, partial, stride, ntiles, sums);
+    hipLaunchKernelGGL(stats_reduce_kernel, dim3(rows), dim3(64), 0, st, partial, stride, ntiles, tile_pix, P, chans, sums);
     return hipGetLastError();
 }
 

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
 #pragma unroll
                 for (int u = 0; u < 32; ++u) {
                     s1 += (double)v[u].x;
-                    s2 += (double)v[u].y;
+                    s2 += tile_x2(v[u].x, v[u].y, 32 * tile_valid(t0 + u * 64 + lane, prm.gtilePix, prm.P));
                 }
             }
 #pragma unroll
@@ -574,9 +574,10 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
             static_assert(NB == 2, "gate tile is z|r");
             const int F = prm.F;
             const int i = g;
+            const float inv_n = 1.f / (float)(32 * tile_valid(tile, 32 * PB, prm.P));
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
-                float s1 = 0.f, s2 = 0.f;
+                float s1 = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int cib = mfma_row(r, half);
@@ -586,14 +587,23 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
 #pragma unroll
                     for (int pb = 0; pb < PB; ++pb) {
                         v[pb] = acc[nb][pb][r] + bv;
-                        if (pm.valid[pb]) {
-                            s1 += v[pb];
-                            s2 += v[pb] * v[pb];
-                        }
+                        if (pm.valid[pb]) s1 += v[pb];
                     }
                     store_row<MAP, PB>(orow, pm, v);
                 }
                 s1 = wave_sum(s1);
+                // second moment about the tile's own mean, from the accumulators still in registers (urnn_common.h tile_x2)
+                const float mt = s1 * inv_n;
+                float s2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float bm = bias[nb * 32 + mfma_row(r, half)] - mt;
+#pragma unroll
+                    for (int pb = 0; pb < PB; ++pb) {
+                        const float d = acc[nb][pb][r] + bm;
+                        if (pm.valid[pb]) s2 = fmaf(d, d, s2);
+                    }
+                }
                 s2 = wave_sum(s2);
                 if (lane == 0) {
                     const int G = 2 * F / 32;
@@ -604,12 +614,13 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
                 }
             }
         } else if constexpr (EPI == EPI_CAND) {
-            // group g owns candidate channels [g*NB*32, (g+1)*NB*32): pre-GroupNorm candidate -> out0 (B,F,P), partial sums per
-            // 32-channel GroupNorm group -> partial[b][F/32][tile][2]
+            // group g owns candidate channels [g*NB*32, (g+1)*NB*32): pre-GroupNorm candidate -> out0 (B,F,P), partial statistics
+            // (sum, centred second moment) per 32-channel GroupNorm group -> partial[b][F/32][tile][2]
             const int F = prm.F;
+            const float inv_n = 1.f / (float)(32 * tile_valid(tile, 32 * PB, prm.P));
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                float s1 = 0.f, s2 = 0.f;
+                float s1 = 0.f;
                 const int grp = g * NB + nb;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -620,14 +631,22 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
 #pragma unroll
                     for (int pb = 0; pb < PB; ++pb) {
                         v[pb] = acc[nb][pb][r] + bv;
-                        if (pm.valid[pb]) {
-                            s1 += v[pb];
-                            s2 += v[pb] * v[pb];
-                        }
+                        if (pm.valid[pb]) s1 += v[pb];
                     }
                     store_row<MAP, PB>(orow, pm, v);
                 }
                 s1 = wave_sum(s1);
+                const float mt = s1 * inv_n;
+                float s2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float bm = bias[nb * 32 + mfma_row(r, half)] - mt;
+#pragma unroll
+                    for (int pb = 0; pb < PB; ++pb) {
+                        const float d = acc[nb][pb][r] + bm;
+                        if (pm.valid[pb]) s2 = fmaf(d, d, s2);
+                    }
+                }
                 s2 = wave_sum(s2);
                 if (lane == 0) {
                     float *pp = prm.partial + (((size_t)b * (F / 32) + grp) * prm.tilesPerSample + tile) * 2;

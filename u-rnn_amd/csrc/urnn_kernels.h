@@ -16,6 +16,7 @@ struct ConvGemmParams {
     const float *gate;    // EPI_CAND: raw gates (B,2F,P); rows F..2F-1 are the reset gate
     const float *gpart;   // EPI_CAND: the gate GEMM's GroupNorm partials [B][2F/32][gtiles][2]; finalised in this kernel's prologue
     int gtiles;           //           tiles per sample of the gate GEMM
+    int gtilePix;         //           pixels per gate-GEMM tile (centred partials, urnn_common.h tile_x2); 0: raw partials (strip mode)
     double gcount;        //           values per (sample, group) = 32 * P
     const float *gn_w, *gn_b;   //     GroupNorm affine of the gates [2F]
     float eps;
@@ -46,7 +47,7 @@ int urnn_cand_nb(int F);      // n-blocks per group of the candidate GEMM
 hipError_t urnn_launch_cand(ConvGemmParams p, int B, int PB, int map, hipStream_t st);
 
 // ---- elementwise / reduction kernels (urnn_elem.hip) ----
-hipError_t urnn_launch_gn_finalize(const float *partial, int ntiles, double count, const float *gamma, const float *beta,
+hipError_t urnn_launch_gn_finalize(const float *partial, int ntiles, int tile_pix, int P, double count, const float *gamma, const float *beta,
                                    float eps, float *ss, float *stat, int B, int C, hipStream_t st);
 hipError_t urnn_launch_blend(const float *g1, const float *c, const float *h, const float *ss1, const float *ss2, float *out,
                              int B, int F, int P, hipStream_t st);
@@ -68,7 +69,9 @@ struct HeadParams {
 hipError_t urnn_launch_head(const HeadParams &p, int phase_mask, hipStream_t st);
 int urnn_head_nblk(int P);        // blocks allocated per (norm, sample) in the partial buffer
 int urnn_head_nblk_used(int P);   // blocks the head kernels write
-hipError_t urnn_launch_stats_reduce(const float *partial, int rows, int stride, int ntiles, double *sums, hipStream_t st);
+hipError_t urnn_launch_stats_reduce(const float *partial, int rows, int stride, int ntiles, int tile_pix, int P, int chans, double *sums,
+                                    hipStream_t st);
+int urnn_head_block_pix(int P);   // pixels per block of the head kernels (the unit of their LayerNorm partials)
 hipError_t urnn_launch_stats_scatter(const double *sums, int rows, int stride, float *partial, hipStream_t st);
 
 hipError_t urnn_launch_preprocess(const float *rain, const float *cumsum, const float *dem, const float *imperv,
@@ -101,6 +104,7 @@ hipError_t urnn_train_reset_gate_bwd(const float *drh, long drh_bs, const float 
                                      float *dy1, float *dh, float *part1, int B, int F, int P, hipStream_t st);
 hipError_t urnn_train_add_slices(float *out, long out_bs, const float *a, long a_bs, const float *a2, long a2_bs, int B, int C, int P,
                                  int accumulate, hipStream_t st);
+hipError_t urnn_train_zero(float *p, size_t n, hipStream_t st);
 size_t urnn_train_wgrad_partial_floats(int B, int N, int K, int P);
 hipError_t urnn_train_wgrad(const float *dy, const float *const seg[3], const int segC[3], int B, int N, int K, int P, float *partial,
                             float *dW, float *db, int accumulate, hipStream_t st);

@@ -261,6 +261,22 @@ __global__ __launch_bounds__(256) void add_slices_kernel(float *out, long out_bs
     }
 }
 
+// Zero-fill as a kernel.  hipMemsetAsync captured into a hipGraph did not execute on replay (ROCm 7.0: the classification
+// branch's gradient blocks kept whatever an earlier tensor of the graph's memory pool had left there -> gradient norm 6e18 in
+// every captured training window, fine in eager mode); a kernel node has no such problem.
+__global__ __launch_bounds__(256) void zero_kernel(float *__restrict__ p, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0.f;
+}
+
+hipError_t urnn_train_zero(float *p, size_t n, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    const size_t b = (n + 1023) / 1024;
+    hipLaunchKernelGGL(zero_kernel, dim3((unsigned)(b > 2048 ? 2048 : b)), dim3(256), 0, st, p, n);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Weight gradient dW[n][k] = sum_{b,p} dY[b][n][p] * X[b][k][p]  (+ row sums of dY for the bias gradient).
 // Block = 4 waves on a 128 n x 128 k output tile and one pixel chunk; per 64-pixel stage the block stages dY[128][64 px]

@@ -31,32 +31,50 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
-class Workspace:
-    """Grow-only scratch buffers per (device, slot) (GroupNorm/LayerNorm partials, gate pre-activations).  Kernel
-    chains that run concurrently on different streams select different slots (``use_slot``)."""
+def workspace(nbytes, device):
+    """A scratch buffer of ``nbytes`` bytes (caller-owned, as the C ABI requires)."""
+    return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
 
-    def __init__(self):
+
+class Arena:
+    """Scratch buffers OWNED BY ONE engine / trainer, keyed by name (GroupNorm / LayerNorm partials, raw gates, backward
+    scratch).  There is deliberately no process-wide pool: a captured hipGraph holds raw pointers into its scratch, so the
+    buffers must live exactly as long as the owner's graphs.  Grow-only; growing a buffer bumps ``generation`` (an owner that
+    captured graphs compares it and re-captures) and is refused while a capture is running."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
         self._buf = {}
-        self.slot = 0
+        self.generation = 0
 
-    def use_slot(self, slot):
-        self.slot = int(slot)
-
-    def get(self, nbytes, device):
-        key = (device.type, device.index, self.slot)
+    def get(self, key, nbytes):
         buf = self._buf.get(key)
         if buf is None or buf.numel() < nbytes:
             if torch.cuda.is_current_stream_capturing():
-                raise RuntimeError("workspace must be pre-sized before graph capture (call reserve())")
-            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+                raise RuntimeError("scratch buffer %r must be sized before graph capture (run the path once eagerly)" % (key,))
+            buf = workspace(nbytes, self.device)
             self._buf[key] = buf
+            self.generation += 1
         return buf
 
-    def reserve(self, nbytes, device):
-        return self.get(nbytes, device)
+
+def _scratch(ws, nbytes, device, key="ws"):
+    """ws: None (a fresh buffer for this call), an Arena (its buffer ``key``) or a uint8 tensor of at least nbytes."""
+    if ws is None:
+        return workspace(nbytes, device)
+    if isinstance(ws, Arena):
+        return ws.get(key, nbytes)
+    if ws.numel() < nbytes:
+        raise RuntimeError(f"workspace of {ws.numel()} bytes given, {nbytes} needed")
+    return ws
 
 
-WORKSPACE = Workspace()
+def gru_cell_workspace_bytes(B, F, H, W):
+    return lib().urnn_gru_cell_workspace_bytes(B, F, H, W)
+
+
+def head_workspace_bytes(B, C, H, W):
+    return lib().urnn_head_workspace_bytes(B, C, H, W)
 
 
 # ---- weight packing ----------------------------------------------------------------------------------
@@ -104,9 +122,10 @@ def stage_conv(x, packed, Cout, pool, out=None, slope=LRELU_SLOPE):
 PHASE_GATES, PHASE_GN1, PHASE_CAND, PHASE_GN2, PHASE_BLEND, PHASE_ALL = 1, 2, 4, 8, 16, 31
 
 
-def gru_cell(x, e, h, packed, gn1_w, gn1_b, gn2_w, gn2_b, I, out=None, eps=NORM_EPS, phases=PHASE_ALL):
+def gru_cell(x, e, h, packed, gn1_w, gn1_b, gn2_w, gn2_b, I, out=None, eps=NORM_EPS, phases=PHASE_ALL, ws=None):
     """ConvGRU (e None) / Skip-ConvGRU step.  x may be None (zeros, I channels).  out may be h (in place).
-    ``phases`` enqueues a subset of the cell's five kernels (profiling only)."""
+    ``phases`` enqueues a subset of the cell's five kernels (profiling only).  ``ws``: the cell's scratch (``_scratch``); the
+    backward pass reads the forward's scratch, so training passes the same buffer to both."""
     _dev_check(x, e, h, packed, gn1_w, gn1_b, gn2_w, gn2_b, out)
     B, F, H, W = h.shape
     if x is not None and tuple(x.shape) != (B, I, H, W):
@@ -114,8 +133,7 @@ def gru_cell(x, e, h, packed, gn1_w, gn1_b, gn2_w, gn2_b, I, out=None, eps=NORM_
     if e is not None and tuple(e.shape) != (B, F, H, W):
         raise RuntimeError(f"gru_cell: e has shape {tuple(e.shape)}, expected {(B, F, H, W)}")
     L = lib()
-    nbytes = L.urnn_gru_cell_workspace_bytes(B, F, H, W)
-    ws = WORKSPACE.get(nbytes, h.device)
+    ws = _scratch(ws, L.urnn_gru_cell_workspace_bytes(B, F, H, W), h.device)
     if out is None:
         out = torch.empty_like(h)
     check(L.urnn_gru_cell_phases_f32(_ptr(x), _ptr(e), _ptr(h), _ptr(packed), _ptr(gn1_w), _ptr(gn1_b), _ptr(gn2_w),
@@ -124,13 +142,13 @@ def gru_cell(x, e, h, packed, gn1_w, gn1_b, gn2_w, gn2_b, I, out=None, eps=NORM_
     return out
 
 
-def gru_cell_strip(x, e, h, packed, gn1_w, gn1_b, gn2_w, gn2_b, I, global_pixels, exchange, out=None, eps=NORM_EPS):
+def gru_cell_strip(x, e, h, packed, gn1_w, gn1_b, gn2_w, gn2_b, I, global_pixels, exchange, out=None, eps=NORM_EPS, ws=None):
     """One horizontal strip of a cell step whose plane of ``global_pixels`` pixels is split over ranks (include/urnn_hip.h,
     "Spatial strips").  ``exchange(sums)`` must all-reduce (sum) the float64 device tensor in place; it is called twice."""
     _dev_check(x, e, h, packed, gn1_w, gn1_b, gn2_w, gn2_b, out)
     B, F, H, W = h.shape
     L = lib()
-    ws = WORKSPACE.get(L.urnn_gru_cell_workspace_bytes(B, F, H, W), h.device)
+    ws = _scratch(ws, L.urnn_gru_cell_workspace_bytes(B, F, H, W), h.device)
     if out is None:
         out = torch.empty_like(h)
 
@@ -156,12 +174,12 @@ def gru_cell_strip(x, e, h, packed, gn1_w, gn1_b, gn2_w, gn2_b, I, global_pixels
 
 
 def head_strip(feat, conv_w, ln_w, ln_b, cls_w, cls_b, reg_w, reg_b, cls_thred, global_pixels, exchange, want_raw=False, eps=NORM_EPS,
-               slope=LRELU_SLOPE):
+               slope=LRELU_SLOPE, ws=None):
     """One strip of the head: ln_w / ln_b are the strip's rows (5,C,H,W); three statistics exchanges (LayerNorm levels)."""
     _dev_check(feat, conv_w, ln_w, ln_b, cls_w, cls_b, reg_w, reg_b)
     B, C, H, W = feat.shape
     L = lib()
-    ws = WORKSPACE.get(L.urnn_head_workspace_bytes(B, C, H, W), feat.device)
+    ws = _scratch(ws, L.urnn_head_workspace_bytes(B, C, H, W), feat.device)
     f32 = dict(dtype=torch.float32, device=feat.device)
     masked, cls = torch.empty((B, H, W), **f32), torch.empty((B, H, W), **f32)
     raw = torch.empty((B, H, W), **f32) if want_raw else None
@@ -196,14 +214,13 @@ def deconv2x2(x, packed, Cout, out=None, slope=LRELU_SLOPE):
 
 
 def head(feat, conv_w, ln_w, ln_b, cls_w, cls_b, reg_w, reg_b, cls_thred, out_masked=None, out_cls=None, out_raw=None,
-         frame_index=None, want_raw=False, eps=NORM_EPS, slope=LRELU_SLOPE):
+         frame_index=None, want_raw=False, eps=NORM_EPS, slope=LRELU_SLOPE, ws=None):
     """Dual head + mask.  Returns (masked, cls, raw|None), each (B,H,W) unless preallocated (T,B,H,W) buffers
     plus a device ``frame_index`` are given."""
     _dev_check(feat, conv_w, ln_w, ln_b, cls_w, cls_b, reg_w, reg_b, out_masked, out_cls, out_raw)
     B, C, H, W = feat.shape
     L = lib()
-    nbytes = L.urnn_head_workspace_bytes(B, C, H, W)
-    ws = WORKSPACE.get(nbytes, feat.device)
+    ws = _scratch(ws, L.urnn_head_workspace_bytes(B, C, H, W), feat.device)
     if out_masked is None:
         out_masked = torch.empty((B, H, W), dtype=torch.float32, device=feat.device)
     if out_cls is None:

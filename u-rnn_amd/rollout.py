@@ -67,15 +67,14 @@ class RolloutEngine:
         self.t_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self.te_dev = torch.zeros(1, dtype=torch.int32, device=dev)   # overlap mode: frame index of the encoder chain
         self.zero_frame = torch.zeros(1, dtype=torch.int32, device=dev)
-        # scratch: size for the largest consumer, before any capture
+        # scratch: OWNED by this engine (a captured graph holds raw pointers into it), one buffer per concurrent kernel chain,
+        # sized for the largest consumer before any capture
         L = lib()
         need = max([L.urnn_head_workspace_bytes(B, 16, H, W)] +
                    [L.urnn_gru_cell_workspace_bytes(B, c.num_features, c.shape[0], c.shape[1])
                     for c in (enc.rnn1, enc.rnn2, enc.rnn3, dec.rnn3, dec.rnn2, dec.rnn1)])
-        for slot in ((0, 1) if self.overlap else (0,)):
-            ops.WORKSPACE.use_slot(slot)
-            ops.WORKSPACE.reserve(need, dev)
-        ops.WORKSPACE.use_slot(0)
+        self._ws = [ops.workspace(need, dev) for _ in range(2 if self.overlap else 1)]
+        self._param_stamp = None    # what the captured graphs' packed weights were made from (see _check_params)
         self._probe = None          # {"enc1": [(start, stop), ...], "dec1": [...]} while probing
         self._graph = None
         self._graphs2 = None
@@ -87,20 +86,21 @@ class RolloutEngine:
         net = self.net
         enc, dec = net.encoder, net.decoder
         e1, e2, e3, d1, d2, d3 = self.states
+        ws = self._ws[0]
         self._stage1(self.t_dev)
-        self._cell("enc1", enc.rnn1, self.a1, None, e1, e1)
+        self._cell("enc1", enc.rnn1, self.a1, None, e1, e1, ws)
         enc.stage2(e1, out=self.a2)
-        self._cell("enc2", enc.rnn2, self.a2, None, e2, e2)
+        self._cell("enc2", enc.rnn2, self.a2, None, e2, e2, ws)
         enc.stage3(e2, out=self.a3)
-        enc.rnn3.step(self.a3, None, e3, out=e3)
-        dec.rnn3.step(None, e3, d1, out=d1)
+        enc.rnn3.step(self.a3, None, e3, out=e3, ws=ws)
+        dec.rnn3.step(None, e3, d1, out=d1, ws=ws)
         dec.stage3(d1, out=self.u3)
-        self._cell("dec2", dec.rnn2, self.u3, e2, d2, d2)
+        self._cell("dec2", dec.rnn2, self.u3, e2, d2, d2, ws)
         dec.stage2(d2, out=self.u2)
-        self._cell("dec1", dec.rnn1, self.u2, e1, d3, d3)
+        self._cell("dec1", dec.rnn1, self.u2, e1, d3, d3, ws)
         dec.stage1(d3, out=self.feat)
         net.head.run(self.feat, out_masked=self.out_masked, out_cls=self.out_cls, out_raw=self.out_raw,
-                     frame_index=self.t_dev)
+                     frame_index=self.t_dev, ws=ws)
         ops.advance_counter(self.t_dev, 1)
 
     def _stage1(self, t_dev):
@@ -114,18 +114,18 @@ class RolloutEngine:
                            self.nums, self.rain_max, self.cumsum_max, out=self.x_in, t_dev=t_dev)
             self.net.encoder.stage1(self.x_in, out=self.a1)
 
-    def _cell(self, name, cell, x, e, h, out):
+    def _cell(self, name, cell, x, e, h, out, ws):
         """One GRU cell; when a probe is active the gate GEMM of the named full-resolution cells is launched on its
         own, bracketed by events on the launch stream (bench.py's live roofline measurement)."""
         if self._probe is not None and name in self._probe:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            cell.step(x, e, h, out=out, phases=ops.PHASE_GATES)
+            cell.step(x, e, h, out=out, phases=ops.PHASE_GATES, ws=ws)
             b.record()
             self._probe[name].append((a, b))
-            cell.step(x, e, h, out=out, phases=ops.PHASE_ALL & ~ops.PHASE_GATES)
+            cell.step(x, e, h, out=out, phases=ops.PHASE_ALL & ~ops.PHASE_GATES, ws=ws)
         else:
-            cell.step(x, e, h, out=out)
+            cell.step(x, e, h, out=out, ws=ws)
 
     def probe_gate_gemm(self, frames=12):
         """Average duration (seconds) of the full- and half-resolution gate-GEMM launches while the rollout runs in this engine's
@@ -154,17 +154,19 @@ class RolloutEngine:
         enc = self.net.encoder
         (p1, p2, p3), (n1, n2, n3) = self._enc_bufs(parity)
 
+        ws = self._ws[0]                       # chain 1 (head + encoder) scratch
+
         def e1():
             self._stage1(self.te_dev)
-            self._cell("enc1", enc.rnn1, self.a1, None, p1, n1)
+            self._cell("enc1", enc.rnn1, self.a1, None, p1, n1, ws)
 
         def e2():
             enc.stage2(n1, out=self.a2)
-            self._cell("enc2", enc.rnn2, self.a2, None, p2, n2)
+            self._cell("enc2", enc.rnn2, self.a2, None, p2, n2, ws)
 
         def e3():
             enc.stage3(n2, out=self.a3)
-            enc.rnn3.step(self.a3, None, p3, out=n3)
+            enc.rnn3.step(self.a3, None, p3, out=n3, ws=ws)
             ops.advance_counter(self.te_dev, 1)
         return [e1, e2, e3]
 
@@ -174,35 +176,33 @@ class RolloutEngine:
         e1, e2, e3 = self._enc_bufs(parity)[1]   # encoder states of frame t (written by E(t))
         _, _, _, d1, d2, d3 = self.states
 
+        ws = self._ws[1]                       # chain 2 (decoder) scratch
+
         def s3():
-            dec.rnn3.step(None, e3, d1, out=d1)
+            dec.rnn3.step(None, e3, d1, out=d1, ws=ws)
             dec.stage3(d1, out=self.u3)
 
         def s2():
-            self._cell("dec2", dec.rnn2, self.u3, e2, d2, d2)
+            self._cell("dec2", dec.rnn2, self.u3, e2, d2, d2, ws)
             dec.stage2(d2, out=self.u2)
 
         def s1():
-            self._cell("dec1", dec.rnn1, self.u2, e1, d3, d3)
+            self._cell("dec1", dec.rnn1, self.u2, e1, d3, d3, ws)
             dec.stage1(d3, out=self.feat if parity == 0 else self.feat_alt)
         return [s3, s2, s1]
 
     def _enc_chain(self, parity):
-        ops.WORKSPACE.use_slot(0)
         for seg in self._enc_segments(parity):
             seg()
 
     def _dec_chain(self, parity):
-        ops.WORKSPACE.use_slot(1)
         for seg in self._dec_segments(parity):
             seg()
-        ops.WORKSPACE.use_slot(0)
 
     def _head_chain(self, parity):
-        """head(t) for t % 2 == parity (reads feat[parity]); shares the encoder chain's stream and workspace slot."""
-        ops.WORKSPACE.use_slot(0)
+        """head(t) for t % 2 == parity (reads feat[parity]); shares the encoder chain's stream and scratch."""
         self.net.head.run(self.feat if parity == 0 else self.feat_alt, out_masked=self.out_masked, out_cls=self.out_cls,
-                          out_raw=self.out_raw, frame_index=self.t_dev)
+                          out_raw=self.out_raw, frame_index=self.t_dev, ws=self._ws[0])
         ops.advance_counter(self.t_dev, 1)
 
     def _iter_overlap(self, parity, with_head=True):
@@ -223,17 +223,14 @@ class RolloutEngine:
                         self._head_chain(1 - parity)
             elif ch == "E":
                 with torch.cuda.stream(s1):
-                    ops.WORKSPACE.use_slot(0)
                     enc[ie]()
                 ie += 1
             elif ch == "D":
                 with torch.cuda.stream(s2):
-                    ops.WORKSPACE.use_slot(1)
                     dec[idd]()
                 idd += 1
         if ie != 3 or idd != 3 or order.count("H") != 1:
             raise RuntimeError("enqueue order must hold one H, three E and three D")
-        ops.WORKSPACE.use_slot(0)
         cur.wait_stream(s1)
         cur.wait_stream(s2)
 
@@ -329,6 +326,7 @@ class RolloutEngine:
             conv = self.net.encoder.stage1.layer
             self._w1.copy_(conv.weight.detach().reshape(conv.out_channels, -1))
             ops.stage1_static(self.dem, self.imperv, self.manhole, ev["dem_min"], ev["dem_max"], self._w1, self.nums, out=self.S1)
+        self._check_params()
         if (ev["dem_min"], ev["dem_max"]) != (self.dem_min, self.dem_max):
             # normalisation bounds are kernel arguments frozen into the graph: re-capture when they change
             self.dem_min, self.dem_max = ev["dem_min"], ev["dem_max"]
@@ -336,7 +334,19 @@ class RolloutEngine:
             self._graphs2 = None
         return T
 
+    def _check_params(self):
+        """A captured timestep holds raw pointers to the PACKED copies of the weights (and to the head's stacked affines), so a
+        weight change must drop the graphs: ``load_state_dict`` / in-place edits bump the tensors' version counters, an
+        optimizer that re-homes or rewrites parameters behind torch's back (``Trainer``) bumps ``net._urnn_generation``."""
+        stamp = (getattr(self.net, "_urnn_generation", 0),) + tuple((p.data_ptr(), p._version) for p in self.net.parameters())
+        if stamp != self._param_stamp:
+            if self._param_stamp is not None:
+                self._graph = None
+                self._graphs2 = None
+            self._param_stamp = stamp
+
     def reset(self):
+        self._check_params()
         for s in self.states:
             s.zero_()
         if self.enc_alt is not None:

@@ -1,17 +1,22 @@
 """ctypes wrappers of the training entry points of the C ABI: backward of the ConvGRU / Skip-ConvGRU cell, the
 stage convs, the transposed convs and the head; the loss; the clipped Adam step.  ``urnn_amd.training`` assembles them into SWP
-windows and the training loop.  Every backward call must directly follow its forward on the same workspace slot."""
+windows and the training loop.  A backward call reads the scratch buffer its forward ran on (``fwd_ws``)."""
 import torch
 
 from . import ops
 from ._lib import check, lib
 
-_BWD_SLOT = 7   # workspace slot of the backward scratch (the forward's scratch must survive until the backward has run)
+
+def _bwd_scratch(scratch, nbytes, dev):
+    """Backward scratch: ``scratch`` is the owner's ``ops.Arena`` (buffer "bwd", shared by all backward calls of a stream) or None
+    (a fresh buffer for this call)."""
+    return ops._scratch(scratch, nbytes, dev, key="bwd")
 
 
-def gru_cell_backward(x, e, h, W1, W2, gn1_w, gn2_w, dh_out, I, grads=None, accumulate=False, packed=None, dh_out2=None):
-    """Gradients of one cell step.  Must directly follow ``ops.gru_cell(x, e, h, ...)`` on the same inputs (same workspace
-    slot, nothing in between): the forward leaves the raw gates / candidate and the GroupNorm statistics in its workspace.
+def gru_cell_backward(x, e, h, W1, W2, gn1_w, gn2_w, dh_out, I, fwd_ws, grads=None, accumulate=False, packed=None, dh_out2=None,
+                      scratch=None):
+    """Gradients of one cell step.  ``fwd_ws`` is the scratch buffer the forward ``ops.gru_cell(x, e, h, ..., ws=fwd_ws)`` of the
+    SAME inputs ran on (untouched since): it holds the raw gates / candidate and the GroupNorm statistics.
     W1 (2F,K[,1,1]) / W2 (F,K[,1,1]): conv weights in the reference layout.  Returns a dict with dx, de (when given), dh and
     dW1, db1, dg1, dbe1, dW2, db2, dg2, dbe2; pass ``grads`` (the dict of a previous call) with ``accumulate=True`` to add
     the parameter gradients of another timestep.  ``packed``: a one-element list the caller keeps per cell for the packed
@@ -24,12 +29,8 @@ def gru_cell_backward(x, e, h, W1, W2, gn1_w, gn2_w, dh_out, I, grads=None, accu
         raise RuntimeError(f"gru_cell_backward: weights do not match I={I}, F={F}, skip={e is not None}")
     L = lib()
     dev = h.device
-    fwd = ops.WORKSPACE.get(L.urnn_gru_cell_workspace_bytes(B, F, H, W), dev)
-    slot = ops.WORKSPACE.slot
-    ops.WORKSPACE.use_slot(_BWD_SLOT)
-    nbytes = L.urnn_gru_cell_backward_workspace_bytes(B, I, F, int(e is not None), H, W)
-    ws = ops.WORKSPACE.get(nbytes, dev)
-    ops.WORKSPACE.use_slot(slot)
+    fwd = ops._scratch(fwd_ws, L.urnn_gru_cell_workspace_bytes(B, F, H, W), dev)
+    ws = _bwd_scratch(scratch, L.urnn_gru_cell_backward_workspace_bytes(B, I, F, int(e is not None), H, W), dev)
     f32 = dict(dtype=torch.float32, device=dev)
     g = grads if grads is not None else {}
     if "dW1" not in g:          # caller-provided buffers (e.g. views of a flat gradient buffer) are written in place
@@ -60,22 +61,14 @@ def gru_cell_backward(x, e, h, W1, W2, gn1_w, gn2_w, dh_out, I, grads=None, accu
     return g
 
 
-def _bwd_workspace(nbytes, dev):
-    slot = ops.WORKSPACE.slot
-    ops.WORKSPACE.use_slot(_BWD_SLOT)
-    ws = ops.WORKSPACE.get(nbytes, dev)
-    ops.WORKSPACE.use_slot(slot)
-    return ws
-
-
-def stage_conv_backward(x, weight, bias, dout, pool, dweight=None, dbias=None, accumulate=False, slope=ops.LRELU_SLOPE):
+def stage_conv_backward(x, weight, bias, dout, pool, dweight=None, dbias=None, accumulate=False, slope=ops.LRELU_SLOPE, scratch=None):
     """Backward of ``ops.stage_conv`` (conv1x1 + LeakyReLU [+ AvgPool2]).  weight (Cout,Cin[,1,1]), bias (Cout).
     Returns (dx, dweight, dbias)."""
     ops._dev_check(x, weight, bias, dout)
     B, Cin, H, W = x.shape
     Cout = weight.shape[0]
     L = lib()
-    ws = _bwd_workspace(L.urnn_stage_conv_backward_workspace_bytes(B, Cin, Cout, H, W), x.device)
+    ws = _bwd_scratch(scratch, L.urnn_stage_conv_backward_workspace_bytes(B, Cin, Cout, H, W), x.device)
     if dweight is None:
         dweight, dbias, accumulate = torch.empty_like(weight), torch.empty_like(bias), False
     dx = torch.empty_like(x)
@@ -86,13 +79,13 @@ def stage_conv_backward(x, weight, bias, dout, pool, dweight=None, dbias=None, a
     return dx, dweight, dbias
 
 
-def deconv2x2_backward(x, weight, out, dout, dweight=None, dbias=None, accumulate=False, slope=ops.LRELU_SLOPE):
+def deconv2x2_backward(x, weight, out, dout, dweight=None, dbias=None, accumulate=False, slope=ops.LRELU_SLOPE, scratch=None):
     """Backward of ``ops.deconv2x2``.  weight (Cin,Cout,2,2); ``out`` is the forward output.  Returns (dx, dweight, dbias)."""
     ops._dev_check(x, weight, out, dout)
     B, Cin, H, W = x.shape
     Cout = weight.shape[1]
     L = lib()
-    ws = _bwd_workspace(L.urnn_deconv2x2_backward_workspace_bytes(B, Cin, Cout, H, W), x.device)
+    ws = _bwd_scratch(scratch, L.urnn_deconv2x2_backward_workspace_bytes(B, Cin, Cout, H, W), x.device)
     if dweight is None:
         dweight, dbias, accumulate = torch.empty_like(weight), torch.empty(Cout, dtype=torch.float32, device=x.device), False
     dx = torch.empty_like(x)
@@ -102,16 +95,16 @@ def deconv2x2_backward(x, weight, out, dout, dweight=None, dbias=None, accumulat
     return dx, dweight, dbias
 
 
-def head_backward(feat, conv_w, ln_w, ln_b, reg_w, out_raw, out_cls, dout, cls_thred, grads=None, accumulate=False,
-                  slope=ops.LRELU_SLOPE):
-    """Backward of ``ops.head`` w.r.t. the masked depth.  Must directly follow the forward on the same ``feat`` (same
-    workspace slot; ``want_raw=True`` so that ``out_raw`` exists).  conv_w (5,C,C), ln_w / ln_b (5,C,H,W), reg_w (C).
+def head_backward(feat, conv_w, ln_w, ln_b, reg_w, out_raw, out_cls, dout, cls_thred, fwd_ws, grads=None, accumulate=False,
+                  slope=ops.LRELU_SLOPE, scratch=None):
+    """Backward of ``ops.head`` w.r.t. the masked depth.  ``fwd_ws``: the scratch the forward on the same ``feat`` ran on
+    (``ops.head(..., want_raw=True, ws=fwd_ws)``, untouched since: it holds the five LayerNorm statistics).  conv_w (5,C,C), ln_w / ln_b (5,C,H,W), reg_w (C).
     Returns a dict: dfeat, dconv_w, dln_w, dln_b, dreg_w, dreg_b."""
     ops._dev_check(feat, conv_w, ln_w, ln_b, reg_w, out_raw, out_cls, dout)
     B, C, H, W = feat.shape
     L = lib()
-    fwd = ops.WORKSPACE.get(L.urnn_head_workspace_bytes(B, C, H, W), feat.device)
-    ws = _bwd_workspace(L.urnn_head_backward_workspace_bytes(B, H, W), feat.device)
+    fwd = ops._scratch(fwd_ws, L.urnn_head_workspace_bytes(B, C, H, W), feat.device)
+    ws = _bwd_scratch(scratch, L.urnn_head_backward_workspace_bytes(B, H, W), feat.device)
     f32 = dict(dtype=torch.float32, device=feat.device)
     g = grads if grads is not None else {}
     if grads is None or not accumulate:
@@ -125,7 +118,7 @@ def head_backward(feat, conv_w, ln_w, ln_b, reg_w, out_raw, out_cls, dout, cls_t
     return g
 
 
-def loss(reg, target, cls_thred=0.0, want_grad=True):
+def loss(reg, target, cls_thred=0.0, want_grad=True, scratch=None):
     """FocalBCE_and_WMSE on a window's outputs.  Returns (components: 5-float device tensor [loss, loss_reg, wet MSE, dry MSE,
     loss_cls], dreg or None)."""
     ops._dev_check(reg, target)
@@ -133,7 +126,7 @@ def loss(reg, target, cls_thred=0.0, want_grad=True):
     if target.numel() != n:
         raise RuntimeError("loss: reg and target differ in size")
     L = lib()
-    ws = _bwd_workspace(L.urnn_loss_workspace_bytes(n), reg.device)
+    ws = _bwd_scratch(scratch, L.urnn_loss_workspace_bytes(n), reg.device)
     comps = torch.empty(5, dtype=torch.float32, device=reg.device)
     dreg = torch.empty_like(reg) if want_grad else None
     check(L.urnn_loss_f32(ops._ptr(reg), ops._ptr(target), float(cls_thred), ops._ptr(comps), ops._ptr(dreg), ops._ptr(ws), ws.numel(), n,
@@ -141,7 +134,8 @@ def loss(reg, target, cls_thred=0.0, want_grad=True):
     return comps, dreg
 
 
-def adam_step(params, grads, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=0.0, step_dev=None):
+def adam_step(params, grads, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=0.0, step_dev=None,
+              scratch=None):
     """In-place Adam step on flat float32 buffers (with optional global-norm clipping).  ``step_dev`` (int32 device scalar)
     overrides ``step`` for graph replay.  Returns a 2-float device tensor: (clip coefficient, gradient norm)."""
     ops._dev_check(params, grads, exp_avg, exp_avg_sq)
@@ -149,7 +143,7 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.9
         raise RuntimeError("adam_step: step_dev must be an int32 device scalar")
     n = params.numel()
     L = lib()
-    ws = _bwd_workspace(L.urnn_adam_workspace_bytes(n), params.device)
+    ws = _bwd_scratch(scratch, L.urnn_adam_workspace_bytes(n), params.device)
     out = torch.empty(2, dtype=torch.float32, device=params.device)
     p = ops._ptr
     check(L.urnn_adam_step_f32(p(params), p(grads), p(exp_avg), p(exp_avg_sq), n, float(lr), float(betas[0]), float(betas[1]), float(eps),

@@ -9,8 +9,6 @@ import torch
 from . import ops, train_ops
 from .dataset import event_to_device
 
-_SLOT0 = 100   # workspace slots 100 + 16 * step + k hold the forward scratch of layer k of step `step` until its backward ran
-
 
 def _cell_params(cell):
     c1, g1, c2, g2 = cell.conv1[0], cell.conv1[1], cell.conv2[0], cell.conv2[1]
@@ -27,20 +25,22 @@ class WindowGradients:
         self.cls_thred_train = float(cls_thred_train)          # classify_outputs threshold of the loop (main.py:598: 0)
         self.device = next(net.parameters()).device
         self._bwd_packed = {}      # per cell: packed weights of the input-gradient GEMMs, valid until the parameters change
+        # scratch owned by this object: ("fwd", step, layer) keeps the forward scratch of layer `layer` of window step `step`
+        # until its backward ran, "bwd" is the backward kernels' scratch
+        self.arena = ops.Arena(self.device)
 
     # -- forward of one timestep, keeping what the backward reads ---------------------------------------------------
     def _forward_step(self, ev, t, states, step, t_dev=None):
         net = self.net
         enc, dec, head = net.encoder, net.decoder, net.head
         e1, e2, e3, d1, d2, d3 = states
-        base = _SLOT0 + 16 * step
-        S = {"prev": list(states)}
+        S = {"prev": list(states), "ws": {}}
         x_in = ops.preprocess(ev["rain"], ev["cumsum"], ev["dem"], ev["imperv"], ev["manhole"], ev["dem_min"], ev["dem_max"], int(t),
                               self.nums, self.rain_max, self.cumsum_max, t_dev=t_dev)
 
         def cell(k, mod, x, e, h):
-            ops.WORKSPACE.use_slot(base + k)
-            return mod.step(x, e, h)
+            S["ws"][k] = self.arena.get(("fwd", step, k), ops.gru_cell_workspace_bytes(h.shape[0], h.shape[1], h.shape[2], h.shape[3]))
+            return mod.step(x, e, h, ws=S["ws"][k])
         S["x_in"] = x_in
         S["a1"] = enc.stage1(x_in)
         S["e1"] = cell(0, enc.rnn1, S["a1"], None, e1)
@@ -54,9 +54,9 @@ class WindowGradients:
         S["u2"] = dec.stage2(S["d2"])
         S["d3"] = cell(5, dec.rnn1, S["u2"], S["e1"], d3)
         S["feat"] = dec.stage1(S["d3"])
-        ops.WORKSPACE.use_slot(base + 6)
-        S["masked"], S["cls"], S["raw"] = head.run(S["feat"], want_raw=True)
-        ops.WORKSPACE.use_slot(0)
+        f = S["feat"]
+        S["ws"][6] = self.arena.get(("fwd", step, 6), ops.head_workspace_bytes(f.shape[0], f.shape[1], f.shape[2], f.shape[3]))
+        S["masked"], S["cls"], S["raw"] = head.run(f, want_raw=True, ws=S["ws"][6])
         return S, [S["e1"], S["e2"], S["e3"], S["d1"], S["d2"], S["d3"]]
 
     # -- backward of one timestep -----------------------------------------------------------------------------------------
@@ -65,7 +65,6 @@ class WindowGradients:
         the following step (or None); returns the gradients w.r.t. the six states this step STARTED from."""
         net = self.net
         enc, dec, head = net.encoder, net.decoder, net.head
-        base = _SLOT0 + 16 * step
         e1p, e2p, e3p, d1p, d2p, d3p = S["prev"]
         dE1, dE2, dE3, dD1, dD2, dD3 = dstate if dstate is not None else [None] * 6
         add = lambda a, b: a if b is None else (b if a is None else a + b)
@@ -74,7 +73,8 @@ class WindowGradients:
             L = mod.layer
             key = f"{name}.{mod._pname}"
             dx, dw, db = train_ops.stage_conv_backward(x, L.weight.detach(), L.bias.detach(), dy, mod.pool, dweight=G.get(key + ".weight"),
-                                                       dbias=G.get(key + ".bias"), accumulate=acc and (key + ".weight") in G)
+                                                       dbias=G.get(key + ".bias"), accumulate=acc and (key + ".weight") in G,
+                                                       scratch=self.arena)
             G[key + ".weight"], G[key + ".bias"] = dw, db
             return dx
 
@@ -82,7 +82,8 @@ class WindowGradients:
             L = mod.layer
             key = f"{name}.{mod._pname}"
             dx, dw, db = train_ops.deconv2x2_backward(x, L.weight.detach(), out, dy, dweight=G.get(key + ".weight"),
-                                                      dbias=G.get(key + ".bias"), accumulate=acc and (key + ".weight") in G)
+                                                      dbias=G.get(key + ".bias"), accumulate=acc and (key + ".weight") in G,
+                                                      scratch=self.arena)
             G[key + ".weight"], G[key + ".bias"] = dw, db
             return dx
 
@@ -90,30 +91,27 @@ class WindowGradients:
             if dout_h is None:
                 dout_h, dout_h2 = dout_h2, None
             c1, g1, c2, g2 = _cell_params(mod)
-            ops.WORKSPACE.use_slot(base + k)
             names = {"dW1": "conv1.0.weight", "db1": "conv1.0.bias", "dg1": "conv1.1.weight", "dbe1": "conv1.1.bias",
                      "dW2": "conv2.0.weight", "db2": "conv2.0.bias", "dg2": "conv2.1.weight", "dbe2": "conv2.1.bias"}
             have = f"{name}.conv1.0.weight" in G
             prev = {k_: (G[f"{name}.{v}"].reshape(-1) if k_ in ("db1", "dg1", "dbe1", "db2", "dg2", "dbe2") else
                          G[f"{name}.{v}"].reshape(G[f"{name}.{v}"].shape[0], -1)) for k_, v in names.items()} if have else None
             g = train_ops.gru_cell_backward(x, e, h, c1.weight.detach(), c2.weight.detach(), g1.weight.detach(), g2.weight.detach(),
-                                            dout_h.contiguous(), mod.input_channels, grads=prev, accumulate=acc and have,
+                                            dout_h.contiguous(), mod.input_channels, S["ws"][k], grads=prev, accumulate=acc and have,
                                             packed=self._bwd_packed.setdefault(name, []),
-                                            dh_out2=None if dout_h2 is None else dout_h2.contiguous())
+                                            dh_out2=None if dout_h2 is None else dout_h2.contiguous(), scratch=self.arena)
             for k_, v in names.items():
                 ref = dict(mod.named_parameters())[v]
                 G[f"{name}.{v}"] = g[k_].reshape(ref.shape)
-            ops.WORKSPACE.use_slot(0)
             return g.get("dx"), g.get("de"), g["dh"]
 
         # head
         fp = head.flat_params()
-        ops.WORKSPACE.use_slot(base + 6)
         hg_prev = G.get("_head") if acc else None
         hg = train_ops.head_backward(S["feat"], fp["conv_w"], fp["ln_w"], fp["ln_b"], head.reg_preds.conv.weight.detach().reshape(-1),
-                                     S["raw"], S["cls"], dout.contiguous(), head.cls_thred, grads=hg_prev, accumulate=hg_prev is not None)
+                                     S["raw"], S["cls"], dout.contiguous(), head.cls_thred, S["ws"][6], grads=hg_prev,
+                                     accumulate=hg_prev is not None, scratch=self.arena)
         G["_head"] = hg
-        ops.WORKSPACE.use_slot(0)
         # decoder.  A state's gradient has two sources -- the layer above in this timestep and the same cell in the next
         # timestep; the cell backward takes them as two terms and adds on the fly (three terms: one torch add)
         du2, dE1_dec, dD3n = cell_bwd(5, "decoder.rnn1", dec.rnn1, S["u2"], S["e1"], d3p, conv_bwd("decoder.stage1", dec.stage1, S["d3"], hg["dfeat"]), dD3)
@@ -144,7 +142,7 @@ class WindowGradients:
             S, states = self._forward_step(ev, t0 + s, states, s, None if t_devs is None else t_devs[s])
             saved.append(S)
         reg = torch.stack([S["masked"] for S in saved], dim=1).contiguous()            # (B,steps,H,W) as main.py concatenates
-        comps, dreg = train_ops.loss(reg, targets, cls_thred=self.cls_thred_train)
+        comps, dreg = train_ops.loss(reg, targets, cls_thred=self.cls_thred_train, scratch=self.arena)
         G, dstate = ({k: v for k, v in grad_buffers.items() if not k.startswith("head.")} if grad_buffers else {}), None
         for s in reversed(range(steps)):
             dstate = self._backward_step(saved[s], s, dreg[:, s], dstate, G, acc=(s != steps - 1))
@@ -215,6 +213,8 @@ class Trainer:
             if cache is not None and hasattr(cache, "clear"):
                 cache.clear()
         self.net.head._stamp = None
+        # engines that captured a rollout graph of this net (inference.Inference, RolloutEngine) compare this counter
+        self.net._urnn_generation = getattr(self.net, "_urnn_generation", 0) + 1
 
 
     def set_lr(self, lr):
@@ -278,7 +278,7 @@ class Trainer:
             from .distributed import allreduce_mean_
             allreduce_mean_(self.gflat, group=self.pg)
         clip = train_ops.adam_step(self.flat, self.gflat, self.m, self.v, max(self.step_count, 1), lr=self.lr, betas=self.betas,
-                                   eps=self.eps, max_grad_norm=self.grad_clip, step_dev=step_dev)
+                                   eps=self.eps, max_grad_norm=self.grad_clip, step_dev=step_dev, scratch=self.wg.arena)
         self._invalidate_packed()
         return out, clip
 
