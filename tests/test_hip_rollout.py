@@ -440,3 +440,29 @@ def test_engine_follows_weight_changes(dev):
     got3 = inf.Inference(net, ev, dev, **kw)
     assert not np.array_equal(want3, want2) and np.array_equal(got3, want3)
     inf._ENGINES.clear()
+
+
+def test_repeated_launches_are_bit_identical_at_full_size(dev):
+    """Races inside a kernel show up as rare run-to-run differences on identical inputs (the bf16-split k-loop once refilled a
+    ring slot whose ds_read had not been waited for: one launch in ~30 differed).  Every cell of the network at its own
+    500x500-level plane, 60 launches each, must reproduce the first launch bit for bit."""
+    import urnn_amd.weights as uw
+    from urnn_amd.rollout import RolloutEngine
+    H = W = 500
+    nums = 30
+    net, _ = make_net(H, W, 2 * nums + 3, 0, dev)
+    eng = RolloutEngine(net, H, W, nums, 6.0, 250.0, max_frames=4, use_graph=False)
+    eng.load_event(uw.make_event(4, H, W, 6.0, seed=42))
+    eng.reset()
+    eng.run(2)
+    torch.cuda.synchronize()
+    enc, dec = net.encoder, net.decoder
+    e1, e2, e3, d1, d2, d3 = [s.clone() for s in eng.states]
+    a1, a2, a3, u3, u2 = (t.clone() for t in (eng.a1, eng.a2, eng.a3, eng.u3, eng.u2))
+    cases = {"enc1": lambda: enc.rnn1.step(a1, None, e1), "enc2": lambda: enc.rnn2.step(a2, None, e2), "enc3": lambda: enc.rnn3.step(a3, None, e3),
+             "dec3": lambda: dec.rnn3.step(None, e3, d1), "dec2": lambda: dec.rnn2.step(u3, e2, d2), "dec1": lambda: dec.rnn1.step(u2, e1, d3),
+             "stage2": lambda: enc.stage2(e1), "deconv2": lambda: dec.stage2(d2), "dec stage1": lambda: dec.stage1(d3)}
+    for name, fn in cases.items():
+        ref = fn().clone()
+        for i in range(60):
+            assert torch.equal(fn(), ref), f"{name}: launch {i + 1} differs from the first"

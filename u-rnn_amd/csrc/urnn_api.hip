@@ -69,7 +69,7 @@ static void pick_tile(long pixels_total, int waves_per_tile, long P, int *pb_out
 extern "C" size_t urnn_packed_conv_floats(int Cin, int Cout)
 {
     const size_t NB = urnn_conv_nb(Cout), NG = urnn_conv_ng(Cout), KT = (Cin + 1) / 2;
-    return NG * slab_floats(KT, NB) + NG * NB * 32;
+    return NG * slab_floats(KT, NB) + NG * NB * 32 + NG * (size_t)urnn_split_slab_dwords((int)KT, (int)NB);
 }
 
 extern "C" int urnn_pack_conv_f32(const float *weight, const float *bias, float *packed, int Cin, int Cout, void *stream)
@@ -85,7 +85,8 @@ extern "C" size_t urnn_packed_gru_floats(int I, int F, int skip)
     if (I < 1 || F < 32 || F % 32 != 0 || F > 128) return 0;
     const size_t KT = (size_t)(((I + 1) & ~1) + (skip ? F : 0) + F) / 2;
     const size_t NB2 = urnn_cand_nb(F);
-    return (size_t)(F / 32) * slab_floats(KT, 2) + 2 * F + (size_t)((F / 32) / NB2) * slab_floats(KT, NB2) + F;
+    return (size_t)(F / 32) * slab_floats(KT, 2) + 2 * F + (size_t)((F / 32) / NB2) * slab_floats(KT, NB2) + F +
+           (size_t)(F / 32) * urnn_split_slab_dwords((int)KT, 2) + (size_t)((F / 32) / NB2) * urnn_split_slab_dwords((int)KT, (int)NB2);
 }
 
 extern "C" int urnn_pack_gru_f32(const float *W1, const float *b1, const float *W2, const float *b2, float *packed, int I, int F,
@@ -136,6 +137,8 @@ extern "C" int urnn_stage_conv_f32(const float *in, const float *packed, float *
     p.aFloats = (int)slab_floats(p.KT, NB);
     p.NG = NG;
     p.bias = packed + (size_t)NG * p.aFloats;
+    p.wsplit = reinterpret_cast<const unsigned *>(p.bias + (size_t)NG * NB * 32);
+    p.sDwords = urnn_split_slab_dwords(p.KT, NB);
     p.P = (int)P;
     p.W = W;
     p.Cout = Cout;
@@ -246,6 +249,10 @@ static int gru_cell_impl(const float *x, const float *e, const float *h, const f
     p.aFloats = (int)slab_floats(KT, 2);
     p.NG = NW;
     p.bias = packed + (size_t)NW * p.aFloats;
+    const int NB2s = urnn_cand_nb(F);
+    const float *split0 = packed + (size_t)NW * p.aFloats + 2 * F + (size_t)(NW / NB2s) * slab_floats(KT, NB2s) + F;
+    p.wsplit = reinterpret_cast<const unsigned *>(split0);
+    p.sDwords = urnn_split_slab_dwords(KT, 2);
     p.P = (int)P;
     p.W = W;
     p.F = F;
@@ -285,6 +292,8 @@ static int gru_cell_impl(const float *x, const float *e, const float *h, const f
     c.aFloats = (int)slab_floats(KT, NB2);
     c.NG = NG2;
     c.bias = c.wt + (size_t)NG2 * c.aFloats;
+    c.wsplit = p.wsplit + (size_t)NW * p.sDwords;
+    c.sDwords = urnn_split_slab_dwords(KT, NB2);
     c.Cout = F;
     c.out0 = ws.cx;
     c.partial = ws.part2;
@@ -432,6 +441,8 @@ static int conv_2seg(const float *in0, int C0, const float *in1, int C1, const f
     p.aFloats = (int)slab_floats(p.KT, NB);
     p.NG = NG;
     p.bias = packed + (size_t)NG * p.aFloats;
+    p.wsplit = reinterpret_cast<const unsigned *>(p.bias + (size_t)NG * NB * 32);
+    p.sDwords = urnn_split_slab_dwords(p.KT, NB);
     p.P = (int)P;
     p.W = W;
     p.Cout = Cout;

@@ -17,6 +17,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 static inline int urnn_round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// Packed weights, SPLIT form (urnn_gemm.hip, bf16 x 6 k-loop): per n-group  [KT / 8 sixteen-k groups][NB][3 pieces hi|mid|lo]
+// [64 lanes][4 dwords]; dword d of lane l holds the bf16 piece of W[k = 2 * (8 * group + 2d) + (l >> 5)][n] in its low half and
+// of k + 2 (the next k-pair) in its high half, n = (g * NB + nb) * 32 + (l & 31): the A operand of v_mfma_f32_32x32x16_bf16 is
+// one conflict-free ds_read_b128 per piece.  Dwords per n-group:
+__host__ __device__ static inline int urnn_split_slab_dwords(int KT, int NB) { return ((KT + 7) / 8) * NB * 3 * 256; }
+
 // Row of the 32x32 MFMA C/D tile held in accumulator register r by a lane of the given half-wave:
 // row = (r & 3) + 8 * (r >> 2) + 4 * half  (cdna_hip_programming.md section 3; col = lane & 31).
 __device__ __forceinline__ int mfma_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
@@ -51,6 +57,19 @@ __device__ __forceinline__ float tanhf_fast(float v)
     const float t = __expf(-2.0f * fabsf(v));
     const float r = (1.0f - t) * __frcp_rn(1.0f + t);
     return copysignf(r, v);
+}
+
+// Truncating three-way bf16 split of an fp32 value (exact: x = hi + mid + lo, 8 significant bits each); piece 0 / 1 / 2 as the
+// 16 bits of the bf16 encoding.
+__device__ __forceinline__ unsigned bf16_piece(float x, int piece)
+{
+    unsigned u = __float_as_uint(x);
+    if (piece == 0) return u >> 16;
+    float r = x - __uint_as_float(u & 0xffff0000u);
+    u = __float_as_uint(r);
+    if (piece == 1) return u >> 16;
+    r = r - __uint_as_float(u & 0xffff0000u);
+    return __float_as_uint(r) >> 16;
 }
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v >= 0.f ? v : v * slope; }

@@ -618,36 +618,56 @@ hipError_t urnn_launch_advance(int *counter, int delta, hipStream_t st)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Weight packers (one-off).  Packed layout: one slab per n-group g (NB 32-column blocks), [KT][NB][64] floats padded to a
+// Weight packers (one-off).  Every conv / cell buffer ends with the SPLIT form of the same slabs (bf16 pieces, urnn_common.h
+// urnn_split_slab_dwords) for the bf16 x 6 k-loop.  fp32 form: one slab per n-group g (NB 32-column blocks), [KT][NB][64] floats padded to a
 // multiple of 256 floats:  slab[g][(kp*NB + nb)*64 + l] = W[row k = 2*kp + (l >> 5)][column n = (g*NB + nb)*32 + (l & 31)]
 // i.e. exactly the image conv_gemm_kernel keeps in LDS (every lane reads its MFMA A operand with one conflict-free
 // ds_read_b32).  The bias of every packed column follows the slabs.
 // ------------------------------------------------------------------------------------------------------------------
 __host__ __device__ static inline int slab_floats(int KT, int NB) { return (KT * NB * 64 + 255) / 256 * 256; }
 
+// dword `r` of an n-group's split slab: (16-k group, n-block, piece, lane, dword) -> the two k-pairs it holds
+__device__ __forceinline__ void split_slot(int r, int NB, int &kp_even, int &nb, int &piece, int &l)
+{
+    const int grp = r / (NB * 768), rr = r - grp * (NB * 768);
+    nb = rr / 768;
+    piece = (rr - nb * 768) / 256;
+    l = (rr & 255) >> 2;
+    kp_even = 8 * grp + 2 * (rr & 3);
+}
+
 __global__ void pack_conv_kernel(const float *__restrict__ w, const float *__restrict__ bias, float *__restrict__ packed, int Cin,
                                  int Cout, int NB, int NG, int KT)
 {
-    const int slab = slab_floats(KT, NB);
+    const int slab = slab_floats(KT, NB), ssd = urnn_split_slab_dwords(KT, NB);
     const int nw = NG * slab, Npad = NG * NB * 32;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= nw + Npad) return;
+    if (idx >= nw + Npad + NG * ssd) return;
+    auto wv = [&](int g, int kp, int nb, int l) {
+        const int k = 2 * kp + (l >> 5), n = (g * NB + nb) * 32 + (l & 31);
+        return (kp < KT && k < Cin && n < Cout) ? w[(size_t)n * Cin + k] : 0.f;
+    };
     if (idx < nw) {
         const int g = idx / slab, r = idx - g * slab;
         const int l = r & 63, row = r >> 6;
         const int kp = row / NB, nb = row - kp * NB;
-        const int k = 2 * kp + (l >> 5), n = (g * NB + nb) * 32 + (l & 31);
-        packed[idx] = (kp < KT && k < Cin && n < Cout) ? w[(size_t)n * Cin + k] : 0.f;
-    } else {
+        packed[idx] = wv(g, kp, nb, l);
+    } else if (idx < nw + Npad) {
         const int n = idx - nw;
         packed[idx] = (bias && n < Cout) ? bias[n] : 0.f;
+    } else {
+        const int q = idx - nw - Npad;
+        const int g = q / ssd;
+        int kp, nb, piece, l;
+        split_slot(q - g * ssd, NB, kp, nb, piece, l);
+        reinterpret_cast<unsigned *>(packed)[idx] = bf16_piece(wv(g, kp, nb, l), piece) | (bf16_piece(wv(g, kp + 1, nb, l), piece) << 16);
     }
 }
 
 hipError_t urnn_launch_pack_conv(const float *w, const float *bias, float *packed, int Cin, int Cout, hipStream_t st)
 {
     const int NB = urnn_conv_nb(Cout), NG = urnn_conv_ng(Cout), KT = (Cin + 1) / 2;
-    const int total = NG * slab_floats(KT, NB) + NG * NB * 32;
+    const int total = NG * slab_floats(KT, NB) + NG * NB * 32 + NG * urnn_split_slab_dwords(KT, NB);
     hipLaunchKernelGGL(pack_conv_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, bias, packed, Cin, Cout, NB, NG, KT);
     return hipGetLastError();
 }
@@ -663,20 +683,27 @@ __global__ void pack_gru_kernel(const float *__restrict__ W1, const float *__res
     const int Fe = skip ? F : 0;
     const int KT = (Ie + Fe + F) / 2, NG = F / 32, Ksrc = I + Fe + F;
     const int slab1 = slab_floats(KT, 2), slab2 = slab_floats(KT, NB2), NG2 = NG / NB2;
-    const int n1 = NG * slab1, nb1 = 2 * F, n2 = NG2 * slab2, nb2 = F;
+    const int ssd1 = urnn_split_slab_dwords(KT, 2), ssd2 = urnn_split_slab_dwords(KT, NB2);
+    const int n1 = NG * slab1, nb1 = 2 * F, n2 = NG2 * slab2, nb2 = F, s1 = NG * ssd1, s2 = NG2 * ssd2;
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n1 + nb1 + n2 + nb2) return;
+    if (idx >= n1 + nb1 + n2 + nb2 + s1 + s2) return;
     auto src_col = [&](int k) {   // packed row k -> source column of W1 / W2, -1: padding row
         if (k < Ie) return k < I ? k : -1;
         return I + (k - Ie);
+    };
+    auto gate_w = [&](int i, int kp, int c, int l) {    // group i = [z_i | r_i], block c
+        const int ks = kp < KT ? src_col(2 * kp + (l >> 5)) : -1;
+        return ks >= 0 ? W1[(size_t)(c * F + i * 32 + (l & 31)) * Ksrc + ks] : 0.f;
+    };
+    auto cand_w = [&](int g, int kp, int nb, int l) {
+        const int ks = kp < KT ? src_col(2 * kp + (l >> 5)) : -1;
+        return ks >= 0 ? W2[(size_t)((g * NB2 + nb) * 32 + (l & 31)) * Ksrc + ks] : 0.f;
     };
     float v = 0.f;
     if (idx < n1) {
         const int i = idx / slab1, r = idx - i * slab1;
         const int l = r & 63, row = r >> 6;
-        const int kp = row / 2, c = row - kp * 2;
-        const int ks = kp < KT ? src_col(2 * kp + (l >> 5)) : -1;
-        if (ks >= 0) v = W1[(size_t)(c * F + i * 32 + (l & 31)) * Ksrc + ks];
+        v = gate_w(i, row / 2, row & 1, l);
     } else if (idx < n1 + nb1) {
         const int n = idx - n1;
         const int i = n / 64, c = (n >> 5) & 1;
@@ -685,11 +712,26 @@ __global__ void pack_gru_kernel(const float *__restrict__ W1, const float *__res
         const int q = idx - n1 - nb1;
         const int g = q / slab2, r = q - g * slab2;
         const int l = r & 63, row = r >> 6;
-        const int kp = row / NB2, nb = row - kp * NB2;
-        const int ks = kp < KT ? src_col(2 * kp + (l >> 5)) : -1;
-        if (ks >= 0) v = W2[(size_t)((g * NB2 + nb) * 32 + (l & 31)) * Ksrc + ks];
-    } else {
+        const int kp = row / NB2;
+        v = cand_w(g, kp, row - kp * NB2, l);
+    } else if (idx < n1 + nb1 + n2 + nb2) {
         v = b2[idx - n1 - nb1 - n2];
+    } else {
+        int q = idx - n1 - nb1 - n2 - nb2;
+        int kp, nb, piece, l;
+        unsigned d;
+        if (q < s1) {
+            const int i = q / ssd1;
+            split_slot(q - i * ssd1, 2, kp, nb, piece, l);
+            d = bf16_piece(gate_w(i, kp, nb, l), piece) | (bf16_piece(gate_w(i, kp + 1, nb, l), piece) << 16);
+        } else {
+            q -= s1;
+            const int g = q / ssd2;
+            split_slot(q - g * ssd2, NB2, kp, nb, piece, l);
+            d = bf16_piece(cand_w(g, kp, nb, l), piece) | (bf16_piece(cand_w(g, kp + 1, nb, l), piece) << 16);
+        }
+        reinterpret_cast<unsigned *>(packed)[idx] = d;
+        return;
     }
     packed[idx] = v;
 }
@@ -700,7 +742,8 @@ hipError_t urnn_launch_pack_gru(const float *W1, const float *b1, const float *W
     const int Ie = (I + 1) & ~1;
     const int KT = (Ie + (skip ? F : 0) + F) / 2;
     const int NB2 = urnn_cand_nb(F);
-    const int total = (F / 32) * slab_floats(KT, 2) + 2 * F + ((F / 32) / NB2) * slab_floats(KT, NB2) + F;
+    const int total = (F / 32) * slab_floats(KT, 2) + 2 * F + ((F / 32) / NB2) * slab_floats(KT, NB2) + F +
+                      (F / 32) * urnn_split_slab_dwords(KT, 2) + ((F / 32) / NB2) * urnn_split_slab_dwords(KT, NB2);
     hipLaunchKernelGGL(pack_gru_kernel, dim3((total + 255) / 256), dim3(256), 0, st, W1, b1, W2, b2, packed, I, F, skip, NB2);
     return hipGetLastError();
 }

@@ -240,7 +240,31 @@ __device__ __forceinline__ void block_role(int NG, int &g, int &slot, int &nslot
 // conv_gemm_kernel: persistent blocks of WPB waves; block owns n-group g (weights resident in LDS), each wave loops over
 // pixel tiles.  gridDim.x is a multiple of 8 * NG.  Dynamic LDS = aFloats*4 + WPB * (D + 1) * SLOT + NB * 128 (bias).
 // ------------------------------------------------------------------------------------------------------------------
-template <int NB, int PB, int MAP, int EPI, int D, int WPB>
+// bf16 pieces of fp32 operands for the 16-bit matrix pipe (SPLIT kernels).  Truncating splits are EXACT: x = hi + mid + lo with
+// 8 significant bits each, so  a*b = hh + hm + mh + hl + lh + mm  up to the three dropped terms (<= 3 * 2^-24 |a*b|, one fp32
+// rounding's worth); measured against float64 on K = 224 dot products: rms error 2.2e-7 of sqrt(sum (w x)^2) vs 2.7e-7 for the
+// fp32 MFMA's own fma chain (tools/ubench/split_mfma.hip, profiles/r02_split_mfma.txt) -- at 16/6 of its rate.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// One dword of each piece from two fp32 values: element 2d = the even k-pair's value, 2d + 1 = the odd one's.
+__device__ __forceinline__ void split_pair(float xe, float xo, unsigned &ph, unsigned &pm, unsigned &pl)
+{
+    const unsigned ue = __float_as_uint(xe), uo = __float_as_uint(xo);
+    ph = __builtin_amdgcn_perm(uo, ue, 0x07060302u);                       // {uo[31:16], ue[31:16]}: truncation to bf16
+    const float re = xe - __uint_as_float(ue & 0xffff0000u), ro = xo - __uint_as_float(uo & 0xffff0000u);   // exact
+    const unsigned ve = __float_as_uint(re), vo = __float_as_uint(ro);
+    pm = __builtin_amdgcn_perm(vo, ve, 0x07060302u);
+    const float se = re - __uint_as_float(ve & 0xffff0000u), so = ro - __uint_as_float(vo & 0xffff0000u);   // exact, <= 8 bits left
+    pl = __builtin_amdgcn_perm(__float_as_uint(so), __float_as_uint(se), 0x07060302u);
+}
+
+__device__ __forceinline__ bf16x8 as_bf16x8(const unsigned (&p)[4]) { return __builtin_bit_cast(bf16x8, u32x4{p[0], p[1], p[2], p[3]}); }
+
+// SPLIT = 0: v_mfma_f32_32x32x2_f32 per k-pair (exact fp32 fma chain).  SPLIT = 1: eight k-pairs at a time on
+// v_mfma_f32_32x32x16_bf16 with both operands split into three bf16 pieces (six MFMAs per 16 k: 2.67x the fp32 matrix rate);
+// needs (KT - kpBegin) % 8 == 0 and, in the candidate GEMM, a plain part that is a positive multiple of 8 k-pairs.
+template <int NB, int PB, int MAP, int EPI, int D, int WPB, int SPLIT>
 __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const ConvGemmParams prm)
 {
     using R = Ring<PB, MAP>;
@@ -250,18 +274,24 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
     int g, slot0, nslots;
     block_role(prm.NG, g, slot0, nslots);
 
-    const float *A = reinterpret_cast<const float *>(urnn_smem);       // [KT][NB][64]
-    char *ring = urnn_smem + (size_t)prm.aFloats * 4 + wave * ((D + 1) * R::SLOT);
+    const float *A = reinterpret_cast<const float *>(urnn_smem);       // [KT][NB][64]  (SPLIT: [KT/8][NB][3][64] x 16 B of bf16 pieces)
+    const size_t slabBytes = SPLIT ? (size_t)prm.sDwords * 4 : (size_t)prm.aFloats * 4;
+    char *ring = urnn_smem + slabBytes + wave * ((D + 1) * R::SLOT);
     char *scratch = ring + D * R::SLOT;                                // one extra slot: sink for the count-keeping dummy DMAs
     const int kp_begin = prm.kpBegin, KT = prm.KT;
     const int n0 = g * (NB * 32);
     // The group's bias row lives in LDS too: a GLOBAL load inside the epilogue would put an s_waitcnt vmcnt(0) in front of
     // every store (loads and stores share the counter), i.e. one full memory round trip per stored row -- measured 1000
     // cycles per store instruction, 49k cycles per 48-KiB tile epilogue.
-    float *bias = reinterpret_cast<float *>(urnn_smem + (size_t)prm.aFloats * 4 + WPB * ((D + 1) * R::SLOT));
+    float *bias = reinterpret_cast<float *>(urnn_smem + slabBytes + WPB * ((D + 1) * R::SLOT));
     float *ssm = bias + NB * 32;                                       // EPI_CAND: [B][F][2] r-gate (scale, shift)
+    // epilogue reads of the bias row: ONE lane-dependent base (+ 4 * half) and compile-time row offsets, so that the reads are
+    // ds_read with immediate offsets instead of 16 * NB precomputed address registers kept live across the k-loop
+    const float *bias_h = bias + 4 * half;
+    auto row_c = [](int r) { return (r & 3) + 8 * (r >> 2); };
     constexpr bool GATED = (EPI == EPI_CAND);
-    stage_weights(prm.wt + (size_t)g * prm.aFloats, urnn_smem, prm.aFloats, wave, WPB, lane);
+    if constexpr (SPLIT) stage_weights(reinterpret_cast<const float *>(prm.wsplit) + (size_t)g * prm.sDwords, urnn_smem, prm.sDwords, wave, WPB, lane);
+    else stage_weights(prm.wt + (size_t)g * prm.aFloats, urnn_smem, prm.aFloats, wave, WPB, lane);
     if (threadIdx.x < NB * 32) bias[threadIdx.x] = prm.bias[n0 + threadIdx.x];
     if constexpr (GATED) {
         // GroupNorm of the gates is finalised HERE instead of in a launch of its own: one wave per (sample, 32-channel
@@ -417,6 +447,109 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
             for (int pb = 0; pb < PB; ++pb) bv[pb] = sigmoidf_fast(gg[pb] * st.x + st.y) * hh[pb];
         };
 
+        if constexpr (SPLIT) {
+            // ---- bf16 x 6 path.  The ring protocol (slots, counted waits, refills D slots ahead) is the fp32 one; a k-pair's
+            // activation fragments are split into bf16 pieces as they arrive (even / odd k-pair -> low / high half of a dword),
+            // the weights' pieces are read ready-made from LDS, and every eighth k-pair the 6 * NB * PB MFMAs of the 16-k group
+            // are issued.  Lane l holds, as element j of its A / B vectors, k = 2 * (8 * group + j) + (l >> 5): any assignment
+            // works as long as A and B agree.  Refills use uniform branches (no pinned schedule here): segment switches are rare.
+            int seg_left = (kp_begin >= k2 ? INT_MAX : (kp_begin >= k1 ? (k2 == INT_MAX || GATED ? INT_MAX : k2 - kp_begin) : k1 == INT_MAX ? INT_MAX : k1 - kp_begin));
+            int seg_cur = s_begin;
+            auto refill_s = [&](int slot) {
+                if (si < nplain) {
+                    R::issue(ring + slot * R::SLOT, rs, vo, soff, lane);
+                    soff += rstep;
+                    if (--seg_left == 0) {                       // next K segment (x -> e -> h)
+                        ++seg_cur;
+                        rs = seg_cur == 1 ? rs1 : rs2;
+                        soff = 0u;
+                        seg_left = (seg_cur == 1 && !GATED && k2 != INT_MAX) ? k2 - k1 : INT_MAX;
+                    }
+                } else if (GATED && si < total) {
+                    const bool hrows = ((si - nplain) & 1) != 0;
+                    R::issue(ring + slot * R::SLOT, hrows ? rs2 : rsg, vo, soff_g, lane);
+                    soff_g += hrows ? rstep : 0u;
+                } else {
+                    R::issue(scratch, rs0, vo, 0xF0000000u, lane);   // past the end: keeps the outstanding-DMA count exact
+                }
+                ++si;
+            };
+            for (int i = 0; i < D; ++i) refill_s(i);
+            float rb[2][PB];                               // raw fp32 activation fragments: rb[0] even k-pairs, rb[1] odd ones
+            unsigned bh[PB][4], bm[PB][4], bl[PB][4];
+            const char *Ap = urnn_smem + lane * 16;
+            auto read_b = [&](int kp, int slot_, bool gated, float (&bv)[PB]) {
+                if (!gated) {
+                    R::read(ring + slot_ * R::SLOT, lane, bv);
+                } else {
+                    float gg[PB], hh[PB];
+                    R::read(ring + slot_ * R::SLOT, lane, gg);
+                    R::read(ring + wrap(slot_ + 1) * R::SLOT, lane, hh);
+                    const f32x2 st = *reinterpret_cast<const f32x2 *>(ssb + 2 * (2 * (kp - kpe) + half));
+#pragma unroll
+                    for (int pb = 0; pb < PB; ++pb) bv[pb] = sigmoidf_fast(gg[pb] * st.x + st.y) * hh[pb];
+                }
+            };
+            wait_vmcnt<(D - 1) * R::NLOAD>();
+            read_b(kp_begin, 0, false, rb[0]);
+            TRACE_STAMP(1);
+            int slot = 0;
+            auto sstep = [&](int kp, auto q_tag, auto cur_tag, auto nxt_tag) {
+                constexpr int Q = decltype(q_tag)::value;
+                constexpr bool CG = decltype(cur_tag)::value, NGT = decltype(nxt_tag)::value;
+                const int nslot = wrap(slot + (CG ? 2 : 1));
+                if constexpr (Q & 1) {
+#pragma unroll
+                    for (int pb = 0; pb < PB; ++pb) split_pair(rb[0][pb], rb[1][pb], bh[pb][Q >> 1], bm[pb][Q >> 1], bl[pb][Q >> 1]);
+                }
+                wait_vmcnt<(D - (CG ? 2 : 1) - (NGT ? 2 : 1)) * R::NLOAD>();       // the next k-pair's slot(s) have landed (or are dummies)
+                // The slot(s) about to be refilled were read one step ago, but an even k-pair's fragments are not CONSUMED before
+                // the next odd step, so nothing has waited for that ds_read yet: without this wait the DMA could (rarely: one
+                // launch in ~30) overwrite the slot before the read had left LDS.  The read is a step old: the wait is free.
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                refill_s(slot);
+                if constexpr (CG) refill_s(wrap(slot + 1));
+                read_b(kp + 1 < KT ? kp + 1 : kp, nslot, NGT, rb[(Q + 1) & 1]);
+                if constexpr (Q == 7) {
+                    const char *ag = Ap + (size_t)(kp >> 3) * (NB * 3 * 1024);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const bf16x8 wh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(ag + (nb * 3 + 0) * 1024));
+                        const bf16x8 wm = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(ag + (nb * 3 + 1) * 1024));
+                        const bf16x8 wl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(ag + (nb * 3 + 2) * 1024));
+                        auto mm = [&](const bf16x8 &wa, const unsigned (&pbv)[PB][4]) {
+#pragma unroll
+                            for (int pb = 0; pb < PB; ++pb)
+                                acc[nb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, as_bf16x8(pbv[pb]), acc[nb][pb], 0, 0, 0);
+                        };
+                        mm(wm, bm); mm(wl, bh); mm(wh, bl); mm(wm, bh); mm(wh, bm); mm(wh, bh);     // small terms first
+                        __builtin_amdgcn_sched_barrier(0);       // keep the next n-block's weight pieces from being loaded early (registers)
+                    }
+                }
+                slot = nslot;
+            };
+            using std::false_type;
+            using std::true_type;
+            auto group = [&](int kp0, auto cur_tag, auto last_nxt_tag) {
+                sstep(kp0 + 0, std::integral_constant<int, 0>{}, cur_tag, cur_tag);
+                sstep(kp0 + 1, std::integral_constant<int, 1>{}, cur_tag, cur_tag);
+                sstep(kp0 + 2, std::integral_constant<int, 2>{}, cur_tag, cur_tag);
+                sstep(kp0 + 3, std::integral_constant<int, 3>{}, cur_tag, cur_tag);
+                sstep(kp0 + 4, std::integral_constant<int, 4>{}, cur_tag, cur_tag);
+                sstep(kp0 + 5, std::integral_constant<int, 5>{}, cur_tag, cur_tag);
+                sstep(kp0 + 6, std::integral_constant<int, 6>{}, cur_tag, cur_tag);
+                sstep(kp0 + 7, std::integral_constant<int, 7>{}, cur_tag, last_nxt_tag);
+            };
+            if constexpr (GATED) {
+                static_assert(D >= 6 && D % 2 == 0, "a gated k-pair and its successor hold four slots");
+                int kp = kp_begin;
+                for (; kp + 8 < kpe; kp += 8) group(kp, false_type{}, false_type{});
+                group(kp, false_type{}, true_type{});                          // last plain group: its last step reads a gated k-pair
+                for (kp += 8; kp < KT; kp += 8) group(kp, true_type{}, true_type{});
+            } else {
+                for (int kp = kp_begin; kp < KT; kp += 8) group(kp, false_type{}, false_type{});
+            }
+        } else {
         // Software pipeline.  A wave issues in order and each fp32 MFMA occupies the pipe for 64 cycles, so everything that is
         // not an MFMA must sit BETWEEN MFMAs (about ten instruction slots hide behind each one) -- traced with s_memtime, the
         // version that did its LDS reads, pointer math and DMA issue after the last MFMA of a k-pair lost 300 of every 1070
@@ -489,8 +622,16 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
         } else {
             for (int kp = kp_begin; kp < KT; ++kp) step(kp, false_type{}, false_type{}, RF0{});
         }
+        }
         wait_vmcnt<0>();
         TRACE_STAMP(2);
+        if constexpr (SPLIT) {
+            // Re-derive the pixel map for the epilogue instead of carrying it in registers across the k-loop (the bf16 pieces
+            // need them: a spilled value reloaded between two stores would serialise the stores, see the bias note above).
+            int tile_e = tile, j_e = j;
+            asm volatile("" : "+s"(tile_e), "+v"(j_e));
+            pm.init(tile_e, j_e, prm.P, prm.W, prm.P2, prm.W2);
+        }
 
         if constexpr (EPI == EPI_LRELU) {
             // out[b][n][p] = lrelu(acc + bias)
@@ -501,7 +642,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
                     const int cib = mfma_row(r, half);
                     const int n = n0 + nb * 32 + cib;
                     if (n < prm.Cout) {
-                        const float bv = bias[nb * 32 + cib];
+                        const float bv = bias_h[nb * 32 + row_c(r)];
                         float v[PB];
 #pragma unroll
                         for (int pb = 0; pb < PB; ++pb) v[pb] = lrelu(acc[nb][pb][r] + bv, prm.slope);
@@ -517,7 +658,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
                     const int cib = mfma_row(r, half);
                     const int n = n0 + nb * 32 + cib;
                     if (n < prm.Cout && pm.valid[0]) {
-                        const float bv = bias[nb * 32 + cib];
+                        const float bv = bias_h[nb * 32 + row_c(r)];
                         float s = 0.f;
 #pragma unroll
                         for (int pb = 0; pb < 4; ++pb) s += lrelu(acc[nb][pb][r] + bv, prm.slope);
@@ -544,7 +685,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
                     const int cib = mfma_row(r, half);
                     const int co = cob * 32 + cib;
                     if (co < prm.Cout) {
-                        const float bv = bias[cob * 32 + cib];
+                        const float bv = bias_h[cob * 32 + row_c(r)];
                         float *oplane = prm.out0 + ((size_t)b * prm.Cout + co) * (4 * (size_t)prm.P);
                         if constexpr (is_pair(MAP)) {
                             // two horizontally adjacent input pixels -> four consecutive output floats (W even, p even)
@@ -577,32 +718,32 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
             const float inv_n = 1.f / (float)(32 * tile_valid(tile, 32 * PB, prm.P));
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
+                // pass 1, registers only: the tile's sum -> its own mean; pass 2: squares about that mean (urnn_common.h tile_x2)
+                // while the rows are stored -- an accumulator row dies with its store, as in a single-pass epilogue
                 float s1 = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int cib = mfma_row(r, half);
-                    const float bv = bias[nb * 32 + cib];
-                    float *orow = prm.out0 + ((size_t)b * 2 * F + nb * F + i * 32 + cib) * prm.P;
+                    const float bv = bias_h[nb * 32 + row_c(r)];
+#pragma unroll
+                    for (int pb = 0; pb < PB; ++pb)
+                        if (pm.valid[pb]) s1 += acc[nb][pb][r] + bv;
+                }
+                s1 = wave_sum(s1);
+                const float mt = s1 * inv_n;
+                float s2 = 0.f;
+                float *obase = prm.out0 + ((size_t)b * 2 * F + nb * F + i * 32 + 4 * half) * prm.P;   // one lane-dependent base, uniform row steps
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float bv = bias_h[nb * 32 + row_c(r)];
+                    float *orow = obase + (size_t)row_c(r) * prm.P;
                     float v[PB];
 #pragma unroll
                     for (int pb = 0; pb < PB; ++pb) {
                         v[pb] = acc[nb][pb][r] + bv;
-                        if (pm.valid[pb]) s1 += v[pb];
-                    }
-                    store_row<MAP, PB>(orow, pm, v);
-                }
-                s1 = wave_sum(s1);
-                // second moment about the tile's own mean, from the accumulators still in registers (urnn_common.h tile_x2)
-                const float mt = s1 * inv_n;
-                float s2 = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float bm = bias[nb * 32 + mfma_row(r, half)] - mt;
-#pragma unroll
-                    for (int pb = 0; pb < PB; ++pb) {
-                        const float d = acc[nb][pb][r] + bm;
+                        const float d = v[pb] - mt;
                         if (pm.valid[pb]) s2 = fmaf(d, d, s2);
                     }
+                    store_row<MAP, PB>(orow, pm, v);
                 }
                 s2 = wave_sum(s2);
                 if (lane == 0) {
@@ -620,32 +761,31 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
             const float inv_n = 1.f / (float)(32 * tile_valid(tile, 32 * PB, prm.P));
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                float s1 = 0.f;
                 const int grp = g * NB + nb;
+                float s1 = 0.f;                                   // pass 1 (registers only) / pass 2 (+ stores) as in the gate epilogue
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int cib = mfma_row(r, half);
-                    const float bv = bias[nb * 32 + cib];
-                    float *orow = prm.out0 + ((size_t)b * F + grp * 32 + cib) * prm.P;
-                    float v[PB];
+                    const float bv = bias_h[nb * 32 + row_c(r)];
 #pragma unroll
-                    for (int pb = 0; pb < PB; ++pb) {
-                        v[pb] = acc[nb][pb][r] + bv;
-                        if (pm.valid[pb]) s1 += v[pb];
-                    }
-                    store_row<MAP, PB>(orow, pm, v);
+                    for (int pb = 0; pb < PB; ++pb)
+                        if (pm.valid[pb]) s1 += acc[nb][pb][r] + bv;
                 }
                 s1 = wave_sum(s1);
                 const float mt = s1 * inv_n;
                 float s2 = 0.f;
+                float *obase = prm.out0 + ((size_t)b * F + grp * 32 + 4 * half) * prm.P;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float bm = bias[nb * 32 + mfma_row(r, half)] - mt;
+                    const float bv = bias_h[nb * 32 + row_c(r)];
+                    float *orow = obase + (size_t)row_c(r) * prm.P;
+                    float v[PB];
 #pragma unroll
                     for (int pb = 0; pb < PB; ++pb) {
-                        const float d = acc[nb][pb][r] + bm;
+                        v[pb] = acc[nb][pb][r] + bv;
+                        const float d = v[pb] - mt;
                         if (pm.valid[pb]) s2 = fmaf(d, d, s2);
                     }
+                    store_row<MAP, PB>(orow, pm, v);
                 }
                 s2 = wave_sum(s2);
                 if (lane == 0) {
@@ -712,20 +852,24 @@ static hipError_t allow_big_lds(K kernel, size_t lds)
 }
 
 // dynamic LDS: weight slab + per-wave rings (D slots + the dummy sink) + bias row + (candidate GEMM) the r-gate scale/shift table
+template <int NB, int PB, int EPI>
+static bool split_ok(const ConvGemmParams &p);
+
 template <int NB, int PB, int MAP, int EPI>
 static size_t conv_lds_bytes(const ConvGemmParams &p, int D, int WPB)
 {
     using R = Ring<PB, MAP>;
-    return (size_t)p.aFloats * 4 + (size_t)WPB * ((D + 1) * R::SLOT) + NB * 128 + (EPI == EPI_CAND ? (size_t)p.B * p.F * 8 : 0);
+    const size_t slab = split_ok<NB, PB, EPI>(p) ? (size_t)p.sDwords * 4 : (size_t)p.aFloats * 4;
+    return slab + (size_t)WPB * ((D + 1) * R::SLOT) + NB * 128 + (EPI == EPI_CAND ? (size_t)p.B * p.F * 8 : 0);
 }
 
-template <int NB, int PB, int MAP, int EPI, int D, int WPB>
-static hipError_t launch_conv_cfg(const ConvGemmParams &p, hipStream_t st, int max_bpc = 2)
+template <int NB, int PB, int MAP, int EPI, int D, int WPB, int SPLIT>
+static hipError_t launch_conv_split(const ConvGemmParams &p, hipStream_t st, int max_bpc)
 {
     using R = Ring<PB, MAP>;
     const size_t lds = conv_lds_bytes<NB, PB, MAP, EPI>(p, D, WPB);
     if (lds > LDS_PER_CU) return hipErrorInvalidValue;
-    auto kern = conv_gemm_kernel<NB, PB, MAP, EPI, D, WPB>;
+    auto kern = conv_gemm_kernel<NB, PB, MAP, EPI, D, WPB, SPLIT>;
     // raise this instantiation's dynamic-LDS cap once (and again only if a launch needs more); one process drives one GPU
     static std::atomic<size_t> allowed{64 * 1024};
     if (lds > allowed.load(std::memory_order_relaxed)) {
@@ -738,6 +882,52 @@ static hipError_t launch_conv_cfg(const ConvGemmParams &p, hipStream_t st, int m
     q.stagger = tune_stagger();
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WPB), lds, st, q);
     return hipGetLastError();
+}
+
+static int tune_ring()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("URNN_TUNE_RING");
+        v = e ? atoi(e) : 8;
+    }
+    return v;
+}
+
+static int tune_split()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("URNN_TUNE_SPLIT");   // development knob: 0 forces the fp32-MFMA k-loop everywhere
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
+
+// Which k-loop: the bf16 x 6 one (2.67x the fp32 matrix rate, fp32-class accuracy) whenever the K range is made of whole
+// 16-k groups -- every layer of the published network -- and the accumulators leave room for the pieces; else the exact
+// fp32-MFMA one (odd channel counts, the 6-block deconv tile).
+template <int NB, int PB, int EPI>
+static bool split_ok(const ConvGemmParams &p)
+{
+    if constexpr (NB * PB * 16 > 128 || EPI == EPI_DECONV) return false;
+    if (!tune_split()) return false;
+    if (p.sDwords <= 0 || !p.wsplit || (size_t)p.sDwords * 4 > LDS_PER_CU - 24 * 1024) return false;
+    if (p.KT % 8 != 0 || p.kpBegin % 8 != 0 || p.KT <= p.kpBegin) return false;      // whole 16-k groups, aligned with the packed ones
+    if constexpr (EPI == EPI_CAND) {
+        const int kpe = p.hKp0 < p.KT ? p.hKp0 : p.KT;
+        if (kpe <= p.kpBegin || kpe % 8 != 0 || kpe >= p.KT) return false;
+    }
+    return true;
+}
+
+template <int NB, int PB, int MAP, int EPI, int D, int WPB>
+static hipError_t launch_conv_cfg(const ConvGemmParams &p, hipStream_t st, int max_bpc = 2)
+{
+    if constexpr (NB * PB * 16 <= 128 && EPI != EPI_DECONV) {
+        if (split_ok<NB, PB, EPI>(p)) return launch_conv_split<NB, PB, MAP, EPI, D, WPB, 1>(p, st, max_bpc);
+    }
+    return launch_conv_split<NB, PB, MAP, EPI, D, WPB, 0>(p, st, max_bpc);
 }
 
 // Block shape: 8 waves (two per SIMD: one wave's epilogue / stalls hide behind the other's MFMAs) with a 4-deep ring when
@@ -764,6 +954,16 @@ static hipError_t launch_conv(const ConvGemmParams &p, hipStream_t st)
             if constexpr (NB * PB * 16 <= 64) {
                 if (2 * conv_lds_bytes<NB, PB, MAP, EPI>(p, 4, 8) <= LDS_PER_CU && enough && tune_block_waves() == 16)
                     return launch_conv_cfg<NB, PB, MAP, EPI, 4, 8>(p, st, 3);
+            }
+            if constexpr (NB * PB * 16 <= 128) {
+                // bf16 x 6 k-loop: a k-pair is consumed in ~200 cycles instead of 512, so a 4-deep ring (3 KiB in flight per
+                // wave) no longer covers the HBM latency -- the dec1 gate GEMM stayed at 113 us with the MFMA and issue time
+                // halved; 8-deep where the LDS allows (development knob URNN_TUNE_RING = 4 | 6 | 8)
+                if (split_ok<NB, PB, EPI>(p) && enough && tune_block_waves() != 4) {
+                    const int want = tune_ring();
+                    if (want >= 8 && conv_lds_bytes<NB, PB, MAP, EPI>(p, 8, 8) <= LDS_PER_CU) return launch_conv_cfg<NB, PB, MAP, EPI, 8, 8>(p, st);
+                    if (want >= 6 && conv_lds_bytes<NB, PB, MAP, EPI>(p, 6, 8) <= LDS_PER_CU) return launch_conv_cfg<NB, PB, MAP, EPI, 6, 8>(p, st);
+                }
             }
             if (conv_lds_bytes<NB, PB, MAP, EPI>(p, 4, 8) <= LDS_PER_CU && enough && tune_block_waves() != 4)
                 return launch_conv_cfg<NB, PB, MAP, EPI, 4, 8>(p, st);

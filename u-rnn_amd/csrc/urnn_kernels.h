@@ -25,6 +25,8 @@ struct ConvGemmParams {
     int B;                // EPI_CAND: samples (size of the reset-gate scale/shift table kept in LDS)
     const float *wt;      // packed weights [NG][KT][NB][64] (group stride aFloats); lane l of row (kp, nb) holds
                           // W[k = 2*kp + (l >> 5)][n = (g*NB + nb)*32 + (l & 31)]
+    const unsigned *wsplit;   // the same weights split into bf16 pieces (urnn_common.h urnn_split_slab_dwords), group stride sDwords
+    int sDwords;          // dwords per n-group split slab (a multiple of 256); 0: no split form (fp32 k-loop only)
     const float *bias;    // bias per packed column [NG*NB*32]
     int aFloats;          // floats per n-group slab, a multiple of 256 (one LDS-DMA instruction moves 256 floats)
     int NG;               // number of n-groups (blocks are specialised per group)
