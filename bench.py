@@ -10,10 +10,10 @@ T=360, one event per GPU, fp32, synthetic event + seeded random weights (no data
 N>1: one process per GPU (torchrun), one independent event per rank, no data-path collective (events are
 independent: test.py:741-746) -> weak scaling; value = total frames of all ranks / max-over-ranks time.
 
-Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel = the fp32-MFMA gate GEMM of the
-full-resolution ConvGRU cells, timed live with events on the launch streams while the rollout runs in the same
-scheduling mode as the timed region) and "cpu_baseline" (the C oracle on the host cores, bounded sample, rank 0
-at N=1 only).
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel = the gate GEMM of the ConvGRU cells,
+timed live with events on the launch streams while the rollout runs in the same scheduling mode as the timed
+region; HBM-bound since the bf16-split k-loop) and "cpu_baseline" (the C oracle on the host cores, bounded sample,
+rank 0 at N=1 only).  `python bench.py --gpus N` without a launcher re-runs itself as N ranks (torch.distributed.run).
 """
 import argparse
 import json
@@ -40,6 +40,8 @@ CONFIGS = {
 MIXED = ("futian", "ukea")     # BASELINE configs[4]: mixed-resolution events on every rank
 
 PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X fp32 matrix peak (MI355X_MICROARCH.md)
+PEAK_MFMA_BF16_TFLOPS = 2517.0  # dense bf16 matrix peak (MI355X_MICROARCH.md: ~2.5 PF; 16x the fp32 matrix rate)
+SPLIT_MFMAS = 6                 # bf16 MFMAs per fp32-equivalent 16-k step of the split k-loop (urnn_gemm.hip)
 PEAK_HBM_TBS = 8.0
 
 
@@ -75,6 +77,13 @@ def gate_gemm_flops(H, W, B=1):
     return {"enc1": P1 * 128 * 80 * 2.0, "dec1": P1 * 128 * 224 * 2.0, "enc2": P2 * 192 * 160 * 2.0, "dec2": P2 * 192 * 288 * 2.0}
 
 
+def gate_gemm_bytes(H, W, B=1):
+    """Algorithmic HBM bytes of the same four launches (SURVEY 8d's per-stage figure: every input plane read once, every
+    output plane written once, fp32): K input channels + 2F raw gate channels per pixel (weights: < 0.3 MB, not counted)."""
+    P1, P2 = B * H * W, B * (H // 2) * (W // 2)
+    return {"enc1": 4.0 * P1 * (80 + 128), "dec1": 4.0 * P1 * (224 + 128), "enc2": 4.0 * P2 * (160 + 192), "dec2": 4.0 * P2 * (288 + 192)}
+
+
 def build_net(H, W, C, dev, seed=0):
     import urnn_amd.weights as uw
     from urnn_amd.net_config import load_net_config
@@ -106,6 +115,8 @@ def cpu_baseline(sd, cfgname, budget_s=15.0, max_frames=8):
         n += 1
     dt = time.time() - t0
     return {"value": n / dt, "unit": "frames/s", "cores": orc.num_threads(), "kind": "port",
+            "arith": "plain-C restatement of the reference's ops (oracle/urnn_oracle.c): fp32 storage, fp64 accumulation, OpenMP; "
+                     "the reference itself is Python/PyTorch and cannot travel to the GPU box",
             "sample": f"{n} frames of the {H}x{W} C={2*nums+3} rollout after 1 warm-up frame ({dt:.1f} s), "
                       f"C oracle with OpenMP on {orc.num_threads()} threads of {os.cpu_count()} logical CPUs"}
 
@@ -339,6 +350,14 @@ def main():
 
     frames = args.steps * B * world
     fps = frames / elapsed
+    long_run = None
+    if args.steps < 360 and world == 1:           # a short timed region (the driver's --steps 20 is ~20 ms): also one full event
+        run_steps(0)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        run_steps(360)
+        torch.cuda.synchronize(dev)
+        long_run = {"steps": 360, "value": 360 * B / (time.perf_counter() - t1), "unit": "frames/s"}
     if len(names) == 1:
         gflop = algorithmic_work(H, W, C)
     else:   # frame-weighted over one cycle of events
@@ -364,6 +383,7 @@ def main():
                                 f" events alternating, {B} event(s) per GPU, one hipGraph per shape"),
                    "events_per_gpu": B, "parallelism": f"event-parallel x{world} (no collective)",
                    "graph": not args.no_graph, "overlap_chains": bool(args.overlap)},
+        "long_run": long_run,
         "gflop_per_frame": gflop,
         "step_mfma_frac": fps / world * gflop / 1e3 / PEAK_MFMA_F32_TFLOPS,
         # frames/s x A_stage / 8 TB/s -- the unfused per-stage traffic model; the step is MFMA-bound (AI 49 FLOP/B)
@@ -371,25 +391,34 @@ def main():
     }
 
     if rank == 0:
-        # dominant kernel: the fp32-MFMA gate GEMM (4 launches per frame share one template instantiation)
+        # dominant kernel: the ConvGRU gate GEMM (4 launches per frame).  With the bf16 x 6 split k-loop its arithmetic
+        # intensity (39 FLOP/B) sits below the ridge of the matrix pipe it runs on (2517 / 6 = 420 TFLOP/s fp32-equivalent
+        # over 8 TB/s = 52 FLOP/B): HBM is the binding roof.  The MFMA view is reported next to it.
         try:
             dur = eng.probe_gate_gemm()          # live, events on the launch streams, same scheduling mode as the timed region
-            fl = gate_gemm_flops(H, W, B)
+            fl, by = gate_gemm_flops(H, W, B), gate_gemm_bytes(H, W, B)
             flops_per_launch = sum(fl.values()) / len(fl)
+            bytes_per_launch = sum(by.values()) / len(by)
             avg = sum(dur[k] for k in fl) / len(fl)
-            achieved = flops_per_launch / avg / 1e12
-            traffic = None
+            achieved = bytes_per_launch / avg / 1e9
+            traffic, tsrc = None, None
             pmc = os.path.join(REPO, "profiles", "pmc_gate_gemm.json")
             if os.path.isfile(pmc) and args.config == "location1" and B == 1:
                 with open(pmc) as fh:
-                    traffic = json.load(fh).get("hbm_bytes_per_launch")
+                    rec = json.load(fh)
+                traffic, tsrc = rec.get("hbm_bytes_per_launch"), rec.get("source")
+            split = os.environ.get("URNN_TUNE_SPLIT", "1") != "0"
+            mfma_peak = PEAK_MFMA_BF16_TFLOPS / SPLIT_MFMAS if split else PEAK_MFMA_F32_TFLOPS
             result["roofline"] = {
-                "bound": "mfma", "kernel": "conv_gemm_kernel<2, 4, 0, 3, 4, 8> = <NB=2,PB=4,MAP_VEC,EPI_GRU1,D=4,WPB=8> (ConvGRU gate GEMM, fp32 MFMA "
-                          "32x32x2; 4 launches per frame: enc1, dec1 at full and enc2, dec2 at half resolution)",
-                "achieved": achieved, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_MFMA_F32_TFLOPS,
-                "traffic": traffic,
-                "avg_launch_us": avg * 1e6, "launch_us": {k: v * 1e6 for k, v in dur.items()},
-                "flops_per_launch": flops_per_launch,
+                "bound": "hbm",
+                "kernel": ("conv_gemm_kernel<NB=2,PB=4,MAP_VEC,EPI_GRU1,D,WPB=8,SPLIT=1> (ConvGRU gate GEMM z|r; fp32 operands split into 3 bf16 "
+                           "pieces, 6 x v_mfma_f32_32x32x16_bf16 per 16 k, fp32 accumulate; 4 launches per frame: enc1, dec1 at full and "
+                           "enc2, dec2 at half resolution)") if split else "conv_gemm_kernel<2,4,0,3,4,8,0> (fp32 MFMA 32x32x2 k-loop)",
+                "achieved": achieved, "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s", "frac": achieved / (PEAK_HBM_TBS * 1e3),
+                "traffic": traffic, "traffic_source": tsrc,
+                "bytes_per_launch": bytes_per_launch, "avg_launch_us": avg * 1e6, "launch_us": {k: v * 1e6 for k, v in dur.items()},
+                "mfma": {"flops_per_launch": flops_per_launch, "achieved_tflops": flops_per_launch / avg / 1e12,
+                         "peak_tflops_fp32_equivalent": mfma_peak, "frac": flops_per_launch / avg / 1e12 / mfma_peak},
             }
         except Exception as exc:  # keep the headline number even if the side measurement fails
             result["roofline"] = {"error": repr(exc)}

@@ -33,10 +33,12 @@ def test_library_exports_every_declared_symbol(built):
 def test_packed_sizes_and_argument_errors_without_gpu(built):
     lib = built.lib()
     # pure host-side size arithmetic
-    assert lib.urnn_packed_conv_floats(63, 16) == 32 * 1 * 64 + 32
-    # gate slabs [F/32 groups][KT][z|r][64] + b1, candidate slab(s) [KT][F/32 blocks][64] + b2
-    assert lib.urnn_packed_gru_floats(16, 64, 0) == 2 * (40 * 2 * 64) + 128 + 40 * 2 * 64 + 64
-    assert lib.urnn_packed_gru_floats(96, 64, 1) == 2 * (112 * 2 * 64) + 128 + 112 * 2 * 64 + 64
+    # fp32 slab [KT][NB][64] + bias row, then the same slab as bf16 pieces [ceil(KT/8)][NB][3][64][4 dwords]
+    split = lambda KT, NB: ((KT + 7) // 8) * NB * 3 * 256
+    assert lib.urnn_packed_conv_floats(63, 16) == 32 * 1 * 64 + 32 + split(32, 1)
+    # gate slabs [F/32 groups][KT][z|r][64] + b1, candidate slab(s) [KT][F/32 blocks][64] + b2, then both in split form
+    assert lib.urnn_packed_gru_floats(16, 64, 0) == 2 * (40 * 2 * 64) + 128 + 40 * 2 * 64 + 64 + 2 * split(40, 2) + split(40, 2)
+    assert lib.urnn_packed_gru_floats(96, 64, 1) == 2 * (112 * 2 * 64) + 128 + 112 * 2 * 64 + 64 + 2 * split(112, 2) + split(112, 2)
     assert lib.urnn_gru_cell_workspace_bytes(1, 64, 500, 500) > 3 * 64 * 250000 * 4
     # argument validation happens before any HIP call
     assert lib.urnn_stage_conv_f32(0, 0, 0, 1, 8, 16, 4, 4, 0, 0.2, 0) == -2      # URNN_ENULL

@@ -17,7 +17,7 @@ def _free_port():
 def _worker(rank, world, port, num_events, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     import torch.distributed as dist
-    from urnn_amd.distributed import allreduce_mean_, env_ranks, gather_event_results, max_over_ranks, shard_events
+    from urnn_amd.distributed import OverlappedGradientMean, allreduce_mean_, env_ranks, gather_event_results, max_over_ranks, shard_events
     dist.init_process_group("gloo", rank=rank, world_size=world)
     assert env_ranks() == (rank, rank, world)
     mine = shard_events(num_events, rank, world)
@@ -29,6 +29,14 @@ def _worker(rank, world, port, num_events, out_dir):
     flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)
     allreduce_mean_(flat, bucket_floats=256)
     mean_ok = torch.equal(flat, torch.arange(1000, dtype=torch.float32) * (sum(range(1, world + 1)) / world))
+    # the same mean in two parts, as the trainer runs it: the tail (head gradients) first, while the front is still being written
+    flat2 = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    flat2[:300] = -1.0                                   # not final yet when the tail's all-reduce starts
+    red = OverlappedGradientMean(flat2, 300, bucket_floats=256)
+    red.start_tail()
+    flat2[:300] = torch.arange(300, dtype=torch.float32) * (rank + 1)
+    red.finish()
+    mean_ok = mean_ok and torch.equal(flat2, flat)
     dist.barrier()
     ok = mean_ok and slowest == float(world) and len(gathered) == num_events and all(float(g[0, 0, 0]) == i for i, g in enumerate(gathered))
     np.save(os.path.join(out_dir, f"rank{rank}.npy"), np.array([int(ok)] + mine))

@@ -260,14 +260,19 @@ def test_swp_training_loop_vs_reference(dev):
         assert_close(s.cpu().numpy(), g[f"loop_state{i}"], 2e-3, f"carried state {i}")
 
 
-def _ddp_worker(rank, world, port, out_dir):
+def _ddp_worker(rank, world, port, out_dir, backend="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
     import urnn_amd.weights as uw
     from urnn_amd.training import Trainer
-    dist.init_process_group("gloo", rank=rank, world_size=world)      # both ranks share the one GPU of the test box
-    dev = torch.device("cuda:0")
+    if backend == "nccl":                                             # one GPU per rank, RCCL over xGMI
+        dev = torch.device("cuda", rank)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)  # both ranks share the one GPU of the test box
+        dev = torch.device("cuda:0")
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_loop_16x16.npz"))
     net, sd = _loop_net(g, dev)
     H, W, nums = int(g["loop_H"]), int(g["loop_W"]), int(g["loop_nums"])
@@ -290,6 +295,22 @@ def test_two_rank_ddp_training_keeps_replicas_identical(dev, tmp_path):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    f0, f1 = np.load(tmp_path / "flat0.npy"), np.load(tmp_path / "flat1.npy")
+    g0, g1 = np.load(tmp_path / "grad0.npy"), np.load(tmp_path / "grad1.npy")
+    assert np.array_equal(g0, g1) and np.array_equal(f0, f1)
+    assert np.isfinite(f0).all() and np.abs(g0).max() > 0
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank (the 1-GPU test box cannot host two)")
+def test_two_rank_ddp_training_over_rccl(tmp_path):
+    """The same two-rank run with one GPU per rank and the nccl (= RCCL) backend: the head's gradient all-reduce overlaps the
+    rest of the backward pass (`OverlappedGradientMean`), the replicas stay bit-identical."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_ddp_worker, args=(2, port, str(tmp_path), "nccl"), nprocs=2, join=True)
     f0, f1 = np.load(tmp_path / "flat0.npy"), np.load(tmp_path / "flat1.npy")
     g0, g1 = np.load(tmp_path / "grad0.npy"), np.load(tmp_path / "grad1.npy")
     assert np.array_equal(g0, g1) and np.array_equal(f0, f1)

@@ -102,7 +102,7 @@ extern "C" int urnn_pack_gru_f32(const float *W1, const float *b1, const float *
 extern "C" size_t urnn_packed_deconv_floats(int Cin, int Cout)
 {
     const size_t NB = 2 * (size_t)((Cout + 31) / 32), KT = (Cin + 1) / 2;
-    return 2 * slab_floats(KT, NB) + 2 * NB * 32;
+    return 2 * slab_floats(KT, NB) + 2 * NB * 32 + 2 * (size_t)urnn_split_slab_dwords((int)KT, (int)NB);
 }
 
 extern "C" int urnn_pack_deconv_f32(const float *weight, const float *bias, float *packed, int Cin, int Cout, void *stream)
@@ -660,6 +660,8 @@ extern "C" int urnn_deconv2x2_f32(const float *in, const float *packed, float *o
     p.aFloats = (int)slab_floats(p.KT, NB);
     p.NG = 2;
     p.bias = packed + (size_t)2 * p.aFloats;
+    p.wsplit = reinterpret_cast<const unsigned *>(p.bias + (size_t)2 * NB * 32);
+    p.sDwords = urnn_split_slab_dwords(p.KT, NB);
     p.P = (int)P;
     p.W = W;
     p.Cout = Cout;

@@ -169,18 +169,35 @@ __device__ __forceinline__ void head_conv(const float *__restrict__ w, const flo
     }
 }
 
-// x <- SiLU((x - mean) * rstd * gamma[c][p] + beta[c][p])
+// x <- SiLU((x - mean) * rstd * gamma[c][p] + beta[c][p]); the affines are streamed four channels at a time (8 independent
+// loads in flight per thread without holding all 32 vectors)
 template <int V>
 __device__ __forceinline__ void head_ln_silu(float (&x)[HEAD_C][V], const float *__restrict__ gamma, const float *__restrict__ beta,
                                              int P, int p, float mean, float rstd)
 {
-    float g[HEAD_C][V], bt[HEAD_C][V];
-    head_load<V>(gamma, P, p, g);
-    head_load<V>(beta, P, p, bt);
 #pragma unroll
-    for (int c = 0; c < HEAD_C; ++c)
+    for (int c0 = 0; c0 < HEAD_C; c0 += 4) {
+        float g[4][V], bt[4][V];
 #pragma unroll
-        for (int k = 0; k < V; ++k) x[c][k] = siluf_fast((x[c][k] - mean) * rstd * g[c][k] + bt[c][k]);
+        for (int c = 0; c < 4; ++c) {
+            if constexpr (V == 4) {
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(gamma + (size_t)(c0 + c) * P + p), b = *reinterpret_cast<const f32x4 *>(beta + (size_t)(c0 + c) * P + p);
+                g[c][0] = a.x; g[c][1] = a.y; g[c][2] = a.z; g[c][3] = a.w;
+                bt[c][0] = b.x; bt[c][1] = b.y; bt[c][2] = b.z; bt[c][3] = b.w;
+            } else if constexpr (V == 2) {
+                const f32x2 a = *reinterpret_cast<const f32x2 *>(gamma + (size_t)(c0 + c) * P + p), b = *reinterpret_cast<const f32x2 *>(beta + (size_t)(c0 + c) * P + p);
+                g[c][0] = a.x; g[c][1] = a.y;
+                bt[c][0] = b.x; bt[c][1] = b.y;
+            } else {
+                g[c][0] = gamma[(size_t)(c0 + c) * P + p];
+                bt[c][0] = beta[(size_t)(c0 + c) * P + p];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int k = 0; k < V; ++k) x[c0 + c][k] = siluf_fast((x[c0 + c][k] - mean) * rstd * g[c][k] + bt[c][k]);
+    }
 }
 
 template <int V>
@@ -225,23 +242,33 @@ __device__ __forceinline__ void head_block_sum2(float &a, float &b)
     b = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
 }
 
-// LayerNorm partial statistics of up to two tensors held in registers by the block: (sum, second moment about the block's own
-// mean) each (urnn_common.h tile_x2).  Threads outside the plane pass live = false (their registers are not read).
+// LayerNorm partial statistics (sum, second moment about the block's own mean -- urnn_common.h tile_x2) of up to two tensors from
+// per-thread scalars: a thread reduces its HEAD_C * V values to (sum s, squares q about its own mean) while they are in
+// registers, so the values can be stored and die before any block-wide step; the block then combines the threads exactly
+// (Chan): Q = sum_threads [ q + n (m_thread - m_block)^2 ].  Threads outside the plane pass n = 0.
 template <int V>
-__device__ __forceinline__ void head_block_stats2(const float (&ua)[HEAD_C][V], const float (&ub)[HEAD_C][V], bool live, bool two, int nvalid,
-                                                  float *dst_a, float *dst_b)
+__device__ __forceinline__ void head_thread_stats(const float (&u)[HEAD_C][V], float &s, float &q)
 {
-    float sa = live ? head_sum<V>(ua) : 0.f, sb = (live && two) ? head_sum<V>(ub) : 0.f;
-    head_block_sum2(sa, sb);
+    s = head_sum<V>(u);
+    q = head_sumsq_about<V>(u, s * (1.f / (HEAD_C * V)));
+}
+
+__device__ __forceinline__ void head_block_stats2(float sa, float qa, float sb, float qb, int n_thread, bool two, int nvalid, float *dst_a,
+                                                  float *dst_b)
+{
+    const float ma = sa * (1.f / 16.f) / (float)(n_thread > 0 ? n_thread / 16 : 1), mb = sb * (1.f / 16.f) / (float)(n_thread > 0 ? n_thread / 16 : 1);
+    float Sa = sa, Sb = sb;
+    head_block_sum2(Sa, Sb);
     const float inv = 1.f / (float)nvalid;
-    float qa = live ? head_sumsq_about<V>(ua, sa * inv) : 0.f, qb = (live && two) ? head_sumsq_about<V>(ub, sb * inv) : 0.f;
-    head_block_sum2(qa, qb);
+    const float da = ma - Sa * inv, db = mb - Sb * inv;
+    float Qa = n_thread > 0 ? fmaf((float)n_thread * da, da, qa) : 0.f, Qb = n_thread > 0 ? fmaf((float)n_thread * db, db, qb) : 0.f;
+    head_block_sum2(Qa, Qb);
     if (threadIdx.x == 0) {
-        dst_a[0] = sa;
-        dst_a[1] = qa;
+        dst_a[0] = Sa;
+        dst_a[1] = Qa;
         if (two) {
-            dst_b[0] = sb;
-            dst_b[1] = qb;
+            dst_b[0] = Sb;
+            dst_b[1] = Qb;
         }
     }
 }
@@ -258,12 +285,15 @@ __global__ __launch_bounds__(256) void head_k1(const HeadParams prm)
     const int b = blockIdx.y;
     const int p = (blockIdx.x * 256 + threadIdx.x) * V;
     const bool live = p < prm.P;
-    float f[HEAD_C][V], u[HEAD_C][V];
+    float s = 0.f, q = 0.f;
     if (live) {
+        float f[HEAD_C][V], u[HEAD_C][V];
         head_load<V>(prm.feat + (size_t)b * HEAD_C * prm.P, prm.P, p, f);
         head_conv<V>(prm.conv_w, f, u);
+        head_thread_stats<V>(u, s, q);
     }
-    head_block_stats2<V>(u, u, live, false, HEAD_C * tile_valid(blockIdx.x, 256 * V, prm.P), head_partial(prm, 0, b, blockIdx.x), nullptr);
+    head_block_stats2(s, q, 0.f, 0.f, live ? HEAD_C * V : 0, false, HEAD_C * tile_valid(blockIdx.x, 256 * V, prm.P), head_partial(prm, 0, b, blockIdx.x),
+                      nullptr);
 }
 
 template <int V>
@@ -272,20 +302,22 @@ __global__ __launch_bounds__(256) void head_k2(const HeadParams prm)
     const int b = blockIdx.y;
     const int p = (blockIdx.x * 256 + threadIdx.x) * V;
     const bool live = p < prm.P;
-    float uc[HEAD_C][V], uq[HEAD_C][V];
+    float sc = 0.f, qc = 0.f, sq = 0.f, qq = 0.f;
     if (live) {
         const size_t CP = (size_t)HEAD_C * prm.P;
         float f[HEAD_C][V], t[HEAD_C][V];
         head_load<V>(prm.feat + b * CP, prm.P, p, f);
         head_conv<V>(prm.conv_w, f, t);
         head_ln_silu<V>(t, prm.ln_w, prm.ln_b, prm.P, p, prm.stats[(0 * prm.B + b) * 2], prm.stats[(0 * prm.B + b) * 2 + 1]);
-        head_conv<V>(prm.conv_w + 1 * HEAD_C * HEAD_C, t, uc);
-        head_store<V>(prm.u1 + b * CP, prm.P, p, uc);
-        head_conv<V>(prm.conv_w + 3 * HEAD_C * HEAD_C, t, uq);
-        head_store<V>(prm.u2 + b * CP, prm.P, p, uq);
+        head_conv<V>(prm.conv_w + 1 * HEAD_C * HEAD_C, t, f);
+        head_thread_stats<V>(f, sc, qc);
+        head_store<V>(prm.u1 + b * CP, prm.P, p, f);
+        head_conv<V>(prm.conv_w + 3 * HEAD_C * HEAD_C, t, f);
+        head_thread_stats<V>(f, sq, qq);
+        head_store<V>(prm.u2 + b * CP, prm.P, p, f);
     }
-    head_block_stats2<V>(uc, uq, live, true, HEAD_C * tile_valid(blockIdx.x, 256 * V, prm.P), head_partial(prm, 1, b, blockIdx.x),
-                         head_partial(prm, 3, b, blockIdx.x));
+    head_block_stats2(sc, qc, sq, qq, live ? HEAD_C * V : 0, true, HEAD_C * tile_valid(blockIdx.x, 256 * V, prm.P), head_partial(prm, 1, b, blockIdx.x),
+                      head_partial(prm, 3, b, blockIdx.x));
 }
 
 template <int V>
@@ -294,21 +326,23 @@ __global__ __launch_bounds__(256) void head_k3(const HeadParams prm)
     const int b = blockIdx.y;
     const int p = (blockIdx.x * 256 + threadIdx.x) * V;
     const bool live = p < prm.P;
-    float uc[HEAD_C][V], uq[HEAD_C][V];
+    float sc = 0.f, qc = 0.f, sq = 0.f, qq = 0.f;
     if (live) {
         const size_t CP = (size_t)HEAD_C * prm.P;
-        float x[HEAD_C][V];
+        float x[HEAD_C][V], u[HEAD_C][V];
         head_load<V>(prm.u1 + b * CP, prm.P, p, x);
         head_ln_silu<V>(x, prm.ln_w + 1 * CP, prm.ln_b + 1 * CP, prm.P, p, prm.stats[(1 * prm.B + b) * 2], prm.stats[(1 * prm.B + b) * 2 + 1]);
-        head_conv<V>(prm.conv_w + 2 * HEAD_C * HEAD_C, x, uc);
-        head_store<V>(prm.u1 + b * CP, prm.P, p, uc);
+        head_conv<V>(prm.conv_w + 2 * HEAD_C * HEAD_C, x, u);
+        head_thread_stats<V>(u, sc, qc);
+        head_store<V>(prm.u1 + b * CP, prm.P, p, u);
         head_load<V>(prm.u2 + b * CP, prm.P, p, x);
         head_ln_silu<V>(x, prm.ln_w + 3 * CP, prm.ln_b + 3 * CP, prm.P, p, prm.stats[(3 * prm.B + b) * 2], prm.stats[(3 * prm.B + b) * 2 + 1]);
-        head_conv<V>(prm.conv_w + 4 * HEAD_C * HEAD_C, x, uq);
-        head_store<V>(prm.u2 + b * CP, prm.P, p, uq);
+        head_conv<V>(prm.conv_w + 4 * HEAD_C * HEAD_C, x, u);
+        head_thread_stats<V>(u, sq, qq);
+        head_store<V>(prm.u2 + b * CP, prm.P, p, u);
     }
-    head_block_stats2<V>(uc, uq, live, true, HEAD_C * tile_valid(blockIdx.x, 256 * V, prm.P), head_partial(prm, 2, b, blockIdx.x),
-                         head_partial(prm, 4, b, blockIdx.x));
+    head_block_stats2(sc, qc, sq, qq, live ? HEAD_C * V : 0, true, HEAD_C * tile_valid(blockIdx.x, 256 * V, prm.P), head_partial(prm, 2, b, blockIdx.x),
+                      head_partial(prm, 4, b, blockIdx.x));
 }
 
 template <int V>
@@ -385,8 +419,10 @@ __global__ __launch_bounds__(64) void ln_finalize_kernel(const HeadParams prm, i
 }
 
 int urnn_head_nblk(int P) { const int n = (P + 255) / 256; return n < 2 ? 2 : n; }   // >= 2: the strip mode's two pseudo-blocks
-int urnn_head_nblk_used(int P) { const int v = P % 2 == 0 ? 2 : 1; return (P + 256 * v - 1) / (256 * v); }
-int urnn_head_block_pix(int P) { return 256 * (P % 2 == 0 ? 2 : 1); }
+// pixels per thread: 8- / 4-byte accesses (16-byte ones put head_k3 / k4 at 256 registers, one wave per SIMD: slower)
+static inline int head_vec(int P) { return P % 2 == 0 ? 2 : 1; }
+int urnn_head_nblk_used(int P) { const int v = head_vec(P); return (P + 256 * v - 1) / (256 * v); }
+int urnn_head_block_pix(int P) { return 256 * head_vec(P); }
 
 template <int V>
 static hipError_t launch_head_v(const HeadParams &p, int mask, hipStream_t st)
@@ -754,29 +790,38 @@ __global__ void pack_deconv_kernel(const float *__restrict__ w, const float *__r
                                    int Cout, int NBC, int KT)
 {
     const int NB = 2 * NBC;
-    const int slab = slab_floats(KT, NB);
+    const int slab = slab_floats(KT, NB), ssd = urnn_split_slab_dwords(KT, NB);
     const int nw = 2 * slab, Npad = 2 * NB * 32;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= nw + Npad) return;
+    if (idx >= nw + Npad + 2 * ssd) return;
+    auto wv = [&](int a, int kp, int nb, int l) {
+        const int k = 2 * kp + (l >> 5);
+        const int bb = nb / NBC, co = (nb - bb * NBC) * 32 + (l & 31);
+        return (kp < KT && k < Cin && co < Cout) ? w[(((size_t)k * Cout + co) * 2 + a) * 2 + bb] : 0.f;
+    };
     if (idx < nw) {
         const int a = idx / slab, r = idx - a * slab;
         const int l = r & 63, row = r >> 6;
-        const int kp = row / NB, nb = row - kp * NB;
-        const int k = 2 * kp + (l >> 5);
-        const int bb = nb / NBC, co = (nb - bb * NBC) * 32 + (l & 31);
-        packed[idx] = (kp < KT && k < Cin && co < Cout) ? w[(((size_t)k * Cout + co) * 2 + a) * 2 + bb] : 0.f;
-    } else {
+        const int kp = row / NB;
+        packed[idx] = wv(a, kp, row - kp * NB, l);
+    } else if (idx < nw + Npad) {
         const int n = idx - nw;
         const int nb = (n % (NB * 32)) / 32;
         const int co = (nb % NBC) * 32 + (n & 31);
         packed[idx] = (bias && co < Cout) ? bias[co] : 0.f;
+    } else {
+        const int q = idx - nw - Npad;
+        const int a = q / ssd;
+        int kp, nb, piece, l;
+        split_slot(q - a * ssd, NB, kp, nb, piece, l);
+        reinterpret_cast<unsigned *>(packed)[idx] = bf16_piece(wv(a, kp, nb, l), piece) | (bf16_piece(wv(a, kp + 1, nb, l), piece) << 16);
     }
 }
 
 hipError_t urnn_launch_pack_deconv(const float *w, const float *bias, float *packed, int Cin, int Cout, hipStream_t st)
 {
     const int NBC = (Cout + 31) / 32, NB = 2 * NBC, KT = (Cin + 1) / 2;
-    const int total = 2 * slab_floats(KT, NB) + 2 * NB * 32;
+    const int total = 2 * slab_floats(KT, NB) + 2 * NB * 32 + 2 * urnn_split_slab_dwords(KT, NB);
     hipLaunchKernelGGL(pack_deconv_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, bias, packed, Cin, Cout, NBC, KT);
     return hipGetLastError();
 }

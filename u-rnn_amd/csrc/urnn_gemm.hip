@@ -910,7 +910,9 @@ static int tune_split()
 template <int NB, int PB, int EPI>
 static bool split_ok(const ConvGemmParams &p)
 {
-    if constexpr (NB * PB * 16 > 128 || EPI == EPI_DECONV) return false;
+    // accumulators + bf16 pieces: <= 128 accumulators in a 256-register wave (8-wave blocks); the deconv's 6-block tile runs one
+    // wave per SIMD (4-wave blocks, 512 registers) and takes its 192
+    if constexpr (EPI == EPI_DECONV ? NB * PB * 16 > 192 : NB * PB * 16 > 128) return false;
     if (!tune_split()) return false;
     if (p.sDwords <= 0 || !p.wsplit || (size_t)p.sDwords * 4 > LDS_PER_CU - 24 * 1024) return false;
     if (p.KT % 8 != 0 || p.kpBegin % 8 != 0 || p.KT <= p.kpBegin) return false;      // whole 16-k groups, aligned with the packed ones
@@ -924,7 +926,7 @@ static bool split_ok(const ConvGemmParams &p)
 template <int NB, int PB, int MAP, int EPI, int D, int WPB>
 static hipError_t launch_conv_cfg(const ConvGemmParams &p, hipStream_t st, int max_bpc = 2)
 {
-    if constexpr (NB * PB * 16 <= 128 && EPI != EPI_DECONV) {
+    if constexpr (EPI == EPI_DECONV ? (NB * PB * 16 <= 192 && WPB == 4) : NB * PB * 16 <= 128) {
         if (split_ok<NB, PB, EPI>(p)) return launch_conv_split<NB, PB, MAP, EPI, D, WPB, 1>(p, st, max_bpc);
     }
     return launch_conv_split<NB, PB, MAP, EPI, D, WPB, 0>(p, st, max_bpc);

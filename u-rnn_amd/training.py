@@ -2,8 +2,8 @@
 `seq_num` timesteps forward with every activation the backward needs kept, the loss on the concatenated outputs, then
 back-propagation through the steps and through the six recurrent states, giving the gradient of all 79 parameter tensors.
 
-What is NOT here yet: the optimizer (Adam + clipping), the epoch / window scheduler, pre-warming, DDP gradient all-reduce.
-The kernels are first versions (correct, deterministic, not tuned)."""
+`Trainer` adds global-norm clipping + Adam on flat buffers, the SWP loop (fast mode and pre-warming) and the DDP gradient mean
+(RCCL, overlapped with the backward pass)."""
 import torch
 
 from . import ops, train_ops
@@ -60,7 +60,7 @@ class WindowGradients:
         return S, [S["e1"], S["e2"], S["e3"], S["d1"], S["d2"], S["d3"]]
 
     # -- backward of one timestep -----------------------------------------------------------------------------------------
-    def _backward_step(self, S, step, dout, dstate, G, acc):
+    def _backward_step(self, S, step, dout, dstate, G, acc, after_head=None):
         """dout: d loss / d masked output of this step (B,H,W); dstate: gradients arriving at this step's six NEW states from
         the following step (or None); returns the gradients w.r.t. the six states this step STARTED from."""
         net = self.net
@@ -112,6 +112,8 @@ class WindowGradients:
                                      S["raw"], S["cls"], dout.contiguous(), head.cls_thred, S["ws"][6], grads=hg_prev,
                                      accumulate=hg_prev is not None, scratch=self.arena)
         G["_head"] = hg
+        if after_head is not None:      # the head's gradients of this window are final here (when this is the first timestep)
+            after_head(hg)
         # decoder.  A state's gradient has two sources -- the layer above in this timestep and the same cell in the next
         # timestep; the cell backward takes them as two terms and adds on the fly (three terms: one torch add)
         du2, dE1_dec, dD3n = cell_bwd(5, "decoder.rnn1", dec.rnn1, S["u2"], S["e1"], d3p, conv_bwd("decoder.stage1", dec.stage1, S["d3"], hg["dfeat"]), dD3)
@@ -124,11 +126,24 @@ class WindowGradients:
         conv_bwd("encoder.stage1", enc.stage1, S["x_in"], da1)
         return [dE1n, dE2n, dE3n, dD1n, dD2n, dD3n]
 
-    def run(self, event, targets, t0, steps, states=None, t_devs=None, grad_buffers=None):
+    def head_gradients(self, hg):
+        """{reference parameter name: tensor} views of the head backward's stacked buffers."""
+        head, grads = self.net.head, {}
+        for i, blk in enumerate(["stems", "cls_convs.0", "cls_convs.1", "reg_convs.0", "reg_convs.1"]):
+            grads[f"head.{blk}.conv.weight"] = hg["dconv_w"][i].reshape(head.channels, head.channels, 1, 1)
+            grads[f"head.{blk}.ln.weight"] = hg["dln_w"][i]
+            grads[f"head.{blk}.ln.bias"] = hg["dln_b"][i]
+        grads["head.reg_preds.conv.weight"] = hg["dreg_w"].reshape(1, -1, 1, 1)
+        grads["head.reg_preds.conv.bias"] = hg["dreg_b"]
+        return grads
+
+    def run(self, event, targets, t0, steps, states=None, t_devs=None, grad_buffers=None, on_head_final=None):
         """event: reference-layout event dict (or already on the device); targets (B,steps,H,W) normalised depths of frames
         t0 .. t0+steps-1; states: six (B,C,h,w) tensors or None (zeros); t_devs: optional list of int32 device scalars holding
         the frame index of every step (hipGraph replay); grad_buffers: optional {parameter name: tensor} the encoder / decoder
-        gradients are written into directly (views of a flat gradient buffer).  See the class docstring for the result."""
+        gradients are written into directly (views of a flat gradient buffer); on_head_final(head gradient dict): called as soon as
+        the head's gradients of the window are complete -- right after the head backward of the FIRST timestep, before that
+        timestep's decoder / encoder backward (DDP starts their all-reduce there).  See the class docstring for the result."""
         ev = event if "rain" in event else event_to_device(event, self.device)
         B = ev["B"]
         if states is None:
@@ -145,15 +160,11 @@ class WindowGradients:
         comps, dreg = train_ops.loss(reg, targets, cls_thred=self.cls_thred_train, scratch=self.arena)
         G, dstate = ({k: v for k, v in grad_buffers.items() if not k.startswith("head.")} if grad_buffers else {}), None
         for s in reversed(range(steps)):
-            dstate = self._backward_step(saved[s], s, dreg[:, s], dstate, G, acc=(s != steps - 1))
+            hook = (lambda hg: on_head_final(self.head_gradients(hg))) if (on_head_final is not None and s == 0) else None
+            dstate = self._backward_step(saved[s], s, dreg[:, s], dstate, G, acc=(s != steps - 1), after_head=hook)
         grads = {k: v for k, v in G.items() if not k.startswith("_")}
-        hg, head = G["_head"], self.net.head
-        for i, blk in enumerate(["stems", "cls_convs.0", "cls_convs.1", "reg_convs.0", "reg_convs.1"]):
-            grads[f"head.{blk}.conv.weight"] = hg["dconv_w"][i].reshape(head.channels, head.channels, 1, 1)
-            grads[f"head.{blk}.ln.weight"] = hg["dln_w"][i]
-            grads[f"head.{blk}.ln.bias"] = hg["dln_b"][i]
-        grads["head.reg_preds.conv.weight"] = hg["dreg_w"].reshape(1, -1, 1, 1)
-        grads["head.reg_preds.conv.bias"] = hg["dreg_b"]
+        head = self.net.head
+        grads.update(self.head_gradients(G["_head"]))
         grads["head.cls_preds.conv.weight"] = torch.zeros_like(head.cls_preds.conv.weight)
         grads["head.cls_preds.conv.bias"] = torch.zeros_like(head.cls_preds.conv.bias)
         return {"loss": comps, "grads": grads, "states": [s.detach() for s in states], "reg": reg, "state_grads": dstate}
@@ -182,6 +193,9 @@ class Trainer:
                  cls_thred_train=0.0, process_group=None, distributed=False, use_graph=False):
         self.net = net
         self.use_graph = bool(use_graph)        # capture one window (forward, loss, backward, clip + Adam) as a hipGraph
+        if use_graph and distributed:
+            import warnings
+            warnings.warn("Trainer: use_graph is ignored with distributed=True (the gradient all-reduce is not captured); running eager")
         self._graph = None
         self.wg = WindowGradients(net, H, W, nums, rain_max, cumsum_max, cls_thred_train)
         self.lr, self.betas, self.eps, self.grad_clip = float(lr), tuple(betas), float(eps), float(grad_clip)
@@ -203,6 +217,10 @@ class Trainer:
             self.views[n] = (off, k, tuple(p.shape))
             off += k
         self.grad_views = {n: self.gflat[off:off + k].view(shape) for n, (off, k, shape) in self.views.items()}
+        # net.named_parameters() lists encoder, decoder, head in this order: the head is the contiguous tail of the flat buffers
+        self.head_offset = min(off for n, (off, k, shape) in self.views.items() if n.startswith("head."))
+        if any(off >= self.head_offset and not n.startswith("head.") for n, (off, k, shape) in self.views.items()):
+            raise RuntimeError("Trainer: expected the head's parameters to be the tail of net.named_parameters()")
         self.step_count = 0
         self.last = None
 
@@ -268,15 +286,31 @@ class Trainer:
             steps = max(steps, int(float(st["step"])))
         self.step_count = steps
 
-    def _window_body(self, ev, targets, t0, steps, states, t_devs=None, step_dev=None):
-        out = self.wg.run(ev, targets, t0, steps, states, t_devs=t_devs, grad_buffers=self.grad_views)
-        for n, g in out["grads"].items():
+    def _scatter(self, grads):
+        """Copy gradients that were not written in place (the head's stacked buffers) into the flat gradient buffer."""
+        for n, g in grads.items():
             off, k, _ = self.views[n]
-            if g.data_ptr() != self.grad_views[n].data_ptr():      # the head's stacked buffers; the rest was written in place
+            if g.data_ptr() != self.grad_views[n].data_ptr():
                 self.gflat[off:off + k].copy_(g.reshape(-1))
+
+    def _window_body(self, ev, targets, t0, steps, states, t_devs=None, step_dev=None):
+        reducer = None
         if self.distributed:
-            from .distributed import allreduce_mean_
-            allreduce_mean_(self.gflat, group=self.pg)
+            # DDP (main.py:384-387): the head's gradients (the flat buffer's tail, 99 % of the bytes) are all-reduced over RCCL
+            # while the first timestep's decoder / encoder backward still runs; the remainder after the backward
+            from .distributed import OverlappedGradientMean
+            reducer = OverlappedGradientMean(self.gflat, self.head_offset, group=self.pg)
+
+            def head_final(head_grads):
+                self._scatter(head_grads)
+                reducer.start_tail()
+        out = self.wg.run(ev, targets, t0, steps, states, t_devs=t_devs, grad_buffers=self.grad_views,
+                          on_head_final=head_final if reducer is not None else None)
+        if reducer is None:
+            self._scatter(out["grads"])
+        else:
+            self._scatter({n: g for n, g in out["grads"].items() if not n.startswith("head.")})
+            reducer.finish()
         clip = train_ops.adam_step(self.flat, self.gflat, self.m, self.v, max(self.step_count, 1), lr=self.lr, betas=self.betas,
                                    eps=self.eps, max_grad_norm=self.grad_clip, step_dev=step_dev, scratch=self.wg.arena)
         self._invalidate_packed()
