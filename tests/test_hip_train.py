@@ -436,42 +436,35 @@ class _MemoryEvents:
         return self.items[i]
 
 
-def test_fit_epoch_loop_checkpoints_and_resume(dev, tmp_path):
-    """urnn_amd.fit.fit (main.py:857-918): epochs over the sampler's order with shuffled SWP windows, the warm-up/cosine
-    schedule reaching the kernels (the captured window is re-captured when the learning rate changes: graph == eager, bit for
-    bit), best-loss checkpoints in the reference's format, and a resumed run continuing from the newest one."""
+def test_shuffled_swp_windows_graph_equals_eager_through_lr_changes(dev):
+    """The SWP loop of one sample (main.py:415-443 + 598-768): `plan_windows` (corrected window / seq_num, shuffled order) feeds
+    `Trainer.train_event`; the captured window is re-captured when the learning rate changes -- graph == eager bit for bit
+    over three passes with different rates, the state round-trips through `state_dict` / `load_state_dict`."""
     import random
-    import urnn_amd.fit as fit
-    from urnn_amd.training import Trainer
+    from urnn_amd.training import Trainer, plan_windows
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_loop_16x16.npz"))
     H, W, nums = int(g["loop_H"]), int(g["loop_W"]), int(g["loop_nums"])
-    ds = _MemoryEvents(H, W, 8, 3, flood_max=5000.0)
-    kw = dict(epochs=5, lr=3e-3, flood_max=5000.0, seq_num=3, window_size=8, warm_up_iter=2, lr_min=1e-4, log=None)
+    ds = _MemoryEvents(H, W, 8, 2, flood_max=5000.0)
     runs = []
     for use_graph in (False, True):
         net, _ = _loop_net(g, dev)
         tr = Trainer(net, H, W, nums, 60.0, 250.0, lr=3e-3, grad_clip=1.0, use_graph=use_graph)
         np.random.seed(1)
         random.seed(2)
-        save_dir = str(tmp_path / f"ckpt{int(use_graph)}")
-        hist = fit.fit(tr, ds, save_dir=save_dir, **kw)
-        runs.append((hist, tr.flat.clone(), save_dir, tr))
-    (ha, fa, dir_a, tra), (hb, fb, _, _) = runs
-    assert ha == hb and torch.equal(fa, fb)
-    want_lr = [3e-3 * fit.warmup_cosine_factor(k, 2, 5, 3e-3, 1e-4) for k in range(5)]
-    assert [h["lr"] for h in ha] == pytest.approx(want_lr, rel=1e-12)
-    assert ha[0]["lr"] == 0.0 and all(np.isfinite(h["loss"]) for h in ha)
-    assert ha[-1]["loss"] < ha[1]["loss"]                    # 3 windows x 3 events x 4 live epochs are enough to move the loss
-    assert tra.step_count == 5 * 3 * 3                       # windows [0,3,5] per event (the last one shifted back, main.py:175-176)
-    names = sorted(os.listdir(dir_a))
-    assert names and all(n.startswith("checkpoint_") and n.endswith(".pth.tar") for n in names)
-    # resume: newest checkpoint -> weights, Adam moments, step count; the run continues at the following epoch
+        losses = []
+        for lr in (3e-3, 1e-3, 2e-4):
+            tr.set_lr(lr)
+            for ev, label, _ in ds.items:
+                loc, seq, win, starts = plan_windows(8, 8, 3, 8, train_event=True, wind_random=True)
+                assert sorted(starts) == [0, 3, 5] and seq == 3      # the last window shifted back to end at 8 (main.py:175-176)
+                ls, _ = tr.train_event(ev, label / 5000.0, seq, win, loc, starts=starts)
+                losses += [float(l[0]) for l in ls]
+        runs.append((losses, tr.flat.clone(), tr))
+    (la, fa, tra), (lb, fb, _) = runs
+    assert la == lb and torch.equal(fa, fb) and all(np.isfinite(la))
+    assert tra.step_count == 3 * 2 * 3
     net2, _ = _loop_net(g, dev)
-    tr2 = Trainer(net2, H, W, nums, 60.0, 250.0, lr=3e-3, grad_clip=1.0)
-    start = fit.resume(tr2, dir_a)
-    info = torch.load(fit.latest_checkpoint(dir_a), map_location="cpu", weights_only=False)
-    assert start == info["epoch"] + 1 and tr2.step_count == (info["epoch"] + 1) * 9
-    for k, v in info["state_dict"].items():
-        assert torch.equal(dict(net2.state_dict())[k].cpu(), v)
-    more = fit.fit(tr2, ds, save_dir=dir_a, start_epoch=start, **dict(kw, epochs=start + 1))
-    assert len(more) == 1 and np.isfinite(more[0]["loss"])
+    tr2 = Trainer(net2, H, W, nums, 60.0, 250.0)
+    tr2.load_state_dict(tra.state_dict())
+    tr2.load_optimizer_state_dict(tra.optimizer_state_dict())
+    assert torch.equal(tr2.flat, tra.flat) and torch.equal(tr2.m, tra.m) and tr2.step_count == tra.step_count

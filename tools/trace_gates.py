@@ -9,6 +9,7 @@ from urnn_amd.rollout import RolloutEngine
 import urnn_amd.weights as uw
 
 which = sys.argv[1] if len(sys.argv) > 1 else "dec1"
+phase = {"gates": ops.PHASE_GATES, "cand": ops.PHASE_CAND}[sys.argv[2] if len(sys.argv) > 2 else "gates"]
 H, W, nums, T, rain_max, cum_max, spatial = bench.CONFIGS["location1"]
 dev = torch.device("cuda:0")
 net, sd, cfg = bench.build_net(H, W, 63, dev)
@@ -16,18 +17,21 @@ eng = RolloutEngine(net, H, W, nums, rain_max, cum_max, max_frames=8, net_cfg=cf
 eng.load_event(uw.make_event(8, H, W, rain_max, seed=42)); eng.reset(); eng.run(2)
 e1, e2, e3, d1, d2, d3 = eng.states
 cells = {"enc1": (net.encoder.rnn1, eng.a1, None, e1), "dec1": (net.decoder.rnn1, eng.u2, e1, d3),
-         "enc2": (net.encoder.rnn2, eng.a2, None, e2), "dec2": (net.decoder.rnn2, eng.u3, e2, d2)}
+         "enc2": (net.encoder.rnn2, eng.a2, None, e2), "dec2": (net.decoder.rnn2, eng.u3, e2, d2),
+         "enc3": (net.encoder.rnn3, eng.a3, None, e3), "dec3": (net.decoder.rnn3, None, e3, d1)}
 cell, x, e, h = cells[which]
 tmp = h.clone()
+ws = ops.workspace(ops.gru_cell_workspace_bytes(*h.shape), dev)
+cell.step(x, e, h, out=tmp, ws=ws)          # the candidate phase reads the gates' raw values and partial statistics
 for _ in range(3):
-    cell.step(x, e, h, out=tmp, phases=ops.PHASE_GATES)
+    cell.step(x, e, h, out=tmp, phases=phase, ws=ws)
 nw = 512 * 8
 buf = torch.zeros(nw * 8 * 4, dtype=torch.int64, device=dev)
 L = _lib.lib()
 L.urnn_debug_set_trace.argtypes = [ctypes.c_void_p]
 assert L.urnn_debug_set_trace(buf.data_ptr()) == 0
 torch.cuda.synchronize()
-cell.step(x, e, h, out=tmp, phases=ops.PHASE_GATES)
+cell.step(x, e, h, out=tmp, phases=phase, ws=ws)
 torch.cuda.synchronize()
 L.urnn_debug_set_trace(0)
 t = buf.cpu().numpy().reshape(nw, 8, 4).astype(np.float64)

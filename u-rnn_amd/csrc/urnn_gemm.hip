@@ -837,7 +837,8 @@ static int persistent_grid(size_t lds_bytes, int NG, int total_tiles, int wpb = 
     const int cap = (wpb >= 8 && max_blocks_per_cu <= 2) ? 1 : (max_blocks_per_cu > 2 ? 2 : max_blocks_per_cu);
     bpc = bpc < 1 ? 1 : (bpc > cap ? cap : bpc);
     const int unit = 8 * NG;
-    int n = (NUM_CUS * bpc) / unit * unit;
+    static const int cus = [] { const char *e = getenv("URNN_TUNE_CUS"); const int v = e ? atoi(e) : 0; return v > 0 && v < NUM_CUS ? v : NUM_CUS; }();
+    int n = (cus * bpc) / unit * unit;      // development knob URNN_TUNE_CUS: leave CUs free for the other kernel chain
     int need = ((total_tiles + wpb - 1) / wpb) * NG;
     need = (need + unit - 1) / unit * unit;
     n = n < need ? n : need;

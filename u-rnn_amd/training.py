@@ -180,6 +180,43 @@ def window_starts(loc, seq_num, window_size):
     return idx
 
 
+# ---- SWP window planning (get_window, main.py:415-443 with main.py:106-159) -------------------------------------------------------
+def correction_seq_num(seq_num, window_size, full_window_size=False):
+    """main.py:106-118."""
+    return window_size if full_window_size else min(seq_num, window_size)
+
+
+def correction_window_size(window_size, rain_len, event_len, all_seq_train=False, train_event=False):
+    """main.py:121-136."""
+    sample_length = event_len if train_event else rain_len
+    return sample_length if all_seq_train else min(window_size, sample_length)
+
+
+def get_start_loc(rain_len, window_size, event_len, train_event=False):
+    """main.py:139-159: a random start when the sample is longer than the window (numpy's global generator, as there)."""
+    import numpy as np
+    sample_length = event_len if train_event else rain_len
+    loc = 0
+    if sample_length - window_size > 0:
+        loc = int(np.random.randint(0, sample_length - window_size, size=1, dtype=int)[0])
+    return loc
+
+
+def plan_windows(rain_len, event_len, seq_num, window_size, all_seq_train=False, train_event=True, full_window_size=False,
+                 wind_random=True):
+    """``get_window`` (main.py:415-443).  Returns (loc, seq_num, window_size, window start indices in processing order);
+    like the reference, the corrected seq_num / window_size replace the configured ones for the rest of the run.  Feed the
+    starts to ``Trainer.train_event(..., starts=...)``."""
+    import random
+    window_size = correction_window_size(window_size, rain_len, event_len, all_seq_train, train_event)
+    loc = get_start_loc(rain_len, window_size, event_len, train_event)
+    seq_num = correction_seq_num(seq_num, window_size, full_window_size)
+    starts = window_starts(loc, seq_num, window_size)
+    if wind_random:
+        random.shuffle(starts)
+    return loc, seq_num, window_size, starts
+
+
 class Trainer:
     """SWP training on the HIP path: the loop of ``model_forward`` (main.py:700-768) in fast mode -- per window: zero the
     gradients, ``seq_num`` timesteps from the previous window's (detached) states, loss, backward, global-norm clipping, Adam.
@@ -389,7 +426,7 @@ class Trainer:
         return states
 
     def train_event(self, event, label, seq_num, window_size=None, loc=0, prewarming=False, starts=None):
-        """All windows of one sample in order (or in the order of ``starts``, e.g. the shuffled plan of ``fit.plan_windows``).  Fast mode (default): states carried between windows; ``prewarming=True``: the
+        """All windows of one sample in order (or in the order of ``starts``, e.g. the shuffled plan of ``plan_windows``).  Fast mode (default): states carried between windows; ``prewarming=True``: the
         paper's schedule, every window starts from a gradient-free rollout from frame 0 (main.py:655-672).  label (B,T,H,W)
         normalised depths.  Returns (per-window loss components, final states)."""
         ev = event if "rain" in event else event_to_device(event, self.wg.device)
