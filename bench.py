@@ -132,7 +132,7 @@ def bench_train(args, dev, dist, world, rank):
     S = args.seq_num
     net, sd, cfg = build_net(H, W, 2 * nums + 3, dev)
     tr = Trainer(net, H, W, nums, rain_max, cum_max, lr=1e-4, grad_clip=1.0, distributed=world > 1,
-                 use_graph=(world == 1 and not args.no_graph))
+                 use_graph=(world == 1 and not args.no_graph), matrix_mode=args.dtype)
     nwin_w, nwin = max(1, (args.warmup + S - 1) // S), max(1, (args.steps + S - 1) // S)
     frames = S * (nwin_w + nwin)
     B = args.batch
@@ -168,7 +168,9 @@ def bench_train(args, dev, dist, world, rank):
         print(json.dumps({
             "metric": "SWP training timesteps/s (forward + backward + clipped Adam), whole job", "value": steps * world / elapsed,
             "unit": "steps/s", "n_gpus": world, "steps": steps, "warmup": nwin_w * S, "ms_per_step": elapsed / steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.dtype == "fp32" else "bf16 GEMM compute (forward + input gradients), fp32 accumulate / norms / weight gradients / Adam",
+            "data": "synthetic",
             "config": {"workload": f"train {name}: {H}x{W} grid, historical_nums={nums}, SWP windows of seq_num={S} (fast mode), "
                                    f"{B} event(s) per GPU, Adam lr 1e-4, grad clip 1.0", "parallelism": f"DDP x{world} (flat-buffer mean all-reduce)"
                        if world > 1 else "single GPU"},
@@ -261,6 +263,8 @@ def main():
                          "clipped Adam, windows of --seq-num steps; N>1: DDP mean all-reduce of the flat gradient buffer over RCCL).  "
                          "strips: ONE event split into horizontal strips over the ranks (single-event latency, strong scaling)")
     ap.add_argument("--seq-num", type=int, default=4, help="train mode: timesteps per SWP window")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="train mode: GEMM arithmetic (bf16 = BASELINE configs[3]'s variant; inference always runs the fp32-exact path)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

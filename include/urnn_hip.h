@@ -36,6 +36,19 @@ extern "C" {
 int urnn_abi_version(void);
 const char *urnn_last_error(void);
 
+/* Arithmetic of the GEMM kernels, process-wide (one process drives one GPU; the launch functions read it when they enqueue, so a
+ * captured hipGraph keeps the mode it was captured with).
+ *   URNN_MATRIX_FP32 (default): the reference's fp32 semantics -- fp32 operands split into three exact bf16 pieces, six
+ *     v_mfma_f32_32x32x16_bf16 per 16 k with fp32 accumulation (fp32-class accuracy, the parity path), or v_mfma_f32_32x32x2_f32
+ *     where the channel counts do not form whole 16-k groups.
+ *   URNN_MATRIX_BF16: bf16 compute for training (BASELINE configs[3]; the reference only declares --amp, config.py:179) --
+ *     activations rounded to bf16, weights to 16 mantissa bits, fp32 accumulation; norms, statistics, states, loss and the
+ *     optimizer stay fp32.  Applies to every forward GEMM and the input-gradient GEMMs; weight gradients stay fp32. */
+#define URNN_MATRIX_FP32 0
+#define URNN_MATRIX_BF16 1
+int urnn_set_matrix_mode(int mode);
+int urnn_get_matrix_mode(void);
+
 /* ---- weight packing (one-off, at checkpoint-load time) ------------------------------------------ */
 
 /* Packed 1x1-conv weights: transposed, K padded to 8, N padded to 32, bias appended.

@@ -468,3 +468,42 @@ def test_shuffled_swp_windows_graph_equals_eager_through_lr_changes(dev):
     tr2.load_state_dict(tra.state_dict())
     tr2.load_optimizer_state_dict(tra.optimizer_state_dict())
     assert torch.equal(tr2.flat, tra.flat) and torch.equal(tr2.m, tra.m) and tr2.step_count == tra.step_count
+
+
+def test_bf16_matrix_mode_tracks_fp32(dev):
+    """BASELINE configs[3]'s variant (the reference only declares --amp, config.py:179: judged against this build's own fp32):
+    with `Trainer(matrix_mode="bf16")` the forward and input-gradient GEMMs round activations to bf16 (fp32 accumulation,
+    fp32 norms / loss / Adam).  One cell step stays within bf16 roundoff of the fp32 path, the mode is scoped (the fp32 path is
+    bit-unchanged afterwards), and a short training run follows the fp32 run's losses."""
+    import urnn_amd.weights as uw
+    from urnn_amd import ops
+    from urnn_amd.training import Trainer
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_loop_16x16.npz"))
+    net, _ = _loop_net(g, dev)
+    H, W, nums = int(g["loop_H"]), int(g["loop_W"]), int(g["loop_nums"])
+    gen = torch.Generator(device=dev).manual_seed(3)
+    x = torch.randn(1, 16, H, W, device=dev, generator=gen)
+    h = torch.randn(1, 64, H, W, device=dev, generator=gen) * 0.5
+    ref = net.encoder.rnn1.step(x, None, h)
+    with ops.matrix_mode("bf16"):
+        low = net.encoder.rnn1.step(x, None, h)
+    again = net.encoder.rnn1.step(x, None, h)
+    assert torch.equal(ref, again)
+    err = float((low - ref).abs().max() / ref.abs().max())
+    assert 1e-5 < err < 3e-2, err                               # bf16 inputs: ~2^-9 per product, far from fp32 roundoff, not garbage
+    ev = uw.make_event(6, H, W, 60.0, seed=3)
+    label = torch.from_numpy(g["loop_label"]).to(dev)
+    curves = {}
+    for mode in ("fp32", "bf16"):
+        net_m, _ = _loop_net(g, dev)
+        tr = Trainer(net_m, H, W, nums, 60.0, 250.0, lr=2e-3, grad_clip=1.0, matrix_mode=mode)
+        means = []
+        for epoch in range(8):
+            losses, _ = tr.train_event(ev, label, seq_num=3)
+            means.append(float(torch.stack([l[0] for l in losses]).mean()))
+        curves[mode] = means
+        assert tr.flat.dtype == torch.float32 and bool(torch.isfinite(tr.flat).all())
+    a, b = np.array(curves["fp32"]), np.array(curves["bf16"])
+    assert b[-1] < 0.8 * b[0]                                   # it trains
+    assert np.abs(b - a).max() <= 0.1 * a[0], (a, b)            # and follows the fp32 curve
+    assert ops.lib().urnn_get_matrix_mode() == 0

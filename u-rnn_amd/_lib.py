@@ -18,6 +18,8 @@ _i, _f, _p, _sz = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 SIGNATURES = {
     "urnn_abi_version": (_i, []),
     "urnn_last_error": (ctypes.c_char_p, []),
+    "urnn_set_matrix_mode": (_i, [_i]),
+    "urnn_get_matrix_mode": (_i, []),
     "urnn_packed_conv_floats": (_sz, [_i, _i]),
     "urnn_pack_conv_f32": (_i, [_p, _p, _p, _i, _i, _p]),
     "urnn_packed_gru_floats": (_sz, [_i, _i, _i]),

@@ -259,11 +259,21 @@ __device__ __forceinline__ void split_pair(float xe, float xo, unsigned &ph, uns
     pl = __builtin_amdgcn_perm(__float_as_uint(so), __float_as_uint(se), 0x07060302u);
 }
 
+// bf16 compute mode (SPLIT = 2): one dword of round-to-nearest-even bf16 values (v_cvt_pk_bf16_f32)
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned round_pair(float xe, float xo)
+{
+    const bf16x2 v = {(__bf16)xe, (__bf16)xo};
+    return __builtin_bit_cast(unsigned, v);
+}
+
 __device__ __forceinline__ bf16x8 as_bf16x8(const unsigned (&p)[4]) { return __builtin_bit_cast(bf16x8, u32x4{p[0], p[1], p[2], p[3]}); }
 
 // SPLIT = 0: v_mfma_f32_32x32x2_f32 per k-pair (exact fp32 fma chain).  SPLIT = 1: eight k-pairs at a time on
 // v_mfma_f32_32x32x16_bf16 with both operands split into three bf16 pieces (six MFMAs per 16 k: 2.67x the fp32 matrix rate);
 // needs (KT - kpBegin) % 8 == 0 and, in the candidate GEMM, a plain part that is a positive multiple of 8 k-pairs.
+// SPLIT = 2: bf16 COMPUTE (urnn_set_matrix_mode(URNN_MATRIX_BF16), BASELINE configs[3]): activations rounded to bf16 (RNE), weights
+// kept to 16 mantissa bits (hi + mid pieces), fp32 accumulate -- two MFMAs per 16 k; statistics, norms, states stay fp32.
 template <int NB, int PB, int MAP, int EPI, int D, int WPB, int SPLIT>
 __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const ConvGemmParams prm)
 {
@@ -475,8 +485,9 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
                 ++si;
             };
             for (int i = 0; i < D; ++i) refill_s(i);
+            constexpr bool BF16C = (SPLIT == 2);
             float rb[2][PB];                               // raw fp32 activation fragments: rb[0] even k-pairs, rb[1] odd ones
-            unsigned bh[PB][4], bm[PB][4], bl[PB][4];
+            unsigned bh[PB][4], bm[BF16C ? 1 : PB][4], bl[BF16C ? 1 : PB][4];
             const char *Ap = urnn_smem + lane * 16;
             auto read_b = [&](int kp, int slot_, bool gated, float (&bv)[PB]) {
                 if (!gated) {
@@ -500,7 +511,10 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
                 const int nslot = wrap(slot + (CG ? 2 : 1));
                 if constexpr (Q & 1) {
 #pragma unroll
-                    for (int pb = 0; pb < PB; ++pb) split_pair(rb[0][pb], rb[1][pb], bh[pb][Q >> 1], bm[pb][Q >> 1], bl[pb][Q >> 1]);
+                    for (int pb = 0; pb < PB; ++pb) {
+                        if constexpr (BF16C) bh[pb][Q >> 1] = round_pair(rb[0][pb], rb[1][pb]);
+                        else split_pair(rb[0][pb], rb[1][pb], bh[pb][Q >> 1], bm[pb][Q >> 1], bl[pb][Q >> 1]);
+                    }
                 }
                 wait_vmcnt<(D - (CG ? 2 : 1) - (NGT ? 2 : 1)) * R::NLOAD>();       // the next k-pair's slot(s) have landed (or are dummies)
                 // The slot(s) about to be refilled were read one step ago, but an even k-pair's fragments are not CONSUMED before
@@ -516,13 +530,17 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
                     for (int nb = 0; nb < NB; ++nb) {
                         const bf16x8 wh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(ag + (nb * 3 + 0) * 1024));
                         const bf16x8 wm = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(ag + (nb * 3 + 1) * 1024));
-                        const bf16x8 wl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(ag + (nb * 3 + 2) * 1024));
                         auto mm = [&](const bf16x8 &wa, const unsigned (&pbv)[PB][4]) {
 #pragma unroll
                             for (int pb = 0; pb < PB; ++pb)
                                 acc[nb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, as_bf16x8(pbv[pb]), acc[nb][pb], 0, 0, 0);
                         };
-                        mm(wm, bm); mm(wl, bh); mm(wh, bl); mm(wm, bh); mm(wh, bm); mm(wh, bh);     // small terms first
+                        if constexpr (BF16C) {
+                            mm(wm, bh); mm(wh, bh);
+                        } else {
+                            const bf16x8 wl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(ag + (nb * 3 + 2) * 1024));
+                            mm(wm, bm); mm(wl, bh); mm(wh, bl); mm(wm, bh); mm(wh, bm); mm(wh, bh);     // small terms first
+                        }
                         __builtin_amdgcn_sched_barrier(0);       // keep the next n-block's weight pieces from being loaded early (registers)
                     }
                 }
@@ -895,6 +913,16 @@ static int tune_ring()
     return v;
 }
 
+// Process-wide arithmetic of the GEMMs (urnn_set_matrix_mode): 0 fp32-exact (bf16 x 6 split / fp32 MFMA), 1 bf16 compute.
+static std::atomic<int> g_matrix_mode{0};
+extern "C" int urnn_set_matrix_mode(int mode)
+{
+    if (mode != URNN_MATRIX_FP32 && mode != URNN_MATRIX_BF16) return URNN_EINVAL;
+    g_matrix_mode.store(mode, std::memory_order_relaxed);
+    return URNN_OK;
+}
+extern "C" int urnn_get_matrix_mode(void) { return g_matrix_mode.load(std::memory_order_relaxed); }
+
 static int tune_split()
 {
     static int v = -1;
@@ -928,7 +956,10 @@ template <int NB, int PB, int MAP, int EPI, int D, int WPB>
 static hipError_t launch_conv_cfg(const ConvGemmParams &p, hipStream_t st, int max_bpc = 2)
 {
     if constexpr (EPI == EPI_DECONV ? (NB * PB * 16 <= 192 && WPB == 4) : NB * PB * 16 <= 128) {
-        if (split_ok<NB, PB, EPI>(p)) return launch_conv_split<NB, PB, MAP, EPI, D, WPB, 1>(p, st, max_bpc);
+        if (split_ok<NB, PB, EPI>(p)) {
+            if (g_matrix_mode.load(std::memory_order_relaxed) == URNN_MATRIX_BF16) return launch_conv_split<NB, PB, MAP, EPI, D, WPB, 2>(p, st, max_bpc);
+            return launch_conv_split<NB, PB, MAP, EPI, D, WPB, 1>(p, st, max_bpc);
+        }
     }
     return launch_conv_split<NB, PB, MAP, EPI, D, WPB, 0>(p, st, max_bpc);
 }

@@ -11,6 +11,26 @@ LRELU_SLOPE = 0.2   # get_activation("lrelu"), utils.py:63
 NORM_EPS = 1e-5     # nn.GroupNorm / nn.LayerNorm default eps
 
 
+MATRIX_MODES = {"fp32": 0, "bf16": 1}
+
+
+class matrix_mode:
+    """``with ops.matrix_mode("bf16"):`` -- GEMM arithmetic of the launches enqueued inside (include/urnn_hip.h
+    urnn_set_matrix_mode): "fp32" = the reference's semantics (default), "bf16" = bf16 compute with fp32 accumulation."""
+
+    def __init__(self, mode):
+        self.mode = MATRIX_MODES[mode]
+
+    def __enter__(self):
+        self.prev = lib().urnn_get_matrix_mode()
+        check(lib().urnn_set_matrix_mode(self.mode), "urnn_set_matrix_mode")
+        return self
+
+    def __exit__(self, *exc):
+        lib().urnn_set_matrix_mode(self.prev)
+        return False
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 

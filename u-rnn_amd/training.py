@@ -227,8 +227,13 @@ class Trainer:
     (main.py:384-387)."""
 
     def __init__(self, net, H, W, nums, rain_max, cumsum_max, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_clip=0.0,
-                 cls_thred_train=0.0, process_group=None, distributed=False, use_graph=False):
+                 cls_thred_train=0.0, process_group=None, distributed=False, use_graph=False, matrix_mode="fp32"):
         self.net = net
+        # "fp32": the reference's arithmetic (default).  "bf16": BASELINE configs[3] -- the GEMMs of the forward pass and of the
+        # input gradients run in bf16 compute with fp32 accumulation (ops.matrix_mode); master weights, Adam, norms, loss: fp32
+        if matrix_mode not in ops.MATRIX_MODES:
+            raise ValueError(f"matrix_mode must be one of {sorted(ops.MATRIX_MODES)}")
+        self.matrix_mode = matrix_mode
         self.use_graph = bool(use_graph)        # capture one window (forward, loss, backward, clip + Adam) as a hipGraph
         if use_graph and distributed:
             import warnings
@@ -360,7 +365,7 @@ class Trainer:
         B = ev["B"]
         # the DEM normalisation bounds are kernel ARGUMENTS (frozen into the graph): one capture per (shape, bounds), i.e. per
         # catchment; the event's tensors are copied into static buffers before every replay
-        key = (steps, B, ev["T"], tuple(ev["rain"].shape), ev["dem_min"], ev["dem_max"], self.lr)   # lr: one re-capture per epoch
+        key = (steps, B, ev["T"], tuple(ev["rain"].shape), ev["dem_min"], ev["dem_max"], self.lr, self.matrix_mode)   # lr: one re-capture per epoch
         if self._graph is None or self._graph["key"] != key:
             from .general import initialize_states
             zero = [s.to(dev).repeat(B, 1, 1, 1) for s in initialize_states(dev, self.wg.H, self.wg.W)]
@@ -407,12 +412,13 @@ class Trainer:
         """One window: returns (loss components, final states); the parameters have been updated."""
         ev = event if "rain" in event else event_to_device(event, self.wg.device)
         self.step_count += 1
-        if self.use_graph and not self.distributed:
-            targets = torch.as_tensor(targets, dtype=torch.float32, device=self.wg.device)
-            out, clip = self._train_window_graph(ev, targets, t0, steps, states)
-            self.last = {"loss": out["loss"], "clip": clip, "reg": out["reg"]}        # static buffers: valid until the next window
-            return out["loss"].clone(), [s.clone() for s in out["states"]]
-        out, clip = self._window_body(ev, targets, t0, steps, states)
+        with ops.matrix_mode(self.matrix_mode):
+            if self.use_graph and not self.distributed:
+                targets = torch.as_tensor(targets, dtype=torch.float32, device=self.wg.device)
+                out, clip = self._train_window_graph(ev, targets, t0, steps, states)
+                self.last = {"loss": out["loss"], "clip": clip, "reg": out["reg"]}        # static buffers: valid until the next window
+                return out["loss"].clone(), [s.clone() for s in out["states"]]
+            out, clip = self._window_body(ev, targets, t0, steps, states)
         self.last = {"loss": out["loss"], "clip": clip, "reg": out["reg"]}
         return out["loss"], out["states"]
 
@@ -421,8 +427,9 @@ class Trainer:
         ev = event if "rain" in event else event_to_device(event, self.wg.device)
         from .general import initialize_states
         states = [s.to(self.wg.device).repeat(ev["B"], 1, 1, 1) for s in initialize_states(self.wg.device, self.wg.H, self.wg.W)]
-        for t in range(int(ind)):
-            _, states = self.wg._forward_step(ev, t, states, 0)
+        with ops.matrix_mode(self.matrix_mode):
+            for t in range(int(ind)):
+                _, states = self.wg._forward_step(ev, t, states, 0)
         return states
 
     def train_event(self, event, label, seq_num, window_size=None, loc=0, prewarming=False, starts=None):
