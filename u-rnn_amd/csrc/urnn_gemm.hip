@@ -465,24 +465,26 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
             // works as long as A and B agree.  Refills use uniform branches (no pinned schedule here): segment switches are rare.
             int seg_left = (kp_begin >= k2 ? INT_MAX : (kp_begin >= k1 ? (k2 == INT_MAX || GATED ? INT_MAX : k2 - kp_begin) : k1 == INT_MAX ? INT_MAX : k1 - kp_begin));
             int seg_cur = s_begin;
+            // The common case -- the next row pair of the current plain segment, or a dummy past the end of the stream -- is
+            // straight-line code (two scalar selects); segment switches are rare, not-taken branches.
             auto refill_s = [&](int slot) {
-                if (si < nplain) {
-                    R::issue(ring + slot * R::SLOT, rs, vo, soff, lane);
-                    soff += rstep;
-                    if (--seg_left == 0) {                       // next K segment (x -> e -> h)
-                        ++seg_cur;
-                        rs = seg_cur == 1 ? rs1 : rs2;
-                        soff = 0u;
-                        seg_left = (seg_cur == 1 && !GATED && k2 != INT_MAX) ? k2 - k1 : INT_MAX;
-                    }
-                } else if (GATED && si < total) {
+                if (GATED && si >= nplain && si < total) {            // candidate GEMM: half of its stream
                     const bool hrows = ((si - nplain) & 1) != 0;
                     R::issue(ring + slot * R::SLOT, hrows ? rs2 : rsg, vo, soff_g, lane);
                     soff_g += hrows ? rstep : 0u;
-                } else {
-                    R::issue(scratch, rs0, vo, 0xF0000000u, lane);   // past the end: keeps the outstanding-DMA count exact
+                    ++si;
+                    return;
                 }
+                const bool live = si < nplain;                    // else past the end: the DMA reads out of range (zeros) into the
+                R::issue(live ? ring + slot * R::SLOT : scratch, rs, vo, live ? soff : 0xF0000000u, lane);   // sink slot, which keeps
+                soff += rstep;                                                                                  // every vmcnt exact
                 ++si;
+                if (__builtin_expect(--seg_left == 0, 0)) {      // next K segment (x -> e -> h)
+                    ++seg_cur;
+                    rs = seg_cur == 1 ? rs1 : rs2;
+                    soff = 0u;
+                    seg_left = (seg_cur == 1 && !GATED && k2 != INT_MAX) ? k2 - k1 : INT_MAX;
+                }
             };
             for (int i = 0; i < D; ++i) refill_s(i);
             constexpr bool BF16C = (SPLIT == 2);
