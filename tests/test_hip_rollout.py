@@ -466,3 +466,23 @@ def test_repeated_launches_are_bit_identical_at_full_size(dev):
         ref = fn().clone()
         for i in range(60):
             assert torch.equal(fn(), ref), f"{name}: launch {i + 1} differs from the first"
+
+
+def test_scalar_rain_engine_keeps_its_graph_across_dem_ranges(dev):
+    """Events of different catchments (different DEM min / max, Dynamic2DFlood.py:231-232) through one scalar-rain engine: the
+    DEM is normalised outside the captured timestep, so the graphs are kept -- and the frames equal a fresh engine's."""
+    import urnn_amd.weights as uw
+    from urnn_amd.rollout import RolloutEngine
+    H, W, nums, T = 32, 48, 3, 5
+    net, _ = make_net(H, W, 9, 3, dev)
+    eng = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T, overlap=True)
+    ev_a = uw.make_event(T, H, W, 60.0, seed=1)
+    ev_b = uw.make_event(T, H, W, 60.0, seed=2)
+    ev_b["absolute_DEM"] = ev_b["absolute_DEM"] * 0.5 + 700.0
+    ev_b["max_DEM"], ev_b["min_DEM"] = ev_b["absolute_DEM"].reshape(1, -1).max(1), ev_b["absolute_DEM"].reshape(1, -1).min(1)
+    a = eng.rollout(ev_a).clone()
+    graphs = eng._graphs2
+    b = eng.rollout(ev_b).clone()
+    assert eng._graphs2 is graphs and graphs is not None
+    fresh = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T, overlap=True)
+    assert torch.equal(b, fresh.rollout(ev_b)) and not torch.equal(a, b)

@@ -328,10 +328,12 @@ class RolloutEngine:
             ops.stage1_static(self.dem, self.imperv, self.manhole, ev["dem_min"], ev["dem_max"], self._w1, self.nums, out=self.S1)
         self._check_params()
         if (ev["dem_min"], ev["dem_max"]) != (self.dem_min, self.dem_max):
-            # normalisation bounds are kernel arguments frozen into the graph: re-capture when they change
             self.dem_min, self.dem_max = ev["dem_min"], ev["dem_max"]
-            self._graph = None
-            self._graphs2 = None
+            if self.S1 is None:
+                # spatial rain: the bounds are arguments of the captured preprocess kernel -> re-capture when they change.
+                # Scalar rain normalises the DEM in stage1_static above (eager, once per event): the graph does not see them.
+                self._graph = None
+                self._graphs2 = None
         return T
 
     def _check_params(self):
