@@ -115,6 +115,14 @@ def test_strips_over_ranks_reproduce_the_unsplit_rollout(dev, tmp_path, world, s
     d3 = np.concatenate([np.load(tmp_path / f"d3_{r}.npy") for r in range(world)], axis=2)
     assert [np.load(tmp_path / f"d3_{r}.npy").shape[2] for r in range(world)] == [b - a for a, b in (strip_rows(H, r, world) for r in range(world))]
     _close(torch.from_numpy(d3), want_states[5], "final decoder state", rel=1e-4)
+    # ... and against the CPU oracle itself (not only the unsplit HIP rollout): cls-independent quantities within 1e-4, the
+    # masked depth away from the wet/dry threshold
+    from conftest import assert_close, masked_parity
+    from oracle import oracle as orc
+    sd = uw.make_state_dict(H, W, 2 * NUMS + 3, seed=12)
+    ref_frames, ref_states, aux = orc.rollout(orc.OracleNet(sd), ev, T, NUMS, RAIN_MAX, CUM_MAX, want_aux=True)
+    assert_close(d3, ref_states[5], 1e-4, "final decoder state vs oracle")
+    masked_parity(fulls[0].reshape(ref_frames.shape), ref_frames, np.stack([a["cls"] for a in aux]), np.stack([a["reg_raw"] for a in aux]), 1e-4)
 
 
 def test_strip_calls_reject_fused_phases(dev):

@@ -264,7 +264,16 @@ static int gru_cell_impl(const float *x, const float *e, const float *h, const f
     const int tiles1 = gru_tiles(B, F, P, 1, &pb1, &map1);
     const int ftiles1 = global_pixels > 0 ? 2 : tiles1;                              // tiles the finalizes read
     const double count = 32.0 * (double)(global_pixels > 0 ? global_pixels : P);     // values per (sample, norm group)
-    if (phase_mask & URNN_PHASE_GATES) CHECK_HIP(urnn_launch_gru1(p, B, pb1, map1, st), "gru gates");
+    // 32-pixel tiles (small planes: the quarter-resolution cells, the F = 96 candidates at half resolution) take the
+    // activation-stationary kernels of urnn_small.hip: same outputs, same partial layout (development knob URNN_TUNE_SMALL=0)
+    // up to URNN_TUNE_SMALL pixels per launch (default 24 000; 0 disables): at 62 500 pixels the per-block weight stream and
+    // prologue cost more than they save (candidate GEMMs 38 -> 49 and 56 -> 110 us)
+    static const long small_max = getenv("URNN_TUNE_SMALL") ? atol(getenv("URNN_TUNE_SMALL")) : 24000;
+    const bool small_on = (long)B * P <= small_max;
+    if (phase_mask & URNN_PHASE_GATES) {
+        if (small_on && pb1 == 1 && urnn_small_ok(p, 2 * NW, 0)) CHECK_HIP(urnn_launch_small_gates(p, B, st), "gru gates (small plane)");
+        else CHECK_HIP(urnn_launch_gru1(p, B, pb1, map1, st), "gru gates");
+    }
     // GroupNorm finalise of the gates: folded into the candidate GEMM's prologue; launched on its own only when asked for
     // without the candidate phase (profiling)
     if ((phase_mask & URNN_PHASE_GN1) && !(phase_mask & URNN_PHASE_CAND))
@@ -299,12 +308,22 @@ static int gru_cell_impl(const float *x, const float *e, const float *h, const f
     c.partial = ws.part2;
     int pb2, map2;
     const int tiles2 = gru_tiles(B, F, P, 2, &pb2, &map2);
-    if (phase_mask & URNN_PHASE_CAND) CHECK_HIP(urnn_launch_cand(c, B, pb2, map2, st), "gru candidate");
+    if (phase_mask & URNN_PHASE_CAND) {
+        if (small_on && pb2 == 1 && urnn_small_ok(c, NW, 1)) CHECK_HIP(urnn_launch_small_cand(c, B, st), "gru candidate (small plane)");
+        else CHECK_HIP(urnn_launch_cand(c, B, pb2, map2, st), "gru candidate");
+    }
+    // K3: GroupNorm finalize of the candidate + blend.  One launch when both are asked for (the product path); separate
+    // launches for phase-split callers (profiling, strips: the statistics are exchanged in between)
+    static const bool fuse_on = !getenv("URNN_TUNE_FUSE_BLEND") || atoi(getenv("URNN_TUNE_FUSE_BLEND")) != 0;   // development knob
+    const bool fused = fuse_on && (phase_mask & URNN_PHASE_GN2) && (phase_mask & URNN_PHASE_BLEND) && global_pixels <= 0;
+    if (fused) {
+        CHECK_HIP(urnn_launch_blend_fin(ws.g1, ws.cx, h, ws.ss1, h_out, B, F, (int)P, ws.part2, tiles2, 32 * pb2, count, gn2_w, gn2_b, eps, ws.ss2,
+                                        ws.st2, st), "gru finalize + blend");
+        return URNN_OK;
+    }
     if (phase_mask & URNN_PHASE_GN2)
         CHECK_HIP(urnn_launch_gn_finalize(ws.part2, global_pixels > 0 ? 2 : tiles2, global_pixels > 0 ? 0 : 32 * pb2, (int)P, count, gn2_w, gn2_b,
                                           eps, ws.ss2, ws.st2, B, F, st), "gn finalize 2");
-
-    // K3: blend
     if (phase_mask & URNN_PHASE_BLEND) CHECK_HIP(urnn_launch_blend(ws.g1, ws.cx, h, ws.ss1, ws.ss2, h_out, B, F, (int)P, st), "gru blend");
     return URNN_OK;
 }

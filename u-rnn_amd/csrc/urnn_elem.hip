@@ -65,20 +65,79 @@ hipError_t urnn_launch_gn_finalize(const float *partial, int ntiles, int tile_pi
 // GRU blend: z = sigmoid(GN(g_z)); n = tanh(GN(c)); h' = (1 - z) * h + z * n          (ConvRNN.py:183-189)
 // grid = (chunks, B*F): one (sample, channel) plane per blockIdx.y so scale/shift are block-uniform.
 // ------------------------------------------------------------------------------------------------------------------
-template <int V>
+// FIN: the candidate's GroupNorm finalize runs in the block's prologue instead of a launch of its own (six launches fewer per
+// frame): every block folds the per-tile partials of ITS channel's group in double, in a fixed order (thread-strided, xor
+// butterfly, waves 0..3) -- all blocks of a group compute identical bits; the blocks of chunk 0 publish (scale, shift) and
+// (mean, rstd) for the backward pass.
+struct BlendFin {
+    const float *partial;   // [B][F/32][ntiles][2] centred tile partials of the candidate (urnn_common.h tile_x2)
+    int ntiles, tile_pix;
+    double count;
+    const float *gamma, *beta;
+    float eps;
+    float *ss2, *stat2;     // out: [B][F][2] (scale, shift), [B][F/32][2] (mean, rstd)
+};
+
+template <int V, bool FIN>
 __global__ __launch_bounds__(256) void gru_blend_kernel(const float *__restrict__ g1, const float *__restrict__ c,
                                                         const float *h, const float *__restrict__ ss1,
-                                                        const float *__restrict__ ss2, float *out, int F, int P)
+                                                        const float *__restrict__ ss2, float *out, int F, int P, const BlendFin fin)
 {
     const int bc = blockIdx.y;
     const int b = bc / F, f = bc - b * F;
     const float s1 = ss1[((size_t)b * 2 * F + f) * 2], t1 = ss1[((size_t)b * 2 * F + f) * 2 + 1];
-    const float s2 = ss2[((size_t)b * F + f) * 2], t2 = ss2[((size_t)b * F + f) * 2 + 1];
+    float s2, t2;
+    if constexpr (FIN) {
+        __shared__ double red[2][4];
+        __shared__ float st[2];
+        const int G = F / 32, g = f >> 5;
+        const float *pp = fin.partial + ((size_t)b * G + g) * fin.ntiles * 2;
+        double a1 = 0.0, a2 = 0.0;
+        for (int t = threadIdx.x; t < fin.ntiles; t += 256) {
+            const f32x2 v = *reinterpret_cast<const f32x2 *>(pp + 2 * t);
+            a1 += (double)v.x;
+            a2 += tile_x2(v.x, v.y, 32 * tile_valid(t, fin.tile_pix, P));
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            a1 += __shfl_xor(a1, m, 64);
+            a2 += __shfl_xor(a2, m, 64);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            red[0][threadIdx.x >> 6] = a1;
+            red[1][threadIdx.x >> 6] = a2;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double S1 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), S2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+            const double mean = S1 / fin.count;
+            double var = S2 / fin.count - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            const double rstd = 1.0 / sqrt(var + (double)fin.eps);
+            const double sc = (double)fin.gamma[f] * rstd;
+            st[0] = (float)sc;
+            st[1] = (float)((double)fin.beta[f] - mean * sc);
+            if (blockIdx.x == 0) {
+                fin.ss2[((size_t)b * F + f) * 2] = st[0];
+                fin.ss2[((size_t)b * F + f) * 2 + 1] = st[1];
+                if ((f & 31) == 0 && fin.stat2) {
+                    fin.stat2[((size_t)b * G + g) * 2] = (float)mean;
+                    fin.stat2[((size_t)b * G + g) * 2 + 1] = (float)rstd;
+                }
+            }
+        }
+        __syncthreads();
+        s2 = st[0];
+        t2 = st[1];
+    } else {
+        s2 = ss2[((size_t)b * F + f) * 2];
+        t2 = ss2[((size_t)b * F + f) * 2 + 1];
+    }
     const float *gz = g1 + ((size_t)b * 2 * F + f) * P;
     const float *cc = c + ((size_t)bc) * P;
     const float *hh = h + ((size_t)bc) * P;
     float *oo = out + ((size_t)bc) * P;
-    constexpr int ITER = 4;
+    constexpr int ITER = FIN ? 8 : 4;      // fused finalize: fewer, larger blocks (the prologue is per block)
     const int base = blockIdx.x * (256 * V * ITER);
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
@@ -110,8 +169,23 @@ hipError_t urnn_launch_blend(const float *g1, const float *c, const float *h, co
     const bool v4 = (P % 4) == 0;
     const int per_block = 256 * (v4 ? 4 : 1) * 4;
     dim3 grid((P + per_block - 1) / per_block, B * F);
-    if (v4) hipLaunchKernelGGL(gru_blend_kernel<4>, grid, dim3(256), 0, st, g1, c, h, ss1, ss2, out, F, P);
-    else hipLaunchKernelGGL(gru_blend_kernel<1>, grid, dim3(256), 0, st, g1, c, h, ss1, ss2, out, F, P);
+    const BlendFin none = {};
+    if (v4) hipLaunchKernelGGL((gru_blend_kernel<4, false>), grid, dim3(256), 0, st, g1, c, h, ss1, ss2, out, F, P, none);
+    else hipLaunchKernelGGL((gru_blend_kernel<1, false>), grid, dim3(256), 0, st, g1, c, h, ss1, ss2, out, F, P, none);
+    return hipGetLastError();
+}
+
+// GroupNorm finalize of the candidate + blend in one launch (see gru_blend_kernel FIN)
+hipError_t urnn_launch_blend_fin(const float *g1, const float *c, const float *h, const float *ss1, float *out, int B, int F, int P,
+                                 const float *partial, int ntiles, int tile_pix, double count, const float *gamma, const float *beta, float eps,
+                                 float *ss2, float *stat2, hipStream_t st)
+{
+    const bool v4 = (P % 4) == 0;
+    const int per_block = 256 * (v4 ? 4 : 1) * 8;
+    dim3 grid((P + per_block - 1) / per_block, B * F);
+    const BlendFin fin = {partial, ntiles, tile_pix, count, gamma, beta, eps, ss2, stat2};
+    if (v4) hipLaunchKernelGGL((gru_blend_kernel<4, true>), grid, dim3(256), 0, st, g1, c, h, ss1, nullptr, out, F, P, fin);
+    else hipLaunchKernelGGL((gru_blend_kernel<1, true>), grid, dim3(256), 0, st, g1, c, h, ss1, nullptr, out, F, P, fin);
     return hipGetLastError();
 }
 

@@ -240,35 +240,6 @@ __device__ __forceinline__ void block_role(int NG, int &g, int &slot, int &nslot
 // conv_gemm_kernel: persistent blocks of WPB waves; block owns n-group g (weights resident in LDS), each wave loops over
 // pixel tiles.  gridDim.x is a multiple of 8 * NG.  Dynamic LDS = aFloats*4 + WPB * (D + 1) * SLOT + NB * 128 (bias).
 // ------------------------------------------------------------------------------------------------------------------
-// bf16 pieces of fp32 operands for the 16-bit matrix pipe (SPLIT kernels).  Truncating splits are EXACT: x = hi + mid + lo with
-// 8 significant bits each, so  a*b = hh + hm + mh + hl + lh + mm  up to the three dropped terms (<= 3 * 2^-24 |a*b|, one fp32
-// rounding's worth); measured against float64 on K = 224 dot products: rms error 2.2e-7 of sqrt(sum (w x)^2) vs 2.7e-7 for the
-// fp32 MFMA's own fma chain (tools/ubench/split_mfma.hip, profiles/r02_split_mfma.txt) -- at 16/6 of its rate.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// One dword of each piece from two fp32 values: element 2d = the even k-pair's value, 2d + 1 = the odd one's.
-__device__ __forceinline__ void split_pair(float xe, float xo, unsigned &ph, unsigned &pm, unsigned &pl)
-{
-    const unsigned ue = __float_as_uint(xe), uo = __float_as_uint(xo);
-    ph = __builtin_amdgcn_perm(uo, ue, 0x07060302u);                       // {uo[31:16], ue[31:16]}: truncation to bf16
-    const float re = xe - __uint_as_float(ue & 0xffff0000u), ro = xo - __uint_as_float(uo & 0xffff0000u);   // exact
-    const unsigned ve = __float_as_uint(re), vo = __float_as_uint(ro);
-    pm = __builtin_amdgcn_perm(vo, ve, 0x07060302u);
-    const float se = re - __uint_as_float(ve & 0xffff0000u), so = ro - __uint_as_float(vo & 0xffff0000u);   // exact, <= 8 bits left
-    pl = __builtin_amdgcn_perm(__float_as_uint(so), __float_as_uint(se), 0x07060302u);
-}
-
-// bf16 compute mode (SPLIT = 2): one dword of round-to-nearest-even bf16 values (v_cvt_pk_bf16_f32)
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned round_pair(float xe, float xo)
-{
-    const bf16x2 v = {(__bf16)xe, (__bf16)xo};
-    return __builtin_bit_cast(unsigned, v);
-}
-
-__device__ __forceinline__ bf16x8 as_bf16x8(const unsigned (&p)[4]) { return __builtin_bit_cast(bf16x8, u32x4{p[0], p[1], p[2], p[3]}); }
-
 // SPLIT = 0: v_mfma_f32_32x32x2_f32 per k-pair (exact fp32 fma chain).  SPLIT = 1: eight k-pairs at a time on
 // v_mfma_f32_32x32x16_bf16 with both operands split into three bf16 pieces (six MFMAs per 16 k: 2.67x the fp32 matrix rate);
 // needs (KT - kpBegin) % 8 == 0 and, in the candidate GEMM, a plain part that is a positive multiple of 8 k-pairs.
@@ -1090,7 +1061,9 @@ hipError_t urnn_launch_gru1(ConvGemmParams p, int B, int PB, int map, hipStream_
 // Candidate GEMM: C = W2 . [x; e; sigmoid(GN(r)) * h] + b2, NG groups of NB n-blocks (urnn_cand_nb).
 int urnn_cand_nb(int F)
 {
+    static const int forced = [] { const char *e = getenv("URNN_TUNE_CAND_NB"); return e ? atoi(e) : 0; }();   // development knob
     const int nblk = F / 32;
+    if (forced > 0 && nblk % forced == 0) return forced;
     return nblk <= 3 ? nblk : 2;
 }
 

@@ -45,6 +45,11 @@ hipError_t urnn_launch_conv_flat(ConvGemmParams p, int B, int PB, int map, hipSt
 hipError_t urnn_launch_conv_pool(ConvGemmParams p, int B, hipStream_t st);
 hipError_t urnn_launch_deconv(ConvGemmParams p, int B, int PB, int map, hipStream_t st);
 hipError_t urnn_launch_gru1(ConvGemmParams p, int B, int PB, int map, hipStream_t st);
+// small planes (urnn_small.hip): activation-stationary gate / candidate GEMMs; same outputs and 32-pixel partial tiles as the
+// regular kernels with PB = 1
+bool urnn_small_ok(const ConvGemmParams &p, int nblk_total, int gated);
+hipError_t urnn_launch_small_gates(ConvGemmParams p, int B, hipStream_t st);
+hipError_t urnn_launch_small_cand(ConvGemmParams p, int B, hipStream_t st);
 int urnn_cand_nb(int F);      // n-blocks per group of the candidate GEMM
 hipError_t urnn_launch_cand(ConvGemmParams p, int B, int PB, int map, hipStream_t st);
 
@@ -53,6 +58,9 @@ hipError_t urnn_launch_gn_finalize(const float *partial, int ntiles, int tile_pi
                                    float eps, float *ss, float *stat, int B, int C, hipStream_t st);
 hipError_t urnn_launch_blend(const float *g1, const float *c, const float *h, const float *ss1, const float *ss2, float *out,
                              int B, int F, int P, hipStream_t st);
+hipError_t urnn_launch_blend_fin(const float *g1, const float *c, const float *h, const float *ss1, float *out, int B, int F, int P,
+                                 const float *partial, int ntiles, int tile_pix, double count, const float *gamma, const float *beta, float eps,
+                                 float *ss2, float *stat2, hipStream_t st);
 
 struct HeadParams {
     const float *feat;

@@ -1,0 +1,280 @@
+// urnn_small.hip -- the gate / candidate GEMMs of the ConvGRU cells on SMALL planes (the quarter- and half-resolution stages:
+// 15 625 / 62 500 pixels at 500x500), activation-stationary.
+//
+// conv_gemm_kernel (urnn_gemm.hip) keeps an n-group's weights in LDS and streams activations; on a small plane a wave gets a
+// single 32-pixel tile and its k-loop is one serial chain of K/2 ring steps (~270 cycles each for a dozen MFMAs per 16 k):
+// 20 us for 0.9 GFLOP, and every n-group re-splits the same activations.  Here the roles are swapped:
+//   * a block owns 64 pixels and ALL output channels.  Its prologue loads the tile's K input rows once, forms the candidate's
+//     gated rows sigmoid(GN(r)) * h once, splits everything into the three bf16 pieces once, and leaves them in LDS as
+//     ready-made MFMA B fragments ([16-k group][pixel block][piece][lane] x 16 B);
+//   * one wave per (32-channel block, 32-pixel block): its k-loop is K/16 steps of {3 x 16-B weight-piece loads straight from
+//     the packed split slab in global memory (L2-resident, prefetched three groups ahead), 3 ds_read_b128, 6 MFMAs} -- no
+//     VALU, no ring, no per-k-pair bookkeeping;
+//   * epilogue per wave: bias, centred GroupNorm partials of its 32 x 32 tile (tile = 32 pixels for the consumers), stores.
+// Same arithmetic as the split k-loop (three exact bf16 pieces, six v_mfma_f32_32x32x16_bf16 per 16 k, fp32 accumulate) and
+// the same outputs / workspace layout, so the blend, the backward pass and the strip mode read them unchanged.
+#include "urnn_common.h"
+#include "urnn_kernels.h"
+
+#include <limits.h>
+
+extern __shared__ __attribute__((aligned(16))) char urnn_small_smem[];
+
+// GATED = 0: gate GEMM (EPI_GRU1 semantics).  GATED = 1: candidate GEMM (EPI_CAND): rows >= hKp0 are sigmoid(GN(r)) * h; the
+// gates' GroupNorm is finalised in the prologue (block 0 of each sample publishes the tables, as conv_gemm_kernel does).
+template <int GATED, int MODE>
+__global__ __launch_bounds__(1024) void small_cell_gemm_kernel(const ConvGemmParams prm, int nblk_total, int NBG)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int j = lane & 31, half = lane >> 5;
+    const int blocksPerSample = (prm.P + 63) >> 6;
+    const int b = blockIdx.x / blocksPerSample, blk = blockIdx.x - b * blocksPerSample;
+    const int P = prm.P, F = prm.F;
+    const int kg0 = prm.kpBegin >> 3, KG = (prm.KT - prm.kpBegin) >> 3;   // 16-k groups [kg0, kg0 + KG)
+
+    unsigned *Bp = reinterpret_cast<unsigned *>(urnn_small_smem);       // [KG][2][3][64][4] dwords
+    float *bias = reinterpret_cast<float *>(Bp + (size_t)KG * 2 * 3 * 256);
+    float *ssm = bias + nblk_total * 32;                                // GATED: [F][2] r-gate (scale, shift) of sample b
+    if (threadIdx.x < nblk_total * 32) bias[threadIdx.x] = prm.bias[threadIdx.x];
+
+    if constexpr (GATED) {
+        // GroupNorm of the gates, folded from the gate GEMM's per-tile partials in double, fixed order (as in conv_gemm_kernel):
+        // one wave per 32-channel group of sample b; the r half stays in LDS, block 0 of the sample publishes everything
+        const int G1 = 2 * F / 32;
+        for (int grp = wave; grp < G1; grp += nwaves) {
+            const float *pp = prm.gpart + ((size_t)b * G1 + grp) * prm.gtiles * 2;
+            double s1 = 0.0, s2 = 0.0;
+            for (int t = lane; t < prm.gtiles; t += 64) {
+                const f32x2 v = *reinterpret_cast<const f32x2 *>(pp + 2 * t);
+                s1 += (double)v.x;
+                s2 += tile_x2(v.x, v.y, 32 * tile_valid(t, prm.gtilePix, P));
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                s1 += __shfl_xor(s1, m, 64);
+                s2 += __shfl_xor(s2, m, 64);
+            }
+            const double mean = s1 / prm.gcount;
+            double var = s2 / prm.gcount - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            const double rstd = 1.0 / sqrt(var + (double)prm.eps);
+            if (lane < 32) {
+                const int c = grp * 32 + lane;
+                const double sc = (double)prm.gn_w[c] * rstd;
+                const float fsc = (float)sc, fsh = (float)((double)prm.gn_b[c] - mean * sc);
+                if (c >= F) {
+                    ssm[(c - F) * 2] = fsc;
+                    ssm[(c - F) * 2 + 1] = fsh;
+                }
+                if (blk == 0) {
+                    prm.ss_out[((size_t)b * 2 * F + c) * 2] = fsc;
+                    prm.ss_out[((size_t)b * 2 * F + c) * 2 + 1] = fsh;
+                    if (lane == 0 && prm.stat_out) {
+                        prm.stat_out[((size_t)b * G1 + grp) * 2] = (float)mean;
+                        prm.stat_out[((size_t)b * G1 + grp) * 2 + 1] = (float)rstd;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- prologue: the tile's input rows -> bf16 pieces in LDS, once for all output channels -------------------------------------
+    // unit u = (group gq, dword d, row parity hf): k-pairs kp0 = 8 (kg0 + gq) + 2d and kp0 + 1, channel row hf of each; lane = pixel
+    {
+        const int px = blk * 64 + lane;
+        const bool pix_ok = px < P;
+        const int pb = lane >> 5;
+        const int k1 = prm.segKp0[1], k2 = prm.segKp0[2];
+        auto act = [&](int kp, int hf) -> float {
+            if (!pix_ok) return 0.f;
+            if (GATED && kp >= prm.hKp0) {
+                const int ch = 2 * (kp - prm.hKp0) + hf;
+                const float g = prm.gate[((size_t)b * 2 * F + F + ch) * P + px], hv = prm.seg[2][((size_t)b * F + ch) * P + px];
+                return sigmoidf_fast(g * ssm[2 * ch] + ssm[2 * ch + 1]) * hv;
+            }
+            const int sg = kp >= k2 ? 2 : (kp >= k1 ? 1 : 0);
+            const int ch = 2 * (kp - (sg == 2 ? k2 : (sg == 1 ? k1 : 0))) + hf;
+            return ch < prm.segC[sg] ? prm.seg[sg][((size_t)b * prm.segC[sg] + ch) * P + px] : 0.f;    // pad row of an odd channel count
+        };
+        const int nunits = KG * 8;
+        for (int u0 = wave; u0 < nunits; u0 += 4 * nwaves) {                // four units in flight per wave
+            float v0[4], v1[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int u = u0 + q * nwaves;
+                if (u < nunits) {
+                    const int gq = u >> 3, d = (u >> 1) & 3, hf = u & 1;
+                    const int kp0 = 8 * (kg0 + gq) + 2 * d;
+                    v0[q] = act(kp0, hf);
+                    v1[q] = act(kp0 + 1, hf);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int u = u0 + q * nwaves;
+                if (u < nunits) {
+                    const int gq = u >> 3, d = (u >> 1) & 3, hf = u & 1;
+                    unsigned ph, pm, pl;
+                    if constexpr (MODE == 2) {
+                        ph = round_pair(v0[q], v1[q]);
+                        pm = pl = 0u;
+                    } else {
+                        split_pair(v0[q], v1[q], ph, pm, pl);
+                    }
+                    unsigned *dst = Bp + ((((size_t)gq * 2 + pb) * 3) * 64 + ((lane & 31) + 32 * hf)) * 4 + d;
+                    dst[0] = ph;
+                    dst[256] = pm;
+                    dst[512] = pl;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- main loop: wave = (32-channel block nbg, pixel block pbw) -------------------------------------------------------------------
+    const int nbg = wave >> 1, pbw = wave & 1;
+    const int g = nbg / NBG, nb = nbg - g * NBG;                          // n-group / block inside it, as packed
+    const u32x4 *Aw = reinterpret_cast<const u32x4 *>(prm.wsplit + (size_t)g * prm.sDwords) + lane;
+    auto a_ptr = [&](int gq, int piece) { return Aw + ((size_t)((kg0 + gq) * NBG + nb) * 3 + piece) * 64; };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    constexpr int PF = 3;                                                 // weight pieces prefetched PF groups ahead
+    u32x4 ah[PF], am[PF], al[PF];
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+        const int gq = q < KG ? q : KG - 1;
+        ah[q] = *a_ptr(gq, 0);
+        am[q] = *a_ptr(gq, 1);
+        if constexpr (MODE != 2) al[q] = *a_ptr(gq, 2);
+    }
+    const u32x4 *Bw = reinterpret_cast<const u32x4 *>(Bp) + (size_t)pbw * 3 * 64 + lane;
+    for (int gq0 = 0; gq0 < KG; gq0 += PF) {
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const int gq = gq0 + q;
+            if (gq < KG) {
+                const u32x4 bh = Bw[(size_t)gq * 2 * 3 * 64], bm = Bw[(size_t)gq * 2 * 3 * 64 + 64], bl = Bw[(size_t)gq * 2 * 3 * 64 + 128];
+                const bf16x8 wh = __builtin_bit_cast(bf16x8, ah[q]), wm = __builtin_bit_cast(bf16x8, am[q]);
+                const bf16x8 xh = __builtin_bit_cast(bf16x8, bh);
+                if constexpr (MODE == 2) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc, 0, 0, 0);
+                } else {
+                    const bf16x8 wl = __builtin_bit_cast(bf16x8, al[q]), xm = __builtin_bit_cast(bf16x8, bm), xl = __builtin_bit_cast(bf16x8, bl);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xm, acc, 0, 0, 0);       // small terms first
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xm, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc, 0, 0, 0);
+                }
+                const int gn = gq + PF < KG ? gq + PF : KG - 1;           // refill this prefetch slot
+                ah[q] = *a_ptr(gn, 0);
+                am[q] = *a_ptr(gn, 1);
+                if constexpr (MODE != 2) al[q] = *a_ptr(gn, 2);
+            }
+        }
+    }
+
+    // ---- epilogue: bias, centred GroupNorm partials of the 32 x 32 tile, stores -----------------------------------------------------
+    const int tile = blk * 2 + pbw;                                       // 32-pixel tile index inside the sample
+    const int px = tile * 32 + j;
+    const bool ok = px < P;
+    const int nvalid = tile_valid(tile, 32, P);
+    if (nvalid <= 0) return;                                              // (whole-wave: a tile past the end of an odd plane)
+    int ch0, Cout;                                                        // first output channel of this wave's block
+    if constexpr (GATED) {
+        ch0 = nbg * 32;
+        Cout = F;
+    } else {
+        ch0 = nb * F + g * 32;                                            // group g = [z_g | r_g]
+        Cout = 2 * F;
+    }
+    const float *bias_h = bias + nbg * 32 + 4 * half;
+    auto row_c = [](int r) { return (r & 3) + 8 * (r >> 2); };
+    float s1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if (ok) s1 += acc[r] + bias_h[row_c(r)];
+    s1 = wave_sum(s1);
+    const float mt = s1 / (float)(32 * nvalid);
+    float s2 = 0.f;
+    float *obase = prm.out0 + ((size_t)b * Cout + ch0 + 4 * half) * P + px;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float v = acc[r] + bias_h[row_c(r)];
+        const float d = v - mt;
+        if (ok) {
+            s2 = fmaf(d, d, s2);
+            obase[(size_t)row_c(r) * P] = v;
+        }
+    }
+    s2 = wave_sum(s2);
+    if (lane == 0) {
+        const int grp = GATED ? nbg : nb * (F / 32) + g;
+        const int G = GATED ? F / 32 : 2 * F / 32;
+        float *pp = prm.partial + (((size_t)b * G + grp) * prm.tilesPerSample + tile) * 2;
+        pp[0] = s1;
+        pp[1] = s2;
+    }
+}
+
+size_t urnn_small_lds_bytes(const ConvGemmParams &p, int nblk_total, int gated)
+{
+    const size_t KG = (size_t)(p.KT - p.kpBegin) / 8;
+    return KG * 2 * 3 * 1024 + (size_t)nblk_total * 128 + (gated ? (size_t)p.F * 8 : 0);
+}
+
+// Eligibility mirrors split_ok() of urnn_gemm.hip (whole, aligned 16-k groups; a split slab) plus the block shape limits.
+bool urnn_small_ok(const ConvGemmParams &p, int nblk_total, int gated)
+{
+    if (p.sDwords <= 0 || !p.wsplit) return false;
+    if (p.KT % 8 != 0 || p.kpBegin % 8 != 0 || p.KT <= p.kpBegin) return false;
+    if (gated) {
+        const int kpe = p.hKp0 < p.KT ? p.hKp0 : p.KT;
+        if (kpe % 8 != 0 || kpe >= p.KT) return false;
+    }
+    if (nblk_total < 1 || nblk_total * 2 > 16) return false;             // one wave per (block, pixel block): <= 1024 threads
+    return urnn_small_lds_bytes(p, nblk_total, gated) <= 150 * 1024;
+}
+
+template <int GATED>
+static hipError_t launch_small(const ConvGemmParams &p, int B, int nblk_total, int NBG, int mode, hipStream_t st)
+{
+    const size_t lds = urnn_small_lds_bytes(p, nblk_total, GATED);
+    auto k1 = small_cell_gemm_kernel<GATED, 1>;
+    auto k2 = small_cell_gemm_kernel<GATED, 2>;
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
+    const int blocks = B * ((p.P + 63) / 64);
+    const dim3 grid(blocks), blk(64 * nblk_total * 2);
+    if (mode == URNN_MATRIX_BF16) hipLaunchKernelGGL(k2, grid, blk, lds, st, p, nblk_total, NBG);
+    else hipLaunchKernelGGL(k1, grid, blk, lds, st, p, nblk_total, NBG);
+    return hipGetLastError();
+}
+
+// p as for urnn_launch_gru1 / urnn_launch_cand (tilesPerSample is set here: 32-pixel tiles)
+hipError_t urnn_launch_small_gates(ConvGemmParams p, int B, hipStream_t st)
+{
+    p.tilesPerSample = (p.P + 31) / 32;
+    p.totalTiles = B * p.tilesPerSample;
+    return launch_small<0>(p, B, p.NG * 2, 2, urnn_get_matrix_mode(), st);
+}
+
+hipError_t urnn_launch_small_cand(ConvGemmParams p, int B, hipStream_t st)
+{
+    const int NB = urnn_cand_nb(p.F);
+    p.B = B;
+    p.NG = (p.F / 32) / NB;
+    p.tilesPerSample = (p.P + 31) / 32;
+    p.totalTiles = B * p.tilesPerSample;
+    return launch_small<1>(p, B, p.F / 32, NB, urnn_get_matrix_mode(), st);
+}
