@@ -996,6 +996,11 @@ int urnn_conv_nb(int Cout)
     // n-blocks per group: all of them up to three; else 3 or 2 when that divides the count; else 3 with the last group
     // padded by zero columns (7 blocks -> 3 groups instead of 7 groups of one block that would each re-read the input)
     const int nblk = (Cout + 31) / 32;
+    // 96 output channels: three groups of one block.  A 3-block wave tile (192 accumulators with 128-pixel / pooled tiles) cannot
+    // take the split k-loop; three 1-block groups can, and the second and third read of the input hit the XCD's L2 (pooled
+    // 96 -> 96 conv at 250x250: 37 -> 22 us).  Development knob URNN_TUNE_CONV_NB3=3 restores one group.
+    static const int nb3 = [] { const char *e = getenv("URNN_TUNE_CONV_NB3"); return e ? atoi(e) : 1; }();
+    if (nblk == 3) return nb3 == 3 ? 3 : 1;
     return nblk <= 3 ? nblk : (nblk % 3 == 0 ? 3 : (nblk % 2 == 0 ? 2 : 3));
 }
 
