@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void gru_blend_kernel(const float *__restrict_
                 const float n = tanhf_fast(cv[k] * s2 + t2);
                 o[k] = (1.f - z) * hv[k] + z * n;
             }
-            *reinterpret_cast<f32x4 *>(oo + p) = o;
+            *reinterpret_cast<f32x4 *>(oo + p) = o;           // (the state is re-read soon: non-temporal stores cost 1 %)
         } else {
             const float z = sigmoidf_fast(gz[p] * s1 + t1);
             const float n = tanhf_fast(cc[p] * s2 + t2);

@@ -141,7 +141,15 @@ __device__ __forceinline__ void store_row(float *row, const PixelMap<MAP, PB> &p
     if constexpr (MAP == MAP_VEC) {
 #pragma unroll
         for (int qd = 0; qd < PB / 4; ++qd)
-            if (pm.valid[4 * qd]) *reinterpret_cast<f32x4 *>(row + pm.off[4 * qd]) = f32x4{v[4 * qd], v[4 * qd + 1], v[4 * qd + 2], v[4 * qd + 3]};
+            if (pm.valid[4 * qd]) {
+                // 128-pixel tiles are the big planes: tens of MB per launch that no kernel re-reads out of the 4-MiB L2s.  Non-temporal
+                // stores keep them from evicting the activation rows the other n-group is about to re-read (+2.7 % frames/s)
+#ifndef URNN_PLAIN_STORES
+                __builtin_nontemporal_store(f32x4{v[4 * qd], v[4 * qd + 1], v[4 * qd + 2], v[4 * qd + 3]}, reinterpret_cast<f32x4 *>(row + pm.off[4 * qd]));
+#else
+                *reinterpret_cast<f32x4 *>(row + pm.off[4 * qd]) = f32x4{v[4 * qd], v[4 * qd + 1], v[4 * qd + 2], v[4 * qd + 3]};
+#endif
+            }
     } else if constexpr (is_pair(MAP)) {
         if (pm.valid[0]) *reinterpret_cast<f32x2 *>(row + pm.off[0]) = f32x2{v[0], v[1]};
     } else {
@@ -686,7 +694,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
                                 v.y = lrelu(acc[NBC + cob][0][r] + bv, prm.slope);
                                 v.z = lrelu(acc[cob][1][r] + bv, prm.slope);
                                 v.w = lrelu(acc[NBC + cob][1][r] + bv, prm.slope);
-                                *reinterpret_cast<f32x4 *>(oplane + (size_t)oy[0] * W2 + ox[0]) = v;
+                                *reinterpret_cast<f32x4 *>(oplane + (size_t)oy[0] * W2 + ox[0]) = v;   // (non-temporal here: -1 %)
                             }
                         } else {
 #pragma unroll
