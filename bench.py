@@ -253,6 +253,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="events per GPU (the reference entry points use 1)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of the captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-long-run", action="store_true", help="skip the additional 360-step figure of short runs (counter-collection passes)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="control-plane backend for N>1 (nccl = RCCL over xGMI; gloo only for single-GPU dry runs of the N>1 path)")
     ap.add_argument("--share-gpu", action="store_true", help="dry run: every rank uses cuda:0 (needs --dist-backend gloo)")
@@ -355,7 +356,7 @@ def main():
     frames = args.steps * B * world
     fps = frames / elapsed
     long_run = None
-    if args.steps < 360 and world == 1:           # a short timed region (the driver's --steps 20 is ~20 ms): also one full event
+    if args.steps < 360 and world == 1 and not args.no_long_run:           # a short timed region (the driver's --steps 20 is ~20 ms): also one full event
         run_steps(0)
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()

@@ -6,15 +6,15 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=${1:-r02}
 O=$R/gpurun_out/$TAG; P=/tmp/prof_$TAG
 mkdir -p $O $P; cd /tmp; export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 14 --warmup 2 --no-cpu-baseline --overlap 0 --no-graph"
+CMD="python $R/bench.py --steps 14 --warmup 2 --no-cpu-baseline --no-long-run --overlap 0 --no-graph"
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   name=$(echo $pass | cut -d' ' -f1)
-  rocprofv3 --kernel-trace --pmc $pass -d $P/pmc_$name -o p -- $CMD > $P/pmc_$name.log 2>&1
+  timeout 420 rocprofv3 --kernel-trace --pmc $pass -d $P/pmc_$name -o p -- $CMD > $P/pmc_$name.log 2>&1
   { echo "# rocprofv3 --kernel-trace --pmc $pass -- $CMD"; python $R/tools/pmc_summary.py $P/pmc_$name/p_results.db "" --frames=-1; } > $O/pmc_$name.txt 2>&1
 done
-rocprofv3 --kernel-trace --stats -d $P/stats_default -o d -- python $R/bench.py --no-cpu-baseline > $O/bench_default_under_rocprof.log 2>&1
+timeout 420 rocprofv3 --kernel-trace --stats -d $P/stats_default -o d -- python $R/bench.py --no-cpu-baseline > $O/bench_default_under_rocprof.log 2>&1
 python $R/tools/prof_summary.py $P/stats_default/d_results.db > $O/kernel_stats.txt 2>&1
-rocprofv3 --kernel-trace --stats -d $P/stats_ov0 -o o -- python $R/bench.py --no-cpu-baseline --overlap 0 > $O/bench_overlap0_under_rocprof.log 2>&1
+timeout 420 rocprofv3 --kernel-trace --stats -d $P/stats_ov0 -o o -- python $R/bench.py --no-cpu-baseline --overlap 0 > $O/bench_overlap0_under_rocprof.log 2>&1
 python $R/tools/prof_summary.py $P/stats_ov0/o_results.db > $O/kernel_stats_overlap0.txt 2>&1
 python $R/bench.py > $O/bench_default.log 2>&1
 python $R/bench.py --overlap 0 --no-cpu-baseline > $O/bench_overlap0.log 2>&1

@@ -302,25 +302,60 @@ struct WgradParams {
 // too, 8.9 vs 8.2 ms per training step: two independent 4-wave blocks hide each other's barriers.)
 constexpr int WG_T = 128, WG_LD = 68;   // 68: rows stay 16-byte aligned (one ds_write_b128 per staged float4); column reads are 2-way conflicted, cheap next to the MFMAs
 
-// one 64-pixel stage of a wave: AN x AK MFMA tiles, pixel pairs [sLo, sLo + sCnt) of the stage
-template <int AN, int AK>
+// one 64-pixel stage of a wave: AN x AK MFMA tiles, pixel pairs [sLo, sLo + sCnt) of the stage.
+// MODE 0: v_mfma_f32_32x32x2_f32.  MODE 1: both operands split into three exact bf16 pieces when their fragment (8 consecutive
+// pixels of a row: two ds_read_b128) leaves LDS, six v_mfma_f32_32x32x16_bf16 per 16 pixels, small products first -- the
+// arithmetic of the forward GEMMs (urnn_gemm.hip), fp32-class error at 2.67x the matrix rate.  MODE 2 (bf16 training variant):
+// operands rounded to bf16, one MFMA per 16 pixels.
+template <int AN, int AK, int MODE>
 __device__ __forceinline__ void wgrad_stage(const float *__restrict__ pa, const float *__restrict__ pb, int sLo, int sCnt, f32x16 (&acc)[2][2])
 {
-    for (int s4 = sLo; s4 < sLo + sCnt; s4 += 4) {         // sCnt is 8, 16 or 32
+    if constexpr (MODE == 0) {
+        for (int s4 = sLo; s4 < sLo + sCnt; s4 += 4) {         // sCnt is 8, 16 or 32
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int s_ = s4 + u;
-            const float a0 = pa[2 * s_], b0 = pb[2 * s_];
-            const float a1 = AN > 1 ? pa[32 * WG_LD + 2 * s_] : 0.f, b1 = AK > 1 ? pb[32 * WG_LD + 2 * s_] : 0.f;
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            if (AK > 1) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            if (AN > 1) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            if (AN > 1 && AK > 1) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            for (int u = 0; u < 4; ++u) {
+                const int s_ = s4 + u;
+                const float a0 = pa[2 * s_], b0 = pb[2 * s_];
+                const float a1 = AN > 1 ? pa[32 * WG_LD + 2 * s_] : 0.f, b1 = AK > 1 ? pb[32 * WG_LD + 2 * s_] : 0.f;
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                if (AK > 1) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                if (AN > 1) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                if (AN > 1 && AK > 1) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        }
+    } else {
+        constexpr int NP = MODE == 1 ? 3 : 1;
+        for (int s8 = sLo; s8 < sLo + sCnt; s8 += 8) {         // 16 pixels per MFMA: lane (j, half) holds pixels 8*half .. 8*half+7
+            unsigned fa[AN][NP][4];
+            auto pieces = [&](const float *src, unsigned (&f)[NP][4]) {
+                const f32x4 lo = *reinterpret_cast<const f32x4 *>(src), hi = *reinterpret_cast<const f32x4 *>(src + 4);
+                const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    if constexpr (MODE == 1) split_pair(v[2 * d], v[2 * d + 1], f[0][d], f[1][d], f[2][d]);
+                    else f[0][d] = round_pair(v[2 * d], v[2 * d + 1]);
+                }
+            };
+#pragma unroll
+            for (int a = 0; a < AN; ++a) pieces(pa + a * 32 * WG_LD + 2 * s8, fa[a]);
+#pragma unroll
+            for (int c = 0; c < AK; ++c) {                     // one X fragment at a time: its pieces live only across its own MFMAs
+                unsigned fb[NP][4];
+                pieces(pb + c * 32 * WG_LD + 2 * s8, fb);
+                auto mm = [&](int qa, int qb) {
+#pragma unroll
+                    for (int a = 0; a < AN; ++a)
+                        acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fa[a][qa]), as_bf16x8(fb[qb]), acc[a][c], 0, 0, 0);
+                };
+                if constexpr (MODE == 1) { mm(1, 1); mm(2, 0); mm(0, 2); mm(1, 0); mm(0, 1); mm(0, 0); }
+                else mm(0, 0);
+            }
         }
     }
 }
 
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams prm)
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams prm)
 {
     extern __shared__ __attribute__((aligned(16))) float wg_smem[];
     float *tA = wg_smem, *tB = wg_smem + WG_T * WG_LD;
@@ -396,7 +431,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams prm)
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
     float rsum = 0.f;   // threads < 128 of the k-column 0 blocks: row sum of dY row n0 + threadIdx.x
     const bool sums = prm.rowpart && blockIdx.x == 0 && threadIdx.x < WG_T && n0 + (int)threadIdx.x < prm.N;
-    const float *pa = tA + (row0 * 32 + j) * WG_LD + half, *pb = tB + (col0 * 32 + j) * WG_LD + half;
+    const int fo = MODE == 0 ? half : 8 * half;            // fp32 MFMA: lane half -> pixel of the pair; bf16 MFMA: -> 8 of the 16 pixels
+    const float *pa = tA + (row0 * 32 + j) * WG_LD + fo, *pb = tB + (col0 * 32 + j) * WG_LD + fo;
 
     load_stage(p_lo);
     for (int p0 = p_lo; p0 < p_hi; p0 += 64) {
@@ -413,10 +449,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams prm)
             for (int c = 0; c < 64; ++c) s_ += tA[threadIdx.x * WG_LD + c];
             rsum += s_;
         }
-        if (an == 2 && ak == 2) wgrad_stage<2, 2>(pa, pb, sLo, sCnt, acc);
-        else if (an == 2) wgrad_stage<2, 1>(pa, pb, sLo, sCnt, acc);
-        else if (ak == 2) wgrad_stage<1, 2>(pa, pb, sLo, sCnt, acc);
-        else wgrad_stage<1, 1>(pa, pb, sLo, sCnt, acc);
+        if (an == 2 && ak == 2) wgrad_stage<2, 2, MODE>(pa, pb, sLo, sCnt, acc);
+        else if (an == 2) wgrad_stage<2, 1, MODE>(pa, pb, sLo, sCnt, acc);
+        else if (ak == 2) wgrad_stage<1, 2, MODE>(pa, pb, sLo, sCnt, acc);
+        else wgrad_stage<1, 1, MODE>(pa, pb, sLo, sCnt, acc);
         __syncthreads();
     }
     if (owners < 4) {                                      // waves owners .. 3 hand their accumulators to the owning waves
@@ -642,13 +678,21 @@ hipError_t urnn_train_wgrad(const float *dy, const float *const seg[3], const in
     w.partial = partial;
     w.rowpart = db ? partial + (size_t)chunks * N * K : nullptr;
     const size_t lds = (size_t)2 * WG_T * WG_LD * sizeof(float);
-    static bool big = false;
-    if (!big) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // arithmetic follows the forward GEMMs: bf16x6 split (fp32-class) by default, rounded bf16 in the bf16 training variant,
+    // the fp32 MFMA under URNN_TUNE_SPLIT=0 (development knob)
+    static const int split = [] {
+        const char *e = getenv("URNN_TUNE_SPLIT"), *w = getenv("URNN_TUNE_WGRAD");   // URNN_TUNE_WGRAD=0: only this kernel back on the fp32 MFMA
+        return (e ? atoi(e) : 1) && (w ? atoi(w) : 1);
+    }();
+    const int mode = !split ? 0 : (urnn_get_matrix_mode() == URNN_MATRIX_BF16 ? 2 : 1);
+    void (*kern)(const WgradParams) = mode == 0 ? wgrad_kernel<0> : (mode == 1 ? wgrad_kernel<1> : wgrad_kernel<2>);
+    static bool big[3] = {false, false, false};
+    if (!big[mode]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        big = true;
+        big[mode] = true;
     }
-    hipLaunchKernelGGL(wgrad_kernel, dim3((K + WG_T - 1) / WG_T, (N + WG_T - 1) / WG_T, chunks), dim3(256), lds, st, w);
+    hipLaunchKernelGGL(kern, dim3((K + WG_T - 1) / WG_T, (N + WG_T - 1) / WG_T, chunks), dim3(256), lds, st, w);
     const long cntW = (long)N * K, cntB = db ? N : 0;
     hipLaunchKernelGGL(wgrad_finalize_kernel, dim3((unsigned)((cntW + cntB + 15) / 16)), dim3(256), 0, st, partial, w.rowpart, chunks,
                        cntW, cntB, dW, db, accumulate);
