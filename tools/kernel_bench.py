@@ -49,7 +49,7 @@ def main():
 
     def add(name, fn, mac, mbytes):
         us = timeit(fn)
-        rows.append((name, us, 2 * mac / 157.3e12 * 1e6, mbytes * 1e6 / 8e12 * 1e6))
+        rows.append((name, us, 2 * mac / 419.5e12 * 1e6, mbytes * 1e6 / 8e12 * 1e6))
 
     add("preprocess", lambda: ops.preprocess(eng.rain, eng.cumsum, eng.dem, eng.imperv, eng.manhole, 0., 1., 3, nums, rain_max,
                                              cum_max, out=eng.x_in), 0, P1 * C * 4 / 1e6)
