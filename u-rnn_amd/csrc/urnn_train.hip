@@ -279,10 +279,17 @@ hipError_t urnn_train_zero(float *p, size_t n, hipStream_t st)
 
 // ------------------------------------------------------------------------------------------------------------------
 // Weight gradient dW[n][k] = sum_{b,p} dY[b][n][p] * X[b][k][p]  (+ row sums of dY for the bias gradient).
-// Block = 4 waves on a 128 n x 128 k output tile and one pixel chunk; per 64-pixel stage the block stages dY[128][64 px]
-// and X[128][64 px] in LDS (rows padded to 68 floats), each wave multiplies its share of the VALID 32 x 32 tiles with
-// v_mfma_f32_32x32x2_f32 (an MFMA fragment reads a COLUMN of the LDS tile: lane l -> row l & 31).
-// X rows come from up to three tensors (x | e | h-or-rh), k < K.  partial[chunk][N][K]; grid (K/128, N/128, chunks).
+// The contraction runs over PIXELS, which are contiguous in both operands' rows, and both operands are activations.  Block = 4
+// waves on a 128 n x 128 k output tile and one pixel chunk.  Per 32-pixel stage every thread splits the 4 x 4 pixels of dY
+// and of X it fetched (16-byte global loads, one stage ahead, in registers) into three exact bf16 pieces -- ONCE per element,
+// not once per wave that multiplies it -- and parks them in LDS as [operand][piece][128 rows][32 px bf16 + 16 B pad]: a lane's
+// MFMA operand (8 consecutive pixels of its row) is then one conflict-free ds_read_b128 per piece (row pitch 80 B: 16
+// consecutive rows tile the 64 banks).  The compute phase is LDS reads and six v_mfma_f32_32x32x16_bf16 per 32 x 32 tile and
+// 16 pixels (small products first: the arithmetic of the forward GEMMs, fp32-class error at 2.67x the fp32 matrix rate); the
+// bf16 training variant (NP = 1) rounds the operands and issues one.  61 KB of LDS: two blocks per CU hide each other's barriers.
+// X rows come from up to three tensors (x | e | h-or-rh), k < K.  partial[chunk][N][K].
+// History: fp32 MFMA out of an fp32 LDS tile: 62 us per launch on average at 500 x 500; the same tile with the split done on the
+// fragments of every wave: 50 us (each element split twice, VALU and LDS latency in front of every MFMA group).
 // ------------------------------------------------------------------------------------------------------------------
 struct WgradParams {
     const float *dy;          // (B,N,P)
@@ -292,135 +299,143 @@ struct WgradParams {
     int N, K, P, B;
     int chunkPix;             // pixels per chunk (multiple of 64), chunks cover B*ceil(P/chunkPix)
     int chunksPerSample;
+    int tilesK, tilesN;       // 128 x 128 output tiles
+    int xcdMap;               // 0: tiles of a chunk on consecutive workgroups = different XCDs (development knob URNN_TUNE_WGRAD_MAP=0)
     float *partial;           // [chunks][N][K]
-    float *rowpart;           // [chunks][N] sums of dY (written by the blockIdx.x == 0 column), may be nullptr
+    float *rowpart;           // [chunks][N] sums of dY (written by the k-column 0 blocks), may be nullptr
 };
 
-// 16-byte global loads of the NEXT 64-pixel stage go into registers while the current one is multiplied out of LDS; row bases
-// (incl. the K segment lookup) are resolved once per block.  (The first version -- 64 x 64 tiles, scalar staging -- was 5x
-// slower; one 8-wave block per CU on 128 x 256 / 64 x 512 / 256 x 128 tiles -- fewer staged bytes per MFMA -- measured slower
-// too, 8.9 vs 8.2 ms per training step: two independent 4-wave blocks hide each other's barriers.)
-constexpr int WG_T = 128, WG_LD = 68;   // 68: rows stay 16-byte aligned (one ds_write_b128 per staged float4); column reads are 2-way conflicted, cheap next to the MFMAs
+constexpr int WG_T = 128, WG_BK = 32, WG_PITCH = 80, WG_PIECE = WG_T * WG_PITCH;
+constexpr int WG_RED_BYTES = 2 * 2 * 2 * 16 * 64 * 4;      // accumulator hand-over of two waves
 
-// one 64-pixel stage of a wave: AN x AK MFMA tiles, pixel pairs [sLo, sLo + sCnt) of the stage.
-// MODE 0: v_mfma_f32_32x32x2_f32.  MODE 1: both operands split into three exact bf16 pieces when their fragment (8 consecutive
-// pixels of a row: two ds_read_b128) leaves LDS, six v_mfma_f32_32x32x16_bf16 per 16 pixels, small products first -- the
-// arithmetic of the forward GEMMs (urnn_gemm.hip), fp32-class error at 2.67x the matrix rate.  MODE 2 (bf16 training variant):
-// operands rounded to bf16, one MFMA per 16 pixels.
-template <int AN, int AK, int MODE>
-__device__ __forceinline__ void wgrad_stage(const float *__restrict__ pa, const float *__restrict__ pb, int sLo, int sCnt, f32x16 (&acc)[2][2])
+// one 16-pixel group of a wave: AN x AK MFMA tiles
+template <int AN, int AK, int NP>
+__device__ __forceinline__ void wgrad_group(const char *__restrict__ pa, const char *__restrict__ pb, f32x16 (&acc)[2][2])
 {
-    if constexpr (MODE == 0) {
-        for (int s4 = sLo; s4 < sLo + sCnt; s4 += 4) {         // sCnt is 8, 16 or 32
+    bf16x8 fa[AN][NP];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int s_ = s4 + u;
-                const float a0 = pa[2 * s_], b0 = pb[2 * s_];
-                const float a1 = AN > 1 ? pa[32 * WG_LD + 2 * s_] : 0.f, b1 = AK > 1 ? pb[32 * WG_LD + 2 * s_] : 0.f;
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                if (AK > 1) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                if (AN > 1) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                if (AN > 1 && AK > 1) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-            }
-        }
-    } else {
-        constexpr int NP = MODE == 1 ? 3 : 1;
-        for (int s8 = sLo; s8 < sLo + sCnt; s8 += 8) {         // 16 pixels per MFMA: lane (j, half) holds pixels 8*half .. 8*half+7
-            unsigned fa[AN][NP][4];
-            auto pieces = [&](const float *src, unsigned (&f)[NP][4]) {
-                const f32x4 lo = *reinterpret_cast<const f32x4 *>(src), hi = *reinterpret_cast<const f32x4 *>(src + 4);
-                const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    for (int a = 0; a < AN; ++a)
 #pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    if constexpr (MODE == 1) split_pair(v[2 * d], v[2 * d + 1], f[0][d], f[1][d], f[2][d]);
-                    else f[0][d] = round_pair(v[2 * d], v[2 * d + 1]);
-                }
-            };
+        for (int q = 0; q < NP; ++q) fa[a][q] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(pa + q * WG_PIECE + a * 32 * WG_PITCH));
 #pragma unroll
-            for (int a = 0; a < AN; ++a) pieces(pa + a * 32 * WG_LD + 2 * s8, fa[a]);
+    for (int c = 0; c < AK; ++c) {                         // one X fragment at a time: its pieces live only across its own MFMAs
+        bf16x8 fb[NP];
 #pragma unroll
-            for (int c = 0; c < AK; ++c) {                     // one X fragment at a time: its pieces live only across its own MFMAs
-                unsigned fb[NP][4];
-                pieces(pb + c * 32 * WG_LD + 2 * s8, fb);
-                auto mm = [&](int qa, int qb) {
+        for (int q = 0; q < NP; ++q) fb[q] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(pb + q * WG_PIECE + c * 32 * WG_PITCH));
+        auto mm = [&](int qa, int qb) {
 #pragma unroll
-                    for (int a = 0; a < AN; ++a)
-                        acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fa[a][qa]), as_bf16x8(fb[qb]), acc[a][c], 0, 0, 0);
-                };
-                if constexpr (MODE == 1) { mm(1, 1); mm(2, 0); mm(0, 2); mm(1, 0); mm(0, 1); mm(0, 0); }
-                else mm(0, 0);
-            }
-        }
+            for (int a = 0; a < AN; ++a) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][qa], fb[qb], acc[a][c], 0, 0, 0);
+        };
+        if constexpr (NP == 3) { mm(1, 1); mm(2, 0); mm(0, 2); mm(1, 0); mm(0, 1); mm(0, 0); }
+        else mm(0, 0);
     }
 }
 
-template <int MODE>
+template <int NP>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams prm)
 {
-    extern __shared__ __attribute__((aligned(16))) float wg_smem[];
-    float *tA = wg_smem, *tB = wg_smem + WG_T * WG_LD;
+    extern __shared__ __attribute__((aligned(16))) char wg_smem[];
+    char *tA = wg_smem, *tB = wg_smem + NP * WG_PIECE;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, half = lane >> 5;
-    const int n0 = blockIdx.y * WG_T, k0 = blockIdx.x * WG_T;
-    const int chunk = blockIdx.z, b = chunk / prm.chunksPerSample;
+    // 1-D grid, XCD-aware: workgroups go round-robin over the 8 XCDs, so the KX x NY output tiles of one pixel chunk are given
+    // consecutive slots of ONE XCD -- they stream the same dY / X rows at about the same time and all but the first read of a
+    // row can hit that XCD's L2.
+    const int per = prm.tilesK * prm.tilesN;
+    const int slot = prm.xcdMap ? blockIdx.x >> 3 : blockIdx.x, tsel = slot % per;
+    const int chunk = prm.xcdMap ? (slot / per) * 8 + (blockIdx.x & 7) : slot / per;
+    if (chunk >= prm.B * prm.chunksPerSample) return;
+    const int n0 = (tsel / prm.tilesK) * WG_T, k0 = (tsel % prm.tilesK) * WG_T;
+    const int b = chunk / prm.chunksPerSample;
     const int p_lo = (chunk - b * prm.chunksPerSample) * prm.chunkPix;
     const int p_hi = min(prm.P, p_lo + prm.chunkPix);
     const bool vec = (prm.P & 3) == 0;                     // rows 16-byte aligned
 
     // Only the 32 x 32 tiles that hold real outputs are multiplied (the layers run from 16 x 16 to 384 x 96, 192 x 288: a
-    // fixed 128 x 128 grid of MFMAs would mostly multiply padding).  The four waves share what is there: a block with at
-    // most 2 x 2 valid tiles gives every wave ALL its tiles on a quarter of each stage's pixels, one with at most two valid
-    // tile rows (or columns) pairs the waves on halves of the pixels, a full block gives each wave a 2 x 2 quadrant.  Waves
-    // that share tiles add their accumulators in wave order through LDS at the end.
+    // fixed 128 x 128 grid of MFMAs would mostly multiply padding).  A full block gives each wave a 2 x 2 quadrant on both
+    // 16-pixel groups of a stage; with at most two valid tile rows (or columns) the waves pair up on the tiles and take one
+    // group each, and add their accumulators through LDS at the end (fixed order).
     const int rowsV = min(4, (prm.N - n0 + 31) >> 5), colsV = min(4, (prm.K - k0 + 31) >> 5);
-    int row0, col0, sLo, sCnt;
-    if (rowsV <= 2 && colsV <= 2) { row0 = 0; col0 = 0; sLo = 8 * wave; sCnt = 8; }
-    else if (rowsV <= 2) { row0 = 0; col0 = 2 * (wave & 1); sLo = 16 * (wave >> 1); sCnt = 16; }
-    else if (colsV <= 2) { row0 = 2 * (wave & 1); col0 = 0; sLo = 16 * (wave >> 1); sCnt = 16; }
-    else { row0 = 2 * (wave >> 1); col0 = 2 * (wave & 1); sLo = 0; sCnt = 32; }
-    const int owners = sCnt / 8;                           // 4, 2 or 1 ... waves 0 .. owners-1 own a distinct tile set each
-    const int an = min(2, rowsV - row0), ak = min(2, colsV - col0);
+    int row0, col0, g0, gn, akmax = 2;
+    if (rowsV > 2 && colsV > 2) { row0 = 2 * (wave >> 1); col0 = 2 * (wave & 1); g0 = 0; gn = 2; }
+    else if (rowsV <= 2 && colsV <= 2) { row0 = 0; col0 = wave & 1; akmax = 1; g0 = wave >> 1; gn = 1; }
+    else if (rowsV <= 2) { row0 = 0; col0 = 2 * (wave & 1); g0 = wave >> 1; gn = 1; }
+    else { row0 = 2 * (wave & 1); col0 = 0; g0 = wave >> 1; gn = 1; }
+    const int owners = gn == 2 ? 4 : 2;                    // waves 0 .. owners-1 own a distinct tile set each
+    const int an = max(0, min(2, rowsV - row0)), ak = max(0, min(akmax, colsV - col0));
 
-    // this thread stages rows r0 + 16*i (i < 8) of both operands, 4 consecutive pixels at column c4
-    const int r0 = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;
-    const float *rowA[8], *rowB[8];
+    // this thread stages rows r0 + 32*i (i < 4) of both operands, 4 consecutive pixels at column c4.  dY rows: one uniform base
+    // and a 32-bit offset per row; X rows come from up to three tensors: a pointer each.  Rows that are not staged (beyond N /
+    // K, or a missing segment) point at a valid dummy row so that the main loop's loads need no branch.
+    const int r0 = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
+    const float *dyb = prm.dy + (size_t)b * prm.N * prm.P;
+    unsigned okA = 0, okB = 0, zeroB = 0;                  // bit i: row r0 + 32*i is staged / staged as zeros (missing segment inside K)
+    int offA[4];
+    const float *ptrB[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int n = n0 + r0 + 16 * i;
-        rowA[i] = n < prm.N ? prm.dy + ((size_t)b * prm.N + n) * prm.P : nullptr;
-        const int k = k0 + r0 + 16 * i;
-        rowB[i] = nullptr;
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + r0 + 32 * i;
+        okA |= (n < prm.N ? 1u : 0u) << i;
+        offA[i] = min(n, prm.N - 1) * prm.P + c4;
+        const int k = k0 + r0 + 32 * i;
+        ptrB[i] = dyb + c4;
         if (k < prm.K) {
             const int sg = k >= prm.segK0[2] ? 2 : (k >= prm.segK0[1] ? 1 : 0);
             const int ch = k - prm.segK0[sg];
-            if (ch < prm.segC[sg]) rowB[i] = prm.seg[sg] + ((size_t)b * prm.segC[sg] + ch) * prm.P;
+            if (ch < prm.segC[sg]) {
+                ptrB[i] = prm.seg[sg] + ((size_t)b * prm.segC[sg] + ch) * prm.P + c4;
+                okB |= 1u << i;
+            } else {
+                zeroB |= 1u << i;
+            }
         }
     }
-    // rows of a missing segment (x == nullptr) are inside K: they are staged as zeros; rows beyond N / K are never staged --
-    // an output only depends on ITS row of dY and ITS row of X, and the outputs beyond N / K are not stored
-    bool zeroB[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) zeroB[i] = rowB[i] == nullptr && k0 + r0 + 16 * i < prm.K;
-    f32x4 ra[8], rb[8];
-    auto fetch = [&](const float *row, int p) -> f32x4 {
+    // rows beyond N / K are never staged -- an output only depends on ITS row of dY and ITS row of X, and the outputs beyond
+    // N / K are not stored
+    f32x4 ra[2][4], rb[2][4];                              // two 32-pixel stages in flight (bytes in flight are what bounds the stream)
+    auto fetch = [&](const float *row, bool ok, int p) -> f32x4 {           // row already includes c4
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (row) {
-            if (vec && p + 3 < p_hi) v = *reinterpret_cast<const f32x4 *>(row + p);
+        if (ok) {
+            const int q = p + c4;
+            if (vec && q + 3 < p_hi) v = *reinterpret_cast<const f32x4 *>(row + p);
             else {
-                if (p < p_hi) v.x = row[p];
-                if (p + 1 < p_hi) v.y = row[p + 1];
-                if (p + 2 < p_hi) v.z = row[p + 2];
-                if (p + 3 < p_hi) v.w = row[p + 3];
+                if (q < p_hi) v.x = row[p];
+                if (q + 1 < p_hi) v.y = row[p + 1];
+                if (q + 2 < p_hi) v.z = row[p + 2];
+                if (q + 3 < p_hi) v.w = row[p + 3];
             }
         }
         return v;
     };
-    auto load_stage = [&](int p0) {
+    auto load_stage = [&](int p0, f32x4 (&a4)[4], f32x4 (&b4)[4]) {      // any stage: bounds-checked, zero-filled (tails, unaligned planes)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            ra[i] = fetch(rowA[i], p0 + c4);
-            rb[i] = fetch(rowB[i], p0 + c4);
+        for (int i = 0; i < 4; ++i) {
+            a4[i] = fetch(dyb + offA[i], (okA >> i) & 1, p0);
+            b4[i] = fetch(ptrB[i], (okB >> i) & 1, p0);
         }
+    };
+    // Full, aligned stages: unconditional 16-byte loads.  No control flow between issue and use, so the compiler keeps COUNTED
+    // vmcnt waits and the stage after next really stays in flight -- with the bounds-checked fetch inside the loop it fell
+    // back to vmcnt(0) at every park and the second stage in flight made the kernel slower (dec1 gates 116 -> 166 us).
+    auto load_fast = [&](int p0, f32x4 (&a4)[4], f32x4 (&b4)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a4[i] = *reinterpret_cast<const f32x4 *>(dyb + offA[i] + p0);
+            b4[i] = *reinterpret_cast<const f32x4 *>(ptrB[i] + p0);
+        }
+    };
+    // four pixels -> two dwords of each piece, 8 bytes per piece at (row, c4)
+    auto park = [&](char *base, int row, const f32x4 &v) {
+        unsigned q0[NP], q1[NP];
+        if constexpr (NP == 3) {
+            split_pair(v.x, v.y, q0[0], q0[1], q0[2]);
+            split_pair(v.z, v.w, q1[0], q1[1], q1[2]);
+        } else {
+            q0[0] = round_pair(v.x, v.y);
+            q1[0] = round_pair(v.z, v.w);
+        }
+#pragma unroll
+        for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2 *>(base + q * WG_PIECE + row * WG_PITCH + c4 * 2) = make_uint2(q0[q], q1[q]);
     };
     f32x16 acc[2][2];
 #pragma unroll
@@ -429,34 +444,67 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams prm)
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
-    float rsum = 0.f;   // threads < 128 of the k-column 0 blocks: row sum of dY row n0 + threadIdx.x
-    const bool sums = prm.rowpart && blockIdx.x == 0 && threadIdx.x < WG_T && n0 + (int)threadIdx.x < prm.N;
-    const int fo = MODE == 0 ? half : 8 * half;            // fp32 MFMA: lane half -> pixel of the pair; bf16 MFMA: -> 8 of the 16 pixels
-    const float *pa = tA + (row0 * 32 + j) * WG_LD + fo, *pb = tB + (col0 * 32 + j) * WG_LD + fo;
+    const bool sums = prm.rowpart && k0 == 0;              // bias gradient: row sums of dY, taken from the staged registers
+    float rsum[4] = {0.f, 0.f, 0.f, 0.f};
+    const char *pa = tA + (row0 * 32 + j) * WG_PITCH + half * 16, *pb = tB + (col0 * 32 + j) * WG_PITCH + half * 16;
 
-    load_stage(p_lo);
-    for (int p0 = p_lo; p0 < p_hi; p0 += 64) {
+    auto park_stage = [&](f32x4 (&a4)[4], f32x4 (&b4)[4]) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (rowA[i]) *reinterpret_cast<f32x4 *>(tA + (r0 + 16 * i) * WG_LD + c4) = ra[i];
-            if (rowB[i] || zeroB[i]) *reinterpret_cast<f32x4 *>(tB + (r0 + 16 * i) * WG_LD + c4) = rb[i];
+        for (int i = 0; i < 4; ++i) {
+            if ((okA >> i) & 1) park(tA, r0 + 32 * i, a4[i]);
+            if ((okB >> i) & 1) park(tB, r0 + 32 * i, b4[i]);
+            else if ((zeroB >> i) & 1) park(tB, r0 + 32 * i, f32x4{0.f, 0.f, 0.f, 0.f});
+            if (sums) rsum[i] += (a4[i].x + a4[i].y) + (a4[i].z + a4[i].w);
         }
+    };
+    auto multiply = [&]() {
+        if (an > 0 && ak > 0) {
+            const char *qa = pa + g0 * 32, *qb = pb + g0 * 32;
+            if (an == 2 && ak == 2) {
+                wgrad_group<2, 2, NP>(qa, qb, acc);
+                if (gn == 2) wgrad_group<2, 2, NP>(qa + 32, qb + 32, acc);
+            } else if (an == 2) {
+                wgrad_group<2, 1, NP>(qa, qb, acc);
+                if (gn == 2) wgrad_group<2, 1, NP>(qa + 32, qb + 32, acc);
+            } else if (ak == 2) {
+                wgrad_group<1, 2, NP>(qa, qb, acc);
+                if (gn == 2) wgrad_group<1, 2, NP>(qa + 32, qb + 32, acc);
+            } else {
+                wgrad_group<1, 1, NP>(qa, qb, acc);
+                if (gn == 2) wgrad_group<1, 1, NP>(qa + 32, qb + 32, acc);
+            }
+        }
+    };
+    // main part: pairs of full 32-pixel stages, two stages in flight; the last pair re-fetches itself instead of branching
+    const int npair = vec ? (p_hi - p_lo) / (2 * WG_BK) : 0;
+    if (npair > 0) {
+        const int p_last = p_lo + (npair - 1) * 2 * WG_BK;
+        load_fast(p_lo, ra[0], rb[0]);
+        load_fast(p_lo + WG_BK, ra[1], rb[1]);
+        for (int p0 = p_lo; p0 <= p_last; p0 += 2 * WG_BK) {
+            const int pn = min(p0 + 2 * WG_BK, p_last);
+            park_stage(ra[0], rb[0]);
+            __syncthreads();
+            load_fast(pn, ra[0], rb[0]);
+            multiply();
+            __syncthreads();
+            park_stage(ra[1], rb[1]);
+            __syncthreads();
+            load_fast(pn + WG_BK, ra[1], rb[1]);
+            multiply();
+            __syncthreads();
+        }
+    }
+    // the rest (< 64 pixels; everything when the rows are not 16-byte aligned): bounds-checked stages, nothing in flight
+    for (int p0 = p_lo + npair * 2 * WG_BK; p0 < p_hi; p0 += WG_BK) {
+        load_stage(p0, ra[0], rb[0]);
+        park_stage(ra[0], rb[0]);
         __syncthreads();
-        if (p0 + 64 < p_hi) load_stage(p0 + 64);          // in flight while this stage is multiplied
-        if (sums) {
-            float s_ = 0.f;
-#pragma unroll 16
-            for (int c = 0; c < 64; ++c) s_ += tA[threadIdx.x * WG_LD + c];
-            rsum += s_;
-        }
-        if (an == 2 && ak == 2) wgrad_stage<2, 2, MODE>(pa, pb, sLo, sCnt, acc);
-        else if (an == 2) wgrad_stage<2, 1, MODE>(pa, pb, sLo, sCnt, acc);
-        else if (ak == 2) wgrad_stage<1, 2, MODE>(pa, pb, sLo, sCnt, acc);
-        else wgrad_stage<1, 1, MODE>(pa, pb, sLo, sCnt, acc);
+        multiply();
         __syncthreads();
     }
-    if (owners < 4) {                                      // waves owners .. 3 hand their accumulators to the owning waves
-        float *red = wg_smem;                              // [wave][2][2][16][64] = 64 KiB of the 68 KiB staging area
+    if (owners < 4) {                                      // waves 2, 3 hand their accumulators to waves 0, 1
+        float *red = reinterpret_cast<float *>(wg_smem);   // [wave - 2][2][2][16][64]
         if (wave >= owners) {
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -464,18 +512,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams prm)
                 for (int c = 0; c < 2; ++c)
                     if (a < an && c < ak)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) red[(((wave * 2 + a) * 2 + c) * 16 + r) * 64 + lane] = acc[a][c][r];
+                        for (int r = 0; r < 16; ++r) red[((((wave - owners) * 2 + a) * 2 + c) * 16 + r) * 64 + lane] = acc[a][c][r];
         }
         __syncthreads();
         if (wave < owners)
-            for (int o = wave + owners; o < 4; o += owners)
 #pragma unroll
-                for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-                    for (int c = 0; c < 2; ++c)
-                        if (a < an && c < ak)
+                for (int c = 0; c < 2; ++c)
+                    if (a < an && c < ak)
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) acc[a][c][r] += red[(((o * 2 + a) * 2 + c) * 16 + r) * 64 + lane];
+                        for (int r = 0; r < 16; ++r) acc[a][c][r] += red[(((wave * 2 + a) * 2 + c) * 16 + r) * 64 + lane];
     }
     float *out = prm.partial + (size_t)chunk * prm.N * prm.K;
     if (wave < owners) {
@@ -490,7 +537,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams prm)
                         if (n < prm.N && k < prm.K) out[(size_t)n * prm.K + k] = acc[a][c][r];
                     }
     }
-    if (sums) prm.rowpart[(size_t)chunk * prm.N + n0 + threadIdx.x] = rsum;
+    if (sums) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = rsum[i];                             // the row's 8 threads are 8 consecutive lanes
+            v += __shfl_xor(v, 1, 64);
+            v += __shfl_xor(v, 2, 64);
+            v += __shfl_xor(v, 4, 64);
+            const int n = n0 + r0 + 32 * i;
+            if ((threadIdx.x & 7) == 0 && n < prm.N) prm.rowpart[(size_t)chunk * prm.N + n] = v;
+        }
+    }
 }
 
 // dW[i] (+)= sum over chunks (double, fixed order); the same for the bias row sums
@@ -647,15 +704,17 @@ size_t urnn_train_wgrad_partial_floats(int B, int N, int K, int P)
     return (size_t)B * urnn_train_wgrad_chunks(B, N, K, P) * ((size_t)N * K + N);
 }
 
-// pixel chunks per sample of the weight-gradient GEMM: enough blocks (~768) to fill the chip whatever the plane and the
-// N x K tile count, at least one 64-pixel stage per chunk, at most 256 chunks (their partial tiles are summed afterwards)
+// pixel chunks per sample of the weight-gradient GEMM: ONE round of blocks (two per CU: 512) whatever the plane and the N x K
+// tile count -- every block resident from the start keeps the most bytes in flight and leaves no half-empty second round --
+// at least one 64-pixel stage pair per chunk, at most 512 chunks (their partial tiles are summed afterwards)
 int urnn_train_wgrad_chunks(int B, int N, int K, int P)
 {
+    static const int target = [] { const char *e = getenv("URNN_TUNE_WGRAD_BLOCKS"); return e ? atoi(e) : 512; }();
     const int tiles = ((N + WG_T - 1) / WG_T) * ((K + WG_T - 1) / WG_T) * B;
-    int n = (768 + tiles - 1) / tiles;
+    int n = target / tiles;
     const int most = (P + 63) / 64;
     n = n > most ? most : n;
-    n = n > 256 ? 256 : n;
+    n = n > 512 ? 512 : n;
     return n < 1 ? 1 : n;
 }
 
@@ -677,22 +736,22 @@ hipError_t urnn_train_wgrad(const float *dy, const float *const seg[3], const in
     const int chunks = B * w.chunksPerSample;
     w.partial = partial;
     w.rowpart = db ? partial + (size_t)chunks * N * K : nullptr;
-    const size_t lds = (size_t)2 * WG_T * WG_LD * sizeof(float);
-    // arithmetic follows the forward GEMMs: bf16x6 split (fp32-class) by default, rounded bf16 in the bf16 training variant,
-    // the fp32 MFMA under URNN_TUNE_SPLIT=0 (development knob)
-    static const int split = [] {
-        const char *e = getenv("URNN_TUNE_SPLIT"), *w = getenv("URNN_TUNE_WGRAD");   // URNN_TUNE_WGRAD=0: only this kernel back on the fp32 MFMA
-        return (e ? atoi(e) : 1) && (w ? atoi(w) : 1);
-    }();
-    const int mode = !split ? 0 : (urnn_get_matrix_mode() == URNN_MATRIX_BF16 ? 2 : 1);
-    void (*kern)(const WgradParams) = mode == 0 ? wgrad_kernel<0> : (mode == 1 ? wgrad_kernel<1> : wgrad_kernel<2>);
-    static bool big[3] = {false, false, false};
-    if (!big[mode]) {
+    // arithmetic follows the forward GEMMs: bf16x6 split (fp32-class) by default, rounded bf16 in the bf16 training variant
+    const int np = urnn_get_matrix_mode() == URNN_MATRIX_BF16 ? 1 : 3;
+    size_t lds = (size_t)2 * np * WG_PIECE;
+    lds = lds < WG_RED_BYTES ? WG_RED_BYTES : lds;
+    void (*kern)(const WgradParams) = np == 3 ? wgrad_kernel<3> : wgrad_kernel<1>;
+    static bool big[2] = {false, false};
+    if (!big[np == 3]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        big[mode] = true;
+        big[np == 3] = true;
     }
-    hipLaunchKernelGGL(kern, dim3((K + WG_T - 1) / WG_T, (N + WG_T - 1) / WG_T, chunks), dim3(256), lds, st, w);
+    w.tilesK = (K + WG_T - 1) / WG_T;
+    w.tilesN = (N + WG_T - 1) / WG_T;
+    static const int xcd_map = [] { const char *e = getenv("URNN_TUNE_WGRAD_MAP"); return e ? atoi(e) : 1; }();
+    w.xcdMap = xcd_map;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((chunks + 7) / 8 * 8 * w.tilesK * w.tilesN)), dim3(256), lds, st, w);
     const long cntW = (long)N * K, cntB = db ? N : 0;
     hipLaunchKernelGGL(wgrad_finalize_kernel, dim3((unsigned)((cntW + cntB + 15) / 16)), dim3(256), 0, st, partial, w.rowpart, chunks,
                        cntW, cntB, dW, db, accumulate);
