@@ -305,6 +305,9 @@ struct WgradParams {
     float *rowpart;           // [chunks][N] sums of dY (written by the k-column 0 blocks), may be nullptr
 };
 
+#ifndef WG_ABL
+#define WG_ABL 0
+#endif
 constexpr int WG_T = 128, WG_BK = 32, WG_PITCH = 80, WG_PIECE = WG_T * WG_PITCH;
 constexpr int WG_RED_BYTES = 2 * 2 * 2 * 16 * 64 * 4;      // accumulator hand-over of two waves
 
@@ -324,10 +327,17 @@ __device__ __forceinline__ void wgrad_group(const char *__restrict__ pa, const c
         for (int q = 0; q < NP; ++q) fb[q] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(pb + q * WG_PIECE + c * 32 * WG_PITCH));
         auto mm = [&](int qa, int qb) {
 #pragma unroll
-            for (int a = 0; a < AN; ++a) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][qa], fb[qb], acc[a][c], 0, 0, 0);
+            for (int a = 0; a < AN; ++a) {
+#if (WG_ABL & 1)
+                acc[a][c][0] += __builtin_bit_cast(f32x4, fa[a][qa]).x * __builtin_bit_cast(f32x4, fb[qb]).x;
+#else
+                acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][qa], fb[qb], acc[a][c], 0, 0, 0);
+#endif
+            }
         };
         if constexpr (NP == 3) { mm(1, 1); mm(2, 0); mm(0, 2); mm(1, 0); mm(0, 1); mm(0, 0); }
         else mm(0, 0);
+        __builtin_amdgcn_sched_barrier(0);                 // keep the next fragment's pieces from being loaded early (registers)
     }
 }
 
@@ -428,8 +438,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams prm)
     auto park = [&](char *base, int row, const f32x4 &v) {
         unsigned q0[NP], q1[NP];
         if constexpr (NP == 3) {
+#if (WG_ABL & 2)
+            q0[0] = __float_as_uint(v.x); q0[1] = __float_as_uint(v.y); q0[2] = __float_as_uint(v.z);
+            q1[0] = __float_as_uint(v.w); q1[1] = __float_as_uint(v.x); q1[2] = __float_as_uint(v.y);
+#else
             split_pair(v.x, v.y, q0[0], q0[1], q0[2]);
             split_pair(v.z, v.w, q1[0], q1[1], q1[2]);
+#endif
         } else {
             q0[0] = round_pair(v.x, v.y);
             q1[0] = round_pair(v.z, v.w);
@@ -485,12 +500,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams prm)
             const int pn = min(p0 + 2 * WG_BK, p_last);
             park_stage(ra[0], rb[0]);
             __syncthreads();
+#if !(WG_ABL & 4)
             load_fast(pn, ra[0], rb[0]);
+#endif
             multiply();
             __syncthreads();
             park_stage(ra[1], rb[1]);
             __syncthreads();
+#if !(WG_ABL & 4)
             load_fast(pn + WG_BK, ra[1], rb[1]);
+#endif
             multiply();
             __syncthreads();
         }
