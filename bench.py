@@ -391,9 +391,17 @@ def main():
         "long_run": long_run,
         "gflop_per_frame": gflop,
         "step_mfma_frac": fps / world * gflop / 1e3 / PEAK_MFMA_F32_TFLOPS,
-        # frames/s x A_stage / 8 TB/s -- the unfused per-stage traffic model; the step is MFMA-bound (AI 49 FLOP/B)
+        # frames/s x A_stage / 8 TB/s -- the unfused per-stage traffic model (algorithmic bytes)
         "step_hbm_frac_a_stage": (fps / world * a_stage_bytes(H, W, C) / (PEAK_HBM_TBS * 1e12)) if len(names) == 1 else None,
+        # the same with the bytes the counters saw (FETCH_SIZE / WRITE_SIZE passes of this build, profiles/pmc_gate_gemm.json)
+        "step_hbm_frac_measured_traffic": None,
     }
+    pmc_path = os.path.join(REPO, "profiles", "pmc_gate_gemm.json")
+    if os.path.isfile(pmc_path) and args.config == "location1" and B == 1:
+        with open(pmc_path) as fh:
+            ws = json.load(fh).get("whole_step")
+        if ws:
+            result["step_hbm_frac_measured_traffic"] = fps / world * ws["hbm_bytes_per_frame"] / (PEAK_HBM_TBS * 1e12)
 
     if rank == 0:
         # dominant kernel: the ConvGRU gate GEMM (4 launches per frame).  With the bf16 x 6 split k-loop its arithmetic

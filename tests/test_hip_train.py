@@ -58,7 +58,7 @@ def test_cell_backward_vs_reference_autograd(dev, tag):
     check_grads(grads, want, tag)
 
 
-@pytest.mark.parametrize("I,F,skip,H,W,B", [(5, 32, 0, 12, 20, 2), (33, 96, 1, 9, 7, 1), (16, 64, 0, 70, 66, 1), (7, 128, 1, 6, 14, 2)])
+@pytest.mark.parametrize("I,F,skip,H,W,B", [(5, 32, 0, 12, 20, 2), (33, 96, 1, 9, 7, 1), (16, 64, 0, 70, 66, 1), (7, 128, 1, 6, 14, 2), (16, 64, 1, 25, 25, 1)])
 def test_cell_backward_shapes_vs_oracle(dev, I, F, skip, H, W, B):
     from oracle import train_oracle as tro
     rs = np.random.RandomState(77 + I + F + H)

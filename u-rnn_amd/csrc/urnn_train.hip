@@ -427,11 +427,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams prm)
     // Full, aligned stages: unconditional 16-byte loads.  No control flow between issue and use, so the compiler keeps COUNTED
     // vmcnt waits and the stage after next really stays in flight -- with the bounds-checked fetch inside the loop it fell
     // back to vmcnt(0) at every park and the second stage in flight made the kernel slower (dec1 gates 116 -> 166 us).
+    // (rows of an odd plane -- 125 x 125 at quarter resolution -- are only 4-byte aligned: global_load_dwordx4 takes that)
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
     auto load_fast = [&](int p0, f32x4 (&a4)[4], f32x4 (&b4)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            a4[i] = *reinterpret_cast<const f32x4 *>(dyb + offA[i] + p0);
-            b4[i] = *reinterpret_cast<const f32x4 *>(ptrB[i] + p0);
+            a4[i] = *reinterpret_cast<const f32x4u *>(dyb + offA[i] + p0);
+            b4[i] = *reinterpret_cast<const f32x4u *>(ptrB[i] + p0);
         }
     };
     // four pixels -> two dwords of each piece, 8 bytes per piece at (row, c4)
@@ -491,7 +493,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams prm)
         }
     };
     // main part: pairs of full 32-pixel stages, two stages in flight; the last pair re-fetches itself instead of branching
-    const int npair = vec ? (p_hi - p_lo) / (2 * WG_BK) : 0;
+    const int npair = (p_hi - p_lo) / (2 * WG_BK);
     if (npair > 0) {
         const int p_last = p_lo + (npair - 1) * 2 * WG_BK;
         load_fast(p_lo, ra[0], rb[0]);
@@ -514,7 +516,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams prm)
             __syncthreads();
         }
     }
-    // the rest (< 64 pixels; everything when the rows are not 16-byte aligned): bounds-checked stages, nothing in flight
+    // the rest (< 64 pixels): bounds-checked stages, nothing in flight
     for (int p0 = p_lo + npair * 2 * WG_BK; p0 < p_hi; p0 += WG_BK) {
         load_stage(p0, ra[0], rb[0]);
         park_stage(ra[0], rb[0]);
