@@ -1,8 +1,8 @@
 // urnn_train.hip -- kernels of the training path: backward of the ConvGRU / Skip-ConvGRU cell, the
 // stage convs, the transposed convs and the head; loss; clipped Adam.  Deterministic reductions (per-chunk fp32 partials ->
-// fixed-order double); fp32 MFMA for the two contraction shapes:
+// fixed-order double); the two contraction shapes run the forward path's arithmetic (bf16 x 6 split, fp32 accumulate):
 //   dX = W^T . dY   -- the forward GEMM kernel (urnn_gemm.hip) on gathered / transposed packed weights, identity epilogue;
-//   dW = dY . X^T   -- wgrad_kernel below: contraction over PIXELS, operands transposed through LDS.
+//   dW = dY . X^T   -- wgrad_kernel below: contraction over PIXELS, both operands split into bf16 pieces on the way into LDS.
 #include "urnn_common.h"
 #include "urnn_kernels.h"
 
@@ -586,13 +586,18 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float *__rest
     const long stride = isW ? cntW : cntB;
     double s = 0.0;
     if (live) {
-        int c = q;
-        for (; c + 48 < nchunk; c += 64) {
-            const float v0 = src[(size_t)c * stride], v1 = src[(size_t)(c + 16) * stride], v2 = src[(size_t)(c + 32) * stride],
-                        v3 = src[(size_t)(c + 48) * stride];
-            s += (double)v0; s += (double)v1; s += (double)v2; s += (double)v3;
+        // 32 independent loads in flight per thread (512 chunks = one batch), added in chunk order: the sum is a chain of
+        // memory round trips otherwise (8 us per launch, 22 launches per training timestep)
+        for (int c0 = q; c0 < nchunk; c0 += 16 * 32) {
+            float v[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                const int c = c0 + 16 * u;
+                v[u] = c < nchunk ? src[(size_t)c * stride] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 32; ++u) s += (double)v[u];
         }
-        for (; c < nchunk; c += 16) s += (double)src[(size_t)c * stride];
     }
     sub[q][io] = s;
     __syncthreads();
