@@ -591,12 +591,12 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float *__rest
         for (int c0 = q; c0 < nchunk; c0 += 16 * 32) {
             float v[32];
 #pragma unroll
-            for (int u = 0; u < 32; ++u) {
+            for (int u = 0; u < 32; ++u) {             // unconditional loads (clamped index): a predicated load is a branch and a wait each
                 const int c = c0 + 16 * u;
-                v[u] = c < nchunk ? src[(size_t)c * stride] : 0.f;
+                v[u] = src[(size_t)(c < nchunk ? c : nchunk - 1) * stride];
             }
 #pragma unroll
-            for (int u = 0; u < 32; ++u) s += (double)v[u];
+            for (int u = 0; u < 32; ++u) s += (c0 + 16 * u < nchunk) ? (double)v[u] : 0.0;
         }
     }
     sub[q][io] = s;
