@@ -123,6 +123,37 @@ def test_stage_conv_backward_vs_reference_autograd(dev, layers, tag, pool):
     assert torch.allclose(dw2, 2 * T(k("dw"), dev), rtol=5e-4, atol=1e-5 * float(np.abs(k("dw")).max()))
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W,pool", [
+    (1, 16, 16, 40, 50, False),      # one 32 x 32 tile, two waves multiply
+    (2, 63, 16, 33, 31, False),      # odd plane (4-byte aligned rows), 1 x 2 tiles, two samples
+    (1, 130, 100, 25, 25, False),    # 4 x 5 tiles over two k-blocks (XCD-grouped), odd plane
+    (1, 288, 192, 18, 22, True),     # 2 x 3 output tiles of 128 x 128, pooled layer
+    (3, 96, 200, 12, 10, True),      # two n-blocks, short chunks (one stage pair + a tail)
+    (1, 64, 64, 7, 9, False),        # 63 pixels: only the bounds-checked tail path
+])
+def test_stage_conv_backward_shapes_vs_float64_autograd(dev, B, Cin, Cout, H, W, pool):
+    """The weight-gradient GEMM (pixel contraction, split bf16 pieces staged in LDS) and the input-gradient GEMM across tile /
+    chunk / alignment cases the network's own layers do not hit, against float64 torch autograd of the same layer
+    (encoder.py:140-151 forward; main.py:727-735 backward)."""
+    import torch.nn.functional as Fn
+    from urnn_amd import train_ops
+    rs = np.random.RandomState(B * 1000 + Cin + Cout + H)
+    x = torch.from_numpy(rs.standard_normal((B, Cin, H, W)).astype(np.float32)).to(dev)
+    w = torch.from_numpy((rs.standard_normal((Cout, Cin, 1, 1)) / np.sqrt(Cin)).astype(np.float32)).to(dev)
+    b = torch.from_numpy((0.1 * rs.standard_normal(Cout)).astype(np.float32)).to(dev)
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    dy = torch.from_numpy(rs.standard_normal((B, Cout, Ho, Wo)).astype(np.float32)).to(dev)
+    dx, dw, db = train_ops.stage_conv_backward(x, w, b, dy, pool)
+    x64, w64, b64 = (t.double().requires_grad_(True) for t in (x, w, b))
+    y = Fn.leaky_relu(Fn.conv2d(x64, w64, b64), 0.2)
+    if pool:
+        y = Fn.avg_pool2d(y, 2)
+    y.backward(dy.double())
+    assert_close(dx.cpu().numpy(), x64.grad.cpu().numpy(), GRAD_TOL, "dx")
+    assert_close(dw.cpu().numpy(), w64.grad.cpu().numpy(), GRAD_TOL, "dw")
+    assert_close(db.cpu().numpy(), b64.grad.cpu().numpy(), GRAD_TOL, "db")
+
+
 @pytest.mark.parametrize("tag", ["dc3", "dc2"])
 def test_deconv_backward_vs_reference_autograd(dev, layers, tag):
     from urnn_amd import ops, train_ops
