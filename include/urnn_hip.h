@@ -170,16 +170,21 @@ int urnn_gru_cell_backward_f32(const float *x, const float *e, const float *h, c
 /* Backward of urnn_stage_conv_f32 (conv1x1 + LeakyReLU [+ AvgPool2d(2,2)]): weight (Cout,Cin), bias (Cout) in the reference
  * layout; dout has the forward output's shape; din (B,Cin,H,W) is overwritten, dweight / dbias overwritten or accumulated. */
 size_t urnn_stage_conv_backward_workspace_bytes(int B, int Cin, int Cout, int H, int W);
+/* bwd_packed (urnn_stage_conv_backward_packed_floats floats, 16-byte aligned, caller-owned): the layer's packed weights for the
+ * backward GEMMs, filled when repack != 0 and reused by later calls until the parameters change (once per SWP window, like
+ * urnn_gru_cell_backward_f32); NULL: packed into the workspace on every call. */
+size_t urnn_stage_conv_backward_packed_floats(int Cin, int Cout);
 int urnn_stage_conv_backward_f32(const float *in, const float *weight, const float *bias, const float *dout, float *din, float *dweight,
-                                 float *dbias, void *workspace, size_t workspace_bytes, int B, int Cin, int Cout, int H, int W,
-                                 int pool, float slope, int accumulate, void *stream);
+                                 float *dbias, float *bwd_packed, int repack, void *workspace, size_t workspace_bytes, int B, int Cin,
+                                 int Cout, int H, int W, int pool, float slope, int accumulate, void *stream);
 
 /* Backward of urnn_deconv2x2_f32: weight (Cin,Cout,2,2); out = the forward output (B,Cout,2H,2W) (LeakyReLU keeps the sign
  * of its input), dout the same shape; din (B,Cin,H,W) overwritten, dweight / dbias overwritten or accumulated. */
 size_t urnn_deconv2x2_backward_workspace_bytes(int B, int Cin, int Cout, int H, int W);
+size_t urnn_deconv2x2_backward_packed_floats(int Cin, int Cout);      /* bwd_packed / repack: as for the stage conv */
 int urnn_deconv2x2_backward_f32(const float *in, const float *weight, const float *out, const float *dout, float *din, float *dweight,
-                                float *dbias, void *workspace, size_t workspace_bytes, int B, int Cin, int Cout, int H, int W,
-                                float slope, int accumulate, void *stream);
+                                float *dbias, float *bwd_packed, int repack, void *workspace, size_t workspace_bytes, int B, int Cin,
+                                int Cout, int H, int W, float slope, int accumulate, void *stream);
 
 /* Backward of urnn_head_f32 w.r.t. its first output (the masked depth; the loss never sees the probability map).  Call it
  * after the forward on the same feat with the forward's workspace untouched (fwd_workspace: the five LayerNorm statistics) and

@@ -40,9 +40,11 @@ SIGNATURES = {
     "urnn_gru_cell_backward_packed_floats": (_sz, [_i, _i, _i]),
     "urnn_gru_cell_backward_f32": (_i, [_p] * 22 + [_i, _p, _sz, _i, _i, _i, _i, _i, _i, _p]),
     "urnn_stage_conv_backward_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "urnn_stage_conv_backward_f32": (_i, [_p] * 8 + [_sz, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "urnn_stage_conv_backward_packed_floats": (_sz, [_i, _i]),
+    "urnn_stage_conv_backward_f32": (_i, [_p] * 8 + [_i, _p, _sz, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
     "urnn_deconv2x2_backward_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "urnn_deconv2x2_backward_f32": (_i, [_p] * 8 + [_sz, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "urnn_deconv2x2_backward_packed_floats": (_sz, [_i, _i]),
+    "urnn_deconv2x2_backward_f32": (_i, [_p] * 8 + [_i, _p, _sz, _i, _i, _i, _i, _i, _f, _i, _p]),
     "urnn_head_backward_workspace_bytes": (_sz, [_i, _i, _i]),
     "urnn_head_backward_f32": (_i, [_p] * 16 + [_sz, _i, _i, _i, _i, _f, _f, _i, _p]),
     "urnn_loss_workspace_bytes": (_sz, [ctypes.c_long]),

@@ -474,11 +474,16 @@ static int conv_2seg(const float *in0, int C0, const float *in1, int C1, const f
 }
 
 // dX = W^T . dY through the forward GEMM kernel: "weight" = W^T (K x N), identity epilogue, no bias.  out (B,K,P).
-static int dx_gemm(const float *dy, const float *w, float *wt, float *packed, float *out, int B, int N, int K, int H, int W, hipStream_t st,
-                   const char *what)
+// pack_transposed builds the packed W^T (once per parameter update), dx_gemm runs the GEMM.
+static int pack_transposed(const float *w, float *wt, float *packed, int N, int K, hipStream_t st, const char *what)
 {
     CHECK_HIP(urnn_train_transpose(w, wt, N, K, st), what);
     CHECK_HIP(urnn_launch_pack_conv(wt, nullptr, packed, N, K, st), what);
+    return URNN_OK;
+}
+
+static int dx_gemm(const float *dy, const float *packed, float *out, int B, int N, int K, int H, int W, hipStream_t st)
+{
     return urnn_stage_conv_f32(dy, packed, out, B, N, K, H, W, 0, 1.0f, st);
 }
 
@@ -602,28 +607,45 @@ extern "C" size_t urnn_stage_conv_backward_workspace_bytes(int B, int Cin, int C
     return carve_conv_bwd(nullptr, B, Cin, Cout, (long)H * W, 0).bytes;
 }
 
+// packed weights of the backward pass, kept by the caller across calls until the parameters change: [forward pack | W^T pack]
+static size_t conv_bwd_packed_split(int Cin, int N) { return align_up(urnn_packed_conv_floats(Cin, N) * sizeof(float), 256) / sizeof(float); }
+
+extern "C" size_t urnn_stage_conv_backward_packed_floats(int Cin, int Cout)
+{
+    if (Cin < 1 || Cout < 1) return 0;
+    return conv_bwd_packed_split(Cin, Cout) + urnn_packed_conv_floats(Cout, Cin);
+}
+
 extern "C" int urnn_stage_conv_backward_f32(const float *in, const float *weight, const float *bias, const float *dout, float *din,
-                                            float *dweight, float *dbias, void *workspace, size_t workspace_bytes, int B, int Cin,
-                                            int Cout, int H, int W, int pool, float slope, int accumulate, void *stream)
+                                            float *dweight, float *dbias, float *bwd_packed, int repack, void *workspace,
+                                            size_t workspace_bytes, int B, int Cin, int Cout, int H, int W, int pool, float slope,
+                                            int accumulate, void *stream)
 {
     if (!in || !weight || !bias || !dout || !din || !dweight || !dbias || !workspace)
         return fail(URNN_ENULL, "urnn_stage_conv_backward_f32: NULL argument");
     if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || (pool && (H < 2 || W < 2)))
         return fail(URNN_EINVAL, "urnn_stage_conv_backward_f32: bad dims");
+    if (bwd_packed && !aligned16(bwd_packed)) return fail(URNN_EALIGN, "urnn_stage_conv_backward_f32: bwd_packed must be 16-byte aligned");
     const long P = (long)H * W;
     const ConvBwdWs ws = carve_conv_bwd(workspace, B, Cin, Cout, P, 0);
     if (workspace_bytes < ws.bytes)
         return fail(URNN_EWORKSPACE, "urnn_stage_conv_backward_f32: workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
     hipStream_t st = (hipStream_t)stream;
+    // bwd_packed == NULL: packs live in the workspace and are rebuilt by every call
+    float *pk = bwd_packed ? bwd_packed : ws.pk, *pkt = bwd_packed ? bwd_packed + conv_bwd_packed_split(Cin, Cout) : ws.pkt;
+    if (repack || !bwd_packed) {
+        CHECK_HIP(urnn_launch_pack_conv(weight, bias, pk, Cin, Cout, st), "pack");
+        const int rc = pack_transposed(weight, ws.wt, pkt, Cout, Cin, st, "input-gradient weights");
+        if (rc) return rc;
+    }
     // pre-activation u = W.x + b (the forward kernel with an identity epilogue), then du = (un-pooled) dout * lrelu'(u)
-    CHECK_HIP(urnn_launch_pack_conv(weight, bias, ws.pk, Cin, Cout, st), "pack");
-    int rc = urnn_stage_conv_f32(in, ws.pk, ws.u, B, Cin, Cout, H, W, 0, 1.0f, stream);
+    int rc = urnn_stage_conv_f32(in, pk, ws.u, B, Cin, Cout, H, W, 0, 1.0f, stream);
     if (rc) return rc;
     CHECK_HIP(urnn_train_lrelu_pool_bwd(ws.u, dout, B, Cout, H, W, pool, slope, st), "lrelu backward");
     const float *seg[3] = {in, nullptr, nullptr};
     const int segC[3] = {Cin, 0, 0};
     CHECK_HIP(urnn_train_wgrad(ws.u, seg, segC, B, Cout, Cin, (int)P, ws.wpart, dweight, dbias, accumulate, st), "weight gradient");
-    return dx_gemm(ws.u, weight, ws.wt, ws.pkt, din, B, Cout, Cin, H, W, st, "input gradient");
+    return dx_gemm(ws.u, pkt, din, B, Cout, Cin, H, W, st);
 }
 
 extern "C" size_t urnn_deconv2x2_backward_workspace_bytes(int B, int Cin, int Cout, int H, int W)
@@ -632,13 +654,21 @@ extern "C" size_t urnn_deconv2x2_backward_workspace_bytes(int B, int Cin, int Co
     return carve_conv_bwd(nullptr, B, Cin, 4 * Cout, (long)H * W, 1).bytes;
 }
 
+extern "C" size_t urnn_deconv2x2_backward_packed_floats(int Cin, int Cout)
+{
+    if (Cin < 1 || Cout < 1) return 0;
+    return urnn_packed_conv_floats(4 * Cout, Cin);
+}
+
 extern "C" int urnn_deconv2x2_backward_f32(const float *in, const float *weight, const float *out, const float *dout, float *din,
-                                           float *dweight, float *dbias, void *workspace, size_t workspace_bytes, int B, int Cin,
-                                           int Cout, int H, int W, float slope, int accumulate, void *stream)
+                                           float *dweight, float *dbias, float *bwd_packed, int repack, void *workspace,
+                                           size_t workspace_bytes, int B, int Cin, int Cout, int H, int W, float slope, int accumulate,
+                                           void *stream)
 {
     if (!in || !weight || !out || !dout || !din || !dweight || !dbias || !workspace)
         return fail(URNN_ENULL, "urnn_deconv2x2_backward_f32: NULL argument");
     if (B < 1 || Cin < 1 || Cout < 1 || Cout > 96 || H < 1 || W < 1) return fail(URNN_EINVAL, "urnn_deconv2x2_backward_f32: bad dims");
+    if (bwd_packed && !aligned16(bwd_packed)) return fail(URNN_EALIGN, "urnn_deconv2x2_backward_f32: bwd_packed must be 16-byte aligned");
     const long P = (long)H * W;
     const int N = 4 * Cout;
     const ConvBwdWs ws = carve_conv_bwd(workspace, B, Cin, N, P, 1);
@@ -646,13 +676,18 @@ extern "C" int urnn_deconv2x2_backward_f32(const float *in, const float *weight,
         return fail(URNN_EWORKSPACE, "urnn_deconv2x2_backward_f32: workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
     hipStream_t st = (hipStream_t)stream;
     // the transposed conv is a 1x1 conv to 4*Cout channels (one per output parity) followed by a pixel shuffle
+    float *pkt = bwd_packed ? bwd_packed : ws.pkt;
+    if (repack || !bwd_packed) {
+        CHECK_HIP(urnn_train_deconv_weight_rows(weight, ws.rows, Cin, Cout, st), "deconv weight rows");
+        const int rc = pack_transposed(ws.rows, ws.wt, pkt, N, Cin, st, "input-gradient weights");
+        if (rc) return rc;
+    }
     CHECK_HIP(urnn_train_deconv_unshuffle(dout, out, ws.u, B, Cout, H, W, slope, st), "deconv un-shuffle");
-    CHECK_HIP(urnn_train_deconv_weight_rows(weight, ws.rows, Cin, Cout, st), "deconv weight rows");
     const float *seg[3] = {in, nullptr, nullptr};
     const int segC[3] = {Cin, 0, 0};
     CHECK_HIP(urnn_train_wgrad(ws.u, seg, segC, B, N, Cin, (int)P, ws.wpart, ws.drows, ws.dsum, 0, st), "weight gradient");
     CHECK_HIP(urnn_train_deconv_rows_weight(ws.drows, ws.dsum, dweight, dbias, Cin, Cout, accumulate, st), "weight gradient layout");
-    return dx_gemm(ws.u, ws.rows, ws.wt, ws.pkt, din, B, N, Cin, H, W, st, "input gradient");
+    return dx_gemm(ws.u, pkt, din, B, N, Cin, H, W, st);
 }
 
 // ---- deconv ----------------------------------------------------------------------------------------------------------
@@ -886,7 +921,9 @@ extern "C" int urnn_head_backward_f32(const float *feat, const float *conv_w, co
         const float *seg[3] = {in, nullptr, nullptr};
         const int segC[3] = {16, 0, 0};
         CHECK_HIP(urnn_train_wgrad(cur, seg, segC, B, 16, 16, Pi, ws.wpart, dconv_w + k * 256, nullptr, accumulate, st), "head: conv weights");
-        int rc = dx_gemm(cur, conv_w + k * 256, ws.wt, ws.pkt, other, B, 16, 16, H, W, st, "head: input gradient");
+        int rc = pack_transposed(conv_w + k * 256, ws.wt, ws.pkt, 16, 16, st, "head: input-gradient weights");
+        if (rc) return rc;
+        rc = dx_gemm(cur, ws.pkt, other, B, 16, 16, H, W, st);
         if (rc) return rc;
         float *t = cur;
         cur = other;

@@ -61,7 +61,19 @@ def gru_cell_backward(x, e, h, W1, W2, gn1_w, gn2_w, dh_out, I, fwd_ws, grads=No
     return g
 
 
-def stage_conv_backward(x, weight, bias, dout, pool, dweight=None, dbias=None, accumulate=False, slope=ops.LRELU_SLOPE, scratch=None):
+def _layer_packs(packed, nfloats, dev):
+    """Caller-kept packed weights of a layer's backward GEMMs: ``packed`` is None (pack per call) or a list that receives the
+    buffer on first use and hands it back afterwards (the caller clears it when the parameters change).  -> (buffer, repack)"""
+    if packed is None:
+        return None, 1
+    if not packed:
+        packed.append(torch.empty(nfloats, dtype=torch.float32, device=dev))
+        return packed[0], 1
+    return packed[0], 0
+
+
+def stage_conv_backward(x, weight, bias, dout, pool, dweight=None, dbias=None, accumulate=False, slope=ops.LRELU_SLOPE, scratch=None,
+                        packed=None):
     """Backward of ``ops.stage_conv`` (conv1x1 + LeakyReLU [+ AvgPool2]).  weight (Cout,Cin[,1,1]), bias (Cout).
     Returns (dx, dweight, dbias)."""
     ops._dev_check(x, weight, bias, dout)
@@ -73,13 +85,15 @@ def stage_conv_backward(x, weight, bias, dout, pool, dweight=None, dbias=None, a
         dweight, dbias, accumulate = torch.empty_like(weight), torch.empty_like(bias), False
     dx = torch.empty_like(x)
     p = ops._ptr
-    check(L.urnn_stage_conv_backward_f32(p(x), p(weight), p(bias), p(dout), p(dx), p(dweight), p(dbias), p(ws), ws.numel(), B, Cin,
-                                         Cout, H, W, int(bool(pool)), slope, int(bool(accumulate)), ops._stream()),
+    pk, repack = _layer_packs(packed, L.urnn_stage_conv_backward_packed_floats(Cin, Cout), x.device)
+    check(L.urnn_stage_conv_backward_f32(p(x), p(weight), p(bias), p(dout), p(dx), p(dweight), p(dbias), p(pk), repack, p(ws), ws.numel(),
+                                         B, Cin, Cout, H, W, int(bool(pool)), slope, int(bool(accumulate)), ops._stream()),
           "urnn_stage_conv_backward_f32")
     return dx, dweight, dbias
 
 
-def deconv2x2_backward(x, weight, out, dout, dweight=None, dbias=None, accumulate=False, slope=ops.LRELU_SLOPE, scratch=None):
+def deconv2x2_backward(x, weight, out, dout, dweight=None, dbias=None, accumulate=False, slope=ops.LRELU_SLOPE, scratch=None,
+                       packed=None):
     """Backward of ``ops.deconv2x2``.  weight (Cin,Cout,2,2); ``out`` is the forward output.  Returns (dx, dweight, dbias)."""
     ops._dev_check(x, weight, out, dout)
     B, Cin, H, W = x.shape
@@ -90,8 +104,9 @@ def deconv2x2_backward(x, weight, out, dout, dweight=None, dbias=None, accumulat
         dweight, dbias, accumulate = torch.empty_like(weight), torch.empty(Cout, dtype=torch.float32, device=x.device), False
     dx = torch.empty_like(x)
     p = ops._ptr
-    check(L.urnn_deconv2x2_backward_f32(p(x), p(weight), p(out), p(dout), p(dx), p(dweight), p(dbias), p(ws), ws.numel(), B, Cin, Cout,
-                                        H, W, slope, int(bool(accumulate)), ops._stream()), "urnn_deconv2x2_backward_f32")
+    pk, repack = _layer_packs(packed, L.urnn_deconv2x2_backward_packed_floats(Cin, Cout), x.device)
+    check(L.urnn_deconv2x2_backward_f32(p(x), p(weight), p(out), p(dout), p(dx), p(dweight), p(dbias), p(pk), repack, p(ws), ws.numel(), B,
+                                        Cin, Cout, H, W, slope, int(bool(accumulate)), ops._stream()), "urnn_deconv2x2_backward_f32")
     return dx, dweight, dbias
 
 

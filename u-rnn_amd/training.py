@@ -74,7 +74,7 @@ class WindowGradients:
             key = f"{name}.{mod._pname}"
             dx, dw, db = train_ops.stage_conv_backward(x, L.weight.detach(), L.bias.detach(), dy, mod.pool, dweight=G.get(key + ".weight"),
                                                        dbias=G.get(key + ".bias"), accumulate=acc and (key + ".weight") in G,
-                                                       scratch=self.arena)
+                                                       scratch=self.arena, packed=self._bwd_packed.setdefault(key, []))
             G[key + ".weight"], G[key + ".bias"] = dw, db
             return dx
 
@@ -83,7 +83,7 @@ class WindowGradients:
             key = f"{name}.{mod._pname}"
             dx, dw, db = train_ops.deconv2x2_backward(x, L.weight.detach(), out, dy, dweight=G.get(key + ".weight"),
                                                       dbias=G.get(key + ".bias"), accumulate=acc and (key + ".weight") in G,
-                                                      scratch=self.arena)
+                                                      scratch=self.arena, packed=self._bwd_packed.setdefault(key, []))
             G[key + ".weight"], G[key + ".bias"] = dw, db
             return dx
 
