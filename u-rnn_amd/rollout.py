@@ -246,11 +246,32 @@ class RolloutEngine:
         self._head_chain(1)
         torch.cuda.synchronize(self.device)
         graphs = {}
-        for key, parity, with_head in (("first", 0, False), (0, 0, True), (1, 1, True)):
+        # steady-state iterations (head(t-1) + encoder(t+1) || decoder(t)) per frame parity, the first iteration of a run() call
+        # (no head pending) per parity, and the trailing head that completes a run() call: a short run (bench.py --steps 20
+        # after an odd warm-up) is then a handful of graph replays too instead of ~30 eager launches
+        for key, parity, with_head in ((("first", 0), 0, False), (("first", 1), 1, False), (0, 0, True), (1, 1, True)):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._iter_overlap(parity, with_head=with_head)
             graphs[key] = g
+        for parity in (0, 1):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._head_chain(parity)
+            graphs[("tail", parity)] = g
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._enc_chain(0)          # pipeline prologue E(0) of an event
+        graphs["prologue"] = g
+        # The first launch of an instantiated graph uploads it to the device: pay that here, not in the first frames of the first
+        # event.  Two short valid rollouts touch every graph and write frames 0..2 only (states and counters are restored below).
+        if int(t0.item()) + 3 <= self.Tcap:
+            for seq in (("prologue", ("first", 0), 1, 0, ("tail", 0)), ("prologue", ("first", 0), ("tail", 0), ("first", 1), ("tail", 1))):
+                self.t_dev.copy_(t0)
+                self.te_dev.copy_(t1)
+                for key in seq:
+                    graphs[key].replay()
+            torch.cuda.synchronize(self.device)
         self._graphs2 = graphs
         for s, v in zip(self.states + self.enc_alt, saved):
             s.copy_(v)
@@ -266,20 +287,21 @@ class RolloutEngine:
             self._capture_overlap()
         for i in range(frames):
             t = self._frames_done
-            if t == 0:
-                self._enc_chain(0)      # pipeline prologue: E(0)
-            first = i == 0              # no head pending at the start of a run() call
-            if first:
-                if self.use_graph and t % 2 == 0:
-                    self._graphs2["first"].replay()
+            if t == 0:                  # pipeline prologue: E(0)
+                if self.use_graph:
+                    self._graphs2["prologue"].replay()
                 else:
-                    self._iter_overlap(t % 2, with_head=False)   # eager: only when a run() resumes at an odd frame
-            elif self.use_graph:
-                self._graphs2[t % 2].replay()
+                    self._enc_chain(0)
+            first = i == 0              # no head pending at the start of a run() call
+            if self.use_graph:
+                self._graphs2[("first", t % 2) if first else t % 2].replay()
             else:
-                self._iter_overlap(t % 2)
+                self._iter_overlap(t % 2, with_head=not first)
             self._frames_done += 1
-        self._head_chain((self._frames_done - 1) % 2)
+        if self.use_graph:
+            self._graphs2[("tail", (self._frames_done - 1) % 2)].replay()
+        else:
+            self._head_chain((self._frames_done - 1) % 2)
 
     def final_states(self):
         """The six states after the frames run so far (overlap mode keeps the newest encoder states in the buffer
