@@ -390,7 +390,8 @@ def main():
                    "graph": not args.no_graph, "overlap_chains": bool(args.overlap)},
         "long_run": long_run,
         "gflop_per_frame": gflop,
-        "step_mfma_frac": fps / world * gflop / 1e3 / PEAK_MFMA_F32_TFLOPS,
+        "step_mfma_frac": fps / world * gflop / 1e3 / PEAK_MFMA_F32_TFLOPS,                          # of the fp32 matrix peak (round 1's pipe)
+        "step_mfma_frac_split_pipe": fps / world * gflop / 1e3 / (PEAK_MFMA_BF16_TFLOPS / SPLIT_MFMAS),  # of 2517 / 6: the pipe the GEMMs run on
         # frames/s x A_stage / 8 TB/s -- the unfused per-stage traffic model (algorithmic bytes)
         "step_hbm_frac_a_stage": (fps / world * a_stage_bytes(H, W, C) / (PEAK_HBM_TBS * 1e12)) if len(names) == 1 else None,
         # the same with the bytes the counters saw (FETCH_SIZE / WRITE_SIZE passes of this build, profiles/pmc_gate_gemm.json)
