@@ -121,6 +121,36 @@ def cpu_baseline(sd, cfgname, budget_s=15.0, max_frames=8):
                       f"C oracle with OpenMP on {orc.num_threads()} threads of {os.cpu_count()} logical CPUs"}
 
 
+def torch_cpu_baseline(sd, cfgname, threads, budget_s=10.0, max_frames=4):
+    """SURVEY 8(d)'s CPU path: the same step in plain float32 torch ops on the host cores (tests/torch_ref.py, the restatement
+    that is pinned to the reference's goldens next to the C oracle), input assembly by the oracle's numpy preprocess_inputs."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import torch_ref
+    from oracle import oracle as orc
+    import urnn_amd.weights as uw
+    H, W, nums, T, rain_max, cum_max, spatial = CONFIGS[cfgname]
+    prev = torch.get_num_threads()
+    torch.set_num_threads(int(threads))
+    try:
+        p = {k: torch.from_numpy(v) for k, v in sd.items()}
+        ev = uw.make_event(min(T, max_frames + 1), H, W, rain_max, seed=42, spatial_rain=spatial)
+        st = [torch.from_numpy(s) for s in orc.zero_states(1, H, W)]
+        with torch.no_grad():
+            x = torch.from_numpy(orc.preprocess_inputs(0, ev, nums, rain_max, cum_max)[:, 0])
+            _, _, _, st = torch_ref.step(p, x, st, H, W)            # untimed warm-up frame
+            n, t0 = 0, time.time()
+            while n < max_frames and (time.time() - t0) < budget_s:
+                x = torch.from_numpy(orc.preprocess_inputs(n + 1, ev, nums, rain_max, cum_max)[:, 0])
+                _, _, _, st = torch_ref.step(p, x, st, H, W)
+                n += 1
+            dt = time.time() - t0
+    finally:
+        torch.set_num_threads(prev)
+    return {"value": n / dt, "unit": "frames/s", "cores": int(threads),
+            "arith": "plain float32 torch ops on CPU tensors (tests/torch_ref.py: conv2d / group_norm / layer_norm ...), the reference's own arithmetic",
+            "sample": f"{n} frames of the {H}x{W} C={2*nums+3} rollout after 1 warm-up frame ({dt:.1f} s), torch {torch.__version__} with {int(threads)} threads"}
+
+
 def bench_train(args, dev, dist, world, rank):
     """SWP training throughput (BASELINE configs 3-4 shape of work, fp32): a step = one training timestep of one event per GPU
     (forward with kept activations, backward through the window, loss; per window one gradient mean over the ranks and one
@@ -439,6 +469,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline and len(names) == 1:
             try:
                 result["cpu_baseline"] = cpu_baseline(sd, args.config)
+                try:    # the torch-CPU restatement beside it; the C oracle stays the headline CPU figure
+                    result["cpu_baseline"]["torch_cpu"] = torch_cpu_baseline(sd, args.config, result["cpu_baseline"]["cores"])
+                except Exception as exc:
+                    result["cpu_baseline"]["torch_cpu"] = {"error": repr(exc)}
             except Exception as exc:
                 result["cpu_baseline"] = {"error": repr(exc)}
         print(json.dumps(result))
