@@ -96,6 +96,19 @@ def build_net(H, W, C, dev, seed=0):
     return net.to(dev).eval(), sd, cfg
 
 
+def cpu_model():
+    """Host CPU model string (BASELINE.md section 4 asks for it beside the core count)."""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
 def cpu_baseline(sd, cfgname, budget_s=15.0, max_frames=8):
     """The C oracle (oracle/urnn_oracle.c, OpenMP) on the host cores: same synthetic event, first frames of the
     rollout, input assembly included -- frames/s like the reference's Inference timer."""
@@ -118,7 +131,8 @@ def cpu_baseline(sd, cfgname, budget_s=15.0, max_frames=8):
             "arith": "plain-C restatement of the reference's ops (oracle/urnn_oracle.c): fp32 storage, fp64 accumulation, OpenMP; "
                      "the reference itself is Python/PyTorch and cannot travel to the GPU box",
             "sample": f"{n} frames of the {H}x{W} C={2*nums+3} rollout after 1 warm-up frame ({dt:.1f} s), "
-                      f"C oracle with OpenMP on {orc.num_threads()} threads of {os.cpu_count()} logical CPUs"}
+                      f"C oracle with OpenMP on {orc.num_threads()} threads of {os.cpu_count()} logical CPUs ({cpu_model()})",
+            "cpu_model": cpu_model()}
 
 
 def torch_cpu_baseline(sd, cfgname, threads, budget_s=10.0, max_frames=4):
@@ -199,7 +213,7 @@ def bench_train(args, dev, dist, world, rank):
             "metric": "SWP training timesteps/s (forward + backward + clipped Adam), whole job", "value": steps * world / elapsed,
             "unit": "steps/s", "n_gpus": world, "steps": steps, "warmup": nwin_w * S, "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.dtype == "fp32" else "bf16 GEMM compute (forward + input gradients), fp32 accumulate / norms / weight gradients / Adam",
+            "dtype": "f32" if args.dtype == "fp32" else "bf16 GEMM operands (forward, input- and weight-gradient GEMMs), fp32 accumulate / norms / stored gradients / Adam",
             "data": "synthetic",
             "config": {"workload": f"train {name}: {H}x{W} grid, historical_nums={nums}, SWP windows of seq_num={S} (fast mode), "
                                    f"{B} event(s) per GPU, Adam lr 1e-4, grad clip 1.0", "parallelism": f"DDP x{world} (flat-buffer mean all-reduce)"
@@ -274,12 +288,46 @@ def self_launch(n):
     sys.exit(subprocess.call(cmd, env=env))
 
 
+def kernel_source_hash():
+    """sha256 over the HIP sources + headers the library is built from (u-rnn_amd/build_ext.py): identifies the kernels whatever
+    machine compiled them (the .so bytes may differ between two builds of the same sources; its own hash is recorded beside)."""
+    import hashlib
+    csrc = os.path.join(REPO, "u-rnn_amd", "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h"))) + [os.path.join(REPO, "include", "urnn_hip.h")]
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def load_pmc_record():
+    """profiles/pmc_gate_gemm.json (tools/make_pmc_json.py) if it was measured with THIS build's kernels, else (None, why): the
+    record carries the hash of the kernel sources the counters were collected with; a stale file must not pass as a measurement."""
+    path = os.path.join(REPO, "profiles", "pmc_gate_gemm.json")
+    if not os.path.isfile(path):
+        return None, "no profiles/pmc_gate_gemm.json"
+    with open(path) as fh:
+        rec = json.load(fh)
+    if os.environ.get("URNN_LIB"):
+        return None, "URNN_LIB override (tuning variant): counter traffic of the product build not reported"
+    now = kernel_source_hash()
+    if rec.get("kernel_source_sha256") != now:
+        return None, (f"profiles/pmc_gate_gemm.json was collected with kernel sources {str(rec.get('kernel_source_sha256'))[:12]}, this tree is "
+                      f"{now[:12]}: counter traffic not reported (re-run tools/collect_profiles.sh)")
+    return rec, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=360)
     ap.add_argument("--warmup", type=int, default=36)
     ap.add_argument("--config", default="location1", choices=sorted(CONFIGS) + ["mixed"])
+    ap.add_argument("--exp-config", default=None, help="a reference experiment YAML (config.py:55-213 keys: input_height/width, "
+                    "historical_nums, rain_max, cumsum_rain_max, duration): the workload is sized from it instead of --config")
+    ap.add_argument("--spatial-rain", action="store_true", help="with --exp-config: (T,H,W) rainfall (Futian / UKEA style)")
     ap.add_argument("--batch", type=int, default=1, help="events per GPU (the reference entry points use 1)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of the captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -298,6 +346,11 @@ def main():
                     help="train mode: GEMM arithmetic (bf16 = BASELINE configs[3]'s variant; inference always runs the fp32-exact path)")
     args = ap.parse_args()
 
+    if args.exp_config:
+        from urnn_amd.exp_config import load_exp_config, workload
+        name = "yaml:" + os.path.splitext(os.path.basename(args.exp_config))[0]
+        CONFIGS[name] = workload(load_exp_config(args.exp_config), args.spatial_rain)
+        args.config = name
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args.gpus)                      # plain `python bench.py --gpus N`: become N ranks (one per GPU)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -427,12 +480,12 @@ def main():
         # the same with the bytes the counters saw (FETCH_SIZE / WRITE_SIZE passes of this build, profiles/pmc_gate_gemm.json)
         "step_hbm_frac_measured_traffic": None,
     }
-    pmc_path = os.path.join(REPO, "profiles", "pmc_gate_gemm.json")
-    if os.path.isfile(pmc_path) and args.config == "location1" and B == 1:
-        with open(pmc_path) as fh:
-            ws = json.load(fh).get("whole_step")
+    pmc_rec, pmc_why = load_pmc_record()       # counter figures of a profiled run: only if they belong to the library loaded here
+    if pmc_rec is not None and args.config == "location1" and B == 1:
+        ws = pmc_rec.get("whole_step")
         if ws:
             result["step_hbm_frac_measured_traffic"] = fps / world * ws["hbm_bytes_per_frame"] / (PEAK_HBM_TBS * 1e12)
+            result["step_hbm_bytes_per_frame_counters"] = ws["hbm_bytes_per_frame"]
 
     if rank == 0:
         # dominant kernel: the ConvGRU gate GEMM (4 launches per frame).  With the bf16 x 6 split k-loop its arithmetic
@@ -445,12 +498,9 @@ def main():
             bytes_per_launch = sum(by.values()) / len(by)
             avg = sum(dur[k] for k in fl) / len(fl)
             achieved = bytes_per_launch / avg / 1e9
-            traffic, tsrc = None, None
-            pmc = os.path.join(REPO, "profiles", "pmc_gate_gemm.json")
-            if os.path.isfile(pmc) and args.config == "location1" and B == 1:
-                with open(pmc) as fh:
-                    rec = json.load(fh)
-                traffic, tsrc = rec.get("hbm_bytes_per_launch"), rec.get("source")
+            traffic, tsrc = None, pmc_why
+            if pmc_rec is not None and args.config == "location1" and B == 1:
+                traffic, tsrc = pmc_rec.get("hbm_bytes_per_launch"), pmc_rec.get("source")
             split = os.environ.get("URNN_TUNE_SPLIT", "1") != "0"
             mfma_peak = PEAK_MFMA_BF16_TFLOPS / SPLIT_MFMAS if split else PEAK_MFMA_F32_TFLOPS
             result["roofline"] = {

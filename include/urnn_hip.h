@@ -38,12 +38,16 @@ const char *urnn_last_error(void);
 
 /* Arithmetic of the GEMM kernels, process-wide (one process drives one GPU; the launch functions read it when they enqueue, so a
  * captured hipGraph keeps the mode it was captured with).
- *   URNN_MATRIX_FP32 (default): the reference's fp32 semantics -- fp32 operands split into three exact bf16 pieces, six
- *     v_mfma_f32_32x32x16_bf16 per 16 k with fp32 accumulation (fp32-class accuracy, the parity path), or v_mfma_f32_32x32x2_f32
+ *   URNN_MATRIX_FP32 (default): the reference's fp32 semantics on the 16-bit matrix pipe.  Forward GEMMs: both fp32 operands
+ *     as two scaled f16 pieces (22 significant bits; activations x 2^5, weights x 2^10, result x 2^-15 -- all exact), three
+ *     v_mfma_f32_32x32x16_f16 per 16 k, fp32 accumulation (rms error 1.8e-7 of the dot product's natural scale, below the fp32
+ *     fma chain's 2.7e-7; finite for |activation| < 2047 and |weight| < 64, beyond that the outputs turn NaN).  Gradient GEMMs
+ *     (no lower bound on the magnitudes): three exact bf16 pieces, six v_mfma_f32_32x32x16_bf16 per 16 k.  v_mfma_f32_32x32x2_f32
  *     where the channel counts do not form whole 16-k groups.
  *   URNN_MATRIX_BF16: bf16 compute for training (BASELINE configs[3]; the reference only declares --amp, config.py:179) --
- *     activations rounded to bf16, weights to 16 mantissa bits, fp32 accumulation; norms, statistics, states, loss and the
- *     optimizer stay fp32.  Applies to every forward GEMM and the input-gradient GEMMs; weight gradients stay fp32. */
+ *     GEMM operands rounded to bf16 (weights keep 16 mantissa bits in the forward / input-gradient GEMMs), fp32 accumulation;
+ *     norms, statistics, states, loss and the optimizer stay fp32.  Applies to every forward GEMM, the input-gradient GEMMs AND
+ *     the weight-gradient GEMMs (dY and X rounded to bf16, fp32 accumulate); gradients are stored in fp32. */
 #define URNN_MATRIX_FP32 0
 #define URNN_MATRIX_BF16 1
 int urnn_set_matrix_mode(int mode);

@@ -71,6 +71,24 @@ def rnd(rs, *shape, scale=1.0):
     return (scale * rs.standard_normal(shape)).astype(np.float32)
 
 
+class head_taps:
+    """Forward hooks on the reference head while a whole ED.forward / test.Inference runs: per call the class map
+    (YOLOXHead output channel 1, flood_head.py:166-177) and the pre-mask regression (reg_preds output, flood_head.py:160-164),
+    each as (B, H, W) -- the head flattens its two leading dims (flood_head.py:145-150), whichever order the caller used."""
+
+    def __init__(self, net):
+        self.net, self.cls, self.raw, self._h = net, [], [], []
+
+    def __enter__(self):
+        self._h.append(self.net.head.register_forward_hook(lambda m, i, o: self.cls.append(o.detach().reshape((-1,) + tuple(o.shape[-3:]))[:, 1].numpy().copy())))
+        self._h.append(self.net.head.reg_preds.register_forward_hook(lambda m, i, o: self.raw.append(o.detach()[:, 0].numpy().copy())))
+        return self
+
+    def __exit__(self, *a):
+        for h in self._h:
+            h.remove()
+
+
 def gen_kernels(path):
     """Per-kernel vectors at 16x16 (and 8x8 / 4x4 deep stages) from the reference sub-modules."""
     rs = np.random.RandomState(1234)
@@ -129,11 +147,14 @@ def gen_kernels(path):
             shapes = [(B, 64, H, W), (B, 96, H // 2, W // 2), (B, 96, H // 4, W // 4),
                       (B, 96, H // 4, W // 4), (B, 96, H // 2, W // 2), (B, 64, H, W)]
             st = [rnd(rs, *s, scale=0.5) for s in shapes]
-            res = net(T(x), *[T(s) for s in st])
+            with head_taps(net) as tap:
+                res = net(T(x), *[T(s) for s in st])
             out[f"step_x_{tag}"] = x
             for k, s in enumerate(st):
                 out[f"step_state{k}_{tag}"] = s
             out[f"step_reg_{tag}"] = res[0].numpy()
+            # the class map and the pre-mask regression of the same call (flood_head.py:166-177), for the flip-tolerant comparison
+            out[f"step_cls_{tag}"], out[f"step_raw_{tag}"] = tap.cls[0], tap.raw[0]
             for k in range(6):
                 out[f"step_newstate{k}_{tag}"] = res[1 + k].numpy()
     np.savez_compressed(path, **out)
@@ -217,10 +238,11 @@ def gen_inference_entry(path):
     C = 2 * nums + 3
     net, sd = ref_net(H, W, C, seed=11)
     ev = uw.make_event(Tn, H, W, 60.0, seed=5, batch=1)
-    y = ref_test.Inference(net, event_to_torch(ev), torch.device("cpu"), historical_nums=nums, rain_max=60.0,
-                           cumsum_rain_max=250.0, input_height=H, input_width=W, net_cfg=CFG)
+    with head_taps(net) as tap:
+        y = ref_test.Inference(net, event_to_torch(ev), torch.device("cpu"), historical_nums=nums, rain_max=60.0,
+                               cumsum_rain_max=250.0, input_height=H, input_width=W, net_cfg=CFG)
     np.savez_compressed(path, H=H, W=W, nums=nums, T=Tn, rain_max=60.0, cumsum_max=250.0, weights_seed=11,
-                        event_seed=5, out=y)
+                        event_seed=5, out=y, cls=np.concatenate(tap.cls), raw=np.concatenate(tap.raw))
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 

@@ -33,12 +33,14 @@ def test_library_exports_every_declared_symbol(built):
 def test_packed_sizes_and_argument_errors_without_gpu(built):
     lib = built.lib()
     # pure host-side size arithmetic
-    # fp32 slab [KT][NB][64] + bias row, then the same slab as bf16 pieces [ceil(KT/8)][NB][3][64][4 dwords]
+    # fp32 slab [KT][NB][64] + bias row, then the same slab as bf16 pieces [ceil(KT/8)][NB][3][64][4 dwords] (gradient GEMMs) and as
+    # scaled f16 pieces [ceil(KT/8)][NB][2][64][4 dwords] (forward GEMMs)
     split = lambda KT, NB: ((KT + 7) // 8) * NB * 3 * 256
-    assert lib.urnn_packed_conv_floats(63, 16) == 32 * 1 * 64 + 32 + split(32, 1)
-    # gate slabs [F/32 groups][KT][z|r][64] + b1, candidate slab(s) [KT][F/32 blocks][64] + b2, then both in split form
-    assert lib.urnn_packed_gru_floats(16, 64, 0) == 2 * (40 * 2 * 64) + 128 + 40 * 2 * 64 + 64 + 2 * split(40, 2) + split(40, 2)
-    assert lib.urnn_packed_gru_floats(96, 64, 1) == 2 * (112 * 2 * 64) + 128 + 112 * 2 * 64 + 64 + 2 * split(112, 2) + split(112, 2)
+    f16 = lambda KT, NB: ((KT + 7) // 8) * NB * 2 * 256
+    assert lib.urnn_packed_conv_floats(63, 16) == 32 * 1 * 64 + 32 + split(32, 1) + f16(32, 1)
+    # gate slabs [F/32 groups][KT][z|r][64] + b1, candidate slab(s) [KT][F/32 blocks][64] + b2, then both in split and f16 form
+    assert lib.urnn_packed_gru_floats(16, 64, 0) == 2 * (40 * 2 * 64) + 128 + 40 * 2 * 64 + 64 + 3 * split(40, 2) + 3 * f16(40, 2)
+    assert lib.urnn_packed_gru_floats(96, 64, 1) == 2 * (112 * 2 * 64) + 128 + 112 * 2 * 64 + 64 + 3 * split(112, 2) + 3 * f16(112, 2)
     assert lib.urnn_gru_cell_workspace_bytes(1, 64, 500, 500) > 3 * 64 * 250000 * 4
     # argument validation happens before any HIP call
     assert lib.urnn_stage_conv_f32(0, 0, 0, 1, 8, 16, 4, 4, 0, 0.2, 0) == -2      # URNN_ENULL
@@ -135,3 +137,26 @@ def test_swp_window_schedule():
     assert window_starts(5, 4, 12) == [5, 9, 13]
     assert window_starts(0, 4, 10) == [0, 4, 6]
     assert window_starts(0, 8, 8) == [0]
+
+
+def test_exp_config_keys_match_the_benchmarked_workloads(tmp_path):
+    """The experiment YAMLs of the reference (configs/*.yaml, keys of config.py:55-213) parse to the workload tuples bench.py
+    ships for the BASELINE configs -- values restated here from location1_scratch.yaml:41-58, lite.yaml:31-58,
+    futian_scratch.yaml:41-68, ukea_scratch.yaml:43-70 (the reference tree does not travel with the tests)."""
+    import bench
+    from urnn_amd.exp_config import load_exp_config, workload
+    shipped = {
+        "location1": dict(input_height=500, input_width=500, historical_nums=30, rain_max=6.0, cumsum_rain_max=250.0, duration=360,
+                          flood_max=5000, seq_num=12, window_size=36),
+        "lite128": dict(input_height=128, input_width=128, historical_nums=3, rain_max=60.0, cumsum_rain_max=250.0, duration=36),
+        "futian": dict(input_height=400, input_width=560, historical_nums=6, rain_max=5.0, cumsum_rain_max=100.0, duration=72),
+        "ukea": dict(input_height=52, input_width=120, historical_nums=6, rain_max=10.0, cumsum_rain_max=150.0, duration=36),
+    }
+    import yaml
+    for name, keys in shipped.items():
+        path = tmp_path / f"{name}.yaml"
+        path.write_text(yaml.safe_dump({**keys, "lr": 0.01, "loss_name": "FocalBCE_and_WMSE"}))
+        cfg = load_exp_config(str(path))
+        assert workload(cfg, bench.CONFIGS[name][6]) == bench.CONFIGS[name], name
+        assert cfg["lr"] == 0.01 and isinstance(cfg["seq_num"], int)          # unknown keys kept, defaults typed
+    assert load_exp_config(str(tmp_path / "location1.yaml"), duration=None, test_list_file="x.txt")["test_list_file"] == "x.txt"

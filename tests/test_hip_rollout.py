@@ -47,6 +47,9 @@ def test_rollout_vs_reference(golden, dev, name, use_graph):
     cls = eng.out_cls[:T:every, 0].cpu().numpy()
     raw = eng.out_raw[:T:every, 0].cpu().numpy()
     tol = 1e-4
+    print(f"{name} graph={use_graph}: cls {rel_err(cls, g['cls']):.2e} (floor 0.1 max) / {rel_err(cls, g['cls'], 1e-3):.2e} (strict 1e-3 max); "
+          f"pre-mask reg {rel_err(raw, g['raw']):.2e} / {rel_err(raw, g['raw'], 1e-3):.2e}; states " +
+          ", ".join(f"{rel_err(eng.states[k].cpu().numpy(), g[f'final_state{k}']):.1e}/{rel_err(eng.states[k].cpu().numpy(), g[f'final_state{k}'], 1e-3):.1e}" for k in range(6)))
     assert_close(cls, g["cls"], tol, "cls over rollout")
     assert_close(raw, g["raw"], tol, "pre-mask reg over rollout")
     for k in range(6):
@@ -72,8 +75,10 @@ def test_inference_entry_matches_reference(golden, dev):
     out = Inference(net, {k: torch.from_numpy(np.asarray(v)) for k, v in ev.items()}, dev, historical_nums=nums,
                     rain_max=float(g["rain_max"]), cumsum_rain_max=float(g["cumsum_max"]), input_height=H, input_width=W)
     assert out.shape == g["out"].shape and out.dtype == np.float32
-    diff = np.abs(out - g["out"])
-    assert (diff > 1e-4 * max(1e-3, np.abs(g["out"]).max())).mean() < 0.01
+    # every pixel whose reference class map is not within 1e-5 of the threshold (the goldens hold the reference's cls / pre-mask
+    # regression of the same test.Inference call, make_golden.py head_taps)
+    excluded = masked_parity(out, g["out"], g["cls"], g["raw"], 1e-4)
+    assert excluded <= 2
 
 
 def test_graph_replay_is_deterministic(dev):
@@ -206,15 +211,20 @@ def _check_rollout_vs_oracle(eng, frames, T, ref, what, state_yardstick=None):
     (state_yardstick = the plain-fp32-torch errors of _torch_fp32_state_errors), no further from the oracle than 3x what the
     reference's own fp32 arithmetic is (the rule of test_rollout_vs_reference)."""
     ref_frames, ref_states, ref_raw, ref_cls = ref
-    assert_close(eng.out_raw[:T].cpu().numpy(), ref_raw, 1e-4, f"pre-mask reg, {what}")
-    assert_close(eng.out_cls[:T].cpu().numpy(), ref_cls, 1e-4, f"cls, {what}")
+    got_raw, got_cls = eng.out_raw[:T].cpu().numpy(), eng.out_cls[:T].cpu().numpy()
+    # both floors are printed (SURVEY 8c proposes 1e-3 * max|b|; conftest.rel_err explains the 0.1 * max|b| the 1e-4 bar uses)
+    print(f"{what}: worst frame, pre-mask reg: {rel_err(got_raw, ref_raw):.2e} (floor 0.1 max) / {rel_err(got_raw, ref_raw, 1e-3):.2e} (strict floor "
+          f"1e-3 max); cls: {rel_err(got_cls, ref_cls):.2e} / {rel_err(got_cls, ref_cls, 1e-3):.2e}")
+    assert_close(got_raw, ref_raw, 1e-4, f"pre-mask reg, {what}")
+    assert_close(got_cls, ref_cls, 1e-4, f"cls, {what}")
     report = []
     for k, (got, want) in enumerate(zip(eng.final_states(), ref_states)):
-        err = rel_err(got.cpu().numpy(), want)
+        g = got.cpu().numpy()
+        err = rel_err(g, want)
         bar = 1e-4 if state_yardstick is None else max(1e-4, 3.0 * state_yardstick[k])
-        report.append((k, err, None if state_yardstick is None else state_yardstick[k]))
+        report.append((k, f"{err:.2e}", f"strict {rel_err(g, want, 1e-3):.2e}", None if state_yardstick is None else f"torch {state_yardstick[k]:.2e}"))
         assert err <= bar, f"final state {k}, {what}: rel err {err:.3e} > {bar:.1e} (plain fp32 torch: {state_yardstick and state_yardstick[k]})"
-    print(f"{what}: final-state errors (state, HIP vs oracle, plain fp32 torch vs oracle): {report}")
+    print(f"{what}: final-state errors (state, HIP vs oracle, same under the strict floor, plain fp32 torch vs oracle): {report}")
     excluded = masked_parity(frames, ref_frames, ref_cls, ref_raw, 1e-4)
     assert excluded < 1e-3 * frames.size, f"{excluded} threshold pixels excluded, {what}"     # |cls - 0.5| <= 1e-5: ~1e-4 of the pixels
 
@@ -239,6 +249,26 @@ def test_full_size_rollout_vs_oracle(dev, overlap):
     _check_rollout_vs_oracle(eng, frames, T, ref, f"500x500 overlap={overlap}", state_yardstick=yard)
     again = eng.rollout(ev).cpu().numpy()           # second event through the same captured graphs
     assert np.array_equal(frames, again)
+
+
+def test_mid_event_slice_vs_oracle(dev):
+    """Frames 60 .. 179 of the location1 event (BASELINE configs[1]: 500x500, C = 63, seed 42 -- the stretch where roundoff is
+    amplified most, profiles/r02_parity_T360.txt) on the benchmarked schedule: the engine rolls frames 0 .. 59, hands its states
+    to the CPU oracle and to plain float32 torch (the reference's own arithmetic), and all three run the next 120 frames
+    (tests/slice_parity.py; test.py:352-371).  Every frame's cls / pre-mask regression and the final states within
+    max(1e-4, 3x the torch-fp32 error of the same frame); relaxed- and strict-floor errors are printed side by side; and over
+    the slice the HIP path must not be further from the oracle than the reference's arithmetic is (mean error ratio <= 1)."""
+    import slice_parity
+    res = slice_parity.run_slice(dev, t0=60, n=120)
+    slice_parity.report(res)
+    for r in res["rows"]:
+        assert r[1] <= max(1e-4, 3.0 * r[2]), f"frame {r[0]}: pre-mask reg {r[1]:.2e} (torch-fp32 {r[2]:.2e})"
+        assert r[3] <= max(1e-4, 3.0 * r[4]), f"frame {r[0]}: cls {r[3]:.2e} (torch-fp32 {r[4]:.2e})"
+    for k, eh, et, _, _ in res["states"]:
+        assert eh <= max(1e-4, 3.0 * et), f"state {k}: {eh:.2e} (torch-fp32 {et:.2e})"
+    ratio_reg = float(np.mean([r[1] / r[2] for r in res["rows"]]))
+    ratio_cls = float(np.mean([r[3] / r[4] for r in res["rows"]]))
+    assert ratio_reg <= 1.0 and ratio_cls <= 1.0, f"mean HIP / torch-fp32 error ratio: reg {ratio_reg:.2f}, cls {ratio_cls:.2f}"
 
 
 def test_benchmarked_schedule_is_bit_stable_over_whole_events(dev):

@@ -179,39 +179,51 @@ def _bench_net(dev, H, W, C, seed=0):
     return net.to(dev).eval(), sd
 
 
-def _train_inputs(dev, H, W, rain_max, frames, seed=7):
+def _train_inputs(dev, H, W, rain_max, frames, seed=7, batch=1):
     import urnn_amd.weights as uw
-    ev = uw.make_event(frames, H, W, rain_max, seed=42)
+    ev = uw.make_event(frames, H, W, rain_max, seed=42, batch=batch)
     g = torch.Generator(device=dev).manual_seed(seed)
-    label = torch.rand(1, frames, H, W, device=dev, generator=g) ** 3
+    label = torch.rand(batch, frames, H, W, device=dev, generator=g) ** 3
     label[label < 0.1] = 0
     return ev, label
 
 
-def test_window_full_size(dev):
-    """One SWP window at BASELINE configs[3]'s grid (location1: 500x500, historical_nums 30 -> C = 63; main.py:598-768): four
-    timesteps from non-zero states through `WindowGradients.run`, every one of the 79 parameter gradients against float64
-    torch autograd of tests/torch_ref.py on the GPU (the restatement takes the fp32 path's LeakyReLU / wet-dry branches where
-    that path materialises the activation, so threshold pixels cannot enter), and everything finite."""
-    import torch_ref
+def _zero_states(dev, B, H, W):
+    from oracle import oracle as orc
+    return [torch.zeros(s.shape, device=dev) for s in orc.zero_states(B, H, W)]
+
+
+def _window_setup(dev, H, W, nums, rain_max, cum_max, steps, t0, B):
+    """Net, event, labels and the states after a gradient-free pre-roll of t0 frames (the window starts from real states)."""
     from urnn_amd.dataset import event_to_device
     from urnn_amd.training import WindowGradients
-    H = W = 500
-    nums, rain_max, cum_max, steps, t0 = 30, 6.0, 250.0, 4, 2
     net, sd = _bench_net(dev, H, W, 2 * nums + 3)
-    ev_np, label = _train_inputs(dev, H, W, rain_max, t0 + steps)
+    ev_np, label = _train_inputs(dev, H, W, rain_max, t0 + steps, batch=B)
     ev = event_to_device(ev_np, dev)
     wg = WindowGradients(net, H, W, nums, rain_max, cum_max)
-    states = None
-    from urnn_amd.general import initialize_states
-    states = [s.to(dev) for s in initialize_states(dev, H, W)]
-    for t in range(t0):                                   # gradient-free pre-roll: the window starts from real states
+    states = _zero_states(dev, B, H, W)
+    for t in range(t0):
         _, states = wg._forward_step(ev, t, states, 0)
-    start = [s.clone() for s in states]
+    return net, sd, ev, label, wg, [s.clone() for s in states]
+
+
+@pytest.mark.parametrize("name,H,W,nums,rain_max,cum_max,steps,t0,B", [
+    # BASELINE configs[3]'s grid (location1: 500x500, historical_nums 30 -> C = 63; location1_scratch.yaml:56-58)
+    ("location1", 500, 500, 30, 6.0, 250.0, 4, 2, 1),
+    # BASELINE configs[2]: the lightweight grid with 8 events per GPU and the reference's seq_num = 12 windows (lite.yaml:31-36,56-58)
+    ("lite128xB8", 128, 128, 3, 60.0, 250.0, 12, 2, 8),
+])
+def test_window_full_size(dev, name, H, W, nums, rain_max, cum_max, steps, t0, B):
+    """One SWP window (main.py:598-768) at a BASELINE training configuration's own size, from non-zero states, through
+    `WindowGradients.run`: every one of the 79 parameter gradients against float64 torch autograd of tests/torch_ref.py on the
+    GPU (the restatement takes the fp32 path's LeakyReLU / wet-dry branches where that path materialises the activation, so
+    threshold pixels cannot enter), and everything finite."""
+    import torch_ref
+    net, sd, ev, label, wg, start = _window_setup(dev, H, W, nums, rain_max, cum_max, steps, t0, B)
     out = wg.run(ev, label[:, t0:t0 + steps], t0, steps, states=[s.clone() for s in start])
     torch.cuda.synchronize()
-    for name, gr in out["grads"].items():
-        assert bool(torch.isfinite(gr).all()), f"non-finite gradient in {name}"
+    for pname, gr in out["grads"].items():
+        assert bool(torch.isfinite(gr).all()), f"non-finite gradient in {pname}"
 
     # float64 autograd of the same window; branch decisions from the fp32 forward of each step
     p = {k: torch.from_numpy(v).to(dev).double().requires_grad_(True) for k, v in sd.items()}
@@ -221,23 +233,63 @@ def test_window_full_size(dev):
         S, st_hip = wg._forward_step(ev, t0 + s, st_hip, 0)
         hip = {k: S[k].double() for k in ("a1", "u3", "u2", "feat", "raw", "cls")}
         masked, _, _, st64 = torch_ref.step(p, S["x_in"].double(), st64, H, W, hip=hip)
-        assert_close(masked.detach().cpu().numpy(), S["masked"].cpu().numpy(), 1e-4, f"step {s}: forward output")
+        assert_close(masked.detach().cpu().numpy(), S["masked"].cpu().numpy(), 1e-4, f"{name} step {s}: forward output")
         regs.append(masked)
     loss = torch_ref.wmse(torch.stack(regs, dim=1), label[:, t0:t0 + steps].double())
     loss.backward()
     assert float(out["loss"][1]) == pytest.approx(float(loss), rel=2e-4)
     worst = ("", 0.0)
-    for name in sd:
-        ref = p[name].grad
-        got = out["grads"][name].double().reshape(p[name].shape)
+    for pname in sd:
+        ref = p[pname].grad
+        got = out["grads"][pname].double().reshape(p[pname].shape)
         if ref is None:                                   # classification branch: cut off by the wet/dry comparison
-            assert float(got.abs().max()) == 0.0, name
+            assert float(got.abs().max()) == 0.0, pname
             continue
         scale = float(ref.abs().max())
         err = float((got - ref).abs().max()) / max(scale, 1e-30)
-        worst = max(worst, (name, err), key=lambda t: t[1])
-        assert err <= 1e-3, (name, err, scale)            # the bar of the 16x16 window test (test_hip_train.py)
-    print("worst gradient at 500x500:", worst)
+        worst = max(worst, (pname, err), key=lambda t: t[1])
+        assert err <= 1e-3, (pname, err, scale)           # the bar of the 16x16 window test (test_hip_train.py)
+    print(f"worst gradient, {name} {H}x{W} B={B} seq {steps}:", worst)
+
+
+def test_bf16_window_full_size(dev):
+    """BASELINE configs[3]'s bf16 arm at its own grid (500x500, C = 63): the reference only declares --amp (config.py:179), so
+    the bf16 compute mode (urnn_set_matrix_mode: GEMM operands rounded to bf16 -- forward, input- and weight-gradient GEMMs --
+    fp32 accumulation, fp32 norms / states / loss / Adam) is judged against this build's own fp32 window, whose 79 gradients
+    test_window_full_size pins to float64 autograd.  Stated bounds: bf16 keeps 8 significant bits (2^-9 = 2e-3 per rounded
+    operand); through four recurrent steps and ~40 GEMMs the loss stays within 2 % and every gradient tensor within 10 % of its
+    own max-abs and at cosine >= 0.995 of the fp32 gradient; the fp32 mode is bit-unchanged afterwards."""
+    from urnn_amd import ops
+    H = W = 500
+    nums, rain_max, cum_max, steps, t0 = 30, 6.0, 250.0, 4, 2
+    net, sd, ev, label, wg, start = _window_setup(dev, H, W, nums, rain_max, cum_max, steps, t0, 1)
+    ref = wg.run(ev, label[:, t0:t0 + steps], t0, steps, states=[s.clone() for s in start])
+    ref_g = {k: v.clone() for k, v in ref["grads"].items()}
+    ref_loss = float(ref["loss"][1])
+    with ops.matrix_mode("bf16"):
+        low = wg.run(ev, label[:, t0:t0 + steps], t0, steps, states=[s.clone() for s in start])
+        low_g = {k: v.clone() for k, v in low["grads"].items()}
+        low_loss = float(low["loss"][1])
+    again = wg.run(ev, label[:, t0:t0 + steps], t0, steps, states=[s.clone() for s in start])
+    torch.cuda.synchronize()
+    assert all(torch.equal(again["grads"][k], ref_g[k]) for k in ref_g), "fp32 mode must be bit-unchanged after the bf16 scope"
+    assert low_loss == pytest.approx(ref_loss, rel=2e-2), (low_loss, ref_loss)
+    worst_rel, worst_cos, differs = ("", 0.0), ("", 1.0), 0
+    for k, r in ref_g.items():
+        g = low_g[k]
+        assert bool(torch.isfinite(g).all()), k
+        scale = float(r.abs().max())
+        if scale == 0.0:                                   # classification branch: exactly zero in both modes
+            assert float(g.abs().max()) == 0.0, k
+            continue
+        rel = float((g - r).abs().max()) / scale
+        cos = float((g.double() * r.double()).sum() / (g.double().norm() * r.double().norm()))
+        differs += int(rel > 1e-5)
+        worst_rel = max(worst_rel, (k, rel), key=lambda t: t[1])
+        worst_cos = min(worst_cos, (k, cos), key=lambda t: t[1])
+        assert rel <= 0.10 and cos >= 0.995, (k, rel, cos)
+    print(f"bf16 vs fp32 window at 500x500: loss {low_loss:.6f} vs {ref_loss:.6f}; worst |dg|/max {worst_rel}; worst cosine {worst_cos}")
+    assert differs > 40, "the bf16 mode must actually change the arithmetic"
 
 
 def test_trainer_graph_equals_eager_full_size(dev):

@@ -69,7 +69,8 @@ static void pick_tile(long pixels_total, int waves_per_tile, long P, int *pb_out
 extern "C" size_t urnn_packed_conv_floats(int Cin, int Cout)
 {
     const size_t NB = urnn_conv_nb(Cout), NG = urnn_conv_ng(Cout), KT = (Cin + 1) / 2;
-    return NG * slab_floats(KT, NB) + NG * NB * 32 + NG * (size_t)urnn_split_slab_dwords((int)KT, (int)NB);
+    return NG * slab_floats(KT, NB) + NG * NB * 32 + NG * (size_t)urnn_split_slab_dwords((int)KT, (int)NB) +
+           NG * (size_t)urnn_f16_slab_dwords((int)KT, (int)NB);
 }
 
 extern "C" int urnn_pack_conv_f32(const float *weight, const float *bias, float *packed, int Cin, int Cout, void *stream)
@@ -86,7 +87,8 @@ extern "C" size_t urnn_packed_gru_floats(int I, int F, int skip)
     const size_t KT = (size_t)(((I + 1) & ~1) + (skip ? F : 0) + F) / 2;
     const size_t NB2 = urnn_cand_nb(F);
     return (size_t)(F / 32) * slab_floats(KT, 2) + 2 * F + (size_t)((F / 32) / NB2) * slab_floats(KT, NB2) + F +
-           (size_t)(F / 32) * urnn_split_slab_dwords((int)KT, 2) + (size_t)((F / 32) / NB2) * urnn_split_slab_dwords((int)KT, (int)NB2);
+           (size_t)(F / 32) * urnn_split_slab_dwords((int)KT, 2) + (size_t)((F / 32) / NB2) * urnn_split_slab_dwords((int)KT, (int)NB2) +
+           (size_t)(F / 32) * urnn_f16_slab_dwords((int)KT, 2) + (size_t)((F / 32) / NB2) * urnn_f16_slab_dwords((int)KT, (int)NB2);
 }
 
 extern "C" int urnn_pack_gru_f32(const float *W1, const float *b1, const float *W2, const float *b2, float *packed, int I, int F,
@@ -102,7 +104,8 @@ extern "C" int urnn_pack_gru_f32(const float *W1, const float *b1, const float *
 extern "C" size_t urnn_packed_deconv_floats(int Cin, int Cout)
 {
     const size_t NB = 2 * (size_t)((Cout + 31) / 32), KT = (Cin + 1) / 2;
-    return 2 * slab_floats(KT, NB) + 2 * NB * 32 + 2 * (size_t)urnn_split_slab_dwords((int)KT, (int)NB);
+    return 2 * slab_floats(KT, NB) + 2 * NB * 32 + 2 * (size_t)urnn_split_slab_dwords((int)KT, (int)NB) +
+           2 * (size_t)urnn_f16_slab_dwords((int)KT, (int)NB);
 }
 
 extern "C" int urnn_pack_deconv_f32(const float *weight, const float *bias, float *packed, int Cin, int Cout, void *stream)
@@ -114,8 +117,18 @@ extern "C" int urnn_pack_deconv_f32(const float *weight, const float *bias, floa
 }
 
 // ---- stage conv ------------------------------------------------------------------------------------------------------
+static int stage_conv_impl(const float *in, const float *packed, float *out, int B, int Cin, int Cout, int H, int W, int pool, float slope,
+                           int wide, void *stream);
+
 extern "C" int urnn_stage_conv_f32(const float *in, const float *packed, float *out, int B, int Cin, int Cout, int H, int W,
                                    int pool, float slope, void *stream)
+{
+    return stage_conv_impl(in, packed, out, B, Cin, Cout, H, W, pool, slope, 0, stream);
+}
+
+// wide = 1: `in` holds gradients (the input-gradient GEMMs of the backward pass): bf16 x 6 split instead of f16 x 3
+static int stage_conv_impl(const float *in, const float *packed, float *out, int B, int Cin, int Cout, int H, int W, int pool, float slope,
+                           int wide, void *stream)
 {
     if (!in || !packed || !out) return fail(URNN_ENULL, "urnn_stage_conv_f32: NULL argument");
     if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return fail(URNN_EINVAL, "urnn_stage_conv_f32: bad dims");
@@ -139,11 +152,14 @@ extern "C" int urnn_stage_conv_f32(const float *in, const float *packed, float *
     p.bias = packed + (size_t)NG * p.aFloats;
     p.wsplit = reinterpret_cast<const unsigned *>(p.bias + (size_t)NG * NB * 32);
     p.sDwords = urnn_split_slab_dwords(p.KT, NB);
+    p.wf16 = p.wsplit + (size_t)NG * p.sDwords;
+    p.fDwords = urnn_f16_slab_dwords(p.KT, NB);
     p.P = (int)P;
     p.W = W;
     p.Cout = Cout;
     p.slope = slope;
     p.out0 = out;
+    p.wide = wide;
     hipStream_t st = (hipStream_t)stream;
     if (pool) {
         p.W2 = W / 2;
@@ -253,6 +269,8 @@ static int gru_cell_impl(const float *x, const float *e, const float *h, const f
     const float *split0 = packed + (size_t)NW * p.aFloats + 2 * F + (size_t)(NW / NB2s) * slab_floats(KT, NB2s) + F;
     p.wsplit = reinterpret_cast<const unsigned *>(split0);
     p.sDwords = urnn_split_slab_dwords(KT, 2);
+    p.wf16 = p.wsplit + (size_t)NW * p.sDwords + (size_t)(NW / NB2s) * urnn_split_slab_dwords(KT, NB2s);
+    p.fDwords = urnn_f16_slab_dwords(KT, 2);
     p.P = (int)P;
     p.W = W;
     p.F = F;
@@ -303,6 +321,8 @@ static int gru_cell_impl(const float *x, const float *e, const float *h, const f
     c.bias = c.wt + (size_t)NG2 * c.aFloats;
     c.wsplit = p.wsplit + (size_t)NW * p.sDwords;
     c.sDwords = urnn_split_slab_dwords(KT, NB2);
+    c.wf16 = p.wf16 + (size_t)NW * p.fDwords;
+    c.fDwords = urnn_f16_slab_dwords(KT, NB2);
     c.Cout = F;
     c.out0 = ws.cx;
     c.partial = ws.part2;
@@ -462,11 +482,14 @@ static int conv_2seg(const float *in0, int C0, const float *in1, int C1, const f
     p.bias = packed + (size_t)NG * p.aFloats;
     p.wsplit = reinterpret_cast<const unsigned *>(p.bias + (size_t)NG * NB * 32);
     p.sDwords = urnn_split_slab_dwords(p.KT, NB);
+    p.wf16 = p.wsplit + (size_t)NG * p.sDwords;
+    p.fDwords = urnn_f16_slab_dwords(p.KT, NB);
     p.P = (int)P;
     p.W = W;
     p.Cout = Cout;
     p.slope = 1.0f;
     p.out0 = out;
+    p.wide = 1;                                    // gradients: no lower bound on the magnitudes -> bf16 x 6, not f16 x 3
     int pb, map;
     pick_tile((long)B * P, NG, P, &pb, &map, "URNN_TUNE_PB_CONV", 1024);
     CHECK_HIP(urnn_launch_conv_flat(p, B, pb, map, st), what);
@@ -484,7 +507,7 @@ static int pack_transposed(const float *w, float *wt, float *packed, int N, int 
 
 static int dx_gemm(const float *dy, const float *packed, float *out, int B, int N, int K, int H, int W, hipStream_t st)
 {
-    return urnn_stage_conv_f32(dy, packed, out, B, N, K, H, W, 0, 1.0f, st);
+    return stage_conv_impl(dy, packed, out, B, N, K, H, W, 0, 1.0f, 1, st);
 }
 
 extern "C" int urnn_gru_cell_backward_f32(const float *x, const float *e, const float *h, const float *W1, const float *W2,
@@ -716,6 +739,8 @@ extern "C" int urnn_deconv2x2_f32(const float *in, const float *packed, float *o
     p.bias = packed + (size_t)2 * p.aFloats;
     p.wsplit = reinterpret_cast<const unsigned *>(p.bias + (size_t)2 * NB * 32);
     p.sDwords = urnn_split_slab_dwords(p.KT, NB);
+    p.wf16 = p.wsplit + (size_t)2 * p.sDwords;
+    p.fDwords = urnn_f16_slab_dwords(p.KT, NB);
     p.P = (int)P;
     p.W = W;
     p.Cout = Cout;

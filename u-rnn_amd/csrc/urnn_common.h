@@ -23,6 +23,10 @@ static inline int urnn_round_up(int v, int m) { return (v + m - 1) / m * m; }
 // one conflict-free ds_read_b128 per piece.  Dwords per n-group:
 __host__ __device__ static inline int urnn_split_slab_dwords(int KT, int NB) { return ((KT + 7) / 8) * NB * 3 * 256; }
 
+// Packed weights, F16 form (urnn_gemm.hip SPLIT = 3, the f16 x 3 k-loop): the same image with TWO f16 pieces (hi | lo) of
+// W * 2^URNN_F16_WEXP per 16-k group and n-block:  [KT / 8][NB][2 pieces][64 lanes][4 dwords].  Dwords per n-group:
+__host__ __device__ static inline int urnn_f16_slab_dwords(int KT, int NB) { return ((KT + 7) / 8) * NB * 2 * 256; }
+
 // Row of the 32x32 MFMA C/D tile held in accumulator register r by a lane of the given half-wave:
 // row = (r & 3) + 8 * (r >> 2) + 4 * half  (cdna_hip_programming.md section 3; col = lane & 31).
 __device__ __forceinline__ int mfma_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
@@ -49,14 +53,64 @@ __device__ __forceinline__ double tile_x2(float s1, float y, int n)
     return n > 0 ? (double)y + (double)s1 * (double)s1 / (double)n : (double)y;
 }
 
-__device__ __forceinline__ float sigmoidf_fast(float v) { return __frcp_rn(1.0f + __expf(-v)); }
+// Activations.  URNN_ACT = 0: hardware exp2 / rcp (v_exp_f32 on x * log2(e): the argument's rounding costs |x| * 2^-24 relative,
+// and 1 - t cancels for small |x|); 1: argument reduction in two pieces (x * log2e split into hi + lo so that the exponent's
+// fraction is exact to ~2^-30) and tanh through expm1-style evaluation for small arguments -- ~1 ulp results, the errors unbiased.
+#ifndef URNN_ACT
+#define URNN_ACT 1
+#endif
+// exp(x) for x <= 0 (the only sign the activations need), ~1 ulp: 2^n * 2^f with n = rint(x * log2e) and f accurate to 2^-30
+__device__ __forceinline__ float exp_neg(float x)
+{
+#if URNN_ACT == 0
+    return __expf(x);
+#else
+    const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-08f;   // log2(e) = hi + lo
+    const float t = x * L2E_HI;
+    const float n = rintf(t);
+    float f = fmaf(x, L2E_HI, -n);          // exact product, one rounding of a value in [-0.5, 0.5]
+    f = fmaf(x, L2E_LO, f);
+    const float e = __builtin_amdgcn_exp2f(f);          // v_exp_f32, 1 ulp, f in [-0.5, 0.5]
+    return ldexpf(e, (int)n);                           // v_ldexp_f32 (underflows to 0 / denormals like expf)
+#endif
+}
+__device__ __forceinline__ float sigmoidf_fast(float v)
+{
+#if URNN_ACT == 0
+    return __frcp_rn(1.0f + __expf(-v));
+#else
+    // sigmoid(v) = 1 / (1 + exp(-|v|)) for v >= 0, exp(-|v|) / (1 + exp(-|v|)) for v < 0: exp of a non-positive argument only
+    const float e = exp_neg(-fabsf(v));
+    const float r = __frcp_rn(1.0f + e);
+    return v >= 0.f ? r : e * r;
+#endif
+}
 
 __device__ __forceinline__ float tanhf_fast(float v)
 {
+#if URNN_ACT == 0
     // tanh(v) = sign(v) * (1 - t) / (1 + t), t = exp(-2|v|)  (absolute error ~1e-7)
     const float t = __expf(-2.0f * fabsf(v));
     const float r = (1.0f - t) * __frcp_rn(1.0f + t);
     return copysignf(r, v);
+#else
+    const float a = fabsf(v);
+    float r;
+    if (a < 0.4f) {
+        // Taylor series to a^13 on [0, 0.4]: tanh(a) = a + a^3 P(a^2), truncation < 4e-9 relative
+        const float s = a * a;
+        float p = fmaf(s, 21844.0f / 6081075.0f, -1382.0f / 155925.0f);     // +a^13, -a^11
+        p = fmaf(s, p, 62.0f / 2835.0f);
+        p = fmaf(s, p, -17.0f / 315.0f);
+        p = fmaf(s, p, 2.0f / 15.0f);
+        p = fmaf(s, p, -1.0f / 3.0f);
+        r = fmaf(a * s, p, a);
+    } else {
+        const float t = exp_neg(-2.0f * a);
+        r = (1.0f - t) * __frcp_rn(1.0f + t);            // t <= 0.33: 1 - t loses no more than one bit
+    }
+    return copysignf(r, v);
+#endif
 }
 
 // Truncating three-way bf16 split of an fp32 value (exact: x = hi + mid + lo, 8 significant bits each); piece 0 / 1 / 2 as the
@@ -93,6 +147,45 @@ __device__ __forceinline__ void split_pair(float xe, float xo, unsigned &ph, uns
     const float se = re - __uint_as_float(ve & 0xffff0000u), so = ro - __uint_as_float(vo & 0xffff0000u);   // exact, <= 8 bits left
     pl = __builtin_amdgcn_perm(__float_as_uint(so), __float_as_uint(se), 0x07060302u);
 }
+
+// ---- f16 x 3 (SPLIT = 3): the forward GEMMs' arithmetic ------------------------------------------------------------------------
+// x = hi + lo with hi = RNE_f16(x * 2^a), lo = RNE_f16(x * 2^a - hi) (the residual is exact in fp32): 22 significant bits, and
+// a*b = hh + hl + lh up to 2^-22 |ab| -- three v_mfma_f32_32x32x16_f16 per 16 k instead of six bf16 ones, two VALU per element
+// instead of 5.5.  f16 has 5 exponent bits, so both operands are scaled by powers of two (exact) into its comfortable range and
+// the accumulator is scaled back in the epilogue: activations by 2^5 (lo keeps all its bits for |x| >= 2^-8, below that the
+// absolute error is <= 2^-30; finite up to |x| < 2047), weights by 2^10 (full precision for |w| >= 2^-13, finite for |w| < 64).
+// Measured against float64 (K = 224, tools/ubench/split_mfma.hip, profiles/r02_split_mfma.txt): rms 1.8e-7 of sqrt(sum (w x)^2)
+// (fp32 MFMA chain 2.7e-7, bf16 x 6 2.2e-7).  Gradients (unbounded below) keep the bf16 x 6 split, which has fp32's exponent range.
+// An activation beyond the f16 range turns into inf -> NaN statistics -> NaN frames: loud, not silent.
+#define URNN_F16_AEXP 5
+#define URNN_F16_WEXP 10
+#define URNN_F16_ASCALE 32.0f
+#define URNN_F16_WSCALE 1024.0f
+#define URNN_F16_DESCALE 0x1p-15f
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// One dword of each f16 piece from two fp32 values (low half: xe, high half: xo), both scaled by s (a power of two).
+__device__ __forceinline__ void split2_pair(float xe, float xo, float s, unsigned &ph, unsigned &pl)
+{
+    // v_fma_mix*: fp32 fma whose result is rounded (RNE) into one half of the destination; op_sel_hi marks an f16 source, op_sel
+    // picks its high half.  hi = rne(x*s); lo = rne(x*s - hi): four VALU for two elements.
+    asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
+        "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
+        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(ph), "=&v"(pl)
+        : "v"(xe), "v"(xo), "s"(s));
+}
+// the same split of one value (weight packers): piece 0 = hi, 1 = lo, as the 16 bits of the f16 encoding
+__host__ __device__ static inline unsigned f16_piece(float x, int piece)
+{
+    const _Float16 h = (_Float16)x;
+    const _Float16 v = piece == 0 ? h : (_Float16)(x - (float)h);
+    unsigned short u;
+    __builtin_memcpy(&u, &v, 2);
+    return u;
+}
+__device__ __forceinline__ f16x8 as_f16x8(const unsigned (&p)[4]) { return __builtin_bit_cast(f16x8, u32x4{p[0], p[1], p[2], p[3]}); }
 
 // bf16 compute mode (SPLIT = 2): one dword of round-to-nearest-even bf16 values (v_cvt_pk_bf16_f32)
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));

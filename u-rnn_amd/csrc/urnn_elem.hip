@@ -746,17 +746,39 @@ __device__ __forceinline__ void split_slot(int r, int NB, int &kp_even, int &nb,
     kp_even = 8 * grp + 2 * (rr & 3);
 }
 
+// dword `r` of an n-group's f16 slab (two pieces per n-block)
+__device__ __forceinline__ void f16_slot(int r, int NB, int &kp_even, int &nb, int &piece, int &l)
+{
+    const int grp = r / (NB * 512), rr = r - grp * (NB * 512);
+    nb = rr / 512;
+    piece = (rr - nb * 512) / 256;
+    l = (rr & 255) >> 2;
+    kp_even = 8 * grp + 2 * (rr & 3);
+}
+__device__ __forceinline__ unsigned f16_pair(float we, float wo, int piece)
+{
+    return f16_piece(we * URNN_F16_WSCALE, piece) | (f16_piece(wo * URNN_F16_WSCALE, piece) << 16);
+}
+
 __global__ void pack_conv_kernel(const float *__restrict__ w, const float *__restrict__ bias, float *__restrict__ packed, int Cin,
                                  int Cout, int NB, int NG, int KT)
 {
-    const int slab = slab_floats(KT, NB), ssd = urnn_split_slab_dwords(KT, NB);
+    const int slab = slab_floats(KT, NB), ssd = urnn_split_slab_dwords(KT, NB), fsd = urnn_f16_slab_dwords(KT, NB);
     const int nw = NG * slab, Npad = NG * NB * 32;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= nw + Npad + NG * ssd) return;
+    if (idx >= nw + Npad + NG * ssd + NG * fsd) return;
     auto wv = [&](int g, int kp, int nb, int l) {
         const int k = 2 * kp + (l >> 5), n = (g * NB + nb) * 32 + (l & 31);
         return (kp < KT && k < Cin && n < Cout) ? w[(size_t)n * Cin + k] : 0.f;
     };
+    if (idx >= nw + Npad + NG * ssd) {
+        const int q = idx - nw - Npad - NG * ssd;
+        const int g = q / fsd;
+        int kp, nb, piece, l;
+        f16_slot(q - g * fsd, NB, kp, nb, piece, l);
+        reinterpret_cast<unsigned *>(packed)[idx] = f16_pair(wv(g, kp, nb, l), wv(g, kp + 1, nb, l), piece);
+        return;
+    }
     if (idx < nw) {
         const int g = idx / slab, r = idx - g * slab;
         const int l = r & 63, row = r >> 6;
@@ -777,7 +799,7 @@ __global__ void pack_conv_kernel(const float *__restrict__ w, const float *__res
 hipError_t urnn_launch_pack_conv(const float *w, const float *bias, float *packed, int Cin, int Cout, hipStream_t st)
 {
     const int NB = urnn_conv_nb(Cout), NG = urnn_conv_ng(Cout), KT = (Cin + 1) / 2;
-    const int total = NG * slab_floats(KT, NB) + NG * NB * 32 + NG * urnn_split_slab_dwords(KT, NB);
+    const int total = NG * slab_floats(KT, NB) + NG * NB * 32 + NG * urnn_split_slab_dwords(KT, NB) + NG * urnn_f16_slab_dwords(KT, NB);
     hipLaunchKernelGGL(pack_conv_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, bias, packed, Cin, Cout, NB, NG, KT);
     return hipGetLastError();
 }
@@ -794,9 +816,10 @@ __global__ void pack_gru_kernel(const float *__restrict__ W1, const float *__res
     const int KT = (Ie + Fe + F) / 2, NG = F / 32, Ksrc = I + Fe + F;
     const int slab1 = slab_floats(KT, 2), slab2 = slab_floats(KT, NB2), NG2 = NG / NB2;
     const int ssd1 = urnn_split_slab_dwords(KT, 2), ssd2 = urnn_split_slab_dwords(KT, NB2);
-    const int n1 = NG * slab1, nb1 = 2 * F, n2 = NG2 * slab2, nb2 = F, s1 = NG * ssd1, s2 = NG2 * ssd2;
+    const int fsd1 = urnn_f16_slab_dwords(KT, 2), fsd2 = urnn_f16_slab_dwords(KT, NB2);
+    const int n1 = NG * slab1, nb1 = 2 * F, n2 = NG2 * slab2, nb2 = F, s1 = NG * ssd1, s2 = NG2 * ssd2, f1 = NG * fsd1, f2 = NG2 * fsd2;
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n1 + nb1 + n2 + nb2 + s1 + s2) return;
+    if (idx >= n1 + nb1 + n2 + nb2 + s1 + s2 + f1 + f2) return;
     auto src_col = [&](int k) {   // packed row k -> source column of W1 / W2, -1: padding row
         if (k < Ie) return k < I ? k : -1;
         return I + (k - Ie);
@@ -830,7 +853,19 @@ __global__ void pack_gru_kernel(const float *__restrict__ W1, const float *__res
         int q = idx - n1 - nb1 - n2 - nb2;
         int kp, nb, piece, l;
         unsigned d;
-        if (q < s1) {
+        if (q >= s1 + s2) {                       // f16 forms: gate groups, then candidate groups
+            q -= s1 + s2;
+            if (q < f1) {
+                const int i = q / fsd1;
+                f16_slot(q - i * fsd1, 2, kp, nb, piece, l);
+                d = f16_pair(gate_w(i, kp, nb, l), gate_w(i, kp + 1, nb, l), piece);
+            } else {
+                q -= f1;
+                const int g = q / fsd2;
+                f16_slot(q - g * fsd2, NB2, kp, nb, piece, l);
+                d = f16_pair(cand_w(g, kp, nb, l), cand_w(g, kp + 1, nb, l), piece);
+            }
+        } else if (q < s1) {
             const int i = q / ssd1;
             split_slot(q - i * ssd1, 2, kp, nb, piece, l);
             d = bf16_piece(gate_w(i, kp, nb, l), piece) | (bf16_piece(gate_w(i, kp + 1, nb, l), piece) << 16);
@@ -853,7 +888,8 @@ hipError_t urnn_launch_pack_gru(const float *W1, const float *b1, const float *W
     const int KT = (Ie + (skip ? F : 0) + F) / 2;
     const int NB2 = urnn_cand_nb(F);
     const int total = (F / 32) * slab_floats(KT, 2) + 2 * F + ((F / 32) / NB2) * slab_floats(KT, NB2) + F +
-                      (F / 32) * urnn_split_slab_dwords(KT, 2) + ((F / 32) / NB2) * urnn_split_slab_dwords(KT, NB2);
+                      (F / 32) * urnn_split_slab_dwords(KT, 2) + ((F / 32) / NB2) * urnn_split_slab_dwords(KT, NB2) +
+                      (F / 32) * urnn_f16_slab_dwords(KT, 2) + ((F / 32) / NB2) * urnn_f16_slab_dwords(KT, NB2);
     hipLaunchKernelGGL(pack_gru_kernel, dim3((total + 255) / 256), dim3(256), 0, st, W1, b1, W2, b2, packed, I, F, skip, NB2);
     return hipGetLastError();
 }
@@ -864,15 +900,23 @@ __global__ void pack_deconv_kernel(const float *__restrict__ w, const float *__r
                                    int Cout, int NBC, int KT)
 {
     const int NB = 2 * NBC;
-    const int slab = slab_floats(KT, NB), ssd = urnn_split_slab_dwords(KT, NB);
+    const int slab = slab_floats(KT, NB), ssd = urnn_split_slab_dwords(KT, NB), fsd = urnn_f16_slab_dwords(KT, NB);
     const int nw = 2 * slab, Npad = 2 * NB * 32;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= nw + Npad + 2 * ssd) return;
+    if (idx >= nw + Npad + 2 * ssd + 2 * fsd) return;
     auto wv = [&](int a, int kp, int nb, int l) {
         const int k = 2 * kp + (l >> 5);
         const int bb = nb / NBC, co = (nb - bb * NBC) * 32 + (l & 31);
         return (kp < KT && k < Cin && co < Cout) ? w[(((size_t)k * Cout + co) * 2 + a) * 2 + bb] : 0.f;
     };
+    if (idx >= nw + Npad + 2 * ssd) {
+        const int q = idx - nw - Npad - 2 * ssd;
+        const int a = q / fsd;
+        int kp, nb, piece, l;
+        f16_slot(q - a * fsd, NB, kp, nb, piece, l);
+        reinterpret_cast<unsigned *>(packed)[idx] = f16_pair(wv(a, kp, nb, l), wv(a, kp + 1, nb, l), piece);
+        return;
+    }
     if (idx < nw) {
         const int a = idx / slab, r = idx - a * slab;
         const int l = r & 63, row = r >> 6;
@@ -895,7 +939,7 @@ __global__ void pack_deconv_kernel(const float *__restrict__ w, const float *__r
 hipError_t urnn_launch_pack_deconv(const float *w, const float *bias, float *packed, int Cin, int Cout, hipStream_t st)
 {
     const int NBC = (Cout + 31) / 32, NB = 2 * NBC, KT = (Cin + 1) / 2;
-    const int total = 2 * slab_floats(KT, NB) + 2 * NB * 32 + 2 * urnn_split_slab_dwords(KT, NB);
+    const int total = 2 * slab_floats(KT, NB) + 2 * NB * 32 + 2 * urnn_split_slab_dwords(KT, NB) + 2 * urnn_f16_slab_dwords(KT, NB);
     hipLaunchKernelGGL(pack_deconv_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, bias, packed, Cin, Cout, NBC, KT);
     return hipGetLastError();
 }

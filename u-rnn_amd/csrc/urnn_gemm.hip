@@ -253,6 +253,9 @@ __device__ __forceinline__ void block_role(int NG, int &g, int &slot, int &nslot
 // needs (KT - kpBegin) % 8 == 0 and, in the candidate GEMM, a plain part that is a positive multiple of 8 k-pairs.
 // SPLIT = 2: bf16 COMPUTE (urnn_set_matrix_mode(URNN_MATRIX_BF16), BASELINE configs[3]): activations rounded to bf16 (RNE), weights
 // kept to 16 mantissa bits (hi + mid pieces), fp32 accumulate -- two MFMAs per 16 k; statistics, norms, states stay fp32.
+// SPLIT = 3: f16 x 3 (urnn_common.h): both operands as two scaled f16 pieces, three v_mfma_f32_32x32x16_f16 per 16 k, fp32-class
+// accuracy at half the matrix work and a third of the VALU work of SPLIT = 1 -- the forward path's arithmetic; SPLIT = 1 stays
+// for the backward pass's gradients (prm.wide), whose magnitudes have no lower bound.
 template <int NB, int PB, int MAP, int EPI, int D, int WPB, int SPLIT>
 __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const ConvGemmParams prm)
 {
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
     block_role(prm.NG, g, slot0, nslots);
 
     const float *A = reinterpret_cast<const float *>(urnn_smem);       // [KT][NB][64]  (SPLIT: [KT/8][NB][3][64] x 16 B of bf16 pieces)
-    const size_t slabBytes = SPLIT ? (size_t)prm.sDwords * 4 : (size_t)prm.aFloats * 4;
+    const size_t slabBytes = SPLIT == 3 ? (size_t)prm.fDwords * 4 : (SPLIT ? (size_t)prm.sDwords * 4 : (size_t)prm.aFloats * 4);
     char *ring = urnn_smem + slabBytes + wave * ((D + 1) * R::SLOT);
     char *scratch = ring + D * R::SLOT;                                // one extra slot: sink for the count-keeping dummy DMAs
     const int kp_begin = prm.kpBegin, KT = prm.KT;
@@ -279,7 +282,13 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
     const float *bias_h = bias + 4 * half;
     auto row_c = [](int r) { return (r & 3) + 8 * (r >> 2); };
     constexpr bool GATED = (EPI == EPI_CAND);
-    if constexpr (SPLIT) stage_weights(reinterpret_cast<const float *>(prm.wsplit) + (size_t)g * prm.sDwords, urnn_smem, prm.sDwords, wave, WPB, lane);
+    // epilogue value of an accumulator element: the f16 path's operands were scaled by 2^(AEXP + WEXP)
+    auto fin = [](float a, float bv) {
+        if constexpr (SPLIT == 3) return fmaf(a, URNN_F16_DESCALE, bv);
+        else return a + bv;
+    };
+    if constexpr (SPLIT == 3) stage_weights(reinterpret_cast<const float *>(prm.wf16) + (size_t)g * prm.fDwords, urnn_smem, prm.fDwords, wave, WPB, lane);
+    else if constexpr (SPLIT) stage_weights(reinterpret_cast<const float *>(prm.wsplit) + (size_t)g * prm.sDwords, urnn_smem, prm.sDwords, wave, WPB, lane);
     else stage_weights(prm.wt + (size_t)g * prm.aFloats, urnn_smem, prm.aFloats, wave, WPB, lane);
     if (threadIdx.x < NB * 32) bias[threadIdx.x] = prm.bias[n0 + threadIdx.x];
     if constexpr (GATED) {
@@ -466,9 +475,11 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
                 }
             };
             for (int i = 0; i < D; ++i) refill_s(i);
-            constexpr bool BF16C = (SPLIT == 2);
+            constexpr bool BF16C = (SPLIT == 2), F16 = (SPLIT == 3);
+            constexpr int NPC = F16 ? 2 : 3;               // weight pieces per n-block in the LDS slab
             float rb[2][PB];                               // raw fp32 activation fragments: rb[0] even k-pairs, rb[1] odd ones
-            unsigned bh[PB][4], bm[BF16C ? 1 : PB][4], bl[BF16C ? 1 : PB][4];
+            unsigned bh[PB][4], bm[(BF16C || F16) ? 1 : PB][4], bl[BF16C ? 1 : PB][4];
+            const float asc = URNN_F16_ASCALE;
             const char *Ap = urnn_smem + lane * 16;
             auto read_b = [&](int kp, int slot_, bool gated, float (&bv)[PB]) {
                 if (!gated) {
@@ -494,6 +505,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
 #pragma unroll
                     for (int pb = 0; pb < PB; ++pb) {
                         if constexpr (BF16C) bh[pb][Q >> 1] = round_pair(rb[0][pb], rb[1][pb]);
+                        else if constexpr (F16) split2_pair(rb[0][pb], rb[1][pb], asc, bh[pb][Q >> 1], bl[pb][Q >> 1]);
                         else split_pair(rb[0][pb], rb[1][pb], bh[pb][Q >> 1], bm[pb][Q >> 1], bl[pb][Q >> 1]);
                     }
                 }
@@ -506,11 +518,21 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
                 if constexpr (CG) refill_s(wrap(slot + 1));
                 read_b(kp + 1 < KT ? kp + 1 : kp, nslot, NGT, rb[(Q + 1) & 1]);
                 if constexpr (Q == 7) {
-                    const char *ag = Ap + (size_t)(kp >> 3) * (NB * 3 * 1024);
+                    const char *ag = Ap + (size_t)(kp >> 3) * (NB * NPC * 1024);
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
-                        const bf16x8 wh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(ag + (nb * 3 + 0) * 1024));
-                        const bf16x8 wm = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(ag + (nb * 3 + 1) * 1024));
+                        if constexpr (F16) {
+                            const f16x8 fh = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4 *>(ag + (nb * 2 + 0) * 1024));
+                            const f16x8 fl = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4 *>(ag + (nb * 2 + 1) * 1024));
+                            auto mf = [&](const f16x8 &wa, const unsigned (&pbv)[PB][4]) {
+#pragma unroll
+                                for (int pb = 0; pb < PB; ++pb)
+                                    acc[nb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa, as_f16x8(pbv[pb]), acc[nb][pb], 0, 0, 0);
+                            };
+                            mf(fl, bh); mf(fh, bl); mf(fh, bh);                                          // small terms first
+                        } else {
+                        const bf16x8 wh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(ag + (nb * NPC + 0) * 1024));
+                        const bf16x8 wm = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(ag + (nb * NPC + 1) * 1024));
                         auto mm = [&](const bf16x8 &wa, const unsigned (&pbv)[PB][4]) {
 #pragma unroll
                             for (int pb = 0; pb < PB; ++pb)
@@ -519,8 +541,9 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
                         if constexpr (BF16C) {
                             mm(wm, bh); mm(wh, bh);
                         } else {
-                            const bf16x8 wl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(ag + (nb * 3 + 2) * 1024));
+                            const bf16x8 wl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(ag + (nb * NPC + 2) * 1024));
                             mm(wm, bm); mm(wl, bh); mm(wh, bl); mm(wm, bh); mm(wh, bm); mm(wh, bh);     // small terms first
+                        }
                         }
                         __builtin_amdgcn_sched_barrier(0);       // keep the next n-block's weight pieces from being loaded early (registers)
                     }
@@ -644,7 +667,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
                         const float bv = bias_h[nb * 32 + row_c(r)];
                         float v[PB];
 #pragma unroll
-                        for (int pb = 0; pb < PB; ++pb) v[pb] = lrelu(acc[nb][pb][r] + bv, prm.slope);
+                        for (int pb = 0; pb < PB; ++pb) v[pb] = lrelu(fin(acc[nb][pb][r], bv), prm.slope);
                         store_row<MAP, PB>(prm.out0 + ((size_t)b * prm.Cout + n) * prm.P, pm, v);
                     }
                 }
@@ -660,7 +683,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
                         const float bv = bias_h[nb * 32 + row_c(r)];
                         float s = 0.f;
 #pragma unroll
-                        for (int pb = 0; pb < 4; ++pb) s += lrelu(acc[nb][pb][r] + bv, prm.slope);
+                        for (int pb = 0; pb < 4; ++pb) s += lrelu(fin(acc[nb][pb][r], bv), prm.slope);
                         prm.out0[((size_t)b * prm.Cout + n) * prm.P2 + pm.q] = 0.25f * s;
                     }
                 }
@@ -690,10 +713,10 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
                             // two horizontally adjacent input pixels -> four consecutive output floats (W even, p even)
                             if (pm.valid[0]) {
                                 f32x4 v;
-                                v.x = lrelu(acc[cob][0][r] + bv, prm.slope);
-                                v.y = lrelu(acc[NBC + cob][0][r] + bv, prm.slope);
-                                v.z = lrelu(acc[cob][1][r] + bv, prm.slope);
-                                v.w = lrelu(acc[NBC + cob][1][r] + bv, prm.slope);
+                                v.x = lrelu(fin(acc[cob][0][r], bv), prm.slope);
+                                v.y = lrelu(fin(acc[NBC + cob][0][r], bv), prm.slope);
+                                v.z = lrelu(fin(acc[cob][1][r], bv), prm.slope);
+                                v.w = lrelu(fin(acc[NBC + cob][1][r], bv), prm.slope);
                                 *reinterpret_cast<f32x4 *>(oplane + (size_t)oy[0] * W2 + ox[0]) = v;   // (non-temporal here: -1 %)
                             }
                         } else {
@@ -701,8 +724,8 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
                             for (int pb = 0; pb < PB; ++pb)
                                 if (pm.valid[pb]) {
                                     f32x2 v;
-                                    v.x = lrelu(acc[cob][pb][r] + bv, prm.slope);
-                                    v.y = lrelu(acc[NBC + cob][pb][r] + bv, prm.slope);
+                                    v.x = lrelu(fin(acc[cob][pb][r], bv), prm.slope);
+                                    v.y = lrelu(fin(acc[NBC + cob][pb][r], bv), prm.slope);
                                     *reinterpret_cast<f32x2 *>(oplane + (size_t)oy[pb] * W2 + ox[pb]) = v;
                                 }
                         }
@@ -725,7 +748,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
                     const float bv = bias_h[nb * 32 + row_c(r)];
 #pragma unroll
                     for (int pb = 0; pb < PB; ++pb)
-                        if (pm.valid[pb]) s1 += acc[nb][pb][r] + bv;
+                        if (pm.valid[pb]) s1 += fin(acc[nb][pb][r], bv);
                 }
                 s1 = wave_sum(s1);
                 const float mt = s1 * inv_n;
@@ -738,7 +761,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
                     float v[PB];
 #pragma unroll
                     for (int pb = 0; pb < PB; ++pb) {
-                        v[pb] = acc[nb][pb][r] + bv;
+                        v[pb] = fin(acc[nb][pb][r], bv);
                         const float d = v[pb] - mt;
                         if (pm.valid[pb]) s2 = fmaf(d, d, s2);
                     }
@@ -767,7 +790,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
                     const float bv = bias_h[nb * 32 + row_c(r)];
 #pragma unroll
                     for (int pb = 0; pb < PB; ++pb)
-                        if (pm.valid[pb]) s1 += acc[nb][pb][r] + bv;
+                        if (pm.valid[pb]) s1 += fin(acc[nb][pb][r], bv);
                 }
                 s1 = wave_sum(s1);
                 const float mt = s1 * inv_n;
@@ -780,7 +803,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
                     float v[PB];
 #pragma unroll
                     for (int pb = 0; pb < PB; ++pb) {
-                        v[pb] = acc[nb][pb][r] + bv;
+                        v[pb] = fin(acc[nb][pb][r], bv);
                         const float d = v[pb] - mt;
                         if (pm.valid[pb]) s2 = fmaf(d, d, s2);
                     }
@@ -853,13 +876,16 @@ static hipError_t allow_big_lds(K kernel, size_t lds)
 
 // dynamic LDS: weight slab + per-wave rings (D slots + the dummy sink) + bias row + (candidate GEMM) the r-gate scale/shift table
 template <int NB, int PB, int EPI>
-static bool split_ok(const ConvGemmParams &p);
+static int split_mode(const ConvGemmParams &p);
+template <int NB, int PB, int EPI>
+static bool split_ok(const ConvGemmParams &p) { return split_mode<NB, PB, EPI>(p) != 0; }
 
 template <int NB, int PB, int MAP, int EPI>
 static size_t conv_lds_bytes(const ConvGemmParams &p, int D, int WPB)
 {
     using R = Ring<PB, MAP>;
-    const size_t slab = split_ok<NB, PB, EPI>(p) ? (size_t)p.sDwords * 4 : (size_t)p.aFloats * 4;
+    const int sm = split_mode<NB, PB, EPI>(p);
+    const size_t slab = sm == 3 ? (size_t)p.fDwords * 4 : (sm ? (size_t)p.sDwords * 4 : (size_t)p.aFloats * 4);
     return slab + (size_t)WPB * ((D + 1) * R::SLOT) + NB * 128 + (EPI == EPI_CAND ? (size_t)p.B * p.F * 8 : 0);
 }
 
@@ -914,32 +940,51 @@ static int tune_split()
     return v;
 }
 
-// Which k-loop: the bf16 x 6 one (2.67x the fp32 matrix rate, fp32-class accuracy) whenever the K range is made of whole
-// 16-k groups -- every layer of the published network -- and the accumulators leave room for the pieces; else the exact
-// fp32-MFMA one (odd channel counts, the 6-block deconv tile).
-template <int NB, int PB, int EPI>
-static bool split_ok(const ConvGemmParams &p)
+#ifndef URNN_KEEP_BF16X6
+#define URNN_KEEP_BF16X6 0   // 1 (A/B builds): bf16 x 6 instantiations for every epilogue; URNN_TUNE_F16=0 then selects them
+#endif
+static int tune_f16()
 {
-    // accumulators + bf16 pieces: <= 128 accumulators in a 256-register wave (8-wave blocks); the deconv's 6-block tile runs one
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("URNN_TUNE_F16");     // development knob: 0 = bf16 x 6 instead of f16 x 3 (URNN_KEEP_BF16X6 builds)
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
+
+// Which k-loop (the SPLIT template argument): 3 = f16 x 3 (forward activations), 1 = bf16 x 6 (gradients: prm.wide), 2 = bf16
+// compute mode -- whenever the K range is made of whole 16-k groups (every layer of the published network) and the accumulators
+// leave room for the pieces; else 0 = the exact fp32-MFMA loop (odd channel counts).
+template <int NB, int PB, int EPI>
+static int split_mode(const ConvGemmParams &p)
+{
+    // accumulators + pieces: <= 128 accumulators in a 256-register wave (8-wave blocks); the deconv's 6-block tile runs one
     // wave per SIMD (4-wave blocks, 512 registers) and takes its 192
-    if constexpr (EPI == EPI_DECONV ? NB * PB * 16 > 192 : NB * PB * 16 > 128) return false;
-    if (!tune_split()) return false;
-    if (p.sDwords <= 0 || !p.wsplit || (size_t)p.sDwords * 4 > LDS_PER_CU - 24 * 1024) return false;
-    if (p.KT % 8 != 0 || p.kpBegin % 8 != 0 || p.KT <= p.kpBegin) return false;      // whole 16-k groups, aligned with the packed ones
+    if constexpr (EPI == EPI_DECONV ? NB * PB * 16 > 192 : NB * PB * 16 > 128) return 0;
+    if (!tune_split()) return 0;
+    if (p.KT % 8 != 0 || p.kpBegin % 8 != 0 || p.KT <= p.kpBegin) return 0;      // whole 16-k groups, aligned with the packed ones
     if constexpr (EPI == EPI_CAND) {
         const int kpe = p.hKp0 < p.KT ? p.hKp0 : p.KT;
-        if (kpe <= p.kpBegin || kpe % 8 != 0 || kpe >= p.KT) return false;
+        if (kpe <= p.kpBegin || kpe % 8 != 0 || kpe >= p.KT) return 0;
     }
-    return true;
+    const bool bf_ok = p.sDwords > 0 && p.wsplit && (size_t)p.sDwords * 4 <= LDS_PER_CU - 24 * 1024;
+    const bool f16_ok = p.fDwords > 0 && p.wf16 && (size_t)p.fDwords * 4 <= LDS_PER_CU - 24 * 1024;
+    if (g_matrix_mode.load(std::memory_order_relaxed) == URNN_MATRIX_BF16) return bf_ok ? 2 : 0;
+    const bool want_bf = p.wide || (URNN_KEEP_BF16X6 && !tune_f16());
+    if (want_bf && (EPI == EPI_LRELU || URNN_KEEP_BF16X6)) return bf_ok ? 1 : 0;
+    return f16_ok ? 3 : 0;
 }
 
 template <int NB, int PB, int MAP, int EPI, int D, int WPB>
 static hipError_t launch_conv_cfg(const ConvGemmParams &p, hipStream_t st, int max_bpc = 2)
 {
     if constexpr (EPI == EPI_DECONV ? (NB * PB * 16 <= 192 && WPB == 4) : NB * PB * 16 <= 128) {
-        if (split_ok<NB, PB, EPI>(p)) {
-            if (g_matrix_mode.load(std::memory_order_relaxed) == URNN_MATRIX_BF16) return launch_conv_split<NB, PB, MAP, EPI, D, WPB, 2>(p, st, max_bpc);
-            return launch_conv_split<NB, PB, MAP, EPI, D, WPB, 1>(p, st, max_bpc);
+        const int sm = split_mode<NB, PB, EPI>(p);
+        if (sm == 3) return launch_conv_split<NB, PB, MAP, EPI, D, WPB, 3>(p, st, max_bpc);
+        if (sm == 2) return launch_conv_split<NB, PB, MAP, EPI, D, WPB, 2>(p, st, max_bpc);
+        if constexpr (EPI == EPI_LRELU || URNN_KEEP_BF16X6) {
+            if (sm == 1) return launch_conv_split<NB, PB, MAP, EPI, D, WPB, 1>(p, st, max_bpc);
         }
     }
     return launch_conv_split<NB, PB, MAP, EPI, D, WPB, 0>(p, st, max_bpc);

@@ -27,6 +27,9 @@ struct ConvGemmParams {
                           // W[k = 2*kp + (l >> 5)][n = (g*NB + nb)*32 + (l & 31)]
     const unsigned *wsplit;   // the same weights split into bf16 pieces (urnn_common.h urnn_split_slab_dwords), group stride sDwords
     int sDwords;          // dwords per n-group split slab (a multiple of 256); 0: no split form (fp32 k-loop only)
+    const unsigned *wf16;     // the same weights x 2^URNN_F16_WEXP as two f16 pieces (urnn_f16_slab_dwords), group stride fDwords
+    int fDwords;          // dwords per n-group f16 slab; 0: no f16 form
+    int wide;             // 1: the activations are gradients (unbounded exponent range): bf16 x 6 split instead of f16 x 3
     const float *bias;    // bias per packed column [NG*NB*32]
     int aFloats;          // floats per n-group slab, a multiple of 256 (one LDS-DMA instruction moves 256 floats)
     int NG;               // number of n-groups (blocks are specialised per group)

@@ -17,6 +17,7 @@
 #include "urnn_kernels.h"
 
 #include <limits.h>
+#include <stdlib.h>
 
 extern __shared__ __attribute__((aligned(16))) char urnn_small_smem[];
 
@@ -33,8 +34,9 @@ __global__ __launch_bounds__(1024) void small_cell_gemm_kernel(const ConvGemmPar
     const int P = prm.P, F = prm.F;
     const int kg0 = prm.kpBegin >> 3, KG = (prm.KT - prm.kpBegin) >> 3;   // 16-k groups [kg0, kg0 + KG)
 
-    unsigned *Bp = reinterpret_cast<unsigned *>(urnn_small_smem);       // [KG][2][3][64][4] dwords
-    float *bias = reinterpret_cast<float *>(Bp + (size_t)KG * 2 * 3 * 256);
+    constexpr int NPC = MODE == 3 ? 2 : 3;                              // pieces per operand (MODE 3: f16 hi | lo, urnn_common.h)
+    unsigned *Bp = reinterpret_cast<unsigned *>(urnn_small_smem);       // [KG][2][NPC][64][4] dwords
+    float *bias = reinterpret_cast<float *>(Bp + (size_t)KG * 2 * NPC * 256);
     float *ssm = bias + nblk_total * 32;                                // GATED: [F][2] r-gate (scale, shift) of sample b
     if (threadIdx.x < nblk_total * 32) bias[threadIdx.x] = prm.bias[threadIdx.x];
 
@@ -120,13 +122,16 @@ __global__ __launch_bounds__(1024) void small_cell_gemm_kernel(const ConvGemmPar
                     if constexpr (MODE == 2) {
                         ph = round_pair(v0[q], v1[q]);
                         pm = pl = 0u;
+                    } else if constexpr (MODE == 3) {
+                        split2_pair(v0[q], v1[q], URNN_F16_ASCALE, ph, pm);
+                        pl = 0u;
                     } else {
                         split_pair(v0[q], v1[q], ph, pm, pl);
                     }
-                    unsigned *dst = Bp + ((((size_t)gq * 2 + pb) * 3) * 64 + ((lane & 31) + 32 * hf)) * 4 + d;
+                    unsigned *dst = Bp + ((((size_t)gq * 2 + pb) * NPC) * 64 + ((lane & 31) + 32 * hf)) * 4 + d;
                     dst[0] = ph;
                     dst[256] = pm;
-                    dst[512] = pl;
+                    if constexpr (NPC == 3) dst[512] = pl;
                 }
             }
         }
@@ -136,8 +141,8 @@ __global__ __launch_bounds__(1024) void small_cell_gemm_kernel(const ConvGemmPar
     // ---- main loop: wave = (32-channel block nbg, pixel block pbw) -------------------------------------------------------------------
     const int nbg = wave >> 1, pbw = wave & 1;
     const int g = nbg / NBG, nb = nbg - g * NBG;                          // n-group / block inside it, as packed
-    const u32x4 *Aw = reinterpret_cast<const u32x4 *>(prm.wsplit + (size_t)g * prm.sDwords) + lane;
-    auto a_ptr = [&](int gq, int piece) { return Aw + ((size_t)((kg0 + gq) * NBG + nb) * 3 + piece) * 64; };
+    const u32x4 *Aw = reinterpret_cast<const u32x4 *>(MODE == 3 ? prm.wf16 + (size_t)g * prm.fDwords : prm.wsplit + (size_t)g * prm.sDwords) + lane;
+    auto a_ptr = [&](int gq, int piece) { return Aw + ((size_t)((kg0 + gq) * NBG + nb) * NPC + piece) * 64; };
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -148,21 +153,28 @@ __global__ __launch_bounds__(1024) void small_cell_gemm_kernel(const ConvGemmPar
         const int gq = q < KG ? q : KG - 1;
         ah[q] = *a_ptr(gq, 0);
         am[q] = *a_ptr(gq, 1);
-        if constexpr (MODE != 2) al[q] = *a_ptr(gq, 2);
+        if constexpr (MODE == 1) al[q] = *a_ptr(gq, 2);
     }
-    const u32x4 *Bw = reinterpret_cast<const u32x4 *>(Bp) + (size_t)pbw * 3 * 64 + lane;
+    const u32x4 *Bw = reinterpret_cast<const u32x4 *>(Bp) + (size_t)pbw * NPC * 64 + lane;
     for (int gq0 = 0; gq0 < KG; gq0 += PF) {
 #pragma unroll
         for (int q = 0; q < PF; ++q) {
             const int gq = gq0 + q;
             if (gq < KG) {
-                const u32x4 bh = Bw[(size_t)gq * 2 * 3 * 64], bm = Bw[(size_t)gq * 2 * 3 * 64 + 64], bl = Bw[(size_t)gq * 2 * 3 * 64 + 128];
+                const u32x4 bh = Bw[(size_t)gq * 2 * NPC * 64], bm = Bw[(size_t)gq * 2 * NPC * 64 + 64];
                 const bf16x8 wh = __builtin_bit_cast(bf16x8, ah[q]), wm = __builtin_bit_cast(bf16x8, am[q]);
                 const bf16x8 xh = __builtin_bit_cast(bf16x8, bh);
-                if constexpr (MODE == 2) {
+                if constexpr (MODE == 3) {
+                    const f16x8 fwh = __builtin_bit_cast(f16x8, ah[q]), fwl = __builtin_bit_cast(f16x8, am[q]);
+                    const f16x8 fxh = __builtin_bit_cast(f16x8, bh), fxl = __builtin_bit_cast(f16x8, bm);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwl, fxh, acc, 0, 0, 0);           // small terms first
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwh, fxl, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwh, fxh, acc, 0, 0, 0);
+                } else if constexpr (MODE == 2) {
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xh, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc, 0, 0, 0);
                 } else {
+                    const u32x4 bl = Bw[(size_t)gq * 2 * NPC * 64 + 128];
                     const bf16x8 wl = __builtin_bit_cast(bf16x8, al[q]), xm = __builtin_bit_cast(bf16x8, bm), xl = __builtin_bit_cast(bf16x8, bl);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xm, acc, 0, 0, 0);       // small terms first
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc, 0, 0, 0);
@@ -174,7 +186,7 @@ __global__ __launch_bounds__(1024) void small_cell_gemm_kernel(const ConvGemmPar
                 const int gn = gq + PF < KG ? gq + PF : KG - 1;           // refill this prefetch slot
                 ah[q] = *a_ptr(gn, 0);
                 am[q] = *a_ptr(gn, 1);
-                if constexpr (MODE != 2) al[q] = *a_ptr(gn, 2);
+                if constexpr (MODE == 1) al[q] = *a_ptr(gn, 2);
             }
         }
     }
@@ -195,17 +207,21 @@ __global__ __launch_bounds__(1024) void small_cell_gemm_kernel(const ConvGemmPar
     }
     const float *bias_h = bias + nbg * 32 + 4 * half;
     auto row_c = [](int r) { return (r & 3) + 8 * (r >> 2); };
+    auto fin = [](float a, float bv) {
+        if constexpr (MODE == 3) return fmaf(a, URNN_F16_DESCALE, bv);
+        else return a + bv;
+    };
     float s1 = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-        if (ok) s1 += acc[r] + bias_h[row_c(r)];
+        if (ok) s1 += fin(acc[r], bias_h[row_c(r)]);
     s1 = wave_sum(s1);
     const float mt = s1 / (float)(32 * nvalid);
     float s2 = 0.f;
     float *obase = prm.out0 + ((size_t)b * Cout + ch0 + 4 * half) * P + px;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const float v = acc[r] + bias_h[row_c(r)];
+        const float v = fin(acc[r], bias_h[row_c(r)]);
         const float d = v - mt;
         if (ok) {
             s2 = fmaf(d, d, s2);
@@ -222,10 +238,17 @@ __global__ __launch_bounds__(1024) void small_cell_gemm_kernel(const ConvGemmPar
     }
 }
 
+static int small_mode(const ConvGemmParams &p)
+{
+    if (urnn_get_matrix_mode() == URNN_MATRIX_BF16) return 2;
+    static const int f16 = [] { const char *e = getenv("URNN_TUNE_F16"); return e ? atoi(e) : 1; }();   // development knob (A/B)
+    return (f16 && p.fDwords > 0 && p.wf16) ? 3 : 1;
+}
+
 size_t urnn_small_lds_bytes(const ConvGemmParams &p, int nblk_total, int gated)
 {
     const size_t KG = (size_t)(p.KT - p.kpBegin) / 8;
-    return KG * 2 * 3 * 1024 + (size_t)nblk_total * 128 + (gated ? (size_t)p.F * 8 : 0);
+    return KG * 2 * (small_mode(p) == 3 ? 2 : 3) * 1024 + (size_t)nblk_total * 128 + (gated ? (size_t)p.F * 8 : 0);
 }
 
 // Eligibility mirrors split_ok() of urnn_gemm.hip (whole, aligned 16-k groups; a split slab) plus the block shape limits.
@@ -247,16 +270,19 @@ static hipError_t launch_small(const ConvGemmParams &p, int B, int nblk_total, i
     const size_t lds = urnn_small_lds_bytes(p, nblk_total, GATED);
     auto k1 = small_cell_gemm_kernel<GATED, 1>;
     auto k2 = small_cell_gemm_kernel<GATED, 2>;
+    auto k3 = small_cell_gemm_kernel<GATED, 3>;
     static bool raised = false;
     if (!raised) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         raised = true;
     }
     const int blocks = B * ((p.P + 63) / 64);
     const dim3 grid(blocks), blk(64 * nblk_total * 2);
-    if (mode == URNN_MATRIX_BF16) hipLaunchKernelGGL(k2, grid, blk, lds, st, p, nblk_total, NBG);
+    if (mode == 2) hipLaunchKernelGGL(k2, grid, blk, lds, st, p, nblk_total, NBG);
+    else if (mode == 3) hipLaunchKernelGGL(k3, grid, blk, lds, st, p, nblk_total, NBG);
     else hipLaunchKernelGGL(k1, grid, blk, lds, st, p, nblk_total, NBG);
     return hipGetLastError();
 }
@@ -266,7 +292,7 @@ hipError_t urnn_launch_small_gates(ConvGemmParams p, int B, hipStream_t st)
 {
     p.tilesPerSample = (p.P + 31) / 32;
     p.totalTiles = B * p.tilesPerSample;
-    return launch_small<0>(p, B, p.NG * 2, 2, urnn_get_matrix_mode(), st);
+    return launch_small<0>(p, B, p.NG * 2, 2, small_mode(p), st);
 }
 
 hipError_t urnn_launch_small_cand(ConvGemmParams p, int B, hipStream_t st)
@@ -276,5 +302,5 @@ hipError_t urnn_launch_small_cand(ConvGemmParams p, int B, hipStream_t st)
     p.NG = (p.F / 32) / NB;
     p.tilesPerSample = (p.P + 31) / 32;
     p.totalTiles = B * p.tilesPerSample;
-    return launch_small<1>(p, B, p.F / 32, NB, urnn_get_matrix_mode(), st);
+    return launch_small<1>(p, B, p.F / 32, NB, small_mode(p), st);
 }

@@ -32,3 +32,49 @@ def evaluate_events(net, dataset, device, historical_nums=30, rain_max=6.0, cums
         if keep_outputs:
             outputs[name] = np.asarray(out_mm)
     return metrics, (summarize(metrics) if metrics else None), outputs
+
+
+def main(argv=None):
+    """``python -m urnn_amd.evaluate --exp_config <reference yaml> --device 0 [--test_list_file ...] [--checkpoint ...]``: the
+    evaluation half of the reference's test.py entry (test.py:797-808, config.py:55-213) on the HIP path -- hyper-parameters from
+    the experiment YAML's own keys, events from its data_root / test_list_file, metrics printed per event and as mean / std."""
+    import argparse
+    import json
+
+    import torch
+
+    from .events import Dynamic2DFlood
+    from .exp_config import load_exp_config
+    from .net_config import load_net_config
+    from .networks import ED, get_network_params
+    ap = argparse.ArgumentParser(prog="urnn_amd.evaluate")
+    ap.add_argument("--exp_config", required=True)
+    ap.add_argument("--device", default="0")
+    ap.add_argument("--test_list_file", default=None)
+    ap.add_argument("--data_root", default=None)
+    ap.add_argument("--timestamp", default=None, help="experiment folder name of the reference (only echoed)")
+    ap.add_argument("--checkpoint", default=None, help="reference checkpoint (.pth.tar with 'state_dict'); seeded weights if omitted")
+    a = ap.parse_args(argv)
+    cfg = load_exp_config(a.exp_config, test_list_file=a.test_list_file, data_root=a.data_root)
+    dev = torch.device("cuda", int(str(a.device).split(",")[0]))
+    H, W, C = cfg["input_height"], cfg["input_width"], 2 * cfg["historical_nums"] + 3
+    ep, dp = get_network_params(False, H, W, C, load_net_config())
+    net = ED(False, ep, dp, cfg["cls_thred"], False, H, W)
+    if a.checkpoint:
+        ck = torch.load(a.checkpoint, map_location="cpu")
+        net.load_state_dict(ck.get("state_dict", ck))
+    else:
+        from . import weights as uw
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in uw.make_state_dict(H, W, C, seed=0).items()})
+    net = net.to(dev).eval()
+    ds = Dynamic2DFlood(cfg["data_root"], "test", event_list_file=cfg["test_list_file"] or None, duration=cfg["duration"])
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    metrics, summary, _ = evaluate_events(net, ds, dev, historical_nums=cfg["historical_nums"], rain_max=cfg["rain_max"],
+                                          cumsum_rain_max=cfg["cumsum_rain_max"], flood_max=cfg["flood_max"],
+                                          flood_thres=cfg["flood_thres"], rank=rank, world_size=world)
+    print(json.dumps({"exp_config": a.exp_config, "timestamp": a.timestamp, "rank": rank, "events": metrics, "summary": summary},
+                     default=float))
+
+
+if __name__ == "__main__":
+    main()

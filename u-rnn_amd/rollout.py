@@ -382,6 +382,7 @@ class RolloutEngine:
 
     def run(self, frames):
         """Roll ``frames`` timesteps from the current states / frame counter.  Asynchronous."""
+        self._check_params()        # a Trainer may have updated / re-homed the weights since the graphs were captured (mid-event run)
         if self.overlap:
             return self._run_overlap(frames)
         self._frames_done += frames

@@ -135,6 +135,10 @@ class WindowGradients:
             grads[f"head.{blk}.ln.bias"] = hg["dln_b"][i]
         grads["head.reg_preds.conv.weight"] = hg["dreg_w"].reshape(1, -1, 1, 1)
         grads["head.reg_preds.conv.bias"] = hg["dreg_b"]
+        # the classification branch gets no gradient (cut off by the wet/dry comparison, main.py:500): explicit zeros, so that the
+        # single-GPU and the DDP path (which all-reduces these slots with the head's tail) write the same regions every window
+        grads["head.cls_preds.conv.weight"] = torch.zeros_like(head.cls_preds.conv.weight)
+        grads["head.cls_preds.conv.bias"] = torch.zeros_like(head.cls_preds.conv.bias)
         return grads
 
     def run(self, event, targets, t0, steps, states=None, t_devs=None, grad_buffers=None, on_head_final=None):
@@ -163,10 +167,7 @@ class WindowGradients:
             hook = (lambda hg: on_head_final(self.head_gradients(hg))) if (on_head_final is not None and s == 0) else None
             dstate = self._backward_step(saved[s], s, dreg[:, s], dstate, G, acc=(s != steps - 1), after_head=hook)
         grads = {k: v for k, v in G.items() if not k.startswith("_")}
-        head = self.net.head
         grads.update(self.head_gradients(G["_head"]))
-        grads["head.cls_preds.conv.weight"] = torch.zeros_like(head.cls_preds.conv.weight)
-        grads["head.cls_preds.conv.bias"] = torch.zeros_like(head.cls_preds.conv.bias)
         return {"loss": comps, "grads": grads, "states": [s.detach() for s in states], "reg": reg, "state_grads": dstate}
 
 
@@ -229,8 +230,9 @@ class Trainer:
     def __init__(self, net, H, W, nums, rain_max, cumsum_max, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_clip=0.0,
                  cls_thred_train=0.0, process_group=None, distributed=False, use_graph=False, matrix_mode="fp32"):
         self.net = net
-        # "fp32": the reference's arithmetic (default).  "bf16": BASELINE configs[3] -- the GEMMs of the forward pass and of the
-        # input gradients run in bf16 compute with fp32 accumulation (ops.matrix_mode); master weights, Adam, norms, loss: fp32
+        # "fp32": the reference's arithmetic (default).  "bf16": BASELINE configs[3] -- every GEMM (forward, input gradients and
+        # weight gradients) takes its operands rounded to bf16 and accumulates in fp32 (ops.matrix_mode); master weights, the
+        # stored gradients, Adam, norms and the loss stay fp32 (tests/test_hip_train_fullsize.py::test_bf16_window_full_size)
         if matrix_mode not in ops.MATRIX_MODES:
             raise ValueError(f"matrix_mode must be one of {sorted(ops.MATRIX_MODES)}")
         self.matrix_mode = matrix_mode
@@ -366,7 +368,9 @@ class Trainer:
         # the DEM normalisation bounds are kernel ARGUMENTS (frozen into the graph): one capture per (shape, bounds), i.e. per
         # catchment; the event's tensors are copied into static buffers before every replay
         key = (steps, B, ev["T"], tuple(ev["rain"].shape), ev["dem_min"], ev["dem_max"], self.lr, self.matrix_mode)   # lr: one re-capture per epoch
-        if self._graph is None or self._graph["key"] != key:
+        # (a scratch buffer that grew since the capture -- an eager call with a larger batch through the same arena -- leaves the
+        # graph pointing at freed memory: ops.Arena.generation tells)
+        if self._graph is None or self._graph["key"] != key or self._graph["arena_gen"] != self.wg.arena.generation:
             from .general import initialize_states
             zero = [s.to(dev).repeat(B, 1, 1, 1) for s in initialize_states(dev, self.wg.H, self.wg.W)]
             sev = dict(ev)
@@ -391,7 +395,7 @@ class Trainer:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 out, clip = self._window_body(sev, G["tgt"], 0, steps, G["states"], t_devs=G["t_devs"], step_dev=G["step_dev"])
-            G.update(graph=g, out=out, clip=clip)
+            G.update(graph=g, out=out, clip=clip, arena_gen=self.wg.arena.generation)
             self._graph = G
         G = self._graph
         if ev is not G["ev"]:
