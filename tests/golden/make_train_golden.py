@@ -214,8 +214,70 @@ def gen_training_loop(out, H=16, W=16, nums=3, seq_num=2, windows=3, wseed=21, e
         out[f"loop_state{i}"] = s_.numpy()
 
 
+def gen_ddp_loop(out, H=16, W=16, nums=3, seq_num=2, windows=2, wseed=21, lr=1e-3, grad_clip=1.0, world=2):
+    """DistributedDataParallel (main.py:384-387) emulated in one process: `world` ranks hold the same parameters, every rank runs
+    the reference window (main.py:700-768) on ITS OWN event / labels, the gradients are averaged over the ranks (what DDP's
+    all-reduce leaves in .grad), then clip_grad_norm_ and one Adam step on the shared parameters.  Per window: the per-rank losses
+    and the averaged gradient of every parameter; at the end the parameters.  Events / labels as tests/test_hip_train.py
+    _ddp_worker makes them (event seed 100 + rank, labels of the training-loop golden scaled by 1 + rank / 2)."""
+    C = 2 * nums + 3
+    net, sd = mg.ref_net(H, W, C, wseed)
+    net.train()
+    T = seq_num * windows
+    rs = np.random.RandomState(8 + 1)                      # the label recipe of gen_training_loop (event seed 8)
+    label = (rs.uniform(0, 1, (1, seq_num * 3, H, W)) ** 3).astype(np.float32)
+    label[label < 0.1] = 0.0
+    label = label[:, :T]
+    named = {}
+    for key in sd:
+        named[key] = next(v for k, v in net.state_dict(keep_vars=True).items()
+                          if k.replace("_wrapper.module.", ".").replace(".conv1_module.", ".conv1.").replace(".conv2_module.", ".conv2.") == key)
+    params = list({id(p): p for p in named.values()}.values())
+    opt = torch.optim.Adam(params, lr=lr)
+    lossf = FocalBCE_and_WMSE(gamma=2, alpha=0.25)
+    tevs = [mg.event_to_torch(uw.make_event(T, H, W, 60.0, seed=100 + r)) for r in range(world)]
+    labels = [torch.from_numpy(label * (1.0 + 0.5 * r)) for r in range(world)]
+    states = [None] * world
+    out.update({"ddp_H": H, "ddp_W": W, "ddp_nums": nums, "ddp_seq_num": seq_num, "ddp_windows": windows, "ddp_weights_seed": wseed,
+                "ddp_lr": lr, "ddp_grad_clip": grad_clip, "ddp_world": world, "ddp_label": label})
+    for wdx in range(windows):
+        ind = wdx * seq_num
+        mean_grad = {k: torch.zeros_like(named[k]) for k in sd}
+        for r in range(world):
+            opt.zero_grad()
+            st = states[r] if states[r] is not None else initialize_states(torch.device("cpu"), input_height=H, input_width=W, net_cfg=mg.CFG)
+            pred = None
+            for t in range(ind, ind + seq_num):
+                x = preprocess_inputs(t, tevs[r], torch.device("cpu"), nums=nums, rain_max=60.0, cumsum_rain_max=250.0)
+                res = net(x, *st)
+                o, st = res[0], res[1:]
+                cls = torch.where(o >= 0, 1, 0)
+                pred = {"reg": o, "cls": cls} if pred is None else {"reg": torch.cat((pred["reg"], o), 1), "cls": torch.cat((pred["cls"], cls), 1)}
+            states[r] = [s.detach() for s in st]
+            losses = lossf(pred, labels[r][:, ind:ind + seq_num], epoch=0)
+            losses["loss"].backward()
+            out[f"ddp_w{wdx}_rank{r}_loss"] = np.float64(losses["loss"].item())
+            for k in sd:
+                if named[k].grad is not None:
+                    mean_grad[k] += named[k].grad / world
+        for k in sd:                                            # what every rank holds after DDP's all-reduce
+            named[k].grad = mean_grad[k].clone()
+            out[f"ddp_w{wdx}_grad_{k}"] = mean_grad[k].numpy().copy()
+        norm = torch.nn.utils.clip_grad_norm_(params, grad_clip)
+        out[f"ddp_w{wdx}_gradnorm"] = np.float64(norm.item())
+        opt.step()
+    for k in sd:
+        out[f"ddp_final_{k}"] = named[k].detach().numpy().copy()
+
+
 if __name__ == "__main__":
     sys.modules.setdefault("wandb", types.ModuleType("wandb"))
+    if len(sys.argv) > 1 and sys.argv[1] == "ddp":          # only the DDP golden (the other files stay byte-identical)
+        ddp = {}
+        gen_ddp_loop(ddp)
+        np.savez_compressed(os.path.join(HERE, "train_ddp_16x16.npz"), **ddp)
+        print("wrote train_ddp_16x16.npz", os.path.getsize(os.path.join(HERE, "train_ddp_16x16.npz")) // 1024, "KiB")
+        sys.exit(0)
     out = {}
     gen_loss(out)
     gen_window(out)
@@ -228,6 +290,9 @@ if __name__ == "__main__":
     loop = {}
     gen_training_loop(loop)
     np.savez_compressed(os.path.join(HERE, "train_loop_16x16.npz"), **loop)
+    ddp = {}
+    gen_ddp_loop(ddp)
+    np.savez_compressed(os.path.join(HERE, "train_ddp_16x16.npz"), **ddp)
     path = os.path.join(HERE, "train_window_16x16.npz")
     np.savez_compressed(path, **out)
     ng = sum(1 for k in out if k.startswith("win_grad_"))

@@ -39,8 +39,10 @@ def test_packed_sizes_and_argument_errors_without_gpu(built):
     f16 = lambda KT, NB: ((KT + 7) // 8) * NB * 2 * 256
     assert lib.urnn_packed_conv_floats(63, 16) == 32 * 1 * 64 + 32 + split(32, 1) + f16(32, 1)
     # gate slabs [F/32 groups][KT][z|r][64] + b1, candidate slab(s) [KT][F/32 blocks][64] + b2, then both in split and f16 form
-    assert lib.urnn_packed_gru_floats(16, 64, 0) == 2 * (40 * 2 * 64) + 128 + 40 * 2 * 64 + 64 + 3 * split(40, 2) + 3 * f16(40, 2)
-    assert lib.urnn_packed_gru_floats(96, 64, 1) == 2 * (112 * 2 * 64) + 128 + 112 * 2 * 64 + 64 + 3 * split(112, 2) + 3 * f16(112, 2)
+    # (the f16 gate slab is ONE group of all four 32-column blocks z0 r0 z1 r1 -- same size as two groups of two -- followed by
+    # the gate bias in that order: + 2F)
+    assert lib.urnn_packed_gru_floats(16, 64, 0) == 2 * (40 * 2 * 64) + 128 + 40 * 2 * 64 + 64 + 3 * split(40, 2) + f16(40, 4) + f16(40, 2) + 128
+    assert lib.urnn_packed_gru_floats(96, 64, 1) == 2 * (112 * 2 * 64) + 128 + 112 * 2 * 64 + 64 + 3 * split(112, 2) + f16(112, 4) + f16(112, 2) + 128
     assert lib.urnn_gru_cell_workspace_bytes(1, 64, 500, 500) > 3 * 64 * 250000 * 4
     # argument validation happens before any HIP call
     assert lib.urnn_stage_conv_f32(0, 0, 0, 1, 8, 16, 4, 4, 0, 0.2, 0) == -2      # URNN_ENULL

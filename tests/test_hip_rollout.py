@@ -559,13 +559,19 @@ def test_repeated_launches_are_bit_identical_at_full_size(dev):
     enc, dec = net.encoder, net.decoder
     e1, e2, e3, d1, d2, d3 = [s.clone() for s in eng.states]
     a1, a2, a3, u3, u2 = (t.clone() for t in (eng.a1, eng.a2, eng.a3, eng.u3, eng.u2))
+    feat = dec.stage1(d3).clone()
     cases = {"enc1": lambda: enc.rnn1.step(a1, None, e1), "enc2": lambda: enc.rnn2.step(a2, None, e2), "enc3": lambda: enc.rnn3.step(a3, None, e3),
              "dec3": lambda: dec.rnn3.step(None, e3, d1), "dec2": lambda: dec.rnn2.step(u3, e2, d2), "dec1": lambda: dec.rnn1.step(u2, e1, d3),
-             "stage2": lambda: enc.stage2(e1), "deconv2": lambda: dec.stage2(d2), "dec stage1": lambda: dec.stage1(d3)}
+             "stage2": lambda: enc.stage2(e1), "stage3": lambda: enc.stage3(e2), "deconv2": lambda: dec.stage2(d2), "deconv3": lambda: dec.stage3(d1),
+             "dec stage1": lambda: dec.stage1(d3), "head": lambda: torch.stack(net.head.run(feat, want_raw=True))}
+    launches = int(os.environ.get("URNN_REPEAT_LAUNCHES", "60"))
+    failures = []
     for name, fn in cases.items():
         ref = fn().clone()
-        for i in range(60):
-            assert torch.equal(fn(), ref), f"{name}: launch {i + 1} differs from the first"
+        bad = [i + 1 for i in range(launches) if not torch.equal(fn(), ref)]
+        if bad:
+            failures.append(f"{name}: {len(bad)} of {launches} launches differ from the first (first at launch {bad[0]})")
+    assert not failures, "; ".join(failures)
 
 
 def test_scalar_rain_engine_keeps_its_graph_across_dem_ranges(dev):

@@ -317,6 +317,99 @@ def _ddp_worker(rank, world, port, out_dir, backend="gloo"):
     dist.destroy_process_group()
 
 
+def _ddp_golden_worker(rank, world, port, out_dir, backend="gloo"):
+    """Two windows of the reference-emulated DDP run of tests/golden/make_train_golden.py gen_ddp_loop: rank r trains on event
+    seed 100 + r with labels x (1 + r / 2); after every window the averaged flat gradient, at the end the parameters."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    import urnn_amd.weights as uw
+    from urnn_amd.training import Trainer
+    if backend == "nccl":
+        dev = torch.device("cuda", rank)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dev = torch.device("cuda:0")
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_ddp_16x16.npz"))
+    H, W, nums, S, nwin = (int(g[k]) for k in ("ddp_H", "ddp_W", "ddp_nums", "ddp_seq_num", "ddp_windows"))
+    sd = uw.make_state_dict(H, W, 2 * nums + 3, seed=int(g["ddp_weights_seed"]))
+    from urnn_amd.net_config import load_net_config
+    from urnn_amd.networks import ED, get_network_params
+    ep, dp = get_network_params(False, H, W, 2 * nums + 3, load_net_config())
+    net = ED(False, ep, dp, 0.5, False, H, W)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net = net.to(dev)
+    tr = Trainer(net, H, W, nums, 60.0, 250.0, lr=float(g["ddp_lr"]), grad_clip=float(g["ddp_grad_clip"]), distributed=True)
+    ev = uw.make_event(S * nwin, H, W, 60.0, seed=100 + rank)
+    label = torch.from_numpy(g["ddp_label"]).to(dev) * (1.0 + 0.5 * rank)
+    states = None
+    for w in range(nwin):
+        loss, states = tr.train_window(ev, label[:, w * S:(w + 1) * S], w * S, S, states)
+        torch.cuda.synchronize()
+        np.save(os.path.join(out_dir, f"grad_w{w}_rank{rank}.npy"), tr.gflat.cpu().numpy())
+        np.save(os.path.join(out_dir, f"loss_w{w}_rank{rank}.npy"), loss.cpu().numpy())
+    np.save(os.path.join(out_dir, f"flat_rank{rank}.npy"), tr.flat.cpu().numpy())
+    if rank == 0:
+        np.save(os.path.join(out_dir, "views.npy"), np.array([(n, off, k) for n, (off, k, _) in tr.views.items()], dtype=object), allow_pickle=True)
+    dist.destroy_process_group()
+
+
+def _check_ddp_against_reference(tmp_path):
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_ddp_16x16.npz"))
+    views = np.load(tmp_path / "views.npy", allow_pickle=True)
+    nwin = int(g["ddp_windows"])
+    worst = ("", 0.0)
+    for w in range(nwin):
+        g0, g1 = np.load(tmp_path / f"grad_w{w}_rank0.npy"), np.load(tmp_path / f"grad_w{w}_rank1.npy")
+        assert np.array_equal(g0, g1), f"window {w}: the ranks hold different averaged gradients"
+        for r in (0, 1):        # every rank's own loss (its own event), main.py:750-762
+            assert float(np.load(tmp_path / f"loss_w{w}_rank{r}.npy")[0]) == pytest.approx(float(g[f"ddp_w{w}_rank{r}_loss"]), rel=3e-4)
+        for name, off, k in views:
+            ref = g[f"ddp_w{w}_grad_{name}"].reshape(-1)
+            got = g0[int(off):int(off) + int(k)]
+            scale = float(np.abs(ref).max())
+            if scale == 0.0:
+                assert float(np.abs(got).max()) == 0.0, (w, name)
+                continue
+            err = float(np.abs(got - ref).max()) / scale
+            worst = max(worst, (f"w{w} {name}", err), key=lambda t: t[1])
+            assert err <= 1e-3, (w, name, err)          # the mean of the two ranks' reference-autograd gradients
+    f0, f1 = np.load(tmp_path / "flat_rank0.npy"), np.load(tmp_path / "flat_rank1.npy")
+    assert np.array_equal(f0, f1), "replicas diverged"
+    for name, off, k in views:
+        ref = g[f"ddp_final_{name}"].reshape(-1)
+        got = f0[int(off):int(off) + int(k)]
+        assert np.abs(got - ref).max() <= 3e-4 * max(np.abs(ref).max(), 1e-3) + 3e-5, name      # the bar of the single-rank loop golden
+    print("DDP vs the reference's emulated 2-rank loop: worst averaged-gradient error / tensor max:", worst)
+
+
+def test_two_rank_ddp_matches_the_reference_gradient_mean(dev, tmp_path):
+    """DDP row a12 against the REFERENCE (main.py:384-387,750-762): two ranks with different events; after every window the
+    averaged flat gradient equals the mean of the two per-rank reference-autograd gradients (golden: the reference's own
+    modules, loss and Adam in a 2-rank emulation, make_train_golden.py gen_ddp_loop) within 1e-3 of each tensor's max, each
+    rank's loss is its own event's, and the post-Adam parameters match.  Two processes on the one GPU, gloo as the wire."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_ddp_golden_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    _check_ddp_against_reference(tmp_path)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank (the 1-GPU test box cannot host two)")
+def test_two_rank_ddp_matches_the_reference_gradient_mean_over_rccl(tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_ddp_golden_worker, args=(2, port, str(tmp_path), "nccl"), nprocs=2, join=True)
+    _check_ddp_against_reference(tmp_path)
+
+
 def test_two_rank_ddp_training_keeps_replicas_identical(dev, tmp_path):
     """DDP semantics (main.py:384-387): per-rank events, gradients averaged over the ranks before the optimizer step -- the
     replicas stay bit-identical.  Two processes on the one GPU, gloo as the control plane (RCCL on a multi-GPU node)."""

@@ -84,11 +84,7 @@ extern "C" int urnn_pack_conv_f32(const float *weight, const float *bias, float 
 extern "C" size_t urnn_packed_gru_floats(int I, int F, int skip)
 {
     if (I < 1 || F < 32 || F % 32 != 0 || F > 128) return 0;
-    const size_t KT = (size_t)(((I + 1) & ~1) + (skip ? F : 0) + F) / 2;
-    const size_t NB2 = urnn_cand_nb(F);
-    return (size_t)(F / 32) * slab_floats(KT, 2) + 2 * F + (size_t)((F / 32) / NB2) * slab_floats(KT, NB2) + F +
-           (size_t)(F / 32) * urnn_split_slab_dwords((int)KT, 2) + (size_t)((F / 32) / NB2) * urnn_split_slab_dwords((int)KT, (int)NB2) +
-           (size_t)(F / 32) * urnn_f16_slab_dwords((int)KT, 2) + (size_t)((F / 32) / NB2) * urnn_f16_slab_dwords((int)KT, (int)NB2);
+    return urnn_packed_gru_total(I, F, skip);
 }
 
 extern "C" int urnn_pack_gru_f32(const float *W1, const float *b1, const float *W2, const float *b2, float *packed, int I, int F,
@@ -220,6 +216,14 @@ static int gru_tiles(int B, int F, long P, int which, int *pb_out = nullptr, int
     return (int)((P + 32 * pb - 1) / (32 * pb));
 }
 
+// 32-pixel tiles (small planes: the quarter-resolution cells, the F = 96 candidates at half resolution) take the activation-
+// stationary kernels of urnn_small.hip up to URNN_TUNE_SMALL pixels per launch (default 24 000; 0 disables)
+static bool small_on_gates(int B, long P)
+{
+    static const long small_max = getenv("URNN_TUNE_SMALL") ? atol(getenv("URNN_TUNE_SMALL")) : 24000;
+    return (long)B * P <= small_max;
+}
+
 // global_pixels > 0: this call computes one horizontal STRIP of a plane of global_pixels pixels that is split over ranks
 // (SURVEY 8e); the GroupNorm partials have been replaced by the all-reduced totals (two pseudo-tiles: hi + lo floats of
 // the double sums, urnn_gru_cell_strip_stats_f32) and the statistics are over the whole plane
@@ -269,8 +273,12 @@ static int gru_cell_impl(const float *x, const float *e, const float *h, const f
     const float *split0 = packed + (size_t)NW * p.aFloats + 2 * F + (size_t)(NW / NB2s) * slab_floats(KT, NB2s) + F;
     p.wsplit = reinterpret_cast<const unsigned *>(split0);
     p.sDwords = urnn_split_slab_dwords(KT, 2);
+    // f16 forms: the gate slab in the grouping of urnn_gate_groups (wide groups: the K input planes pass through the CUs fewer times)
+    const GateGroups gg = urnn_gate_groups(F, KT);
     p.wf16 = p.wsplit + (size_t)NW * p.sDwords + (size_t)(NW / NB2s) * urnn_split_slab_dwords(KT, NB2s);
-    p.fDwords = urnn_f16_slab_dwords(KT, 2);
+    p.fDwords = urnn_f16_slab_dwords(KT, gg.NB);
+    p.NGf = gg.NG; p.NBf = gg.NB; p.gHalves = gg.halves; p.gGS = gg.GS;
+    p.biasf = reinterpret_cast<const float *>(p.wf16 + (size_t)gg.NG * p.fDwords + (size_t)(NW / NB2s) * urnn_f16_slab_dwords(KT, NB2s));
     p.P = (int)P;
     p.W = W;
     p.F = F;
@@ -278,18 +286,25 @@ static int gru_cell_impl(const float *x, const float *e, const float *h, const f
     p.out0 = ws.g1;
     p.partial = ws.part1;
     int pb1, map1;
-    // the gate GEMM prefers 128-pixel tiles (one 1-KiB DMA per 8 MFMAs) even when they only fill half the wave slots
-    const int tiles1 = gru_tiles(B, F, P, 1, &pb1, &map1);
+    // the gate GEMM prefers 128-pixel tiles (one 1-KiB DMA per 8 MFMAs) even when they only fill half the wave slots; the grouped
+    // f16 kernel (4 or 3 n-blocks per wave) takes 64-pixel ones.  Strips keep the F/32-group kernel (their statistics exchange
+    // is written against its tile layout).
+    int tiles1 = gru_tiles(B, F, P, 1, &pb1, &map1);
+    const bool small_on = small_on_gates(B, P);
+    const bool small_gates = small_on && pb1 == 1 && urnn_small_ok(p, 2 * NW, 0);
+    if (global_pixels > 0 && gg.NB != 2) { p.wf16 = nullptr; p.fDwords = 0; }        // strips: no f16 form in the F/32 grouping
+    if (!small_gates && global_pixels <= 0) {
+        urnn_gate_plan(p, B, pb1, map1, &pb1, &map1);
+        tiles1 = (int)((P + 32 * pb1 - 1) / (32 * pb1));
+    }
     const int ftiles1 = global_pixels > 0 ? 2 : tiles1;                              // tiles the finalizes read
     const double count = 32.0 * (double)(global_pixels > 0 ? global_pixels : P);     // values per (sample, norm group)
     // 32-pixel tiles (small planes: the quarter-resolution cells, the F = 96 candidates at half resolution) take the
     // activation-stationary kernels of urnn_small.hip: same outputs, same partial layout (development knob URNN_TUNE_SMALL=0)
     // up to URNN_TUNE_SMALL pixels per launch (default 24 000; 0 disables): at 62 500 pixels the per-block weight stream and
     // prologue cost more than they save (candidate GEMMs 38 -> 49 and 56 -> 110 us)
-    static const long small_max = getenv("URNN_TUNE_SMALL") ? atol(getenv("URNN_TUNE_SMALL")) : 24000;
-    const bool small_on = (long)B * P <= small_max;
     if (phase_mask & URNN_PHASE_GATES) {
-        if (small_on && pb1 == 1 && urnn_small_ok(p, 2 * NW, 0)) CHECK_HIP(urnn_launch_small_gates(p, B, st), "gru gates (small plane)");
+        if (small_gates) CHECK_HIP(urnn_launch_small_gates(p, B, st), "gru gates (small plane)");
         else CHECK_HIP(urnn_launch_gru1(p, B, pb1, map1, st), "gru gates");
     }
     // GroupNorm finalise of the gates: folded into the candidate GEMM's prologue; launched on its own only when asked for
@@ -321,8 +336,9 @@ static int gru_cell_impl(const float *x, const float *e, const float *h, const f
     c.bias = c.wt + (size_t)NG2 * c.aFloats;
     c.wsplit = p.wsplit + (size_t)NW * p.sDwords;
     c.sDwords = urnn_split_slab_dwords(KT, NB2);
-    c.wf16 = p.wf16 + (size_t)NW * p.fDwords;
+    c.wf16 = p.wsplit + (size_t)NW * p.sDwords + (size_t)(NW / NB2s) * urnn_split_slab_dwords(KT, NB2s) + (size_t)gg.NG * urnn_f16_slab_dwords(KT, gg.NB);
     c.fDwords = urnn_f16_slab_dwords(KT, NB2);
+    c.biasf = nullptr;
     c.Cout = F;
     c.out0 = ws.cx;
     c.partial = ws.part2;

@@ -53,13 +53,45 @@ __device__ __forceinline__ double tile_x2(float s1, float y, int n)
     return n > 0 ? (double)y + (double)s1 * (double)s1 / (double)n : (double)y;
 }
 
-// Activations.  URNN_ACT = 0: hardware exp2 / rcp (v_exp_f32 on x * log2(e): the argument's rounding costs |x| * 2^-24 relative,
-// and 1 - t cancels for small |x|); 1: argument reduction in two pieces (x * log2e split into hi + lo so that the exponent's
-// fraction is exact to ~2^-30) and tanh through expm1-style evaluation for small arguments -- ~1 ulp results, the errors unbiased.
+// Activations.  URNN_ACT = 0: hardware exp2 / rcp on x * log2(e) (the argument's rounding costs |x| * 2^-24 relative -- a bias of
+// +8.5e-8 on average -- and tanh's 1 - t cancels for small |x|); 1: the argument's rounding error is carried along (exp_neg), the
+// reciprocal is v_rcp_f32 + one Newton step, tanh uses its series for small arguments: ~1-2 ulp results with unbiased errors.
+//
+// The transcendental instructions are issued through trans_exp2 / trans_rcp: inline asm with the source kept alive and eight wait
+// states behind the instruction.  v_exp_f32 / v_rcp_f32 run at quarter rate (four passes of 16 lanes) beside the full-rate VALU;
+// hipcc (ROCm 7.2) schedules `v_mul t; v_exp e, t; v_fma t, ...` back to back, re-using the exp's SOURCE register for the next
+// result, and in the candidate GEMM (MFMAs, LDS-DMA and a second wave on the SIMD) that produced, about once per 10^7 wave
+// instructions, a wrong sigmoid in exactly lanes 16..31 -- the exp's second pass -- of the first element after an s_waitcnt
+// (tools/diag_dec1.py: 17 of 3000 launches of the dec1 cell differed in 16 pixel columns; tools/ubench/trans_hazard.hip could not
+// provoke it in isolation).  With the source pinned and the consumers eight wait states away the launches are bit-stable.
 #ifndef URNN_ACT
 #define URNN_ACT 1
 #endif
-// exp(x) for x <= 0 (the only sign the activations need), ~1 ulp: 2^n * 2^f with n = rint(x * log2e) and f accurate to 2^-30
+__device__ __forceinline__ float trans_exp2(float t)
+{
+    float e;
+    asm volatile("v_exp_f32 %0, %1\n\ts_nop 7" : "=&v"(e) : "v"(t));
+    return e;
+}
+__device__ __forceinline__ float trans_rcp(float d)
+{
+    float r;
+    asm volatile("v_rcp_f32 %0, %1\n\ts_nop 7" : "=&v"(r) : "v"(d));
+    return r;
+}
+// 1 / d for d in [1, 2] (the activations' denominators 1 + e): hardware reciprocal (1 ulp) + one Newton step
+__device__ __forceinline__ float rcp_1to2(float d)
+{
+#if URNN_ACT == 0
+    return __frcp_rn(d);
+#else
+    const float r = trans_rcp(d);
+    return fmaf(fmaf(-d, r, 1.0f), r, r);
+#endif
+}
+// exp(x) for x <= 0 (the only sign the activations need), ~1.5 ulp: v_exp_f32 does its own exact integer / fraction split, so only
+// the argument needs care: t = rn(x * log2e_hi) goes to the hardware exp2, the part of x * log2(e) that t lost -- the product's
+// rounding error (one fma) plus x * log2e_lo -- is at most 2^-24 |t| and enters as the first-order factor 1 + lo * ln 2.
 __device__ __forceinline__ float exp_neg(float x)
 {
 #if URNN_ACT == 0
@@ -67,11 +99,10 @@ __device__ __forceinline__ float exp_neg(float x)
 #else
     const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-08f;   // log2(e) = hi + lo
     const float t = x * L2E_HI;
-    const float n = rintf(t);
-    float f = fmaf(x, L2E_HI, -n);          // exact product, one rounding of a value in [-0.5, 0.5]
-    f = fmaf(x, L2E_LO, f);
-    const float e = __builtin_amdgcn_exp2f(f);          // v_exp_f32, 1 ulp, f in [-0.5, 0.5]
-    return ldexpf(e, (int)n);                           // v_ldexp_f32 (underflows to 0 / denormals like expf)
+    float lo = fmaf(x, L2E_HI, -t);           // exact: what the rounding of t dropped
+    lo = fmaf(x, L2E_LO, lo);
+    const float e = trans_exp2(t);            // v_exp_f32, 1 ulp over the whole range (underflows to 0 like expf)
+    return fmaf(e, lo * 0.693147180559945f, e);
 #endif
 }
 __device__ __forceinline__ float sigmoidf_fast(float v)
@@ -81,7 +112,7 @@ __device__ __forceinline__ float sigmoidf_fast(float v)
 #else
     // sigmoid(v) = 1 / (1 + exp(-|v|)) for v >= 0, exp(-|v|) / (1 + exp(-|v|)) for v < 0: exp of a non-positive argument only
     const float e = exp_neg(-fabsf(v));
-    const float r = __frcp_rn(1.0f + e);
+    const float r = rcp_1to2(1.0f + e);
     return v >= 0.f ? r : e * r;
 #endif
 }
@@ -95,21 +126,17 @@ __device__ __forceinline__ float tanhf_fast(float v)
     return copysignf(r, v);
 #else
     const float a = fabsf(v);
-    float r;
-    if (a < 0.4f) {
-        // Taylor series to a^13 on [0, 0.4]: tanh(a) = a + a^3 P(a^2), truncation < 4e-9 relative
-        const float s = a * a;
-        float p = fmaf(s, 21844.0f / 6081075.0f, -1382.0f / 155925.0f);     // +a^13, -a^11
-        p = fmaf(s, p, 62.0f / 2835.0f);
-        p = fmaf(s, p, -17.0f / 315.0f);
-        p = fmaf(s, p, 2.0f / 15.0f);
-        p = fmaf(s, p, -1.0f / 3.0f);
-        r = fmaf(a * s, p, a);
-    } else {
-        const float t = exp_neg(-2.0f * a);
-        r = (1.0f - t) * __frcp_rn(1.0f + t);            // t <= 0.33: 1 - t loses no more than one bit
-    }
-    return copysignf(r, v);
+    // Taylor series to a^13 on [0, 0.4]: tanh(a) = a + a^3 P(a^2), truncation < 4e-9 relative (branch-free: both forms evaluated)
+    const float s = a * a;
+    float p = fmaf(s, 21844.0f / 6081075.0f, -1382.0f / 155925.0f);     // +a^13, -a^11
+    p = fmaf(s, p, 62.0f / 2835.0f);
+    p = fmaf(s, p, -17.0f / 315.0f);
+    p = fmaf(s, p, 2.0f / 15.0f);
+    p = fmaf(s, p, -1.0f / 3.0f);
+    const float small = fmaf(a * s, p, a);
+    const float t = exp_neg(-2.0f * a);
+    const float big = (1.0f - t) * rcp_1to2(1.0f + t);          // t <= 0.45 here: 1 - t loses no more than one bit
+    return copysignf(a < 0.4f ? small : big, v);
 #endif
 }
 
@@ -165,16 +192,35 @@ __device__ __forceinline__ void split_pair(float xe, float xo, unsigned &ph, uns
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // One dword of each f16 piece from two fp32 values (low half: xe, high half: xo), both scaled by s (a power of two).
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+#ifndef URNN_SPLIT2_ASM
+#define URNN_SPLIT2_ASM 0
+#endif
 __device__ __forceinline__ void split2_pair(float xe, float xo, float s, unsigned &ph, unsigned &pl)
 {
+#if URNN_SPLIT2_ASM
     // v_fma_mix*: fp32 fma whose result is rounded (RNE) into one half of the destination; op_sel_hi marks an f16 source, op_sel
-    // picks its high half.  hi = rne(x*s); lo = rne(x*s - hi): four VALU for two elements.
+    // picks its high half.  hi = rne(x*s); lo = rne(x*s - hi): four VALU for two elements (tuning builds only: partial-register
+    // writes inside an asm statement, nothing pads their hazards)
     asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
         "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
+        "s_nop 1\n\t"
         "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "s_nop 1"
         : "=&v"(ph), "=&v"(pl)
         : "v"(xe), "v"(xo), "s"(s));
+#else
+    // hi = rne_f16(x * s) (v_cvt_pk_f16_f32: both halves in one full-register write); the residual x * s - hi is exact in fp32
+    // (v_fma_mix_f32 with the f16 half as addend); lo = rne_f16(residual).  Compiler-scheduled: hazards and waits are its business.
+    const float se = xe * s, so = xo * s;
+    const f16x2 hi = __builtin_convertvector(f32x2v{se, so}, f16x2);
+    const float re = se - (float)hi.x, ro = so - (float)hi.y;
+    const f16x2 lo = __builtin_convertvector(f32x2v{re, ro}, f16x2);
+    ph = __builtin_bit_cast(unsigned, hi);
+    pl = __builtin_bit_cast(unsigned, lo);
+#endif
 }
 // the same split of one value (weight packers): piece 0 = hi, 1 = lo, as the 16 bits of the f16 encoding
 __host__ __device__ static inline unsigned f16_piece(float x, int piece)

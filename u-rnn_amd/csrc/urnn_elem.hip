@@ -808,18 +808,28 @@ hipError_t urnn_launch_pack_conv(const float *w, const float *bias, float *packe
 // cat(x, [e,] h) (ConvRNN.py:153,165-168).
 //   gate GEMM:      F/32 groups [z_i | r_i] (NB = 2) from W1, then bias [F/32][z_i(32) | r_i(32)]
 //   candidate GEMM: NG2 groups of NB2 = urnn_cand_nb(F) 32-channel blocks from W2, then bias b2 [F]
+//   f16 forms (forward k-loop): the gate slab in the grouping of urnn_gate_groups (NGg groups of NBg blocks, block nb of group g
+//   = canonical block urnn_gate_cb of [z_0 .. | r_0 ..]), the candidate slab as above, then the gate bias in the grouped order.
 __global__ void pack_gru_kernel(const float *__restrict__ W1, const float *__restrict__ b1, const float *__restrict__ W2,
-                                const float *__restrict__ b2, float *__restrict__ packed, int I, int F, int skip, int NB2)
+                                const float *__restrict__ b2, float *__restrict__ packed, int I, int F, int skip, int NB2, int NBg, int NGg,
+                                int halves, int GS)
 {
     const int Ie = (I + 1) & ~1;
     const int Fe = skip ? F : 0;
     const int KT = (Ie + Fe + F) / 2, NG = F / 32, Ksrc = I + Fe + F;
     const int slab1 = slab_floats(KT, 2), slab2 = slab_floats(KT, NB2), NG2 = NG / NB2;
     const int ssd1 = urnn_split_slab_dwords(KT, 2), ssd2 = urnn_split_slab_dwords(KT, NB2);
-    const int fsd1 = urnn_f16_slab_dwords(KT, 2), fsd2 = urnn_f16_slab_dwords(KT, NB2);
-    const int n1 = NG * slab1, nb1 = 2 * F, n2 = NG2 * slab2, nb2 = F, s1 = NG * ssd1, s2 = NG2 * ssd2, f1 = NG * fsd1, f2 = NG2 * fsd2;
+    const int fsd1 = urnn_f16_slab_dwords(KT, NBg), fsd2 = urnn_f16_slab_dwords(KT, NB2);
+    const int n1 = NG * slab1, nb1 = 2 * F, n2 = NG2 * slab2, nb2 = F, s1 = NG * ssd1, s2 = NG2 * ssd2, f1 = NGg * fsd1, f2 = NG2 * fsd2;
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n1 + nb1 + n2 + nb2 + s1 + s2 + f1 + f2) return;
+    if (idx >= n1 + nb1 + n2 + nb2 + s1 + s2 + f1 + f2 + 2 * F) return;
+    if (idx >= n1 + nb1 + n2 + nb2 + s1 + s2 + f1 + f2) {        // gate bias in the f16 grouping's packed column order
+        const int n = idx - (n1 + nb1 + n2 + nb2 + s1 + s2 + f1 + f2);
+        const int g = n / (NBg * 32), nb = (n >> 5) % NBg;
+        const int cb = urnn_gate_cb(halves, GS, NG, g, nb);
+        packed[idx] = b1[(cb / NG) * F + (cb % NG) * 32 + (n & 31)];
+        return;
+    }
     auto src_col = [&](int k) {   // packed row k -> source column of W1 / W2, -1: padding row
         if (k < Ie) return k < I ? k : -1;
         return I + (k - Ie);
@@ -856,9 +866,10 @@ __global__ void pack_gru_kernel(const float *__restrict__ W1, const float *__res
         if (q >= s1 + s2) {                       // f16 forms: gate groups, then candidate groups
             q -= s1 + s2;
             if (q < f1) {
-                const int i = q / fsd1;
-                f16_slot(q - i * fsd1, 2, kp, nb, piece, l);
-                d = f16_pair(gate_w(i, kp, nb, l), gate_w(i, kp + 1, nb, l), piece);
+                const int g = q / fsd1;
+                f16_slot(q - g * fsd1, NBg, kp, nb, piece, l);
+                const int cb = urnn_gate_cb(halves, GS, NG, g, nb);
+                d = f16_pair(gate_w(cb % NG, kp, cb / NG, l), gate_w(cb % NG, kp + 1, cb / NG, l), piece);
             } else {
                 q -= f1;
                 const int g = q / fsd2;
@@ -881,16 +892,27 @@ __global__ void pack_gru_kernel(const float *__restrict__ W1, const float *__res
     packed[idx] = v;
 }
 
+size_t urnn_packed_gru_total(int I, int F, int skip)
+{
+    const int Ie = (I + 1) & ~1;
+    const int KT = (Ie + (skip ? F : 0) + F) / 2;
+    const int NB2 = urnn_cand_nb(F);
+    const GateGroups gg = urnn_gate_groups(F, KT);
+    return (size_t)(F / 32) * slab_floats(KT, 2) + 2 * F + (size_t)((F / 32) / NB2) * slab_floats(KT, NB2) + F +
+           (size_t)(F / 32) * urnn_split_slab_dwords(KT, 2) + (size_t)((F / 32) / NB2) * urnn_split_slab_dwords(KT, NB2) +
+           (size_t)gg.NG * urnn_f16_slab_dwords(KT, gg.NB) + (size_t)((F / 32) / NB2) * urnn_f16_slab_dwords(KT, NB2) + 2 * F;
+}
+
 hipError_t urnn_launch_pack_gru(const float *W1, const float *b1, const float *W2, const float *b2, float *packed, int I,
                                 int F, int skip, hipStream_t st)
 {
     const int Ie = (I + 1) & ~1;
     const int KT = (Ie + (skip ? F : 0) + F) / 2;
     const int NB2 = urnn_cand_nb(F);
-    const int total = (F / 32) * slab_floats(KT, 2) + 2 * F + ((F / 32) / NB2) * slab_floats(KT, NB2) + F +
-                      (F / 32) * urnn_split_slab_dwords(KT, 2) + ((F / 32) / NB2) * urnn_split_slab_dwords(KT, NB2) +
-                      (F / 32) * urnn_f16_slab_dwords(KT, 2) + ((F / 32) / NB2) * urnn_f16_slab_dwords(KT, NB2);
-    hipLaunchKernelGGL(pack_gru_kernel, dim3((total + 255) / 256), dim3(256), 0, st, W1, b1, W2, b2, packed, I, F, skip, NB2);
+    const GateGroups gg = urnn_gate_groups(F, KT);
+    const int total = (int)urnn_packed_gru_total(I, F, skip);
+    hipLaunchKernelGGL(pack_gru_kernel, dim3((total + 255) / 256), dim3(256), 0, st, W1, b1, W2, b2, packed, I, F, skip, NB2, gg.NB, gg.NG,
+                       gg.halves, gg.GS);
     return hipGetLastError();
 }
 

@@ -290,7 +290,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
     if constexpr (SPLIT == 3) stage_weights(reinterpret_cast<const float *>(prm.wf16) + (size_t)g * prm.fDwords, urnn_smem, prm.fDwords, wave, WPB, lane);
     else if constexpr (SPLIT) stage_weights(reinterpret_cast<const float *>(prm.wsplit) + (size_t)g * prm.sDwords, urnn_smem, prm.sDwords, wave, WPB, lane);
     else stage_weights(prm.wt + (size_t)g * prm.aFloats, urnn_smem, prm.aFloats, wave, WPB, lane);
-    if (threadIdx.x < NB * 32) bias[threadIdx.x] = prm.bias[n0 + threadIdx.x];
+    if (threadIdx.x < NB * 32) bias[threadIdx.x] = (EPI == EPI_GRU1 && SPLIT == 3 && prm.biasf ? prm.biasf : prm.bias)[n0 + threadIdx.x];
     if constexpr (GATED) {
         // GroupNorm of the gates is finalised HERE instead of in a launch of its own: one wave per (sample, 32-channel
         // group) folds the gate GEMM's per-tile (sum, sumsq) partials in double, in a fixed order (lane-strided, then an xor
@@ -732,14 +732,16 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
                     }
                 }
         } else if constexpr (EPI == EPI_GRU1) {
-            // group i owns [z_i | r_i]: raw (pre-GroupNorm) gates -> out0 (B,2F,P) and the GroupNorm partial sums of z_i
-            // (group i) and r_i (group F/32 + i) -> partial[b][grp][tile][2].
-            static_assert(NB == 2, "gate tile is z|r");
+            // block nb of group g is canonical block cb of [z_0 .. z_{G-1} | r_0 .. r_{G-1}] (urnn_gate_cb; the fp32 / bf16 slabs:
+            // group i = z_i | r_i): raw (pre-GroupNorm) gates -> out0 (B,2F,P) channels [32 cb, 32 cb + 32) and that block's
+            // GroupNorm partial sums -> partial[b][cb][tile][2].
             const int F = prm.F;
-            const int i = g;
-            const float inv_n = 1.f / (float)(32 * tile_valid(tile, 32 * PB, prm.P));
+            const int G = F / 32;
+            const bool grouped = SPLIT == 3 && prm.biasf != nullptr;
+            const float inv_n = tile == prm.tilesPerSample - 1 ? prm.invTail : prm.invFull;   // 1 / (32 * valid pixels), from the host: no v_rcp here
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
+            for (int nb = 0; nb < NB; ++nb) {
+                const int cb = grouped ? urnn_gate_cb(prm.gHalves, prm.gGS, G, g, nb) : urnn_gate_cb(0, 1, G, g, nb);
                 // pass 1, registers only: the tile's sum -> its own mean; pass 2: squares about that mean (urnn_common.h tile_x2)
                 // while the rows are stored -- an accumulator row dies with its store, as in a single-pass epilogue
                 float s1 = 0.f;
@@ -753,7 +755,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
                 s1 = wave_sum(s1);
                 const float mt = s1 * inv_n;
                 float s2 = 0.f;
-                float *obase = prm.out0 + ((size_t)b * 2 * F + nb * F + i * 32 + 4 * half) * prm.P;   // one lane-dependent base, uniform row steps
+                float *obase = prm.out0 + ((size_t)b * 2 * F + cb * 32 + 4 * half) * prm.P;   // one lane-dependent base, uniform row steps
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float bv = bias_h[nb * 32 + row_c(r)];
@@ -769,9 +771,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
                 }
                 s2 = wave_sum(s2);
                 if (lane == 0) {
-                    const int G = 2 * F / 32;
-                    const int grp = nb * (F / 32) + i;
-                    float *pp = prm.partial + (((size_t)b * G + grp) * prm.tilesPerSample + tile) * 2;
+                    float *pp = prm.partial + (((size_t)b * 2 * G + cb) * prm.tilesPerSample + tile) * 2;
                     pp[0] = s1;
                     pp[1] = s2;
                 }
@@ -780,7 +780,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
             // group g owns candidate channels [g*NB*32, (g+1)*NB*32): pre-GroupNorm candidate -> out0 (B,F,P), partial statistics
             // (sum, centred second moment) per 32-channel GroupNorm group -> partial[b][F/32][tile][2]
             const int F = prm.F;
-            const float inv_n = 1.f / (float)(32 * tile_valid(tile, 32 * PB, prm.P));
+            const float inv_n = tile == prm.tilesPerSample - 1 ? prm.invTail : prm.invFull;   // 1 / (32 * valid pixels), from the host: no v_rcp here
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const int grp = g * NB + nb;
@@ -979,6 +979,11 @@ static int split_mode(const ConvGemmParams &p)
 template <int NB, int PB, int MAP, int EPI, int D, int WPB>
 static hipError_t launch_conv_cfg(const ConvGemmParams &p, hipStream_t st, int max_bpc = 2)
 {
+    if constexpr (EPI == EPI_GRU1 && NB > 2) {          // grouped gate GEMM: exists in the f16 form only (gate_grouped checked the rest)
+        static_assert(NB * PB * 16 <= 128, "grouped gate tiles are 64 pixels wide at most");
+        if (split_mode<NB, PB, EPI>(p) != 3) return hipErrorInvalidValue;
+        return launch_conv_split<NB, PB, MAP, EPI, D, WPB, 3>(p, st, max_bpc);
+    } else
     if constexpr (EPI == EPI_DECONV ? (NB * PB * 16 <= 192 && WPB == 4) : NB * PB * 16 <= 128) {
         const int sm = split_mode<NB, PB, EPI>(p);
         if (sm == 3) return launch_conv_split<NB, PB, MAP, EPI, D, WPB, 3>(p, st, max_bpc);
@@ -1036,7 +1041,9 @@ static hipError_t launch_conv(const ConvGemmParams &p, hipStream_t st)
 template <int NB, int EPI>
 static hipError_t launch_flat(const ConvGemmParams &p, int pb, int map, hipStream_t st)
 {
-    if (map == MAP_VEC && pb == 4) return launch_conv<NB, 4, MAP_VEC, EPI>(p, st);
+    if constexpr (!(EPI == EPI_GRU1 && NB > 2)) {      // the grouped gate kernels run 64- / 32-pixel tiles only
+        if (map == MAP_VEC && pb == 4) return launch_conv<NB, 4, MAP_VEC, EPI>(p, st);
+    }
     if (map == MAP_PAIR16 && pb == 2) return launch_conv<NB, 2, MAP_PAIR16, EPI>(p, st);
     if (map == MAP_PAIR && pb == 2) return launch_conv<NB, 2, MAP_PAIR, EPI>(p, st);
     if (map == MAP_STRIDED && pb == 2) return launch_conv<NB, 2, MAP_STRIDED, EPI>(p, st);
@@ -1107,12 +1114,63 @@ hipError_t urnn_launch_deconv(ConvGemmParams p, int B, int PB, int map, hipStrea
     return launch_conv<6, 1, MAP_STRIDED, EPI_DECONV>(p, st);
 }
 
-// GRU gate GEMM: F/32 groups of [z|r].
+// GRU gate GEMM.  Column grouping of the f16 slab: as many of the 2F columns per wave as the accumulators (128 registers at two
+// waves per SIMD: 4 n-blocks x 64 pixels) and the LDS (slab + 8 rings of 64-pixel slots) allow -- F = 64: one group of all four
+// blocks (z0 r0 z1 r1); F = 96: the z half and the r half (3 blocks each); F = 128: two groups of two pairs.  Development knob
+// URNN_TUNE_GATE_ALLN=0 keeps the F/32 groups of (z_i | r_i).
+GateGroups urnn_gate_groups(int F, int KT)
+{
+    static const int alln = [] { const char *e = getenv("URNN_TUNE_GATE_ALLN"); return e ? atoi(e) : 1; }();
+    const int G = F / 32;
+    auto fits = [&](int NB) { return (size_t)urnn_f16_slab_dwords(KT, NB) * 4 + 8 * 9 * 512 + NB * 128 + 2048 <= LDS_PER_CU; };
+    if (alln && KT % 8 == 0) {
+        if (G == 2 && fits(4)) return GateGroups{4, 1, 0, 2};
+        if (G == 4 && fits(4)) return GateGroups{4, 2, 0, 2};
+        if (G == 3 && fits(3)) return GateGroups{3, 2, 1, 0};
+    }
+    return GateGroups{2, G, 0, 1};
+}
+
+// 1 / (values per GroupNorm tile) for the epilogues' tile means (full tiles / the last, possibly partial one)
+static void set_tile_means(ConvGemmParams &p, int tile_pix)
+{
+    const int tail = p.P - (p.tilesPerSample - 1) * tile_pix;
+    p.invFull = 1.0f / (32.0f * (float)tile_pix);
+    p.invTail = 1.0f / (32.0f * (float)(tail > 0 ? tail : tile_pix));
+}
+
+// f16-eligible launch with a wide grouping -> the grouped kernel on 64-pixel tiles (pair maps need an even plane)
+static bool gate_grouped(const ConvGemmParams &p)
+{
+    if (p.NBf == 2 || !p.wf16 || p.fDwords <= 0 || !p.biasf) return false;
+    if (g_matrix_mode.load(std::memory_order_relaxed) == URNN_MATRIX_BF16 || !tune_split() || !tune_f16()) return false;
+    if (p.KT % 8 != 0 || p.kpBegin % 8 != 0 || p.KT <= p.kpBegin) return false;
+    return true;
+}
+
+int urnn_gate_plan(const ConvGemmParams &p, int B, int pb_legacy, int map_legacy, int *pb, int *map)
+{
+    (void)B;
+    if (!gate_grouped(p)) { *pb = pb_legacy; *map = map_legacy; return 0; }
+    if (pb_legacy >= 2) { *pb = 2; *map = p.P % 4 == 0 ? MAP_PAIR16 : (p.P % 2 == 0 ? MAP_PAIR : MAP_STRIDED); }
+    else { *pb = 1; *map = MAP_STRIDED; }
+    return 1;
+}
+
 hipError_t urnn_launch_gru1(ConvGemmParams p, int B, int PB, int map, hipStream_t st)
 {
     if (p.NG < 1 || p.NG > 4) return hipErrorInvalidValue;
     p.tilesPerSample = (p.P + 32 * PB - 1) / (32 * PB);
     p.totalTiles = B * p.tilesPerSample;
+    set_tile_means(p, 32 * PB);
+    if (gate_grouped(p)) {
+        if (PB > 2) return hipErrorInvalidValue;                  // the caller plans with urnn_gate_plan
+        p.NG = p.NGf;
+        if (p.NBf == 4) return launch_flat<4, EPI_GRU1>(p, PB, map, st);
+        if (p.NBf == 3) return launch_flat<3, EPI_GRU1>(p, PB, map, st);
+        return hipErrorInvalidValue;
+    }
+    if (p.NBf != 2) { p.wf16 = nullptr; p.fDwords = 0; p.biasf = nullptr; }     // the f16 slab is grouped for the other kernel
     return launch_flat<2, EPI_GRU1>(p, PB, map, st);
 }
 
@@ -1133,6 +1191,7 @@ hipError_t urnn_launch_cand(ConvGemmParams p, int B, int PB, int map, hipStream_
     p.NG = (p.F / 32) / NB;
     p.tilesPerSample = (p.P + 32 * PB - 1) / (32 * PB);
     p.totalTiles = B * p.tilesPerSample;
+    set_tile_means(p, 32 * PB);
     if (NB == 1) return launch_flat<1, EPI_CAND>(p, PB, map, st);
     if (NB == 2) return launch_flat<2, EPI_CAND>(p, PB, map, st);
     return launch_flat<3, EPI_CAND>(p, PB, map, st);

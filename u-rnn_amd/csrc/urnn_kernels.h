@@ -30,11 +30,17 @@ struct ConvGemmParams {
     const unsigned *wf16;     // the same weights x 2^URNN_F16_WEXP as two f16 pieces (urnn_f16_slab_dwords), group stride fDwords
     int fDwords;          // dwords per n-group f16 slab; 0: no f16 form
     int wide;             // 1: the activations are gradients (unbounded exponent range): bf16 x 6 split instead of f16 x 3
+    // EPI_GRU1, f16 form only: column grouping of the gate GEMM (urnn_gate_groups): the f16 slab holds NGf groups of NBf n-blocks,
+    // block nb of group g being canonical block cb = urnn_gate_cb(...) of [z_0 .. z_{G-1} | r_0 .. r_{G-1}]; biasf = the bias in
+    // that packed order.  The fp32 / bf16 slabs (wt, wsplit, bias) keep F/32 groups of (z_i | r_i).
+    int NGf, NBf, gHalves, gGS;
+    const float *biasf;
     const float *bias;    // bias per packed column [NG*NB*32]
     int aFloats;          // floats per n-group slab, a multiple of 256 (one LDS-DMA instruction moves 256 floats)
     int NG;               // number of n-groups (blocks are specialised per group)
     int P, W, P2, W2;     // input plane size / width; pooled plane size / width (EPI_POOL)
     int tilesPerSample, totalTiles;
+    float invFull, invTail;   // EPI_GRU1 / EPI_CAND: 1 / (32 * pixels) of a full tile / of the sample's last tile (tile means of the partials)
     int Cout, F;
     float slope;
     float *out0;
@@ -42,12 +48,25 @@ struct ConvGemmParams {
     float *partial;       // EPI_GRU1: [B][2F/32][tiles][2]; EPI_CAND: [B][F/32][tiles][2]
 };
 
+// Gate GEMM column grouping of the f16 slab.  A wave that owns more of the 2F gate columns reads the K input planes fewer times
+// through the CU's load path (the gate GEMM with F/32 groups of z_i|r_i was bound by that path, not by HBM: dec1 moved 576 MB
+// through the CUs for 352 MB of HBM traffic).  halves = 0: group g = the pairs (z_i, r_i), i in [g*GS, (g+1)*GS), NB = 2*GS;
+// halves = 1: group 0 = all z blocks, group 1 = all r blocks, NB = F/32.  Depends on (F, KT) only: packing and launch agree.
+struct GateGroups { int NB, NG, halves, GS; };
+GateGroups urnn_gate_groups(int F, int KT);
+__host__ __device__ static inline int urnn_gate_cb(int halves, int GS, int G, int g, int nb)
+{
+    return halves ? g * G + nb : (nb & 1) * G + g * GS + (nb >> 1);
+}
+// which gate kernel a launch will take: returns 1 (and the tile shape) when the grouped f16 kernel runs, 0 for the F/32-group one
+int urnn_gate_plan(const ConvGemmParams &p, int B, int pb_legacy, int map_legacy, int *pb, int *map);
+
 int urnn_conv_nb(int Cout);   // n-blocks per wave for a Cout-wide 1x1 conv (packing and launch must agree)
 int urnn_conv_ng(int Cout);   // number of n-groups (the last one may be padded with zero columns)
 hipError_t urnn_launch_conv_flat(ConvGemmParams p, int B, int PB, int map, hipStream_t st);
 hipError_t urnn_launch_conv_pool(ConvGemmParams p, int B, hipStream_t st);
 hipError_t urnn_launch_deconv(ConvGemmParams p, int B, int PB, int map, hipStream_t st);
-hipError_t urnn_launch_gru1(ConvGemmParams p, int B, int PB, int map, hipStream_t st);
+hipError_t urnn_launch_gru1(ConvGemmParams p, int B, int PB, int map, hipStream_t st);   // PB / map as urnn_gate_plan returned them
 // small planes (urnn_small.hip): activation-stationary gate / candidate GEMMs; same outputs and 32-pixel partial tiles as the
 // regular kernels with PB = 1
 bool urnn_small_ok(const ConvGemmParams &p, int nblk_total, int gated);
@@ -101,6 +120,7 @@ hipError_t urnn_launch_stage1_scalar(const float *S, const float *rain, const fl
 hipError_t urnn_launch_pack_conv(const float *w, const float *bias, float *packed, int Cin, int Cout, hipStream_t st);
 hipError_t urnn_launch_pack_gru(const float *W1, const float *b1, const float *W2, const float *b2, float *packed, int I,
                                 int F, int skip, hipStream_t st);
+size_t urnn_packed_gru_total(int I, int F, int skip);   // floats of a packed cell buffer (layout: urnn_elem.hip pack_gru_kernel)
 hipError_t urnn_launch_pack_deconv(const float *w, const float *bias, float *packed, int Cin, int Cout, hipStream_t st);
 
 // ---- training building blocks (urnn_train.hip) ----

@@ -38,7 +38,9 @@ __global__ __launch_bounds__(1024) void small_cell_gemm_kernel(const ConvGemmPar
     unsigned *Bp = reinterpret_cast<unsigned *>(urnn_small_smem);       // [KG][2][NPC][64][4] dwords
     float *bias = reinterpret_cast<float *>(Bp + (size_t)KG * 2 * NPC * 256);
     float *ssm = bias + nblk_total * 32;                                // GATED: [F][2] r-gate (scale, shift) of sample b
-    if (threadIdx.x < nblk_total * 32) bias[threadIdx.x] = prm.bias[threadIdx.x];
+    // gate GEMM, f16 form: blocks in the packed order of the grouped slab (urnn_gate_groups), bias likewise
+    const bool grouped = !GATED && MODE == 3 && prm.biasf != nullptr;
+    if (threadIdx.x < nblk_total * 32) bias[threadIdx.x] = (grouped ? prm.biasf : prm.bias)[threadIdx.x];
 
     if constexpr (GATED) {
         // GroupNorm of the gates, folded from the gate GEMM's per-tile partials in double, fixed order (as in conv_gemm_kernel):
@@ -197,12 +199,14 @@ __global__ __launch_bounds__(1024) void small_cell_gemm_kernel(const ConvGemmPar
     const bool ok = px < P;
     const int nvalid = tile_valid(tile, 32, P);
     if (nvalid <= 0) return;                                              // (whole-wave: a tile past the end of an odd plane)
-    int ch0, Cout;                                                        // first output channel of this wave's block
+    int ch0, Cout, cb = 0;                                                // first output channel of this wave's block
     if constexpr (GATED) {
         ch0 = nbg * 32;
         Cout = F;
     } else {
-        ch0 = nb * F + g * 32;                                            // group g = [z_g | r_g]
+        // canonical block of [z_0 .. | r_0 ..]: group g = (z_g | r_g) in the fp32 / bf16 slabs, urnn_gate_cb in the grouped f16 one
+        cb = grouped ? urnn_gate_cb(prm.gHalves, prm.gGS, F / 32, g, nb) : urnn_gate_cb(0, 1, F / 32, g, nb);
+        ch0 = cb * 32;
         Cout = 2 * F;
     }
     const float *bias_h = bias + nbg * 32 + 4 * half;
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(1024) void small_cell_gemm_kernel(const ConvGemmPar
     for (int r = 0; r < 16; ++r)
         if (ok) s1 += fin(acc[r], bias_h[row_c(r)]);
     s1 = wave_sum(s1);
-    const float mt = s1 / (float)(32 * nvalid);
+    const float mt = s1 * (nvalid == 32 ? prm.invFull : prm.invTail);      // 1 / (32 * valid pixels), from the host: no division here
     float s2 = 0.f;
     float *obase = prm.out0 + ((size_t)b * Cout + ch0 + 4 * half) * P + px;
 #pragma unroll
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(1024) void small_cell_gemm_kernel(const ConvGemmPar
     }
     s2 = wave_sum(s2);
     if (lane == 0) {
-        const int grp = GATED ? nbg : nb * (F / 32) + g;
+        const int grp = GATED ? nbg : cb;
         const int G = GATED ? F / 32 : 2 * F / 32;
         float *pp = prm.partial + (((size_t)b * G + grp) * prm.tilesPerSample + tile) * 2;
         pp[0] = s1;
@@ -279,11 +283,17 @@ static hipError_t launch_small(const ConvGemmParams &p, int B, int nblk_total, i
         if (e != hipSuccess) return e;
         raised = true;
     }
+    ConvGemmParams q = p;
+    {
+        const int tail = q.P - (q.tilesPerSample - 1) * 32;
+        q.invFull = 1.0f / 1024.0f;
+        q.invTail = 1.0f / (32.0f * (float)(tail > 0 ? tail : 32));
+    }
     const int blocks = B * ((p.P + 63) / 64);
     const dim3 grid(blocks), blk(64 * nblk_total * 2);
-    if (mode == 2) hipLaunchKernelGGL(k2, grid, blk, lds, st, p, nblk_total, NBG);
-    else if (mode == 3) hipLaunchKernelGGL(k3, grid, blk, lds, st, p, nblk_total, NBG);
-    else hipLaunchKernelGGL(k1, grid, blk, lds, st, p, nblk_total, NBG);
+    if (mode == 2) hipLaunchKernelGGL(k2, grid, blk, lds, st, q, nblk_total, NBG);
+    else if (mode == 3) hipLaunchKernelGGL(k3, grid, blk, lds, st, q, nblk_total, NBG);
+    else hipLaunchKernelGGL(k1, grid, blk, lds, st, q, nblk_total, NBG);
     return hipGetLastError();
 }
 
@@ -292,7 +302,8 @@ hipError_t urnn_launch_small_gates(ConvGemmParams p, int B, hipStream_t st)
 {
     p.tilesPerSample = (p.P + 31) / 32;
     p.totalTiles = B * p.tilesPerSample;
-    return launch_small<0>(p, B, p.NG * 2, 2, small_mode(p), st);
+    const int mode = small_mode(p);
+    return launch_small<0>(p, B, p.NG * 2, mode == 3 ? p.NBf : 2, mode, st);          // blocks per group as packed (f16: grouped)
 }
 
 hipError_t urnn_launch_small_cand(ConvGemmParams p, int B, hipStream_t st)
