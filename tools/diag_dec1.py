@@ -84,6 +84,12 @@ for i in range(M):
     cell.step(x, e, h, out=out, ws=ws)
     torch.cuda.synchronize()
     cur = {"g1": ws[:g1_bytes], "cx": ws[cx_off:cx_off + cx_bytes], "rest": ws[part_off:], "out": out}
+    nan_cx = int(torch.isnan(cur["cx"].view(torch.float32)).sum())
+    if nan_cx:
+        a = cur["cx"].view(torch.float32)
+        idx = torch.nonzero(torch.isnan(a), as_tuple=True)[0].cpu().numpy()
+        ch, px = idx // P, idx % P
+        print(f"  launch {i + 1}: {nan_cx} NaN in cx: channels {len(set(ch.tolist()))}, px {px.min()}..{px.max()}, distinct px {len(set(px.tolist()))}, px % 128 values {sorted(set((px % 128).tolist()))[:20]}")
     diff = [k for k in ref if not torch.equal(ref[k], cur[k])]
     if diff:
         bad += 1

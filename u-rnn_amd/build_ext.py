@@ -9,6 +9,16 @@ SOURCES = ["urnn_gemm.hip", "urnn_small.hip", "urnn_elem.hip", "urnn_train.hip",
 HEADERS = ["urnn_common.h", "urnn_kernels.h", os.path.join("..", "..", "include", "urnn_hip.h")]
 
 
+# No SLP vectorisation: on gfx950 it turns pairs of scalar fp32 operations into packed v_pk_mul_f32 / v_pk_fma_f32.  In the
+# candidate GEMM (MFMAs, LDS-DMA, two waves per SIMD) those produced -- about once per 10^9 instructions, reproducibly on every box
+# -- a wrong LOW element in lanes 16..31 of one wave: 16 pixel columns of one tile off by ~3e-3 in 10-90 of 6000 launches of the
+# dec1 cell, whatever the activation code looked like (hardware transcendentals, padded inline asm, a VALU-only sigmoid) and with
+# every ring slot poisoned with NaN until its DMA landed (no NaN ever appeared: the ring protocol was not the cause).  The same
+# sources without packed instructions: 0 of 8000 launches, 0 of 30 whole-event rollouts, and 1.5 % faster (tools/diag_dec1.py,
+# tools/stress_overlap.py; MI355X_MICROARCH.md prices the packed ops as an anti-lever beside MFMAs anyway).
+NO_PACKED_F32 = ("-fno-slp-vectorize",)
+
+
 def _newest(paths):
     return max(os.path.getmtime(p) for p in paths)
 
@@ -27,7 +37,7 @@ def build(force=False, verbose=False, extra_flags=(), out=None, tag=""):
     for s in srcs:
         o = os.path.join(CSRC, os.path.basename(s).replace(".hip", tag + ".o"))
         objs.append(o)
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *extra_flags, "-c", s, "-o", o]
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *NO_PACKED_F32, *extra_flags, "-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd))
         procs.append(subprocess.Popen(cmd))

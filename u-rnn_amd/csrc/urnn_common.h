@@ -54,38 +54,20 @@ __device__ __forceinline__ double tile_x2(float s1, float y, int n)
 }
 
 // Activations.  URNN_ACT = 0: hardware exp2 / rcp on x * log2(e) (the argument's rounding costs |x| * 2^-24 relative -- a bias of
-// +8.5e-8 on average -- and tanh's 1 - t cancels for small |x|); 1: the argument's rounding error is carried along (exp_neg), the
-// reciprocal is v_rcp_f32 + one Newton step, tanh uses its series for small arguments: ~1-2 ulp results with unbiased errors.
-//
-// The transcendental instructions are issued through trans_exp2 / trans_rcp: inline asm with the source kept alive and eight wait
-// states behind the instruction.  v_exp_f32 / v_rcp_f32 run at quarter rate (four passes of 16 lanes) beside the full-rate VALU;
-// hipcc (ROCm 7.2) schedules `v_mul t; v_exp e, t; v_fma t, ...` back to back, re-using the exp's SOURCE register for the next
-// result, and in the candidate GEMM (MFMAs, LDS-DMA and a second wave on the SIMD) that produced, about once per 10^7 wave
-// instructions, a wrong sigmoid in exactly lanes 16..31 -- the exp's second pass -- of the first element after an s_waitcnt
-// (tools/diag_dec1.py: 17 of 3000 launches of the dec1 cell differed in 16 pixel columns; tools/ubench/trans_hazard.hip could not
-// provoke it in isolation).  With the source pinned and the consumers eight wait states away the launches are bit-stable.
+// +8.5e-8 on average -- and tanh's 1 - t cancels for small |x|); 1 (shipped): the argument's rounding error is carried along
+// (exp_neg), the reciprocal is v_rcp_f32 + one Newton step, tanh uses its series for small arguments: ~1-2 ulp, unbiased.
+// (Round 3 chased rare wrong values in 16 lanes of the candidate GEMM through these functions -- padded inline asm, a VALU-only
+// sigmoid -- before the packed-fp32 instructions turned out to be the cause: u-rnn_amd/build_ext.py, -fno-slp-vectorize.)
 #ifndef URNN_ACT
 #define URNN_ACT 1
 #endif
-__device__ __forceinline__ float trans_exp2(float t)
-{
-    float e;
-    asm volatile("v_exp_f32 %0, %1\n\ts_nop 7" : "=&v"(e) : "v"(t));
-    return e;
-}
-__device__ __forceinline__ float trans_rcp(float d)
-{
-    float r;
-    asm volatile("v_rcp_f32 %0, %1\n\ts_nop 7" : "=&v"(r) : "v"(d));
-    return r;
-}
 // 1 / d for d in [1, 2] (the activations' denominators 1 + e): hardware reciprocal (1 ulp) + one Newton step
 __device__ __forceinline__ float rcp_1to2(float d)
 {
 #if URNN_ACT == 0
     return __frcp_rn(d);
 #else
-    const float r = trans_rcp(d);
+    const float r = __builtin_amdgcn_rcpf(d);
     return fmaf(fmaf(-d, r, 1.0f), r, r);
 #endif
 }
@@ -101,7 +83,7 @@ __device__ __forceinline__ float exp_neg(float x)
     const float t = x * L2E_HI;
     float lo = fmaf(x, L2E_HI, -t);           // exact: what the rounding of t dropped
     lo = fmaf(x, L2E_LO, lo);
-    const float e = trans_exp2(t);            // v_exp_f32, 1 ulp over the whole range (underflows to 0 like expf)
+    const float e = __builtin_amdgcn_exp2f(t);           // v_exp_f32, 1 ulp over the whole range (underflows to 0 like expf)
     return fmaf(e, lo * 0.693147180559945f, e);
 #endif
 }

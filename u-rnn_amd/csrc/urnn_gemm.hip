@@ -474,6 +474,18 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
                     seg_left = (seg_cur == 1 && !GATED && k2 != INT_MAX) ? k2 - k1 : INT_MAX;
                 }
             };
+#ifdef URNN_POISON
+            // diagnosis build: a ring slot holds NaN from the moment its fragment has been consumed until its DMA lands, so a read
+            // that gets ahead of the DMA (whatever s_waitcnt said) shows up as NaN in the output instead of as plausible stale data
+            auto poison = [&](int slot_) {
+                const float qn = __builtin_nanf("");
+#pragma unroll
+                for (int qd = 0; qd < R::SLOT / 1024 + (R::SLOT % 1024 ? 1 : 0); ++qd)
+                    if (qd * 1024 + lane * 16 < R::SLOT) *reinterpret_cast<f32x4 *>(ring + slot_ * R::SLOT + qd * 1024 + lane * 16) = f32x4{qn, qn, qn, qn};
+            };
+            for (int i = 0; i < D; ++i) poison(i);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
             for (int i = 0; i < D; ++i) refill_s(i);
             constexpr bool BF16C = (SPLIT == 2), F16 = (SPLIT == 3);
             constexpr int NPC = F16 ? 2 : 3;               // weight pieces per n-block in the LDS slab
@@ -509,11 +521,16 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
                         else split_pair(rb[0][pb], rb[1][pb], bh[pb][Q >> 1], bm[pb][Q >> 1], bl[pb][Q >> 1]);
                     }
                 }
-                wait_vmcnt<(D - (CG ? 2 : 1) - (NGT ? 2 : 1)) * R::NLOAD>();       // the next k-pair's slot(s) have landed (or are dummies)
+                wait_vmcnt<(D - (CG ? 2 : 1) - (NGT ? 2 : 1)) * R::NLOAD>();   // the next k-pair's slot(s) have landed (or are dummies)
                 // The slot(s) about to be refilled were read one step ago, but an even k-pair's fragments are not CONSUMED before
                 // the next odd step, so nothing has waited for that ds_read yet: without this wait the DMA could (rarely: one
                 // launch in ~30) overwrite the slot before the read had left LDS.  The read is a step old: the wait is free.
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if defined(URNN_POISON) && URNN_POISON >= 2
+                poison(slot);
+                if constexpr (CG) poison(wrap(slot + 1));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
                 refill_s(slot);
                 if constexpr (CG) refill_s(wrap(slot + 1));
                 read_b(kp + 1 < KT ? kp + 1 : kp, nslot, NGT, rb[(Q + 1) & 1]);
@@ -598,7 +615,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
             constexpr bool CG = decltype(cur_tag)::value, NGT = decltype(nxt_tag)::value;
             constexpr int RF = decltype(rf_tag)::value;
             const int nslot = wrap(slot + (CG ? 2 : 1));
-            wait_vmcnt<(D - (CG ? 2 : 1) - (NGT ? 2 : 1)) * R::NLOAD>();       // the next k-pair's slot(s) have landed (or are dummies)
+            wait_vmcnt<(D - (CG ? 2 : 1) - (NGT ? 2 : 1)) * R::NLOAD>();   // the next k-pair's slot(s) have landed (or are dummies)
             const int kn = kp + 1 < KT ? kp + 1 : kp;
             if constexpr (NGT) read_gated(kn, nslot, a_nxt, b_nxt);
             else read_plain(kn, nslot, a_nxt, b_nxt);
