@@ -41,7 +41,7 @@ MIXED = ("futian", "ukea")     # BASELINE configs[4]: mixed-resolution events on
 
 PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X fp32 matrix peak (MI355X_MICROARCH.md)
 PEAK_MFMA_BF16_TFLOPS = 2517.0  # dense bf16 matrix peak (MI355X_MICROARCH.md: ~2.5 PF; 16x the fp32 matrix rate)
-SPLIT_MFMAS = 6                 # bf16 MFMAs per fp32-equivalent 16-k step of the split k-loop (urnn_gemm.hip)
+SPLIT_MFMAS = 3                 # f16 MFMAs per fp32-equivalent 16-k step of the forward k-loop (urnn_gemm.hip, SPLIT = 3)
 PEAK_HBM_TBS = 8.0
 
 
@@ -165,6 +165,50 @@ def torch_cpu_baseline(sd, cfgname, threads, budget_s=10.0, max_frames=4):
             "sample": f"{n} frames of the {H}x{W} C={2*nums+3} rollout after 1 warm-up frame ({dt:.1f} s), torch {torch.__version__} with {int(threads)} threads"}
 
 
+def train_roofline(dev, H, W, B, dtype):
+    """The dominant kernel of the training step -- the weight-gradient GEMM (wgrad_kernel, urnn_train.hip; 12 launches per timestep
+    for the six cells' gate / candidate convolutions) -- against the HBM roof: algorithmic bytes per launch = the dY planes + the X
+    planes it contracts over the pixels (fp32), timed live with events on the launch stream, one launch per cell shape."""
+    from urnn_amd import ops, train_ops
+    try:
+        shapes = []                                            # (name, N, segment channels, plane divisor)
+        for name, I, F, skip, div in (("enc1", 16, 64, 0, 1), ("enc2", 64, 96, 0, 2), ("enc3", 96, 96, 0, 4), ("dec3", 0, 96, 1, 4),
+                                      ("dec2", 96, 96, 1, 2), ("dec1", 96, 64, 1, 1)):
+            segs = ([I] if I else []) + ([F] if skip else []) + [F]
+            shapes += [(name + " gates", 2 * F, segs, div), (name + " candidate", F, segs, div)]
+        gen = torch.Generator(device=dev).manual_seed(11)
+        tot_b = tot_t = 0.0
+        per = {}
+        with ops.matrix_mode(dtype):
+            for name, N, segs, div in shapes:
+                h, w = H // div, W // div
+                dy = torch.randn(B, N, h, w, device=dev, generator=gen)
+                xs = [torch.randn(B, c, h, w, device=dev, generator=gen) for c in segs]
+                ws = ops.workspace(ops.lib().urnn_weight_gradient_workspace_bytes(B, N, sum(segs), h, w), dev)
+                dW, db = train_ops.weight_gradient(dy, xs, scratch=ws)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                reps = 10
+                torch.cuda.synchronize(dev)
+                a.record()
+                for _ in range(reps):
+                    train_ops.weight_gradient(dy, xs, dW=dW, db=db, scratch=ws)
+                b.record()
+                torch.cuda.synchronize(dev)
+                t = a.elapsed_time(b) / reps / 1e3
+                nbytes = 4.0 * B * h * w * (N + sum(segs))
+                per[name] = {"us": t * 1e6, "GB/s": nbytes / t / 1e9}
+                tot_b += nbytes
+                tot_t += t
+        achieved = tot_b / tot_t / 1e9
+        return {"bound": "hbm", "kernel": "wgrad_kernel<NP> + wgrad_finalize (1x1-conv weight gradient over the pixels: dW = dY . X^T; fp32 operands as three "
+                                          "bf16 pieces on v_mfma_f32_32x32x16_bf16 in fp32 mode, one rounded piece in bf16 mode), the 12 cell launches of a timestep",
+                "achieved": achieved, "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s", "frac": achieved / (PEAK_HBM_TBS * 1e3), "traffic": None,
+                "traffic_source": "not collected for the training step (profiles/ holds the per-kernel rocprofv3 times of the same command)",
+                "bytes_per_timestep": tot_b, "us_per_timestep": tot_t * 1e6, "launches": per}
+    except Exception as exc:  # keep the headline number
+        return {"error": repr(exc)}
+
+
 def bench_train(args, dev, dist, world, rank):
     """SWP training throughput (BASELINE configs 3-4 shape of work, fp32): a step = one training timestep of one event per GPU
     (forward with kept activations, backward through the window, loss; per window one gradient mean over the ranks and one
@@ -176,7 +220,7 @@ def bench_train(args, dev, dist, world, rank):
     S = args.seq_num
     net, sd, cfg = build_net(H, W, 2 * nums + 3, dev)
     tr = Trainer(net, H, W, nums, rain_max, cum_max, lr=1e-4, grad_clip=1.0, distributed=world > 1,
-                 use_graph=(world == 1 and not args.no_graph), matrix_mode=args.dtype)
+                 use_graph=not args.no_graph, matrix_mode=args.dtype)      # N > 1: three graphs per window with the gradient mean between them
     nwin_w, nwin = max(1, (args.warmup + S - 1) // S), max(1, (args.steps + S - 1) // S)
     frames = S * (nwin_w + nwin)
     B = args.batch
@@ -220,7 +264,7 @@ def bench_train(args, dev, dist, world, rank):
                        if world > 1 else "single GPU"},
             "gflop_per_step": gflop, "step_mfma_frac": steps / elapsed * gflop / 1e3 / PEAK_MFMA_F32_TFLOPS,
             "loss": float(loss[0]), "grad_norm": gnorm,
-            "roofline": None, "cpu_baseline": None,
+            "roofline": train_roofline(dev, H, W, B, args.dtype), "cpu_baseline": None,
             "note": "training path (DESIGN.md 6a); the BASELINE metric is the default --mode infer"}))
     if dist is not None:
         dist.barrier()
@@ -505,9 +549,10 @@ def main():
             mfma_peak = PEAK_MFMA_BF16_TFLOPS / SPLIT_MFMAS if split else PEAK_MFMA_F32_TFLOPS
             result["roofline"] = {
                 "bound": "hbm",
-                "kernel": ("conv_gemm_kernel<NB=2,PB=4,MAP_VEC,EPI_GRU1,D,WPB=8,SPLIT=1> (ConvGRU gate GEMM z|r; fp32 operands split into 3 bf16 "
-                           "pieces, 6 x v_mfma_f32_32x32x16_bf16 per 16 k, fp32 accumulate; 4 launches per frame: enc1, dec1 at full and "
-                           "enc2, dec2 at half resolution)") if split else "conv_gemm_kernel<2,4,0,3,4,8,0> (fp32 MFMA 32x32x2 k-loop)",
+                "kernel": ("conv_gemm_kernel<NB,PB=2,MAP_PAIR16,EPI_GRU1,D=8,WPB=8,SPLIT=3> (ConvGRU gate GEMM z|r: all 2F gate columns of a 64-pixel "
+                           "tile per wave -- NB = 4 at F = 64, the z / r halves with NB = 3 at F = 96 --; fp32 operands as two scaled f16 pieces, "
+                           "3 x v_mfma_f32_32x32x16_f16 per 16 k, fp32 accumulate; 4 launches per frame: enc1, dec1 at full and enc2, dec2 at half "
+                           "resolution)") if split else "conv_gemm_kernel<2,4,0,3,4,8,0> (fp32 MFMA 32x32x2 k-loop)",
                 "achieved": achieved, "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s", "frac": achieved / (PEAK_HBM_TBS * 1e3),
                 "traffic": traffic, "traffic_source": tsrc,
                 "bytes_per_launch": bytes_per_launch, "avg_launch_us": avg * 1e6, "launch_us": {k: v * 1e6 for k, v in dur.items()},

@@ -171,6 +171,15 @@ int urnn_gru_cell_backward_f32(const float *x, const float *e, const float *h, c
                                float *dgn2_b, float *bwd_packed, int repack, void *workspace, size_t workspace_bytes, int B, int I,
                                int F, int H, int W, int accumulate, void *stream);
 
+/* Weight gradient of a 1x1 convolution over the channel concatenation of up to three inputs (the GEMM every layer backward above
+ * runs; autograd of nn.Conv2d's weight / bias -- utils.py:90-94, ConvRNN.py:94-104):  dW[n][k] (+)= sum_{b,p} dy[b][n][p] * x[b][k][p],
+ * db[n] (+)= sum_{b,p} dy[b][n][p].  dy (B,N,P); seg0 / seg1 / seg2 (B,C_i,P) with C0 + C1 + C2 = K (unused segments: NULL, 0); dW
+ * (N,K) row-major, db (N) or NULL.  Deterministic (fixed-order pixel chunks).  Exposed for measurement (bench.py --mode train
+ * prices this kernel against the HBM roof) and for callers that differentiate a layer of their own. */
+size_t urnn_weight_gradient_workspace_bytes(int B, int N, int K, int H, int W);
+int urnn_weight_gradient_f32(const float *dy, const float *seg0, int C0, const float *seg1, int C1, const float *seg2, int C2, float *dW,
+                             float *db, void *workspace, size_t workspace_bytes, int B, int N, int H, int W, int accumulate, void *stream);
+
 /* Backward of urnn_stage_conv_f32 (conv1x1 + LeakyReLU [+ AvgPool2d(2,2)]): weight (Cout,Cin), bias (Cout) in the reference
  * layout; dout has the forward output's shape; din (B,Cin,H,W) is overwritten, dweight / dbias overwritten or accumulated. */
 size_t urnn_stage_conv_backward_workspace_bytes(int B, int Cin, int Cout, int H, int W);

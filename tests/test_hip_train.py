@@ -317,7 +317,7 @@ def _ddp_worker(rank, world, port, out_dir, backend="gloo"):
     dist.destroy_process_group()
 
 
-def _ddp_golden_worker(rank, world, port, out_dir, backend="gloo"):
+def _ddp_golden_worker(rank, world, port, out_dir, backend="gloo", use_graph=False):
     """Two windows of the reference-emulated DDP run of tests/golden/make_train_golden.py gen_ddp_loop: rank r trains on event
     seed 100 + r with labels x (1 + r / 2); after every window the averaged flat gradient, at the end the parameters."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
@@ -341,7 +341,7 @@ def _ddp_golden_worker(rank, world, port, out_dir, backend="gloo"):
     net = ED(False, ep, dp, 0.5, False, H, W)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     net = net.to(dev)
-    tr = Trainer(net, H, W, nums, 60.0, 250.0, lr=float(g["ddp_lr"]), grad_clip=float(g["ddp_grad_clip"]), distributed=True)
+    tr = Trainer(net, H, W, nums, 60.0, 250.0, lr=float(g["ddp_lr"]), grad_clip=float(g["ddp_grad_clip"]), distributed=True, use_graph=use_graph)
     ev = uw.make_event(S * nwin, H, W, 60.0, seed=100 + rank)
     label = torch.from_numpy(g["ddp_label"]).to(dev) * (1.0 + 0.5 * rank)
     states = None
@@ -399,6 +399,27 @@ def test_two_rank_ddp_matches_the_reference_gradient_mean(dev, tmp_path):
     _check_ddp_against_reference(tmp_path)
 
 
+def test_two_rank_ddp_graph_capture_equals_eager(dev, tmp_path):
+    """The DDP window as three hipGraphs (forward + backward up to the head's final gradients | rest of the backward | clipped
+    Adam) with the two halves of the gradient mean between them: bit-identical to the eager DDP window -- averaged gradients of
+    every window, losses, post-Adam parameters -- and therefore equal to the reference's emulated 2-rank loop as well."""
+    import socket
+    import torch.multiprocessing as mp
+    dirs = {}
+    for graph in (False, True):
+        d = tmp_path / ("graph" if graph else "eager")
+        d.mkdir()
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        mp.spawn(_ddp_golden_worker, args=(2, port, str(d), "gloo", graph), nprocs=2, join=True)
+        dirs[graph] = d
+    for f in sorted(p.name for p in dirs[False].iterdir() if p.name.endswith(".npy") and p.name != "views.npy"):
+        a, b = np.load(dirs[False] / f), np.load(dirs[True] / f)
+        assert np.array_equal(a, b), f"{f}: captured DDP window differs from the eager one"
+    _check_ddp_against_reference(dirs[True])
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank (the 1-GPU test box cannot host two)")
 def test_two_rank_ddp_matches_the_reference_gradient_mean_over_rccl(tmp_path):
     import socket
@@ -406,7 +427,7 @@ def test_two_rank_ddp_matches_the_reference_gradient_mean_over_rccl(tmp_path):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_ddp_golden_worker, args=(2, port, str(tmp_path), "nccl"), nprocs=2, join=True)
+    mp.spawn(_ddp_golden_worker, args=(2, port, str(tmp_path), "nccl", True), nprocs=2, join=True)      # captured windows, RCCL between the graphs
     _check_ddp_against_reference(tmp_path)
 
 
@@ -631,3 +652,21 @@ def test_bf16_matrix_mode_tracks_fp32(dev):
     assert b[-1] < 0.8 * b[0]                                   # it trains
     assert np.abs(b - a).max() <= 0.1 * a[0], (a, b)            # and follows the fp32 curve
     assert ops.lib().urnn_get_matrix_mode() == 0
+
+
+def test_weight_gradient_entry_vs_float64(dev):
+    """urnn_weight_gradient_f32 (the 1x1-conv weight gradient every layer backward runs; autograd of nn.Conv2d's weight / bias,
+    ConvRNN.py:94-104): dW = sum_p dy x^T over one to three concatenated inputs, odd channel counts, ragged plane, accumulate."""
+    from urnn_amd import train_ops
+    gen = torch.Generator(device=dev).manual_seed(5)
+    for B, N, Cs, H, W in ((1, 64, (16, 64), 36, 52), (2, 33, (7,), 20, 12), (1, 128, (96, 64, 64), 40, 48)):
+        dy = torch.randn(B, N, H, W, device=dev, generator=gen)
+        xs = [torch.randn(B, c, H, W, device=dev, generator=gen) for c in Cs]
+        dW, db = train_ops.weight_gradient(dy, xs)
+        x64 = torch.cat(xs, 1).double()
+        ref_w = torch.einsum("bnhw,bkhw->nk", dy.double(), x64)
+        ref_b = dy.double().sum((0, 2, 3))
+        assert_close(dW.cpu().numpy(), ref_w.cpu().numpy(), 2e-5, f"dW {N}x{sum(Cs)}")
+        assert_close(db.cpu().numpy(), ref_b.cpu().numpy(), 2e-5, "db")
+        train_ops.weight_gradient(dy, xs, dW=dW, db=db, accumulate=True)
+        assert_close(dW.cpu().numpy(), 2 * ref_w.cpu().numpy(), 2e-5, "accumulated dW")

@@ -770,6 +770,32 @@ extern "C" int urnn_deconv2x2_f32(const float *in, const float *packed, float *o
     return URNN_OK;
 }
 
+// ---- weight gradient of a 1x1 conv (the building block of every layer backward) ----------------------------------------------------
+extern "C" size_t urnn_weight_gradient_workspace_bytes(int B, int N, int K, int H, int W)
+{
+    if (B < 1 || N < 1 || K < 1 || H < 1 || W < 1) return 0;
+    return align_up(urnn_train_wgrad_partial_floats(B, N, K, H * W) * sizeof(float), 256);
+}
+
+extern "C" int urnn_weight_gradient_f32(const float *dy, const float *seg0, int C0, const float *seg1, int C1, const float *seg2, int C2,
+                                        float *dW, float *db, void *workspace, size_t workspace_bytes, int B, int N, int H, int W,
+                                        int accumulate, void *stream)
+{
+    if (!dy || !seg0 || !dW || !workspace) return fail(URNN_ENULL, "urnn_weight_gradient_f32: NULL argument");
+    if (B < 1 || N < 1 || C0 < 1 || C1 < 0 || C2 < 0 || H < 1 || W < 1 || (C1 > 0) != (seg1 != nullptr) || (C2 > 0) != (seg2 != nullptr))
+        return fail(URNN_EINVAL, "urnn_weight_gradient_f32: bad dims");
+    const int K = C0 + C1 + C2;
+    const long P = (long)H * W;
+    if (!plane_fits(P, N > K ? N : K)) return fail(URNN_EINVAL, "urnn_weight_gradient_f32: plane exceeds the 4-GiB segment limit");
+    if (workspace_bytes < urnn_weight_gradient_workspace_bytes(B, N, K, H, W))
+        return fail(URNN_EWORKSPACE, "urnn_weight_gradient_f32: workspace %zu < %zu bytes", workspace_bytes, urnn_weight_gradient_workspace_bytes(B, N, K, H, W));
+    const float *seg[3] = {seg0, seg1 ? seg1 : seg0, seg2 ? seg2 : seg0};
+    const int segC[3] = {C0, C1, C2};
+    CHECK_HIP(urnn_train_wgrad(dy, seg, segC, B, N, K, (int)P, reinterpret_cast<float *>(workspace), dW, db, accumulate, (hipStream_t)stream),
+              "weight gradient");
+    return URNN_OK;
+}
+
 // ---- head ------------------------------------------------------------------------------------------------------------
 struct HeadWs {
     float *u1, *u2, *partial, *stats;

@@ -3,6 +3,8 @@
 #include "urnn_common.h"
 #include "urnn_kernels.h"
 
+#include <stdlib.h>
+
 // ------------------------------------------------------------------------------------------------------------------
 // GroupNorm finalise: partial (sum, centred second moment) per tile (urnn_common.h tile_x2) -> per-channel (scale, shift) with
 //   y = (v - mean) * rstd * gamma + beta = v * scale + shift.   One wavefront per (sample, 32-channel group).
@@ -353,6 +355,55 @@ __device__ __forceinline__ float *head_partial(const HeadParams &p, int which, i
     return p.partial + ((((size_t)which * p.B + b) * p.nblk) + blk) * 2;
 }
 
+// LayerNorm statistics of tensor `which` of sample b folded from the per-block partials by EVERY wave of the consuming kernel
+// (FIN variants of head_k2 .. k4: no finalize launch in between): lane-strided double sums in ascending block order, then the xor
+// butterfly -- the order ln_finalize_kernel uses, so the fused and the separate path give identical bits and every wave of every
+// block holds the same (mean, rstd).  ~8 loads per lane for a 500x500 plane.
+__device__ __forceinline__ void head_fold_stats(const HeadParams &prm, int which, int b, int nblk_used, int block_pix, float &mean_f, float &rstd_f)
+{
+    const int lane = threadIdx.x & 63;
+    const float *pp = prm.partial + (((size_t)which * prm.B + b) * prm.nblk) * 2;
+    double s1 = 0.0, s2 = 0.0;
+    for (int t0 = 0; t0 < nblk_used; t0 += 64 * 16) {
+        f32x2 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int t = t0 + u * 64 + lane;
+            v[u] = t < nblk_used ? *reinterpret_cast<const f32x2 *>(pp + 2 * t) : f32x2{0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            s1 += (double)v[u].x;
+            s2 += tile_x2(v[u].x, v[u].y, HEAD_C * tile_valid(t0 + u * 64 + lane, block_pix, prm.P));
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        s1 += __shfl_xor(s1, m, 64);
+        s2 += __shfl_xor(s2, m, 64);
+    }
+    const double count = (double)HEAD_C * (double)prm.P;
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    mean_f = (float)mean;
+    rstd_f = (float)(1.0 / sqrt(var + (double)prm.eps));
+    if (blockIdx.x == 0 && threadIdx.x == 0) {       // the backward pass reads the statistics from prm.stats
+        prm.stats[((size_t)which * prm.B + b) * 2] = mean_f;
+        prm.stats[((size_t)which * prm.B + b) * 2 + 1] = rstd_f;
+    }
+}
+// (mean, rstd) of tensor `which`: folded here (FIN) or read from prm.stats (a finalize launch ran: strips, phase-split callers)
+template <bool FIN, int V>
+__device__ __forceinline__ void head_stats(const HeadParams &prm, int which, int b, float &mean, float &rstd)
+{
+    if constexpr (FIN) head_fold_stats(prm, which, b, (prm.P + 256 * V - 1) / (256 * V), 256 * V, mean, rstd);
+    else {
+        mean = prm.stats[(which * prm.B + b) * 2];
+        rstd = prm.stats[(which * prm.B + b) * 2 + 1];
+    }
+}
+
 template <int V>
 __global__ __launch_bounds__(256) void head_k1(const HeadParams prm)
 {
@@ -370,19 +421,21 @@ __global__ __launch_bounds__(256) void head_k1(const HeadParams prm)
                       nullptr);
 }
 
-template <int V>
+template <int V, bool FIN>
 __global__ __launch_bounds__(256) void head_k2(const HeadParams prm)
 {
     const int b = blockIdx.y;
     const int p = (blockIdx.x * 256 + threadIdx.x) * V;
     const bool live = p < prm.P;
     float sc = 0.f, qc = 0.f, sq = 0.f, qq = 0.f;
+    float m0, r0;
+    head_stats<FIN, V>(prm, 0, b, m0, r0);
     if (live) {
         const size_t CP = (size_t)HEAD_C * prm.P;
         float f[HEAD_C][V], t[HEAD_C][V];
         head_load<V>(prm.feat + b * CP, prm.P, p, f);
         head_conv<V>(prm.conv_w, f, t);
-        head_ln_silu<V>(t, prm.ln_w, prm.ln_b, prm.P, p, prm.stats[(0 * prm.B + b) * 2], prm.stats[(0 * prm.B + b) * 2 + 1]);
+        head_ln_silu<V>(t, prm.ln_w, prm.ln_b, prm.P, p, m0, r0);
         head_conv<V>(prm.conv_w + 1 * HEAD_C * HEAD_C, t, f);
         head_thread_stats<V>(f, sc, qc);
         head_store<V>(prm.u1 + b * CP, prm.P, p, f);
@@ -394,23 +447,26 @@ __global__ __launch_bounds__(256) void head_k2(const HeadParams prm)
                       head_partial(prm, 3, b, blockIdx.x));
 }
 
-template <int V>
+template <int V, bool FIN>
 __global__ __launch_bounds__(256) void head_k3(const HeadParams prm)
 {
     const int b = blockIdx.y;
     const int p = (blockIdx.x * 256 + threadIdx.x) * V;
     const bool live = p < prm.P;
     float sc = 0.f, qc = 0.f, sq = 0.f, qq = 0.f;
+    float m1, r1, m3, r3;
+    head_stats<FIN, V>(prm, 1, b, m1, r1);
+    head_stats<FIN, V>(prm, 3, b, m3, r3);
     if (live) {
         const size_t CP = (size_t)HEAD_C * prm.P;
         float x[HEAD_C][V], u[HEAD_C][V];
         head_load<V>(prm.u1 + b * CP, prm.P, p, x);
-        head_ln_silu<V>(x, prm.ln_w + 1 * CP, prm.ln_b + 1 * CP, prm.P, p, prm.stats[(1 * prm.B + b) * 2], prm.stats[(1 * prm.B + b) * 2 + 1]);
+        head_ln_silu<V>(x, prm.ln_w + 1 * CP, prm.ln_b + 1 * CP, prm.P, p, m1, r1);
         head_conv<V>(prm.conv_w + 2 * HEAD_C * HEAD_C, x, u);
         head_thread_stats<V>(u, sc, qc);
         head_store<V>(prm.u1 + b * CP, prm.P, p, u);
         head_load<V>(prm.u2 + b * CP, prm.P, p, x);
-        head_ln_silu<V>(x, prm.ln_w + 3 * CP, prm.ln_b + 3 * CP, prm.P, p, prm.stats[(3 * prm.B + b) * 2], prm.stats[(3 * prm.B + b) * 2 + 1]);
+        head_ln_silu<V>(x, prm.ln_w + 3 * CP, prm.ln_b + 3 * CP, prm.P, p, m3, r3);
         head_conv<V>(prm.conv_w + 4 * HEAD_C * HEAD_C, x, u);
         head_thread_stats<V>(u, sq, qq);
         head_store<V>(prm.u2 + b * CP, prm.P, p, u);
@@ -419,11 +475,14 @@ __global__ __launch_bounds__(256) void head_k3(const HeadParams prm)
                       head_partial(prm, 4, b, blockIdx.x));
 }
 
-template <int V>
+template <int V, bool FIN>
 __global__ __launch_bounds__(256) void head_k4(const HeadParams prm)
 {
     const int b = blockIdx.y;
     const int p = (blockIdx.x * 256 + threadIdx.x) * V;
+    float m2, r2, m4, r4;
+    head_stats<FIN, V>(prm, 2, b, m2, r2);       // (whole waves: before the tail threads leave)
+    head_stats<FIN, V>(prm, 4, b, m4, r4);
     if (p >= prm.P) return;
     const size_t CP = (size_t)HEAD_C * prm.P;
     const int frame = prm.frame_index ? *prm.frame_index : 0;
@@ -431,7 +490,7 @@ __global__ __launch_bounds__(256) void head_k4(const HeadParams prm)
     float x[HEAD_C][V];
     float cls[V], reg[V];
     head_load<V>(prm.u1 + b * CP, prm.P, p, x);
-    head_ln_silu<V>(x, prm.ln_w + 2 * CP, prm.ln_b + 2 * CP, prm.P, p, prm.stats[(2 * prm.B + b) * 2], prm.stats[(2 * prm.B + b) * 2 + 1]);
+    head_ln_silu<V>(x, prm.ln_w + 2 * CP, prm.ln_b + 2 * CP, prm.P, p, m2, r2);
 #pragma unroll
     for (int k = 0; k < V; ++k) {
         float a = prm.cls_b[0];
@@ -440,7 +499,7 @@ __global__ __launch_bounds__(256) void head_k4(const HeadParams prm)
         cls[k] = sigmoidf_fast(a);
     }
     head_load<V>(prm.u2 + b * CP, prm.P, p, x);
-    head_ln_silu<V>(x, prm.ln_w + 4 * CP, prm.ln_b + 4 * CP, prm.P, p, prm.stats[(4 * prm.B + b) * 2], prm.stats[(4 * prm.B + b) * 2 + 1]);
+    head_ln_silu<V>(x, prm.ln_w + 4 * CP, prm.ln_b + 4 * CP, prm.P, p, m4, r4);
 #pragma unroll
     for (int k = 0; k < V; ++k) {
         float a = prm.reg_b[0];
@@ -505,13 +564,24 @@ static hipError_t launch_head_v(const HeadParams &p, int mask, hipStream_t st)
     const int fin = p.Pglobal > 0 ? 2 : nb;          // strip mode: the partials hold the all-reduced totals as two pseudo-blocks
     const int bpix = p.Pglobal > 0 ? 0 : 256 * V;    //             ... which are raw (sum, sum of squares)
     dim3 grid(nb, p.B), blk(256);
+    // whole head in one call, one device: the three finalize launches are folded into their consumers (identical bits; development
+    // knob URNN_TUNE_FUSE_HEAD=0 keeps them).  Strips / phase-split callers exchange or inspect the statistics in between.
+    static const bool fuse_on = !getenv("URNN_TUNE_FUSE_HEAD") || atoi(getenv("URNN_TUNE_FUSE_HEAD")) != 0;
+    const int all = URNN_HEAD_K1 | URNN_HEAD_F1 | URNN_HEAD_K2 | URNN_HEAD_F2 | URNN_HEAD_K3 | URNN_HEAD_F3 | URNN_HEAD_K4;
+    if (fuse_on && (mask & all) == all && p.Pglobal <= 0) {
+        hipLaunchKernelGGL(head_k1<V>, grid, blk, 0, st, p);
+        hipLaunchKernelGGL((head_k2<V, true>), grid, blk, 0, st, p);
+        hipLaunchKernelGGL((head_k3<V, true>), grid, blk, 0, st, p);
+        hipLaunchKernelGGL((head_k4<V, true>), grid, blk, 0, st, p);
+        return hipGetLastError();
+    }
     if (mask & URNN_HEAD_K1) hipLaunchKernelGGL(head_k1<V>, grid, blk, 0, st, p);
     if (mask & URNN_HEAD_F1) hipLaunchKernelGGL(ln_finalize_kernel, dim3(p.B, 1), dim3(64), 0, st, p, 0, 1, fin, bpix);
-    if (mask & URNN_HEAD_K2) hipLaunchKernelGGL(head_k2<V>, grid, blk, 0, st, p);
+    if (mask & URNN_HEAD_K2) hipLaunchKernelGGL((head_k2<V, false>), grid, blk, 0, st, p);
     if (mask & URNN_HEAD_F2) hipLaunchKernelGGL(ln_finalize_kernel, dim3(p.B, 2), dim3(64), 0, st, p, 1, 2, fin, bpix);
-    if (mask & URNN_HEAD_K3) hipLaunchKernelGGL(head_k3<V>, grid, blk, 0, st, p);
+    if (mask & URNN_HEAD_K3) hipLaunchKernelGGL((head_k3<V, false>), grid, blk, 0, st, p);
     if (mask & URNN_HEAD_F3) hipLaunchKernelGGL(ln_finalize_kernel, dim3(p.B, 2), dim3(64), 0, st, p, 2, 2, fin, bpix);
-    if (mask & URNN_HEAD_K4) hipLaunchKernelGGL(head_k4<V>, grid, blk, 0, st, p);
+    if (mask & URNN_HEAD_K4) hipLaunchKernelGGL((head_k4<V, false>), grid, blk, 0, st, p);
     return hipGetLastError();
 }
 

@@ -1078,7 +1078,9 @@ int urnn_conv_nb(int Cout)
     // 96 -> 96 conv at 250x250: 37 -> 22 us).  Development knob URNN_TUNE_CONV_NB3=3 restores one group.
     static const int nb3 = [] { const char *e = getenv("URNN_TUNE_CONV_NB3"); return e ? atoi(e) : 1; }();
     if (nblk == 3) return nb3 == 3 ? 3 : 1;
-    return nblk <= 3 ? nblk : (nblk % 3 == 0 ? 3 : (nblk % 2 == 0 ? 2 : 3));
+    // wider outputs (the backward pass's input-gradient GEMMs: 160 / 192 columns): groups of two blocks, the last one padded -- a
+    // 3-block wave tile of 128 pixels (192 accumulators) would fall back to the fp32 MFMA k-loop (190 us per launch at 500x500)
+    return nblk <= 3 ? nblk : 2;
 }
 
 int urnn_conv_ng(int Cout)

@@ -61,6 +61,24 @@ def gru_cell_backward(x, e, h, W1, W2, gn1_w, gn2_w, dh_out, I, fwd_ws, grads=No
     return g
 
 
+def weight_gradient(dy, segs, dW=None, db=None, accumulate=False, scratch=None):
+    """dW (N,K) = sum over pixels of dy (B,N,H,W) x cat(segs) (B,K,H,W) (1x1-conv weight gradient), db (N) likewise; segs: one to
+    three (B,C_i,H,W) tensors."""
+    L = lib()
+    B, N, H, W = dy.shape
+    Cs = [int(t.shape[1]) for t in segs] + [0] * (3 - len(segs))
+    K = sum(Cs)
+    dev = dy.device
+    dW = torch.empty(N, K, device=dev) if dW is None else dW
+    db = torch.empty(N, device=dev) if db is None else db
+    ws = _bwd_scratch(scratch, L.urnn_weight_gradient_workspace_bytes(B, N, K, H, W), dev)
+    p = ops._ptr
+    ptrs = [p(t) for t in segs] + [None] * (3 - len(segs))
+    check(L.urnn_weight_gradient_f32(p(dy), ptrs[0], Cs[0], ptrs[1], Cs[1], ptrs[2], Cs[2], p(dW), p(db), p(ws), ws.numel(), B, N,
+                                     H, W, int(accumulate), ops._stream()), "urnn_weight_gradient_f32")
+    return dW, db
+
+
 def _layer_packs(packed, nfloats, dev):
     """Caller-kept packed weights of a layer's backward GEMMs: ``packed`` is None (pack per call) or a list that receives the
     buffer on first use and hands it back afterwards (the caller clears it when the parameters change).  -> (buffer, repack)"""

@@ -236,10 +236,10 @@ class Trainer:
         if matrix_mode not in ops.MATRIX_MODES:
             raise ValueError(f"matrix_mode must be one of {sorted(ops.MATRIX_MODES)}")
         self.matrix_mode = matrix_mode
-        self.use_graph = bool(use_graph)        # capture one window (forward, loss, backward, clip + Adam) as a hipGraph
-        if use_graph and distributed:
-            import warnings
-            warnings.warn("Trainer: use_graph is ignored with distributed=True (the gradient all-reduce is not captured); running eager")
+        # capture one window as hipGraphs: single GPU -- one graph (forward, loss, backward, clip + Adam); DDP -- three graphs with
+        # the two halves of the gradient mean enqueued between them (forward + backward up to the point where the head's gradients
+        # are final | the rest of the backward | clip + Adam), main.py:384-387,750-762
+        self.use_graph = bool(use_graph)
         self._graph = None
         self.wg = WindowGradients(net, H, W, nums, rain_max, cumsum_max, cls_thred_train)
         self.lr, self.betas, self.eps, self.grad_clip = float(lr), tuple(betas), float(eps), float(grad_clip)
@@ -360,6 +360,27 @@ class Trainer:
         self._invalidate_packed()
         return out, clip
 
+    def _window_body_ddp_graphs(self, sev, G, steps):
+        """Capture the DDP window as three graphs on the current (side) stream: A ends where the head's gradients of the window are
+        complete (right after the head backward of the first timestep), B holds that timestep's decoder / encoder backward and
+        the hand-over of the remaining gradients, C the clipped Adam step.  Nothing is reduced during capture."""
+        gA, gB, gC = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        pool = torch.cuda.graph_pool_handle()        # one memory pool: activations kept by A are read by B
+        gA.capture_begin(pool=pool)
+
+        def head_final(head_grads):
+            self._scatter(head_grads)
+            gA.capture_end()
+            gB.capture_begin(pool=pool)
+        out = self.wg.run(sev, G["tgt"], 0, steps, G["states"], t_devs=G["t_devs"], grad_buffers=self.grad_views, on_head_final=head_final)
+        self._scatter({n: g for n, g in out["grads"].items() if not n.startswith("head.")})
+        gB.capture_end()
+        gC.capture_begin(pool=pool)
+        clip = train_ops.adam_step(self.flat, self.gflat, self.m, self.v, 1, lr=self.lr, betas=self.betas, eps=self.eps,
+                                   max_grad_norm=self.grad_clip, step_dev=G["step_dev"], scratch=self.wg.arena)
+        gC.capture_end()
+        return (gA, gB, gC), out, clip
+
     def _train_window_graph(self, ev, targets, t0, steps, states):
         """hipGraph path: static input buffers (targets, the six states, the per-step frame indices, the Adam step counter) are
         refreshed on the stream, then the captured window -- ~250 launches per timestep -- replays as one graph."""
@@ -392,10 +413,18 @@ class Trainer:
             for dst, src in zip((self.flat, self.m, self.v), keep):
                 dst.copy_(src)
             self._invalidate_packed()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                out, clip = self._window_body(sev, G["tgt"], 0, steps, G["states"], t_devs=G["t_devs"], step_dev=G["step_dev"])
-            G.update(graph=g, out=out, clip=clip, arena_gen=self.wg.arena.generation)
+            if self.distributed:
+                cap = torch.cuda.Stream(device=dev)
+                cap.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(cap):
+                    graphs, out, clip = self._window_body_ddp_graphs(sev, G, steps)
+                torch.cuda.current_stream(dev).wait_stream(cap)
+                G.update(graph=graphs, out=out, clip=clip, arena_gen=self.wg.arena.generation)
+            else:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    out, clip = self._window_body(sev, G["tgt"], 0, steps, G["states"], t_devs=G["t_devs"], step_dev=G["step_dev"])
+                G.update(graph=g, out=out, clip=clip, arena_gen=self.wg.arena.generation)
             self._graph = G
         G = self._graph
         if ev is not G["ev"]:
@@ -408,7 +437,19 @@ class Trainer:
         for s, td in enumerate(G["t_devs"]):
             td.fill_(int(t0) + s)
         G["step_dev"].fill_(self.step_count)
-        G["graph"].replay()
+        if self.distributed:
+            # graph | the head's share of the gradient mean starts (RCCL: asynchronous, on its own stream) | graph | the rest of the
+            # mean, join | graph: the same kernels and the same reduction order as the eager DDP window
+            from .distributed import OverlappedGradientMean
+            gA, gB, gC = G["graph"]
+            reducer = OverlappedGradientMean(self.gflat, self.head_offset, group=self.pg)
+            gA.replay()
+            reducer.start_tail()
+            gB.replay()
+            reducer.finish()
+            gC.replay()
+        else:
+            G["graph"].replay()
         self._invalidate_packed()       # host-side caches of packed weights now describe the previous parameters
         return G["out"], G["clip"]
 
@@ -417,7 +458,7 @@ class Trainer:
         ev = event if "rain" in event else event_to_device(event, self.wg.device)
         self.step_count += 1
         with ops.matrix_mode(self.matrix_mode):
-            if self.use_graph and not self.distributed:
+            if self.use_graph:
                 targets = torch.as_tensor(targets, dtype=torch.float32, device=self.wg.device)
                 out, clip = self._train_window_graph(ev, targets, t0, steps, states)
                 self.last = {"loss": out["loss"], "clip": clip, "reg": out["reg"]}        # static buffers: valid until the next window
