@@ -31,11 +31,36 @@ __host__ __device__ static inline int urnn_f16_slab_dwords(int KT, int NB) { ret
 // row = (r & 3) + 8 * (r >> 2) + 4 * half  (cdna_hip_programming.md section 3; col = lane & 31).
 __device__ __forceinline__ int mfma_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-__device__ __forceinline__ float wave_sum(float v)
+// Sum over the 64 lanes, returned to every lane; fixed order (bit-reproducible).  The first four steps are DPP adds inside a
+// 16-lane row (quad swaps, half-row mirror, row mirror: VALU speed); only the two cross-row steps go through the LDS crossbar
+// (ds_bpermute, ~100 cycles of latency each).  The all-bpermute butterfly was a chain of six such round trips per sum: the GEMM
+// epilogues spent a third of their time in eight of those chains per tile.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int N>
+__device__ __forceinline__ void wave_sum_n(float (&v)[N])      // N independent sums, their steps interleaved
 {
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+    for (int i = 0; i < N; ++i) v[i] += dpp_move<0xB1>(v[i]);      // quad_perm [1,0,3,2]
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_move<0x4E>(v[i]);      // quad_perm [2,3,0,1]
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_move<0x141>(v[i]);     // row_half_mirror
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_move<0x140>(v[i]);     // row_mirror
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += __shfl_xor(v[i], 16, 64);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += __shfl_xor(v[i], 32, 64);
+}
+__device__ __forceinline__ float wave_sum(float v)
+{
+    float a[1] = {v};
+    wave_sum_n<1>(a);
+    return a[0];
 }
 
 // GroupNorm / LayerNorm partial statistics.  A tile (or block) of n values leaves (s1, m2) = (sum, sum of squared deviations

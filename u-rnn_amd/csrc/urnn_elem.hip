@@ -80,6 +80,11 @@ struct BlendFin {
     float *ss2, *stat2;     // out: [B][F][2] (scale, shift), [B][F/32][2] (mean, rstd)
 };
 
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access at 4-byte alignment (planes of odd size)
+
+// V = 4: 16-byte accesses (P % 4 == 0); V = 5: the same on planes whose size is not a multiple of four (the quarter-resolution
+// 125 x 125 planes: every channel plane starts at a different 4-byte phase) -- unaligned 16-byte accesses for the first P & ~3
+// pixels, dwords for the last P & 3; V = 1: dwords.
 template <int V, bool FIN>
 __global__ __launch_bounds__(256) void gru_blend_kernel(const float *__restrict__ g1, const float *__restrict__ c,
                                                         const float *h, const float *__restrict__ ss1,
@@ -140,12 +145,34 @@ __global__ __launch_bounds__(256) void gru_blend_kernel(const float *__restrict_
     const float *hh = h + ((size_t)bc) * P;
     float *oo = out + ((size_t)bc) * P;
     constexpr int ITER = FIN ? 8 : 4;      // fused finalize: fewer, larger blocks (the prologue is per block)
-    const int base = blockIdx.x * (256 * V * ITER);
+    constexpr int VW = V == 5 ? 4 : V;     // pixels per thread and access
+    const int base = blockIdx.x * (256 * VW * ITER);
+    const int Pv = V == 5 ? (P & ~3) : P;  // pixels covered by vector accesses
+    if constexpr (V == 5) {                // the last P & 3 pixels of the plane: one thread each, first block
+        if (blockIdx.x == 0 && (int)threadIdx.x < P - Pv) {
+            const int p = Pv + threadIdx.x;
+            const float z = sigmoidf_fast(gz[p] * s1 + t1);
+            const float n = tanhf_fast(cc[p] * s2 + t2);
+            oo[p] = (1.f - z) * hh[p] + z * n;
+        }
+    }
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
-        const int p = base + (it * 256 + threadIdx.x) * V;
-        if (p >= P) break;
-        if constexpr (V == 4) {
+        const int p = base + (it * 256 + threadIdx.x) * VW;
+        if (p >= Pv) break;
+        if constexpr (V == 5) {
+            const f32x4 g = *reinterpret_cast<const f32x4u *>(gz + p);
+            const f32x4 cv = *reinterpret_cast<const f32x4u *>(cc + p);
+            const f32x4 hv = *reinterpret_cast<const f32x4u *>(hh + p);
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float z = sigmoidf_fast(g[k] * s1 + t1);
+                const float n = tanhf_fast(cv[k] * s2 + t2);
+                o[k] = (1.f - z) * hv[k] + z * n;
+            }
+            *reinterpret_cast<f32x4u *>(oo + p) = o;
+        } else if constexpr (V == 4) {
             const f32x4 g = *reinterpret_cast<const f32x4 *>(gz + p);
             const f32x4 cv = *reinterpret_cast<const f32x4 *>(cc + p);
             const f32x4 hv = *reinterpret_cast<const f32x4 *>(hh + p);
@@ -168,11 +195,12 @@ __global__ __launch_bounds__(256) void gru_blend_kernel(const float *__restrict_
 hipError_t urnn_launch_blend(const float *g1, const float *c, const float *h, const float *ss1, const float *ss2, float *out,
                              int B, int F, int P, hipStream_t st)
 {
-    const bool v4 = (P % 4) == 0;
-    const int per_block = 256 * (v4 ? 4 : 1) * 4;
+    const bool v4 = (P % 4) == 0, v5 = !v4 && P >= 1024;
+    const int per_block = 256 * ((v4 || v5) ? 4 : 1) * 4;
     dim3 grid((P + per_block - 1) / per_block, B * F);
     const BlendFin none = {};
     if (v4) hipLaunchKernelGGL((gru_blend_kernel<4, false>), grid, dim3(256), 0, st, g1, c, h, ss1, ss2, out, F, P, none);
+    else if (v5) hipLaunchKernelGGL((gru_blend_kernel<5, false>), grid, dim3(256), 0, st, g1, c, h, ss1, ss2, out, F, P, none);
     else hipLaunchKernelGGL((gru_blend_kernel<1, false>), grid, dim3(256), 0, st, g1, c, h, ss1, ss2, out, F, P, none);
     return hipGetLastError();
 }
@@ -182,11 +210,12 @@ hipError_t urnn_launch_blend_fin(const float *g1, const float *c, const float *h
                                  const float *partial, int ntiles, int tile_pix, double count, const float *gamma, const float *beta, float eps,
                                  float *ss2, float *stat2, hipStream_t st)
 {
-    const bool v4 = (P % 4) == 0;
-    const int per_block = 256 * (v4 ? 4 : 1) * 8;
+    const bool v4 = (P % 4) == 0, v5 = !v4 && P >= 1024;
+    const int per_block = 256 * ((v4 || v5) ? 4 : 1) * 8;
     dim3 grid((P + per_block - 1) / per_block, B * F);
     const BlendFin fin = {partial, ntiles, tile_pix, count, gamma, beta, eps, ss2, stat2};
     if (v4) hipLaunchKernelGGL((gru_blend_kernel<4, true>), grid, dim3(256), 0, st, g1, c, h, ss1, nullptr, out, F, P, fin);
+    else if (v5) hipLaunchKernelGGL((gru_blend_kernel<5, true>), grid, dim3(256), 0, st, g1, c, h, ss1, nullptr, out, F, P, fin);
     else hipLaunchKernelGGL((gru_blend_kernel<1, true>), grid, dim3(256), 0, st, g1, c, h, ss1, nullptr, out, F, P, fin);
     return hipGetLastError();
 }

@@ -756,22 +756,26 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
             const int G = F / 32;
             const bool grouped = SPLIT == 3 && prm.biasf != nullptr;
             const float inv_n = tile == prm.tilesPerSample - 1 ? prm.invTail : prm.invFull;   // 1 / (32 * valid pixels), from the host: no v_rcp here
+            // pass 1, registers only: every n-block's tile sum -> its own mean (the NB reductions run interleaved); pass 2: squares
+            // about that mean (urnn_common.h tile_x2) while the rows are stored -- an accumulator row dies with its store
+            float s1[NB], s2[NB];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                const int cb = grouped ? urnn_gate_cb(prm.gHalves, prm.gGS, G, g, nb) : urnn_gate_cb(0, 1, G, g, nb);
-                // pass 1, registers only: the tile's sum -> its own mean; pass 2: squares about that mean (urnn_common.h tile_x2)
-                // while the rows are stored -- an accumulator row dies with its store, as in a single-pass epilogue
-                float s1 = 0.f;
+                s1[nb] = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float bv = bias_h[nb * 32 + row_c(r)];
 #pragma unroll
                     for (int pb = 0; pb < PB; ++pb)
-                        if (pm.valid[pb]) s1 += fin(acc[nb][pb][r], bv);
+                        if (pm.valid[pb]) s1[nb] += fin(acc[nb][pb][r], bv);
                 }
-                s1 = wave_sum(s1);
-                const float mt = s1 * inv_n;
-                float s2 = 0.f;
+            }
+            wave_sum_n<NB>(s1);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int cb = grouped ? urnn_gate_cb(prm.gHalves, prm.gGS, G, g, nb) : urnn_gate_cb(0, 1, G, g, nb);
+                const float mt = s1[nb] * inv_n;
+                s2[nb] = 0.f;
                 float *obase = prm.out0 + ((size_t)b * 2 * F + cb * 32 + 4 * half) * prm.P;   // one lane-dependent base, uniform row steps
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -782,15 +786,19 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
                     for (int pb = 0; pb < PB; ++pb) {
                         v[pb] = fin(acc[nb][pb][r], bv);
                         const float d = v[pb] - mt;
-                        if (pm.valid[pb]) s2 = fmaf(d, d, s2);
+                        if (pm.valid[pb]) s2[nb] = fmaf(d, d, s2[nb]);
                     }
                     store_row<MAP, PB>(orow, pm, v);
                 }
-                s2 = wave_sum(s2);
-                if (lane == 0) {
+            }
+            wave_sum_n<NB>(s2);
+            if (lane == 0) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int cb = grouped ? urnn_gate_cb(prm.gHalves, prm.gGS, G, g, nb) : urnn_gate_cb(0, 1, G, g, nb);
                     float *pp = prm.partial + (((size_t)b * 2 * G + cb) * prm.tilesPerSample + tile) * 2;
-                    pp[0] = s1;
-                    pp[1] = s2;
+                    pp[0] = s1[nb];
+                    pp[1] = s2[nb];
                 }
             }
         } else if constexpr (EPI == EPI_CAND) {
@@ -798,20 +806,24 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
             // (sum, centred second moment) per 32-channel GroupNorm group -> partial[b][F/32][tile][2]
             const int F = prm.F;
             const float inv_n = tile == prm.tilesPerSample - 1 ? prm.invTail : prm.invFull;   // 1 / (32 * valid pixels), from the host: no v_rcp here
+            float s1[NB], s2[NB];                                  // pass 1 (registers only) / pass 2 (+ stores) as in the gate epilogue
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                const int grp = g * NB + nb;
-                float s1 = 0.f;                                   // pass 1 (registers only) / pass 2 (+ stores) as in the gate epilogue
+                s1[nb] = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float bv = bias_h[nb * 32 + row_c(r)];
 #pragma unroll
                     for (int pb = 0; pb < PB; ++pb)
-                        if (pm.valid[pb]) s1 += fin(acc[nb][pb][r], bv);
+                        if (pm.valid[pb]) s1[nb] += fin(acc[nb][pb][r], bv);
                 }
-                s1 = wave_sum(s1);
-                const float mt = s1 * inv_n;
-                float s2 = 0.f;
+            }
+            wave_sum_n<NB>(s1);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int grp = g * NB + nb;
+                const float mt = s1[nb] * inv_n;
+                s2[nb] = 0.f;
                 float *obase = prm.out0 + ((size_t)b * F + grp * 32 + 4 * half) * prm.P;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -822,15 +834,18 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
                     for (int pb = 0; pb < PB; ++pb) {
                         v[pb] = fin(acc[nb][pb][r], bv);
                         const float d = v[pb] - mt;
-                        if (pm.valid[pb]) s2 = fmaf(d, d, s2);
+                        if (pm.valid[pb]) s2[nb] = fmaf(d, d, s2[nb]);
                     }
                     store_row<MAP, PB>(orow, pm, v);
                 }
-                s2 = wave_sum(s2);
-                if (lane == 0) {
-                    float *pp = prm.partial + (((size_t)b * (F / 32) + grp) * prm.tilesPerSample + tile) * 2;
-                    pp[0] = s1;
-                    pp[1] = s2;
+            }
+            wave_sum_n<NB>(s2);
+            if (lane == 0) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    float *pp = prm.partial + (((size_t)b * (F / 32) + g * NB + nb) * prm.tilesPerSample + tile) * 2;
+                    pp[0] = s1[nb];
+                    pp[1] = s2[nb];
                 }
             }
         }
