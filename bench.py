@@ -77,11 +77,26 @@ def gate_gemm_flops(H, W, B=1):
     return {"enc1": P1 * 128 * 80 * 2.0, "dec1": P1 * 128 * 224 * 2.0, "enc2": P2 * 192 * 160 * 2.0, "dec2": P2 * 192 * 288 * 2.0}
 
 
-def gate_gemm_bytes(H, W, B=1):
+def fused_reset_gate_cells(H, W, B=1):
+    """Which of the four timed cells run with the reset gate recomputed inside the candidate kernel (URNN_PHASE_FUSED_R: the gate
+    GEMM then writes the F update-gate planes only) -- asked of the library, which decides by the same rule at launch."""
+    from urnn_amd._lib import lib
+    L = lib()
+    return {"enc1": bool(L.urnn_gru_cell_fused_reset_gate_applies(B, 16, 64, H, W, 0)),
+            "dec1": bool(L.urnn_gru_cell_fused_reset_gate_applies(B, 96, 64, H, W, 1)),
+            "enc2": bool(L.urnn_gru_cell_fused_reset_gate_applies(B, 64, 96, H // 2, W // 2, 0)),
+            "dec2": bool(L.urnn_gru_cell_fused_reset_gate_applies(B, 96, 96, H // 2, W // 2, 1))}
+
+
+def gate_gemm_bytes(H, W, B=1, fused=None):
     """Algorithmic HBM bytes of the same four launches (SURVEY 8d's per-stage figure: every input plane read once, every
-    output plane written once, fp32): K input channels + 2F raw gate channels per pixel (weights: < 0.3 MB, not counted)."""
+    output plane written once, fp32): K input channels + 2F raw gate channels per pixel (weights: < 0.3 MB, not counted) -- F
+    output channels where the cell runs fused (``fused``: fused_reset_gate_cells), whose gate GEMM stores the update gate only."""
     P1, P2 = B * H * W, B * (H // 2) * (W // 2)
-    return {"enc1": 4.0 * P1 * (80 + 128), "dec1": 4.0 * P1 * (224 + 128), "enc2": 4.0 * P2 * (160 + 192), "dec2": 4.0 * P2 * (288 + 192)}
+    fused = fused or {}
+    out = lambda name, F: F if fused.get(name) else 2 * F
+    return {"enc1": 4.0 * P1 * (80 + out("enc1", 64)), "dec1": 4.0 * P1 * (224 + out("dec1", 64)),
+            "enc2": 4.0 * P2 * (160 + out("enc2", 96)), "dec2": 4.0 * P2 * (288 + out("dec2", 96))}
 
 
 def build_net(H, W, C, dev, seed=0):
@@ -537,7 +552,8 @@ def main():
         # over 8 TB/s = 52 FLOP/B): HBM is the binding roof.  The MFMA view is reported next to it.
         try:
             dur = eng.probe_gate_gemm()          # live, events on the launch streams, same scheduling mode as the timed region
-            fl, by = gate_gemm_flops(H, W, B), gate_gemm_bytes(H, W, B)
+            fused_cells = fused_reset_gate_cells(H, W, B)
+            fl, by = gate_gemm_flops(H, W, B), gate_gemm_bytes(H, W, B, fused_cells)
             flops_per_launch = sum(fl.values()) / len(fl)
             bytes_per_launch = sum(by.values()) / len(by)
             avg = sum(dur[k] for k in fl) / len(fl)
@@ -556,6 +572,7 @@ def main():
                 "achieved": achieved, "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s", "frac": achieved / (PEAK_HBM_TBS * 1e3),
                 "traffic": traffic, "traffic_source": tsrc,
                 "bytes_per_launch": bytes_per_launch, "avg_launch_us": avg * 1e6, "launch_us": {k: v * 1e6 for k, v in dur.items()},
+                "bytes_per_launch_by_cell": by, "reset_gate_recomputed_in_candidate_kernel": fused_cells,
                 "mfma": {"flops_per_launch": flops_per_launch, "achieved_tflops": flops_per_launch / avg / 1e12,
                          "peak_tflops_fp32_equivalent": mfma_peak, "frac": flops_per_launch / avg / 1e12 / mfma_peak},
             }

@@ -100,6 +100,17 @@ int urnn_gru_cell_f32(const float *x, const float *e, const float *h, const floa
 #define URNN_PHASE_GN2 8    /* GroupNorm finalise of the candidate                                   */
 #define URNN_PHASE_BLEND 16 /* h' = (1 - z) * h + z * tanh(GN(c))                                    */
 #define URNN_PHASE_ALL 31
+/* Optional modifier (not part of URNN_PHASE_ALL), for callers that do not read the workspace afterwards -- inference rollouts:
+ * the reset gate is RECOMPUTED inside the candidate kernel (W1[r rows].[x;e;h] next to W2.[x;e], same input stream) instead of
+ * being written as F raw planes by the gate GEMM and read back; the gate GEMM keeps r's GroupNorm statistics and stores z only.
+ * Same arithmetic for r (bit-identical accumulators); two plane passes of F channels less per cell (ConvRNN.py:165-180).  Applies
+ * where the cell has that form (F = 64, P % 4 == 0, >= 65 536 pixels per launch, fp32 matrix mode, slabs within the LDS) and is
+ * ignored elsewhere; pass it to every phase-split call of a cell or to none.  The workspace's raw reset-gate planes are then
+ * undefined: the backward pass (urnn_gru_cell_backward_f32) needs a forward WITHOUT this flag. */
+#define URNN_PHASE_FUSED_R 32
+/* 1 when URNN_PHASE_FUSED_R takes effect for a cell of this shape under the current matrix mode (x present; skip: an e input of F
+ * channels), else 0 -- for byte accounting (bench.py) and tests; the cell entry decides by the same rule. */
+int urnn_gru_cell_fused_reset_gate_applies(int B, int I, int F, int H, int W, int skip);
 int urnn_gru_cell_phases_f32(const float *x, const float *e, const float *h, const float *packed, const float *gn1_w,
                              const float *gn1_b, const float *gn2_w, const float *gn2_b, float *h_out, void *workspace,
                              size_t workspace_bytes, int B, int I, int F, int H, int W, float eps, int phase_mask,

@@ -41,8 +41,13 @@ def test_packed_sizes_and_argument_errors_without_gpu(built):
     # gate slabs [F/32 groups][KT][z|r][64] + b1, candidate slab(s) [KT][F/32 blocks][64] + b2, then both in split and f16 form
     # (the f16 gate slab is ONE group of all four 32-column blocks z0 r0 z1 r1 -- same size as two groups of two -- followed by
     # the gate bias in that order: + 2F)
-    assert lib.urnn_packed_gru_floats(16, 64, 0) == 2 * (40 * 2 * 64) + 128 + 40 * 2 * 64 + 64 + 3 * split(40, 2) + f16(40, 4) + f16(40, 2) + 128
-    assert lib.urnn_packed_gru_floats(96, 64, 1) == 2 * (112 * 2 * 64) + 128 + 112 * 2 * 64 + 64 + 3 * split(112, 2) + f16(112, 4) + f16(112, 2) + 128
+    # F = 64 cells whose x | e part is whole 16-k groups also carry the fused-reset-gate candidate slab (URNN_PHASE_FUSED_R): nXE
+    # groups of [r0 r1 c0 c1] + 4 hidden-state groups of [r0 r1], 4 groups of W2[:, h] x [c0 c1] (two f16 pieces x 256 dwords per
+    # block), bias [b1 r | b2]
+    fused = lambda nXE: nXE * 4 * 512 + 4 * 2 * 512 + 4 * 2 * 512 + 128
+    assert lib.urnn_packed_gru_floats(16, 64, 0) == 2 * (40 * 2 * 64) + 128 + 40 * 2 * 64 + 64 + 3 * split(40, 2) + f16(40, 4) + f16(40, 2) + 128 + fused(1)
+    assert lib.urnn_packed_gru_floats(96, 64, 1) == 2 * (112 * 2 * 64) + 128 + 112 * 2 * 64 + 64 + 3 * split(112, 2) + f16(112, 4) + f16(112, 2) + 128 + fused(10)
+    assert lib.urnn_packed_gru_floats(64, 96, 0) == 3 * (80 * 2 * 64) + 192 + 80 * 3 * 64 + 96 + 3 * split(80, 2) + split(80, 3) + 2 * f16(80, 3) + f16(80, 3) + 192
     assert lib.urnn_gru_cell_workspace_bytes(1, 64, 500, 500) > 3 * 64 * 250000 * 4
     # argument validation happens before any HIP call
     assert lib.urnn_stage_conv_f32(0, 0, 0, 1, 8, 16, 4, 4, 0, 0.2, 0) == -2      # URNN_ENULL

@@ -172,6 +172,49 @@ def test_full_size_cell_vs_oracle(dev):
     assert_close(got, ref, 1e-4, "dec1 cell at 500x500")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["enc1", "dec1"])
+def test_fused_reset_gate_cell_vs_three_pass_and_oracle(dev, which):
+    """URNN_PHASE_FUSED_R (the rollout engine's cell: reset gate recomputed inside the candidate kernel, its raw planes never
+    stored; ConvRNN.py:165-180) against the three-pass cell and the CPU oracle on a 500x500 plane, both full-resolution cells.
+    The update gate's raw planes and the gates' folded statistics must be BIT-identical (same accumulators); the candidate sums
+    its hidden-state channels in another order inside each 16-k MFMA group, so h' is compared at rounding level."""
+    from oracle import oracle as orc
+    from urnn_amd import ops
+    H = W = 500
+    net, sd = make_net(H, W, 63, 0, dev)
+    rs = np.random.RandomState(12)
+    if which == "enc1":
+        cell, ocell = net.encoder.rnn1, orc.OracleNet(sd).enc[0]
+        x = (0.5 * rs.standard_normal((1, 16, H, W))).astype(np.float32)
+        e = None
+    else:
+        cell, ocell = net.decoder.rnn1, orc.OracleNet(sd).dec[1]
+        x = (0.5 * rs.standard_normal((1, 96, H, W))).astype(np.float32)
+        e = (0.5 * rs.standard_normal((1, 64, H, W))).astype(np.float32)
+    h = (0.5 * rs.standard_normal((1, 64, H, W))).astype(np.float32)
+    tx, th = torch.from_numpy(x).to(dev), torch.from_numpy(h).to(dev)
+    te = None if e is None else torch.from_numpy(e).to(dev)
+    nbytes = ops.gru_cell_workspace_bytes(1, 64, H, W)
+    ws_a = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    ws_b = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    plain = cell.step(tx, te, th, ws=ws_a)
+    fused = cell.step(tx, te, th, phases=ops.PHASE_ALL | ops.PHASE_FUSED_R, ws=ws_b)
+    torch.cuda.synchronize()
+    P = H * W
+    g1_a, g1_b = ws_a[:2 * 64 * P * 4].view(torch.float32), ws_b[:2 * 64 * P * 4].view(torch.float32)
+    assert torch.equal(g1_a[:64 * P], g1_b[:64 * P]), "raw update gate differs"
+    assert float(g1_b[64 * P:].abs().max()) == 0.0, "the fused cell wrote reset-gate planes"      # (the workspace was zero-filled)
+    assert float(g1_a[64 * P:].abs().max()) > 0.0
+    d = float((plain - fused).abs().max())
+    print(f"{which}: fused vs three-pass max |dh'| = {d:.2e}")
+    assert d <= 2e-6
+    ref = orc.gru_cell(x, e, h, ocell) if e is not None else orc.gru_cell(x, None, h, ocell)
+    assert_close(fused.cpu().numpy(), ref, 1e-4, f"{which} cell (reset gate recomputed) at 500x500")
+    again = cell.step(tx, te, th, phases=ops.PHASE_ALL | ops.PHASE_FUSED_R, ws=ws_b)
+    assert torch.equal(again, fused)
+
+
 _ORACLE_CACHE = {}
 
 

@@ -35,14 +35,23 @@ def main(path, filt="", frames=0):
     if frames < 0:   # auto: one advance_kernel per frame in the one-chain schedule
         frames = max((len(cnt[n]) for n in cnt if "advance_kernel" in n), default=0)
     if frames:
-        tot = defaultdict(float)
+        # the rollout loop's kernels run a whole number of times per frame; everything else (torch's zero-fills of the 1.1 GB of
+        # output frames and the states at engine construction, the weight packers, the once-per-event static part of stage 1) is
+        # setup and is listed apart -- dividing it by the few frames of a counter pass would bill it to the frame
+        is_setup = lambda n: n.startswith("at::native") or "pack_" in n or "stage1_static" in n or len(cnt[n]) % frames != 0
+        loop = [n for n in acc if not is_setup(n)]
+        setup = [n for n in acc if n not in loop]
+        tot, tot_setup = defaultdict(float), defaultdict(float)
         for name in acc:
             for c, v in acc[name].items():
-                tot[c] += v
-        t_all = sum(sum(d.values()) for d in dur.values())
-        print(f"# totals over all kernels above, per frame ({frames} frames): kernel time {t_all/frames/1e3:.1f} us")
+                (tot if name in loop else tot_setup)[c] += v
+        t_all = sum(sum(dur[n].values()) for n in loop)
+        print(f"# totals over the rollout loop's kernels, per frame ({frames} frames): kernel time {t_all/frames/1e3:.1f} us")
         for c, v in sorted(tot.items()):
             print(f"#   {c:32s} {v/frames:18.1f}")
+        print(f"# setup kernels (once per engine / event, NOT in the per-frame totals): {', '.join(sorted(n[:40] for n in setup)) or 'none'}")
+        for c, v in sorted(tot_setup.items()):
+            print(f"#   {c + ' (whole run)':32s} {v:18.1f}")
 
 
 if __name__ == "__main__":

@@ -224,6 +224,27 @@ static bool small_on_gates(int B, long P)
     return (long)B * P <= small_max;
 }
 
+// Does URNN_PHASE_FUSED_R take effect for a cell of this shape (skip: Skip-ConvGRU with an e input of F channels; x present)?
+extern "C" int urnn_gru_cell_fused_reset_gate_applies(int B, int I, int F, int H, int W, int skip)
+{
+    if (B < 1 || I < 1 || F < 32 || H < 1 || W < 1) return 0;
+    const FusedCandLayout fu = urnn_fused_cand_layout(I, F, skip);
+    const long P = (long)H * W;
+    if (!fu.ok || small_on_gates(B, P)) return 0;
+    static const unsigned dummy = 0;
+    ConvGemmParams p = {};
+    const int Ie = (I + 1) & ~1;
+    p.F = F;
+    p.P = (int)P;
+    p.KT = (Ie + (skip ? F : 0) + F) / 2;
+    p.kpBegin = 0;
+    p.hKp0 = (Ie + (skip ? F : 0)) / 2;
+    p.wfused = &dummy;
+    p.fu1Dwords = fu.dw1;
+    p.fu2Dwords = fu.dw2;
+    return urnn_cand_fused_plan(p, B) != 0;
+}
+
 // global_pixels > 0: this call computes one horizontal STRIP of a plane of global_pixels pixels that is split over ranks
 // (SURVEY 8e); the GroupNorm partials have been replaced by the all-reduced totals (two pseudo-tiles: hi + lo floats of
 // the double sums, urnn_gru_cell_strip_stats_f32) and the statistics are over the whole plane
@@ -298,6 +319,23 @@ static int gru_cell_impl(const float *x, const float *e, const float *h, const f
         tiles1 = (int)((P + 32 * pb1 - 1) / (32 * pb1));
     }
     const int ftiles1 = global_pixels > 0 ? 2 : tiles1;                              // tiles the finalizes read
+    // URNN_PHASE_FUSED_R: the reset gate is recomputed inside the candidate kernel and its raw planes are never stored -- when the
+    // cell has that form (F = 64 on a plane of >= 65 536 pixels with P % 4 == 0, f16 arithmetic, slabs + rings within the LDS);
+    // otherwise the flag is ignored and the three-pass cell runs.  Both phase-split calls of one cell take the same decision.
+    ConvGemmParams fz = p;
+    bool fused_r = false;
+    {
+        const FusedCandLayout fu = urnn_fused_cand_layout(I, F, skip);
+        if ((phase_mask & URNN_PHASE_FUSED_R) && fu.ok && global_pixels <= 0 && !small_gates && p.biasf) {
+            fz.hKp0 = Ie / 2 + (skip ? F / 2 : 0);
+            fz.wfused = reinterpret_cast<const unsigned *>(p.biasf + 2 * F);
+            fz.fu1Dwords = fu.dw1;
+            fz.fu2Dwords = fu.dw2;
+            fz.biasfu = reinterpret_cast<const float *>(fz.wfused + fu.dw1 + fu.dw2);
+            fused_r = urnn_cand_fused_plan(fz, B) != 0;
+        }
+    }
+    p.zOnly = fused_r ? 1 : 0;
     const double count = 32.0 * (double)(global_pixels > 0 ? global_pixels : P);     // values per (sample, norm group)
     // 32-pixel tiles (small planes: the quarter-resolution cells, the F = 96 candidates at half resolution) take the
     // activation-stationary kernels of urnn_small.hip: same outputs, same partial layout (development knob URNN_TUNE_SMALL=0)
@@ -343,7 +381,16 @@ static int gru_cell_impl(const float *x, const float *e, const float *h, const f
     c.out0 = ws.cx;
     c.partial = ws.part2;
     int pb2, map2;
-    const int tiles2 = gru_tiles(B, F, P, 2, &pb2, &map2);
+    int tiles2 = gru_tiles(B, F, P, 2, &pb2, &map2);
+    if (fused_r) {
+        pb2 = 2;                                                    // the fused kernel's 64-pixel tiles carry the candidate's partials
+        tiles2 = (int)((P + 63) / 64);
+        fz.zOnly = 0;
+        fz.gpart = c.gpart; fz.gtiles = c.gtiles; fz.gtilePix = c.gtilePix; fz.gcount = c.gcount;
+        fz.gn_w = c.gn_w; fz.gn_b = c.gn_b; fz.eps = c.eps; fz.ss_out = c.ss_out; fz.stat_out = c.stat_out;
+        fz.Cout = F; fz.out0 = ws.cx; fz.partial = ws.part2;
+        if (phase_mask & URNN_PHASE_CAND) CHECK_HIP(urnn_launch_cand_fused(fz, B, st), "gru candidate (reset gate recomputed)");
+    } else
     if (phase_mask & URNN_PHASE_CAND) {
         if (small_on && pb2 == 1 && urnn_small_ok(c, NW, 1)) CHECK_HIP(urnn_launch_small_cand(c, B, st), "gru candidate (small plane)");
         else CHECK_HIP(urnn_launch_cand(c, B, pb2, map2, st), "gru candidate");

@@ -85,7 +85,7 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-by
 // V = 4: 16-byte accesses (P % 4 == 0); V = 5: the same on planes whose size is not a multiple of four (the quarter-resolution
 // 125 x 125 planes: every channel plane starts at a different 4-byte phase) -- unaligned 16-byte accesses for the first P & ~3
 // pixels, dwords for the last P & 3; V = 1: dwords.
-template <int V, bool FIN>
+template <int V, bool FIN, int ITER_ = 0>
 __global__ __launch_bounds__(256) void gru_blend_kernel(const float *__restrict__ g1, const float *__restrict__ c,
                                                         const float *h, const float *__restrict__ ss1,
                                                         const float *__restrict__ ss2, float *out, int F, int P, const BlendFin fin)
@@ -144,7 +144,9 @@ __global__ __launch_bounds__(256) void gru_blend_kernel(const float *__restrict_
     const float *cc = c + ((size_t)bc) * P;
     const float *hh = h + ((size_t)bc) * P;
     float *oo = out + ((size_t)bc) * P;
-    constexpr int ITER = FIN ? 8 : 4;      // fused finalize: fewer, larger blocks (the prologue is per block)
+    // fused finalize: fewer, larger blocks (the prologue is per block) -- on large planes; a small plane (quarter resolution, the
+    // small-grid configs) would leave most CUs idle while ~200 blocks walk through eight dependent memory round trips each
+    constexpr int ITER = ITER_ ? ITER_ : (FIN ? 8 : 4);
     constexpr int VW = V == 5 ? 4 : V;     // pixels per thread and access
     const int base = blockIdx.x * (256 * VW * ITER);
     const int Pv = V == 5 ? (P & ~3) : P;  // pixels covered by vector accesses
@@ -211,12 +213,19 @@ hipError_t urnn_launch_blend_fin(const float *g1, const float *c, const float *h
                                  float *ss2, float *stat2, hipStream_t st)
 {
     const bool v4 = (P % 4) == 0, v5 = !v4 && P >= 1024;
-    const int per_block = 256 * ((v4 || v5) ? 4 : 1) * 8;
+    const int vw = (v4 || v5) ? 4 : 1;
+    auto blocks = [&](int iter) { return (long)((P + 256 * vw * iter - 1) / (256 * vw * iter)) * B * F; };
+    const int iter = blocks(8) >= 512 ? 8 : (blocks(2) >= 512 ? 2 : 1);
+    const int per_block = 256 * vw * iter;
     dim3 grid((P + per_block - 1) / per_block, B * F);
     const BlendFin fin = {partial, ntiles, tile_pix, count, gamma, beta, eps, ss2, stat2};
-    if (v4) hipLaunchKernelGGL((gru_blend_kernel<4, true>), grid, dim3(256), 0, st, g1, c, h, ss1, nullptr, out, F, P, fin);
-    else if (v5) hipLaunchKernelGGL((gru_blend_kernel<5, true>), grid, dim3(256), 0, st, g1, c, h, ss1, nullptr, out, F, P, fin);
-    else hipLaunchKernelGGL((gru_blend_kernel<1, true>), grid, dim3(256), 0, st, g1, c, h, ss1, nullptr, out, F, P, fin);
+#define URNN_BLEND_FIN(V_, I_) hipLaunchKernelGGL((gru_blend_kernel<V_, true, I_>), grid, dim3(256), 0, st, g1, c, h, ss1, nullptr, out, F, P, fin)
+#define URNN_BLEND_FIN_V(V_) do { if (iter == 8) URNN_BLEND_FIN(V_, 8); else if (iter == 2) URNN_BLEND_FIN(V_, 2); else URNN_BLEND_FIN(V_, 1); } while (0)
+    if (v4) URNN_BLEND_FIN_V(4);
+    else if (v5) URNN_BLEND_FIN_V(5);
+    else URNN_BLEND_FIN_V(1);
+#undef URNN_BLEND_FIN_V
+#undef URNN_BLEND_FIN
     return hipGetLastError();
 }
 
@@ -921,7 +930,57 @@ __global__ void pack_gru_kernel(const float *__restrict__ W1, const float *__res
     const int fsd1 = urnn_f16_slab_dwords(KT, NBg), fsd2 = urnn_f16_slab_dwords(KT, NB2);
     const int n1 = NG * slab1, nb1 = 2 * F, n2 = NG2 * slab2, nb2 = F, s1 = NG * ssd1, s2 = NG2 * ssd2, f1 = NGg * fsd1, f2 = NG2 * fsd2;
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n1 + nb1 + n2 + nb2 + s1 + s2 + f1 + f2 + 2 * F) return;
+    const FusedCandLayout fu = urnn_fused_cand_layout(I, F, skip);
+    const int base_fu = n1 + nb1 + n2 + nb2 + s1 + s2 + f1 + f2 + 2 * F;
+    if (idx >= base_fu + (fu.ok ? fu.dw1 + fu.dw2 + 2 * F : 0)) return;
+    if (idx >= base_fu) {
+        // fused-reset-gate candidate (urnn_gemm.hip cand_fused_kernel): phase-1 slab, phase-2 slab, bias [b1 r | b2]
+        int q = idx - base_fu;
+        const int NBF = fu.NBF;
+        auto w1r = [&](int blk, int kp, int l) {                 // reset-gate rows of W1
+            const int k = 2 * kp + (l >> 5);
+            const int ks = k < Ie ? (k < I ? k : -1) : I + (k - Ie);
+            return ks >= 0 ? W1[(size_t)(F + blk * 32 + (l & 31)) * Ksrc + ks] : 0.f;
+        };
+        auto w2x = [&](int blk, int kp, int l) {                 // candidate rows of W2, x | e columns
+            const int k = 2 * kp + (l >> 5);
+            const int ks = k < Ie ? (k < I ? k : -1) : I + (k - Ie);
+            return ks >= 0 ? W2[(size_t)(blk * 32 + (l & 31)) * Ksrc + ks] : 0.f;
+        };
+        if (q < fu.dw1) {
+            const int xe = fu.nXE * (2 * NBF * 512);
+            int grp, blk, rr;
+            bool hgrp = q >= xe;
+            if (!hgrp) {
+                grp = q / (2 * NBF * 512);
+                rr = q - grp * (2 * NBF * 512);
+            } else {
+                grp = fu.nXE + (q - xe) / (NBF * 512);
+                rr = (q - xe) % (NBF * 512);
+            }
+            blk = rr / 512;
+            const int piece = (rr - blk * 512) / 256, l = (rr & 255) >> 2, kp = 8 * grp + 2 * (rr & 3);
+            const unsigned d = blk < NBF ? f16_pair(w1r(blk, kp, l), w1r(blk, kp + 1, l), piece)
+                                         : f16_pair(w2x(blk - NBF, kp, l), w2x(blk - NBF, kp + 1, l), piece);
+            reinterpret_cast<unsigned *>(packed)[idx] = d;
+            return;
+        }
+        q -= fu.dw1;
+        if (q < fu.dw2) {
+            // group (rb, qq): the 16 hidden channels a lane of accumulator block rb holds in rows 8 qq .. 8 qq + 7 of its two halves;
+            // element i of lane half hf <-> channel 32 rb + 16 qq + 8 (i >> 2) + 4 hf + (i & 3)
+            const int grp = q / (NBF * 512), rr = q - grp * (NBF * 512);
+            const int rb = grp >> 1, qq = grp & 1;
+            const int nb = rr / 512, piece = (rr - nb * 512) / 256, l = (rr & 255) >> 2, dd = rr & 3;
+            const int ch0 = 32 * rb + 16 * qq + 8 * (dd >> 1) + 4 * (l >> 5) + 2 * (dd & 1);
+            const size_t row = (size_t)(nb * 32 + (l & 31)) * Ksrc + (size_t)(I + Fe);
+            reinterpret_cast<unsigned *>(packed)[idx] = f16_pair(W2[row + ch0], W2[row + ch0 + 1], piece);
+            return;
+        }
+        q -= fu.dw2;
+        packed[idx] = q < F ? b1[F + q] : b2[q - F];
+        return;
+    }
     if (idx >= n1 + nb1 + n2 + nb2 + s1 + s2 + f1 + f2) {        // gate bias in the f16 grouping's packed column order
         const int n = idx - (n1 + nb1 + n2 + nb2 + s1 + s2 + f1 + f2);
         const int g = n / (NBg * 32), nb = (n >> 5) % NBg;
@@ -999,7 +1058,15 @@ size_t urnn_packed_gru_total(int I, int F, int skip)
     const GateGroups gg = urnn_gate_groups(F, KT);
     return (size_t)(F / 32) * slab_floats(KT, 2) + 2 * F + (size_t)((F / 32) / NB2) * slab_floats(KT, NB2) + F +
            (size_t)(F / 32) * urnn_split_slab_dwords(KT, 2) + (size_t)((F / 32) / NB2) * urnn_split_slab_dwords(KT, NB2) +
-           (size_t)gg.NG * urnn_f16_slab_dwords(KT, gg.NB) + (size_t)((F / 32) / NB2) * urnn_f16_slab_dwords(KT, NB2) + 2 * F;
+           (size_t)gg.NG * urnn_f16_slab_dwords(KT, gg.NB) + (size_t)((F / 32) / NB2) * urnn_f16_slab_dwords(KT, NB2) + 2 * F +
+           urnn_packed_gru_fused_floats(I, F, skip);
+}
+
+// floats appended for the fused-reset-gate candidate kernel (0 when the cell's shape has no such form)
+size_t urnn_packed_gru_fused_floats(int I, int F, int skip)
+{
+    const FusedCandLayout fu = urnn_fused_cand_layout(I, F, skip);
+    return fu.ok ? (size_t)fu.dw1 + fu.dw2 + 2 * F : 0;
 }
 
 hipError_t urnn_launch_pack_gru(const float *W1, const float *b1, const float *W2, const float *b2, float *packed, int I,

@@ -46,7 +46,33 @@ struct ConvGemmParams {
     float *out0;
     int stagger;          // 8-wave blocks: start offset of the second wave of each SIMD, in eighths of half a tile (launcher: 0)
     float *partial;       // EPI_GRU1: [B][2F/32][tiles][2]; EPI_CAND: [B][F/32][tiles][2]
+    // fused-reset-gate cell (URNN_PHASE_FUSED_R): the gate GEMM keeps the reset gate's statistics but does not store its planes
+    // (zOnly), cand_fused_kernel recomputes it from its own slab: phase-1 [W1 r rows | W2 x,e columns], phase-2 W2[:, h] in the
+    // accumulator-row channel order (urnn_fused_cand_layout), bias [b1 r | b2]
+    int zOnly;
+    const unsigned *wfused;
+    int fu1Dwords, fu2Dwords;
+    const float *biasfu;
 };
+
+// Packed layout of the fused candidate slab (appended to a cell's packed buffer when ok): nXE 16-k groups of x | e with 2 NBF blocks
+// (r_0 .. | c_0 ..), nH = F/16 groups of h with NBF blocks (r only), then nH groups (accumulator block rb, half q) of W2[:, h] with NBF
+// candidate blocks; every block = two f16 pieces x 64 lanes x 16 B (urnn_common.h).  Built for the full-resolution cells' F = 64.
+struct FusedCandLayout { int ok, NBF, nXE, nH, dw1, dw2; };
+__host__ __device__ static inline FusedCandLayout urnn_fused_cand_layout(int I, int F, int skip)
+{
+    FusedCandLayout L = {0, F / 32, 0, 0, 0, 0};
+    const int Ie = (I + 1) & ~1, kH = (Ie + (skip ? F : 0)) / 2;      // k-pairs in front of the hidden-state segment
+    if (F != 64 || kH % 8 != 0) return L;
+    L.ok = 1;
+    L.nXE = kH / 8;
+    L.nH = F / 16;
+    L.dw1 = L.nXE * (2 * L.NBF * 512) + L.nH * (L.NBF * 512);
+    L.dw2 = L.nH * (L.NBF * 512);
+    return L;
+}
+int urnn_cand_fused_plan(const ConvGemmParams &p, int B);            // ring depth the fused kernel would run with; 0: not eligible
+hipError_t urnn_launch_cand_fused(ConvGemmParams p, int B, hipStream_t st);
 
 // Gate GEMM column grouping of the f16 slab.  A wave that owns more of the 2F gate columns reads the K input planes fewer times
 // through the CU's load path (the gate GEMM with F/32 groups of z_i|r_i was bound by that path, not by HBM: dec1 moved 576 MB
@@ -120,6 +146,7 @@ hipError_t urnn_launch_stage1_scalar(const float *S, const float *rain, const fl
 hipError_t urnn_launch_pack_conv(const float *w, const float *bias, float *packed, int Cin, int Cout, hipStream_t st);
 hipError_t urnn_launch_pack_gru(const float *W1, const float *b1, const float *W2, const float *b2, float *packed, int I,
                                 int F, int skip, hipStream_t st);
+size_t urnn_packed_gru_fused_floats(int I, int F, int skip);
 size_t urnn_packed_gru_total(int I, int F, int skip);   // floats of a packed cell buffer (layout: urnn_elem.hip pack_gru_kernel)
 hipError_t urnn_launch_pack_deconv(const float *w, const float *bias, float *packed, int Cin, int Cout, hipStream_t st);
 

@@ -49,10 +49,18 @@ __global__ __launch_bounds__(1024) void small_cell_gemm_kernel(const ConvGemmPar
         for (int grp = wave; grp < G1; grp += nwaves) {
             const float *pp = prm.gpart + ((size_t)b * G1 + grp) * prm.gtiles * 2;
             double s1 = 0.0, s2 = 0.0;
-            for (int t = lane; t < prm.gtiles; t += 64) {
-                const f32x2 v = *reinterpret_cast<const f32x2 *>(pp + 2 * t);
-                s1 += (double)v.x;
-                s2 += tile_x2(v.x, v.y, 32 * tile_valid(t, prm.gtilePix, P));
+            for (int t0 = 0; t0 < prm.gtiles; t0 += 64 * 8) {           // 8 independent loads in flight, summed in tile order
+                f32x2 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int t = t0 + u * 64 + lane;
+                    v[u] = t < prm.gtiles ? *reinterpret_cast<const f32x2 *>(pp + 2 * t) : f32x2{0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    s1 += (double)v[u].x;
+                    s2 += tile_x2(v[u].x, v[u].y, 32 * tile_valid(t0 + u * 64 + lane, prm.gtilePix, P));
+                }
             }
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) {
@@ -84,6 +92,23 @@ __global__ __launch_bounds__(1024) void small_cell_gemm_kernel(const ConvGemmPar
         __syncthreads();
     }
 
+    // the wave's first weight pieces are requested BEFORE the activation prologue: their L2 / HBM round trip overlaps with it
+    const int nbg = wave >> 1, pbw = wave & 1;
+    const int g = nbg / NBG, nb = nbg - g * NBG;                          // n-group / block inside it, as packed
+    const u32x4 *Aw = reinterpret_cast<const u32x4 *>(MODE == 3 ? prm.wf16 + (size_t)g * prm.fDwords : prm.wsplit + (size_t)g * prm.sDwords) + lane;
+    auto a_ptr = [&](int gq, int piece) { return Aw + ((size_t)((kg0 + gq) * NBG + nb) * NPC + piece) * 64; };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    constexpr int PF = 4;                                                 // weight pieces prefetched PF groups ahead
+    u32x4 ah[PF], am[PF], al[PF];
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+        const int gq = q < KG ? q : KG - 1;
+        ah[q] = *a_ptr(gq, 0);
+        am[q] = *a_ptr(gq, 1);
+        if constexpr (MODE == 1) al[q] = *a_ptr(gq, 2);
+    }
     // ---- prologue: the tile's input rows -> bf16 pieces in LDS, once for all output channels -------------------------------------
     // unit u = (group gq, dword d, row parity hf): k-pairs kp0 = 8 (kg0 + gq) + 2d and kp0 + 1, channel row hf of each; lane = pixel
     {
@@ -91,35 +116,51 @@ __global__ __launch_bounds__(1024) void small_cell_gemm_kernel(const ConvGemmPar
         const bool pix_ok = px < P;
         const int pb = lane >> 5;
         const int k1 = prm.segKp0[1], k2 = prm.segKp0[2];
-        auto act = [&](int kp, int hf) -> float {
+        // loads only (every unit's requests go out before anything is used): a gated row returns h and leaves its raw r-gate in gv
+        auto act = [&](int kp, int hf, float &gv) -> float {
+            gv = 0.f;
             if (!pix_ok) return 0.f;
             if (GATED && kp >= prm.hKp0) {
                 const int ch = 2 * (kp - prm.hKp0) + hf;
-                const float g = prm.gate[((size_t)b * 2 * F + F + ch) * P + px], hv = prm.seg[2][((size_t)b * F + ch) * P + px];
-                return sigmoidf_fast(g * ssm[2 * ch] + ssm[2 * ch + 1]) * hv;
+                gv = prm.gate[((size_t)b * 2 * F + F + ch) * P + px];
+                return prm.seg[2][((size_t)b * F + ch) * P + px];
             }
             const int sg = kp >= k2 ? 2 : (kp >= k1 ? 1 : 0);
             const int ch = 2 * (kp - (sg == 2 ? k2 : (sg == 1 ? k1 : 0))) + hf;
             return ch < prm.segC[sg] ? prm.seg[sg][((size_t)b * prm.segC[sg] + ch) * P + px] : 0.f;    // pad row of an odd channel count
         };
         const int nunits = KG * 8;
-        for (int u0 = wave; u0 < nunits; u0 += 4 * nwaves) {                // four units in flight per wave
-            float v0[4], v1[4];
+        constexpr int UB = GATED ? 6 : 8;                                   // units in flight per wave (2 loads each, 4 when gated)
+        for (int u0 = wave; u0 < nunits; u0 += UB * nwaves) {
+            float v0[UB], v1[UB], g0[GATED ? UB : 1], g1[GATED ? UB : 1];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < UB; ++q) {
                 const int u = u0 + q * nwaves;
                 if (u < nunits) {
                     const int gq = u >> 3, d = (u >> 1) & 3, hf = u & 1;
                     const int kp0 = 8 * (kg0 + gq) + 2 * d;
-                    v0[q] = act(kp0, hf);
-                    v1[q] = act(kp0 + 1, hf);
+                    float ga, gb;
+                    v0[q] = act(kp0, hf, ga);
+                    v1[q] = act(kp0 + 1, hf, gb);
+                    if constexpr (GATED) {
+                        g0[q] = ga;
+                        g1[q] = gb;
+                    }
                 }
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < UB; ++q) {
                 const int u = u0 + q * nwaves;
                 if (u < nunits) {
                     const int gq = u >> 3, d = (u >> 1) & 3, hf = u & 1;
+                    if constexpr (GATED) {
+                        const int kp0 = 8 * (kg0 + gq) + 2 * d;
+                        if (kp0 >= prm.hKp0) {                               // (whole 16-k groups are gated or plain: hKp0 % 8 == 0)
+                            const int ch = 2 * (kp0 - prm.hKp0) + hf;
+                            v0[q] *= sigmoidf_fast(g0[q] * ssm[2 * ch] + ssm[2 * ch + 1]);
+                            v1[q] *= sigmoidf_fast(g1[q] * ssm[2 * ch + 4] + ssm[2 * ch + 5]);
+                        }
+                    }
                     unsigned ph, pm, pl;
                     if constexpr (MODE == 2) {
                         ph = round_pair(v0[q], v1[q]);
@@ -141,22 +182,6 @@ __global__ __launch_bounds__(1024) void small_cell_gemm_kernel(const ConvGemmPar
     __syncthreads();
 
     // ---- main loop: wave = (32-channel block nbg, pixel block pbw) -------------------------------------------------------------------
-    const int nbg = wave >> 1, pbw = wave & 1;
-    const int g = nbg / NBG, nb = nbg - g * NBG;                          // n-group / block inside it, as packed
-    const u32x4 *Aw = reinterpret_cast<const u32x4 *>(MODE == 3 ? prm.wf16 + (size_t)g * prm.fDwords : prm.wsplit + (size_t)g * prm.sDwords) + lane;
-    auto a_ptr = [&](int gq, int piece) { return Aw + ((size_t)((kg0 + gq) * NBG + nb) * NPC + piece) * 64; };
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    constexpr int PF = 3;                                                 // weight pieces prefetched PF groups ahead
-    u32x4 ah[PF], am[PF], al[PF];
-#pragma unroll
-    for (int q = 0; q < PF; ++q) {
-        const int gq = q < KG ? q : KG - 1;
-        ah[q] = *a_ptr(gq, 0);
-        am[q] = *a_ptr(gq, 1);
-        if constexpr (MODE == 1) al[q] = *a_ptr(gq, 2);
-    }
     const u32x4 *Bw = reinterpret_cast<const u32x4 *>(Bp) + (size_t)pbw * NPC * 64 + lane;
     for (int gq0 = 0; gq0 < KG; gq0 += PF) {
 #pragma unroll

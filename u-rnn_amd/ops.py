@@ -140,6 +140,7 @@ def stage_conv(x, packed, Cout, pool, out=None, slope=LRELU_SLOPE):
 
 
 PHASE_GATES, PHASE_GN1, PHASE_CAND, PHASE_GN2, PHASE_BLEND, PHASE_ALL = 1, 2, 4, 8, 16, 31
+PHASE_FUSED_R = 32     # modifier: reset gate recomputed inside the candidate kernel (include/urnn_hip.h URNN_PHASE_FUSED_R)
 
 
 def gru_cell(x, e, h, packed, gn1_w, gn1_b, gn2_w, gn2_b, I, out=None, eps=NORM_EPS, phases=PHASE_ALL, ws=None):

@@ -15,8 +15,11 @@ from .general import initialize_states
 class RolloutEngine:
     def __init__(self, net, input_height, input_width, historical_nums, rain_max, cumsum_rain_max, batch=1,
                  max_frames=360, spatial_rain=False, net_cfg=None, use_graph=True, keep_raw=False,
-                 device=None, overlap=False):
+                 device=None, overlap=False, fused_reset_gate=True):
         self.net = net
+        # cells whose shape has the form recompute the reset gate inside the candidate kernel instead of round-tripping its raw
+        # planes through HBM (include/urnn_hip.h URNN_PHASE_FUSED_R); the engine never reads a cell's workspace
+        self._cell_flags = ops.PHASE_FUSED_R if fused_reset_gate else 0
         self.H, self.W = int(input_height), int(input_width)
         self.nums = int(historical_nums)
         self.C = 2 * self.nums + 3
@@ -120,12 +123,12 @@ class RolloutEngine:
         if self._probe is not None and name in self._probe:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            cell.step(x, e, h, out=out, phases=ops.PHASE_GATES, ws=ws)
+            cell.step(x, e, h, out=out, phases=ops.PHASE_GATES | self._cell_flags, ws=ws)
             b.record()
             self._probe[name].append((a, b))
-            cell.step(x, e, h, out=out, phases=ops.PHASE_ALL & ~ops.PHASE_GATES, ws=ws)
+            cell.step(x, e, h, out=out, phases=(ops.PHASE_ALL & ~ops.PHASE_GATES) | self._cell_flags, ws=ws)
         else:
-            cell.step(x, e, h, out=out, ws=ws)
+            cell.step(x, e, h, out=out, phases=ops.PHASE_ALL | self._cell_flags, ws=ws)
 
     def probe_gate_gemm(self, frames=12):
         """Average duration (seconds) of the full- and half-resolution gate-GEMM launches while the rollout runs in this engine's
