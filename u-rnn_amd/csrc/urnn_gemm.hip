@@ -1095,27 +1095,31 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void cand_fused_kernel(const Con
             const float *hbase = prm.seg[2] + ((size_t)b * prm.F + 4 * half) * prm.P;
             const float *ssb = ssm + ((size_t)b * prm.F + 4 * half) * 2;
             const char *A2 = urnn_smem + (size_t)prm.fu1Dwords * 4 + lane * 16;
+            // h first (every row of the tile's hidden state: 16 x NBF loads of 8 B per lane), then the sigmoids -- which do not need h
+            // -- while the loads are in flight; r replaces the accumulator it came from
+            float hv[NBF][16][PB];
+#pragma unroll
+            for (int rb = 0; rb < NBF; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) load_row<MAP, PB>(hbase + (size_t)(rb * 32 + row_c(r)) * prm.P, pm, hv[rb][r]);
 #pragma unroll
             for (int rb = 0; rb < NBF; ++rb) {
-                float hv[16][PB];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) load_row<MAP, PB>(hbase + (size_t)(rb * 32 + row_c(r)) * prm.P, pm, hv[r]);
+                for (int r = 0; r < 16; ++r) {
+                    const f32x2 sc = *reinterpret_cast<const f32x2 *>(ssb + 2 * (rb * 32 + row_c(r)));
+                    const float bv = bias_h[rb * 32 + row_c(r)];
+#pragma unroll
+                    for (int pb = 0; pb < PB; ++pb) acc[rb][pb][r] = sigmoidf_fast(fin(acc[rb][pb][r], bv) * sc.x + sc.y);
+                }
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     unsigned ph[PB][4], pl[PB][4];
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
                         const int r0 = 8 * q + 2 * d, r1 = r0 + 1;
-                        const f32x2 st0 = *reinterpret_cast<const f32x2 *>(ssb + 2 * (rb * 32 + row_c(r0)));
-                        const f32x2 st1 = *reinterpret_cast<const f32x2 *>(ssb + 2 * (rb * 32 + row_c(r1)));
-                        const float b0 = bias_h[rb * 32 + row_c(r0)], b1 = bias_h[rb * 32 + row_c(r1)];
 #pragma unroll
-                        for (int pb = 0; pb < PB; ++pb) {
-                            const float g0 = fin(acc[rb][pb][r0], b0), g1 = fin(acc[rb][pb][r1], b1);
-                            const float v0 = sigmoidf_fast(g0 * st0.x + st0.y) * hv[r0][pb];
-                            const float v1 = sigmoidf_fast(g1 * st1.x + st1.y) * hv[r1][pb];
-                            split2_pair(v0, v1, asc, ph[pb][d], pl[pb][d]);
-                        }
+                        for (int pb = 0; pb < PB; ++pb)
+                            split2_pair(acc[rb][pb][r0] * hv[rb][r0][pb], acc[rb][pb][r1] * hv[rb][r1][pb], asc, ph[pb][d], pl[pb][d]);
                     }
                     const char *ag = A2 + (size_t)((rb * 2 + q) * NBF) * 2048;
 #pragma unroll
