@@ -162,8 +162,11 @@ int urnn_stage1_scalar_rain_f32(const float *S, const float *rain, const float *
 /* ---- training: backward of every layer, loss, optimizer step; first version --------------------- */
 
 /* Backward of urnn_gru_cell_f32: gradients of every input and parameter of one ConvGRU / Skip-ConvGRU step
- * (autograd of CGRU_cell.forward -- ConvRNN.py:111-194) given dL/dh' = dh_out (+ dh_out2 when non-NULL: the state's two
- * consumers -- the layer above and the next timestep -- hand in their terms separately and the sum is formed on the fly).
+ * (autograd of CGRU_cell.forward -- ConvRNN.py:111-194) given dL/dh' = dh_out (+ dh_out2, dh_out3, dh_out4 where non-NULL: the
+ * state's consumers -- the layer above, a skip connection's reader, the next timestep -- hand in their terms separately and the
+ * sum is formed on the fly, left to right).  dh2 (optional, (B,F,H,W)): when non-NULL, dL/dh leaves as TWO terms, dh + dh2 (dh2 =
+ * W1[:, h]^T . dgates straight out of its GEMM), for a consumer that sums its terms itself -- the previous timestep's call of this
+ * function; NULL: dh holds the whole gradient.
  * Call it after the forward of the SAME x / e / h with the forward's workspace untouched (fwd_workspace: it holds the raw
  * gates, the raw candidate, the folded GroupNorm tables and the group statistics).  W1 (2F,K) / W2 (F,K) are the conv
  * weights in their reference layout, K ordered x | e | h.  dx / de must be non-NULL exactly when x / e are; dx, de, dh
@@ -176,8 +179,8 @@ size_t urnn_gru_cell_backward_workspace_bytes(int B, int I, int F, int skip, int
  * in place by a single GEMM over the contraction [dgates; dcandidate]. */
 size_t urnn_gru_cell_backward_packed_floats(int I, int F, int skip);
 int urnn_gru_cell_backward_f32(const float *x, const float *e, const float *h, const float *W1, const float *W2, const float *gn1_w,
-                               const float *gn2_w, const void *fwd_workspace, const float *dh_out, const float *dh_out2, float *dx,
-                               float *de, float *dh,
+                               const float *gn2_w, const void *fwd_workspace, const float *dh_out, const float *dh_out2,
+                               const float *dh_out3, const float *dh_out4, float *dx, float *de, float *dh, float *dh2,
                                float *dW1, float *db1, float *dgn1_w, float *dgn1_b, float *dW2, float *db2, float *dgn2_w,
                                float *dgn2_b, float *bwd_packed, int repack, void *workspace, size_t workspace_bytes, int B, int I,
                                int F, int H, int W, int accumulate, void *stream);

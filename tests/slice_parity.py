@@ -54,7 +54,8 @@ def run_slice(dev, t0=60, n=120, weights_seed=0, event_seed=42, cache=None, over
     eng.load_event(ev)
     eng.reset()
     if injected is None:
-        eng.run(t0)
+        if t0 > 0:
+            eng.run(t0)
         torch.cuda.synchronize()
         start = [s.clone() for s in eng.final_states()]
     else:

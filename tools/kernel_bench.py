@@ -65,13 +65,14 @@ def main():
     for name, cell, x, e, h, P, I, F, skip in cells:
         Kx = I + (F if skip else 0)
         tmp = h.clone()
-        add(f"{name} gates GEMM", lambda: cell.step(x, e, h, out=tmp, phases=ops.PHASE_GATES),
+        ws = ops.workspace(ops.gru_cell_workspace_bytes(h.shape[0], F, h.shape[2], h.shape[3]), h.device)   # ONE scratch per cell: the later phases read what the gate phase wrote
+        add(f"{name} gates GEMM", lambda: cell.step(x, e, h, out=tmp, phases=ops.PHASE_GATES, ws=ws),
             P * 2 * F * (Kx + F), P * (Kx + F + 2 * F) * 4 / 1e6)
-        add(f"{name} cand GEMM (+GN1)", lambda: cell.step(x, e, h, out=tmp, phases=ops.PHASE_CAND), P * F * (Kx + F),
+        add(f"{name} cand GEMM (+GN1)", lambda: cell.step(x, e, h, out=tmp, phases=ops.PHASE_CAND, ws=ws), P * F * (Kx + F),
             P * (Kx + 2 * F + F) * 4 / 1e6)
-        add(f"{name} GN2 finalize", lambda: cell.step(x, e, h, out=tmp, phases=ops.PHASE_GN2), 0, 0)
-        add(f"{name} blend", lambda: cell.step(x, e, h, out=tmp, phases=ops.PHASE_BLEND), 0, P * 4 * F * 4 / 1e6)
-        add(f"{name} whole cell", lambda: cell.step(x, e, h, out=tmp), P * 3 * F * (Kx + F), P * (Kx + 2 * F) * 4 / 1e6)
+        add(f"{name} GN2 finalize", lambda: cell.step(x, e, h, out=tmp, phases=ops.PHASE_GN2, ws=ws), 0, 0)
+        add(f"{name} blend", lambda: cell.step(x, e, h, out=tmp, phases=ops.PHASE_BLEND, ws=ws), 0, P * 4 * F * 4 / 1e6)
+        add(f"{name} whole cell", lambda: cell.step(x, e, h, out=tmp, ws=ws), P * 3 * F * (Kx + F), P * (Kx + 2 * F) * 4 / 1e6)
     add("head (7 launches)", lambda: net.head.run(eng.feat, out_masked=eng.out_masked, out_cls=eng.out_cls),
         P1 * (5 * 256 + 32), (P1 * 16 * 11 + 2 * P1) * 4 / 1e6)
     def whole():

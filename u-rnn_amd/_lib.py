@@ -39,7 +39,7 @@ SIGNATURES = {
     "urnn_stage1_scalar_rain_f32": (_i, [_p] * 6 + [_i, _p, _i, _i, _i, _i, _i, _i, _f, _f, _f, _p]),
     "urnn_gru_cell_backward_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "urnn_gru_cell_backward_packed_floats": (_sz, [_i, _i, _i]),
-    "urnn_gru_cell_backward_f32": (_i, [_p] * 22 + [_i, _p, _sz, _i, _i, _i, _i, _i, _i, _p]),
+    "urnn_gru_cell_backward_f32": (_i, [_p] * 25 + [_i, _p, _sz, _i, _i, _i, _i, _i, _i, _p]),
     "urnn_weight_gradient_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "urnn_weight_gradient_f32": (_i, [_p, _p, _i, _p, _i, _p, _i, _p, _p, _p, _sz, _i, _i, _i, _i, _i, _p]),
     "urnn_stage_conv_backward_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),

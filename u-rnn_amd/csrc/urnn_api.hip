@@ -575,7 +575,8 @@ static int dx_gemm(const float *dy, const float *packed, float *out, int B, int 
 
 extern "C" int urnn_gru_cell_backward_f32(const float *x, const float *e, const float *h, const float *W1, const float *W2,
                                           const float *gn1_w, const float *gn2_w, const void *fwd_workspace, const float *dh_out,
-                                          const float *dh_out2, float *dx, float *de, float *dh, float *dW1, float *db1, float *dgn1_w, float *dgn1_b,
+                                          const float *dh_out2, const float *dh_out3, const float *dh_out4, float *dx, float *de, float *dh,
+                                          float *dh2, float *dW1, float *db1, float *dgn1_w, float *dgn1_b,
                                           float *dW2, float *db2, float *dgn2_w, float *dgn2_b, float *bwd_packed, int repack,
                                           void *workspace, size_t workspace_bytes, int B, int I, int F, int H, int W, int accumulate,
                                           void *stream)
@@ -613,7 +614,7 @@ extern "C" int urnn_gru_cell_backward_f32(const float *x, const float *e, const 
     }
 
     // 1. blend: dy2 (normalised candidate), dy1[:, :F] (normalised update gate), dh = dout * (1 - z)
-    CHECK_HIP(urnn_train_blend_bwd(dh_out, dh_out2, fw.g1, fw.cx, h, fw.ss1, fw.ss2, fw.st1, fw.st2, ws.dy2, ws.dy1, dh, ws.chpart, ws.chpart2, B, F,
+    CHECK_HIP(urnn_train_blend_bwd(dh_out, dh_out2, dh_out3, dh_out4, fw.g1, fw.cx, h, fw.ss1, fw.ss2, fw.st1, fw.st2, ws.dy2, ws.dy1, dh, ws.chpart, ws.chpart2, B, F,
                                    Pi, st), "blend backward");
     // 2. GroupNorm of the candidate: dy2 -> dc (in place), dgamma2 / dbeta2
     CHECK_HIP(urnn_train_gn_backward(ws.dy2, fw.cx, fw.st2, gn2_w, B, F, Pi, ws.chpart2, ws.sums, ws.coef, dgn2_w, dgn2_b, accumulate, 1, st),
@@ -652,10 +653,11 @@ extern "C" int urnn_gru_cell_backward_f32(const float *x, const float *e, const 
             CHECK_HIP(urnn_train_add_slices(de, (long)F * P, ws.dxe + (size_t)I * P, bs, nullptr, 0, B, F, Pi, 0, st), "de");
         }
     }
-    // 8. dh += W1[:, h]^T . dg
-    rc = conv_2seg(ws.dy1, 2 * F, nullptr, 0, bwd_packed + pk.h1, ws.tmpF, B, F, H, W, st, "conv1 hidden-state gradient");
+    // 8. dh += W1[:, h]^T . dg -- or, when the caller takes dL/dh as two terms (dh2 != NULL: the previous timestep's cell backward
+    //    sums its dh_out terms on the fly), the GEMM writes the second term straight into dh2 and the adding pass is gone
+    rc = conv_2seg(ws.dy1, 2 * F, nullptr, 0, bwd_packed + pk.h1, dh2 ? dh2 : ws.tmpF, B, F, H, W, st, "conv1 hidden-state gradient");
     if (rc) return rc;
-    CHECK_HIP(urnn_train_add_slices(dh, (long)F * P, ws.tmpF, (long)F * P, nullptr, 0, B, F, Pi, 1, st), "dh");
+    if (!dh2) CHECK_HIP(urnn_train_add_slices(dh, (long)F * P, ws.tmpF, (long)F * P, nullptr, 0, B, F, Pi, 1, st), "dh");
     return URNN_OK;
 }
 

@@ -156,7 +156,8 @@ hipError_t urnn_train_chan_sums(const float *a, long a_bs, const float *v, long 
                                 float *partial, double *sums, hipStream_t st);
 hipError_t urnn_train_gn_backward(float *dy, const float *v, const float *stat, const float *gamma, int B, int C, int P, float *partial,
                                   double *sums, float *coef, float *dgamma, float *dbeta, int accumulate, int have_partials, hipStream_t st);
-hipError_t urnn_train_blend_bwd(const float *dout, const float *dout2, const float *g1, const float *c, const float *h, const float *ss1, const float *ss2,
+hipError_t urnn_train_blend_bwd(const float *dout, const float *dout2, const float *dout3, const float *dout4, const float *g1, const float *c,
+                                const float *h, const float *ss1, const float *ss2,
                                 const float *st1, const float *st2, float *dy2, float *dy1, float *dh, float *part1, float *part2, int B,
                                 int F, int P, hipStream_t st);
 hipError_t urnn_train_reset_gate(const float *g1, const float *h, const float *ss1, float *rh, int B, int F, int P, hipStream_t st);

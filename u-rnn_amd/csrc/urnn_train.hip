@@ -176,7 +176,8 @@ __device__ __forceinline__ void block_partials(float (&v)[4], int n, float *dst0
 
 // Also emits, per (plane, blockIdx.x), the partial sums the two GroupNorm backward passes need (sum dy, sum dy * xhat):
 // part2[(b*F + f)][gx][2] for the candidate, part1[(b*2F + f)][gx][2] for the update-gate half of the gates.
-__global__ __launch_bounds__(256) void blend_bwd_kernel(const float *__restrict__ dout, const float *__restrict__ dout2, const float *__restrict__ g1, const float *__restrict__ c,
+__global__ __launch_bounds__(256) void blend_bwd_kernel(const float *__restrict__ dout, const float *__restrict__ dout2, const float *__restrict__ dout3,
+                                                        const float *__restrict__ dout4, const float *__restrict__ g1, const float *__restrict__ c,
                                                         const float *__restrict__ h, const float *__restrict__ ss1, const float *__restrict__ ss2,
                                                         const float *__restrict__ st1, const float *__restrict__ st2, float *__restrict__ dy2,
                                                         float *__restrict__ dy1, float *__restrict__ dh, float *__restrict__ part1,
@@ -188,14 +189,21 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(const float *__restrict_
     const float mu1 = st1[((size_t)b * (2 * F / 32) + f / 32) * 2], rs1 = st1[((size_t)b * (2 * F / 32) + f / 32) * 2 + 1];
     const float mu2 = st2[((size_t)b * (F / 32) + f / 32) * 2], rs2 = st2[((size_t)b * (F / 32) + f / 32) * 2 + 1];
     const float *gz = g1 + ((size_t)b * 2 * F + f) * P, *cc = c + (size_t)bc * P, *hh = h + (size_t)bc * P, *dd = dout + (size_t)bc * P;
-    const float *dd2 = dout2 ? dout2 + (size_t)bc * P : nullptr;      // dL/dh' may arrive as two terms (layer above + next timestep)
+    // dL/dh' may arrive as up to four terms (the layer above, the skip connection's consumer, and the next timestep's two): summed
+    // here, left to right, instead of by passes of their own
+    const float *dd2 = dout2 ? dout2 + (size_t)bc * P : nullptr;
+    const float *dd3 = dout3 ? dout3 + (size_t)bc * P : nullptr;
+    const float *dd4 = dout4 ? dout4 + (size_t)bc * P : nullptr;
     float *o2 = dy2 + (size_t)bc * P, *o1 = dy1 + ((size_t)b * 2 * F + f) * P, *oh = dh + (size_t)bc * P;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};       // sum dyz, sum dyz * xhat1, sum dy2, sum dy2 * xhat2
     for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += gridDim.x * 256) {
         const float gv = gz[p], cv = cc[p];
         const float z = 1.0f / (1.0f + expf(-(gv * s1 + t1)));
         const float n = tanhf(cv * s2 + t2);
-        const float d = dd2 ? dd[p] + dd2[p] : dd[p];
+        float d = dd[p];
+        if (dd2) d += dd2[p];
+        if (dd3) d += dd3[p];
+        if (dd4) d += dd4[p];
         const float a2 = d * z * (1.0f - n * n);
         const float a1 = d * (n - hh[p]) * z * (1.0f - z);
         o2[p] = a2;
@@ -693,12 +701,13 @@ hipError_t urnn_train_gn_backward(float *dy, const float *v, const float *stat, 
     return hipGetLastError();
 }
 
-hipError_t urnn_train_blend_bwd(const float *dout, const float *dout2, const float *g1, const float *c, const float *h, const float *ss1, const float *ss2,
+hipError_t urnn_train_blend_bwd(const float *dout, const float *dout2, const float *dout3, const float *dout4, const float *g1, const float *c,
+                                const float *h, const float *ss1, const float *ss2,
                                 const float *st1, const float *st2, float *dy2, float *dy1, float *dh, float *part1, float *part2, int B,
                                 int F, int P, hipStream_t st)
 {
-    hipLaunchKernelGGL(blend_bwd_kernel, plane_grid(P, B * F), dim3(256), 0, st, dout, dout2, g1, c, h, ss1, ss2, st1, st2, dy2, dy1, dh, part1, part2,
-                       F, P);
+    hipLaunchKernelGGL(blend_bwd_kernel, plane_grid(P, B * F), dim3(256), 0, st, dout, dout2, dout3, dout4, g1, c, h, ss1, ss2, st1, st2, dy2, dy1, dh,
+                       part1, part2, F, P);
     return hipGetLastError();
 }
 

@@ -14,15 +14,17 @@ def _bwd_scratch(scratch, nbytes, dev):
 
 
 def gru_cell_backward(x, e, h, W1, W2, gn1_w, gn2_w, dh_out, I, fwd_ws, grads=None, accumulate=False, packed=None, dh_out2=None,
-                      scratch=None):
+                      scratch=None, dh_out3=None, dh_out4=None, split_dh=False):
     """Gradients of one cell step.  ``fwd_ws`` is the scratch buffer the forward ``ops.gru_cell(x, e, h, ..., ws=fwd_ws)`` of the
     SAME inputs ran on (untouched since): it holds the raw gates / candidate and the GroupNorm statistics.
     W1 (2F,K[,1,1]) / W2 (F,K[,1,1]): conv weights in the reference layout.  Returns a dict with dx, de (when given), dh and
     dW1, db1, dg1, dbe1, dW2, db2, dg2, dbe2; pass ``grads`` (the dict of a previous call) with ``accumulate=True`` to add
     the parameter gradients of another timestep.  ``packed``: a one-element list the caller keeps per cell for the packed
     weights of the input-gradient GEMMs -- filled on the first call, reused until the caller empties it (after an optimizer
-    step); None: packed on every call.  ``dh_out2``: an optional second term of dL/dh' (added on the fly)."""
-    ops._dev_check(x, e, h, W1, W2, gn1_w, gn2_w, dh_out, dh_out2)
+    step); None: packed on every call.  ``dh_out2`` .. ``dh_out4``: optional further terms of dL/dh' (added on the fly).  ``split_dh``:
+    dL/dh is returned as two terms, ``dh`` + ``dh2`` (the second straight out of its GEMM), for a consumer that sums its terms itself --
+    the previous timestep's call."""
+    ops._dev_check(x, e, h, W1, W2, gn1_w, gn2_w, dh_out, dh_out2, dh_out3, dh_out4)
     B, F, H, W = h.shape
     K = I + (F if e is not None else 0) + F
     if W1.numel() != 2 * F * K or W2.numel() != F * K:
@@ -39,6 +41,7 @@ def gru_cell_backward(x, e, h, W1, W2, gn1_w, gn2_w, dh_out, I, fwd_ws, grads=No
                  dg2=torch.empty(F, **f32), dbe2=torch.empty(F, **f32))
         accumulate = False
     g["dh"] = torch.empty_like(h)
+    g["dh2"] = torch.empty_like(h) if split_dh else None
     if x is not None and e is not None and B == 1:        # one block: a single GEMM writes dx | de in place
         dxe = torch.empty((1, I + F, H, W), **f32)
         g["dx"], g["de"] = dxe[:, :I], dxe[:, I:]
@@ -53,9 +56,9 @@ def gru_cell_backward(x, e, h, W1, W2, gn1_w, gn2_w, dh_out, I, fwd_ws, grads=No
     else:
         pk = packed[0]
     p = ops._ptr
-    check(L.urnn_gru_cell_backward_f32(p(x), p(e), p(h), p(W1), p(W2), p(gn1_w), p(gn2_w), p(fwd), p(dh_out), p(dh_out2), p(g["dx"]),
-                                       p(g["de"]),
-                                       p(g["dh"]), p(g["dW1"]), p(g["db1"]), p(g["dg1"]), p(g["dbe1"]), p(g["dW2"]), p(g["db2"]),
+    check(L.urnn_gru_cell_backward_f32(p(x), p(e), p(h), p(W1), p(W2), p(gn1_w), p(gn2_w), p(fwd), p(dh_out), p(dh_out2), p(dh_out3),
+                                       p(dh_out4), p(g["dx"]), p(g["de"]),
+                                       p(g["dh"]), p(g["dh2"]), p(g["dW1"]), p(g["db1"]), p(g["dg1"]), p(g["dbe1"]), p(g["dW2"]), p(g["db2"]),
                                        p(g["dg2"]), p(g["dbe2"]), p(pk), int(repack), p(ws), ws.numel(), B, I, F, H, W,
                                        int(bool(accumulate)), ops._stream()), "urnn_gru_cell_backward_f32")
     return g

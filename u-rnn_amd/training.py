@@ -66,8 +66,10 @@ class WindowGradients:
         net = self.net
         enc, dec, head = net.encoder, net.decoder, net.head
         e1p, e2p, e3p, d1p, d2p, d3p = S["prev"]
-        dE1, dE2, dE3, dD1, dD2, dD3 = dstate if dstate is not None else [None] * 6
-        add = lambda a, b: a if b is None else (b if a is None else a + b)
+        # a state's gradient arrives as a TUPLE of terms (None entries dropped): the layer above in this timestep, the skip
+        # connection's reader, and the same cell in the next timestep -- which itself hands over two (blend / reset-gate part, and the
+        # gates' GEMM output).  The cell backward sums up to four terms on the fly; nothing is added by a pass of its own.
+        dE1, dE2, dE3, dD1, dD2, dD3 = dstate if dstate is not None else [()] * 6
 
         def conv_bwd(name, mod, x, dy):
             L = mod.layer
@@ -87,9 +89,17 @@ class WindowGradients:
             G[key + ".weight"], G[key + ".bias"] = dw, db
             return dx
 
-        def cell_bwd(k, name, mod, x, e, h, dout_h, dout_h2=None):
-            if dout_h is None:
-                dout_h, dout_h2 = dout_h2, None
+        def cell_bwd(k, name, mod, x, e, h, *terms):
+            """terms: tensors / tuples of tensors / None -- the pieces of dL/dh'.  Returns dx, de, (dh, dh2)."""
+            flat = []
+            for t in terms:
+                if t is None:
+                    continue
+                flat.extend(v for v in (t if isinstance(t, (tuple, list)) else (t,)) if v is not None)
+            flat = [v.contiguous() for v in flat]
+            while len(flat) > 4:                    # (never with this network: at most layer above + skip + two from the next step)
+                flat = [flat[0] + flat[1]] + flat[2:]
+            flat += [None] * (4 - len(flat))
             c1, g1, c2, g2 = _cell_params(mod)
             names = {"dW1": "conv1.0.weight", "db1": "conv1.0.bias", "dg1": "conv1.1.weight", "dbe1": "conv1.1.bias",
                      "dW2": "conv2.0.weight", "db2": "conv2.0.bias", "dg2": "conv2.1.weight", "dbe2": "conv2.1.bias"}
@@ -97,13 +107,13 @@ class WindowGradients:
             prev = {k_: (G[f"{name}.{v}"].reshape(-1) if k_ in ("db1", "dg1", "dbe1", "db2", "dg2", "dbe2") else
                          G[f"{name}.{v}"].reshape(G[f"{name}.{v}"].shape[0], -1)) for k_, v in names.items()} if have else None
             g = train_ops.gru_cell_backward(x, e, h, c1.weight.detach(), c2.weight.detach(), g1.weight.detach(), g2.weight.detach(),
-                                            dout_h.contiguous(), mod.input_channels, S["ws"][k], grads=prev, accumulate=acc and have,
-                                            packed=self._bwd_packed.setdefault(name, []),
-                                            dh_out2=None if dout_h2 is None else dout_h2.contiguous(), scratch=self.arena)
+                                            flat[0], mod.input_channels, S["ws"][k], grads=prev, accumulate=acc and have,
+                                            packed=self._bwd_packed.setdefault(name, []), dh_out2=flat[1], dh_out3=flat[2], dh_out4=flat[3],
+                                            split_dh=True, scratch=self.arena)
             for k_, v in names.items():
                 ref = dict(mod.named_parameters())[v]
                 G[f"{name}.{v}"] = g[k_].reshape(ref.shape)
-            return g.get("dx"), g.get("de"), g["dh"]
+            return g.get("dx"), g.get("de"), (g["dh"], g["dh2"])
 
         # head
         fp = head.flat_params()
@@ -114,15 +124,14 @@ class WindowGradients:
         G["_head"] = hg
         if after_head is not None:      # the head's gradients of this window are final here (when this is the first timestep)
             after_head(hg)
-        # decoder.  A state's gradient has two sources -- the layer above in this timestep and the same cell in the next
-        # timestep; the cell backward takes them as two terms and adds on the fly (three terms: one torch add)
+        # decoder
         du2, dE1_dec, dD3n = cell_bwd(5, "decoder.rnn1", dec.rnn1, S["u2"], S["e1"], d3p, conv_bwd("decoder.stage1", dec.stage1, S["d3"], hg["dfeat"]), dD3)
         du3, dE2_dec, dD2n = cell_bwd(4, "decoder.rnn2", dec.rnn2, S["u3"], S["e2"], d2p, deconv_bwd("decoder.stage2", dec.stage2, S["d2"], S["u2"], du2), dD2)
         _, dE3_dec, dD1n = cell_bwd(3, "decoder.rnn3", dec.rnn3, None, S["e3"], d1p, deconv_bwd("decoder.stage3", dec.stage3, S["d1"], S["u3"], du3), dD1)
         # encoder
         da3, _, dE3n = cell_bwd(2, "encoder.rnn3", enc.rnn3, S["a3"], None, e3p, dE3_dec, dE3)
-        da2, _, dE2n = cell_bwd(1, "encoder.rnn2", enc.rnn2, S["a2"], None, e2p, add(conv_bwd("encoder.stage3", enc.stage3, S["e2"], da3), dE2_dec), dE2)
-        da1, _, dE1n = cell_bwd(0, "encoder.rnn1", enc.rnn1, S["a1"], None, e1p, add(conv_bwd("encoder.stage2", enc.stage2, S["e1"], da2), dE1_dec), dE1)
+        da2, _, dE2n = cell_bwd(1, "encoder.rnn2", enc.rnn2, S["a2"], None, e2p, conv_bwd("encoder.stage3", enc.stage3, S["e2"], da3), dE2_dec, dE2)
+        da1, _, dE1n = cell_bwd(0, "encoder.rnn1", enc.rnn1, S["a1"], None, e1p, conv_bwd("encoder.stage2", enc.stage2, S["e1"], da2), dE1_dec, dE1)
         conv_bwd("encoder.stage1", enc.stage1, S["x_in"], da1)
         return [dE1n, dE2n, dE3n, dD1n, dD2n, dD3n]
 
@@ -168,6 +177,7 @@ class WindowGradients:
             dstate = self._backward_step(saved[s], s, dreg[:, s], dstate, G, acc=(s != steps - 1), after_head=hook)
         grads = {k: v for k, v in G.items() if not k.startswith("_")}
         grads.update(self.head_gradients(G["_head"]))
+        # state_grads: per state the TWO terms of dL/d(initial state) (their sum is the gradient; left unsummed: nobody in the loop reads it)
         return {"loss": comps, "grads": grads, "states": [s.detach() for s in states], "reg": reg, "state_grads": dstate}
 
 
