@@ -403,6 +403,9 @@ def main():
     ap.add_argument("--seq-num", type=int, default=4, help="train mode: timesteps per SWP window")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
                     help="train mode: GEMM arithmetic (bf16 = BASELINE configs[3]'s variant; inference always runs the fp32-exact path)")
+    ap.add_argument("--matrix-mode", default="fp32", choices=["fp32", "fp32_mfma"],
+                    help="infer mode: fp32 = fp32 operands as f16 pieces on the 16-bit matrix pipe (the product default); fp32_mfma = the exact "
+                         "fp32 matrix instructions everywhere (include/urnn_hip.h URNN_MATRIX_FP32_MFMA: slower, tightest long-rollout parity)")
     args = ap.parse_args()
 
     if args.exp_config:
@@ -445,6 +448,10 @@ def main():
     if args.mode == "strips":
         return bench_strips(args, dev, dist, world, rank)
 
+    if args.matrix_mode != "fp32":                          # process-wide; the captured graphs keep it
+        from urnn_amd import ops as _ops
+        from urnn_amd._lib import check as _check, lib as _lib
+        _check(_lib().urnn_set_matrix_mode(_ops.MATRIX_MODES[args.matrix_mode]), "urnn_set_matrix_mode")
     # "mixed" = BASELINE configs[4]: Futian + UKEA events alternating on every rank, one engine (and one captured hipGraph)
     # per grid shape; every other config is a single shape
     names = MIXED if args.config == "mixed" else (args.config,)
@@ -529,7 +536,7 @@ def main():
                                ("mixed: " + " + ".join(f"{n} {CONFIGS[n][0]}x{CONFIGS[n][1]} T={CONFIGS[n][3]}" for n in names) +
                                 f" events alternating, {B} event(s) per GPU, one hipGraph per shape"),
                    "events_per_gpu": B, "parallelism": f"event-parallel x{world} (no collective)",
-                   "graph": not args.no_graph, "overlap_chains": bool(args.overlap)},
+                   "graph": not args.no_graph, "overlap_chains": bool(args.overlap), "matrix_mode": args.matrix_mode},
         "long_run": long_run,
         "gflop_per_frame": gflop,
         "step_mfma_frac": fps / world * gflop / 1e3 / PEAK_MFMA_F32_TFLOPS,                          # of the fp32 matrix peak (round 1's pipe)

@@ -48,8 +48,15 @@ const char *urnn_last_error(void);
  *     GEMM operands rounded to bf16 (weights keep 16 mantissa bits in the forward / input-gradient GEMMs), fp32 accumulation;
  *     norms, statistics, states, loss and the optimizer stay fp32.  Applies to every forward GEMM, the input-gradient GEMMs AND
  *     the weight-gradient GEMMs (dY and X rounded to bf16, fp32 accumulate); gradients are stored in fp32. */
+/*   URNN_MATRIX_FP32_MFMA: every GEMM on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation: the k-loop the other modes
+ *     keep for channel counts that do not form 16-k groups), the cells on their three-pass kernels.  About 0.75x the default
+ *     mode's frames/s.  Per step the default mode is the MORE accurate one (cell output vs float64: 5e-8 against plain fp32
+ *     torch's 1.2e-7 rms at 500x500), but over hundreds of recurrent steps its trajectory ends up 1.3-1.8x further from the
+ *     float64 trajectory than plain fp32 torch's in the heavy-rain part of an event, while this mode's stays at torch's level or
+ *     below (profiles/r03_noise_floor*.txt) -- for callers that compare long rollouts digit by digit. */
 #define URNN_MATRIX_FP32 0
 #define URNN_MATRIX_BF16 1
+#define URNN_MATRIX_FP32_MFMA 2
 int urnn_set_matrix_mode(int mode);
 int urnn_get_matrix_mode(void);
 

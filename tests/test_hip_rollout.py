@@ -294,6 +294,28 @@ def test_full_size_rollout_vs_oracle(dev, overlap):
     assert np.array_equal(frames, again)
 
 
+def test_fp32_mfma_matrix_mode_rollout_vs_oracle(dev):
+    """urnn_set_matrix_mode(URNN_MATRIX_FP32_MFMA): every GEMM on the exact fp32 matrix instructions (the mode for digit-by-digit
+    comparisons of long rollouts) -- the location1 rollout of test_full_size_rollout_vs_oracle under it: same
+    bars; the engine re-captures its graphs when the process-wide mode changes and goes back to the default mode's bits afterwards."""
+    import urnn_amd.weights as uw
+    from urnn_amd import ops
+    from urnn_amd.rollout import RolloutEngine
+    H = W = 500
+    nums, T = 30, 36
+    net, sd = make_net(H, W, 2 * nums + 3, 0, dev)
+    ev = uw.make_event(T, H, W, 6.0, seed=42)
+    eng = RolloutEngine(net, H, W, nums, 6.0, 250.0, max_frames=T, keep_raw=True, overlap=True, use_graph=True)
+    default = eng.rollout(ev).cpu().numpy()
+    ref = _oracle_rollout(sd, ev, T, nums, 6.0, 250.0, ("location1", T))
+    yard = _torch_fp32_state_errors(sd, ev, T, nums, 6.0, 250.0, dev, ref[1], ("location1", T))
+    with ops.matrix_mode("fp32_mfma"):
+        frames = eng.rollout(ev).cpu().numpy()
+        _check_rollout_vs_oracle(eng, frames, T, ref, "500x500 fp32_mfma", state_yardstick=yard)
+    assert not np.array_equal(frames, default)          # (another arithmetic: equal to rounding, not to the bit)
+    assert np.array_equal(eng.rollout(ev).cpu().numpy(), default)
+
+
 def test_mid_event_slice_vs_oracle(dev):
     """Frames 60 .. 179 of the location1 event (BASELINE configs[1]: 500x500, C = 63, seed 42 -- the stretch where roundoff is
     amplified most, profiles/r02_parity_T360.txt) on the benchmarked schedule: the engine rolls frames 0 .. 59, hands its states

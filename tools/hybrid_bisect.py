@@ -129,6 +129,38 @@ def cell_hip_gates_cand(mod, prefix, x, e, h):
     return (1 - z) * h + z * n
 
 
+def f16_pair_weights(w):
+    """the value the f16 x 3 k-loop multiplies by: hi + lo of w * 2^10 as two RNE f16 pieces (urnn_common.h), back in float32 (exact)"""
+    ws_ = w.double() * 1024.0
+    hi = ws_.to(torch.float16)
+    lo = (ws_ - hi.double()).to(torch.float16)
+    return ((hi.double() + lo.double()) / 1024.0).float()
+
+
+def f16_pair_act(x, scale):
+    """what the f16 x 3 k-loop multiplies instead of an activation x: fl32(x * scale) as hi + lo RNE f16 pieces, over scale"""
+    xs = (x * scale)                                 # float32 product (exact for a power of two)
+    hi = xs.to(torch.float16)
+    lo = (xs - hi.float()).to(torch.float16)
+    return ((hi.double() + lo.double()) / scale).float()
+
+
+def cell_repr(prefix, x, e, h, scale):
+    """torch cell whose two convs see the f16-pair representation of their inputs (and weights)"""
+    F = h.shape[1]
+    W1, b1, g1, be1 = (pt[f"{prefix}.conv1.{k}"] for k in ("0.weight", "0.bias", "1.weight", "1.bias"))
+    W2, b2, g2, be2 = (pt[f"{prefix}.conv2.{k}"] for k in ("0.weight", "0.bias", "1.weight", "1.bias"))
+    cat = lambda *t: torch.cat([u for u in t if u is not None], dim=1)
+    q = lambda v: f16_pair_act(v, scale)
+    gates = Fn.group_norm(Fn.conv2d(q(cat(x, e, h)), f16_pair_weights(W1), b1), 2 * F // 32, g1, be1, torch_ref.EPS)
+    z, r = torch.sigmoid(gates[:, :F]), torch.sigmoid(gates[:, F:])
+    n = torch.tanh(Fn.group_norm(Fn.conv2d(q(cat(x, e, r * h)), f16_pair_weights(W2), b2), F // 32, g2, be2, torch_ref.EPS))
+    return (1 - z) * h + z * n
+
+
+FRAME = [0]
+
+
 def run(which, gn_mode=None):
     """which: set of parts computed by the HIP modules: 'stage1', 'cells_full' (enc1, dec1), 'cells_rest', 'convs' (stage 2/3 convs,
     deconvs, decoder stage 1), 'head'."""
@@ -138,7 +170,8 @@ def run(which, gn_mode=None):
         for t in range(N):
             x = preprocess_inputs(t, ev, dev, nums=NUMS, rain_max=RAIN_MAX, cumsum_rain_max=CUM_MAX)[:, 0].contiguous()
             e1, e2, e3, d1, d2, d3 = st
-            hc = lambda key, mod, name, xx, ee, hh: (cell_hip_gates(mod, name, xx.contiguous(), None if ee is None else ee.contiguous(), hh.contiguous()) if (gn_mode == "hip_gates" and key == "cells_full") else cell_hip_gates_cand(mod, name, xx.contiguous(), None if ee is None else ee.contiguous(), hh.contiguous()) if (gn_mode == "hip_gates_cand" and key == "cells_full") else mod.step(xx, ee, hh) if key in which else
+            FRAME[0] = t
+            hc = lambda key, mod, name, xx, ee, hh: (cell_repr(name, xx, ee, hh, 32.0) if (gn_mode == "repr" and key == "cells_full") else cell_repr(name, xx, ee, hh, 32.0 + 2.0 * (FRAME[0] & 7)) if (gn_mode == "repr_dither" and key == "cells_full") else cell_hip_gates(mod, name, xx.contiguous(), None if ee is None else ee.contiguous(), hh.contiguous()) if (gn_mode == "hip_gates" and key == "cells_full") else cell_hip_gates_cand(mod, name, xx.contiguous(), None if ee is None else ee.contiguous(), hh.contiguous()) if (gn_mode == "hip_gates_cand" and key == "cells_full") else mod.step(xx, ee, hh) if key in which else
                                                      (cell_custom(name, xx, ee, hh, gn_mode) if (gn_mode and key == "cells_full") else torch_ref.cell(pt, name, xx, ee, hh)))
             a1 = enc.stage1(x) if "stage1" in which else conv_t("encoder.stage1.conv1_leaky_1", x)
             e1n = hc("cells_full", enc.rnn1, "encoder.rnn1", a1, None, e1)
@@ -185,6 +218,20 @@ variants = [("all torch-fp32", set()), ("all HIP modules (generic stage 1, three
             ("HIP: everything but the cells", ALL - {"cells_full", "cells_rest"})]
 show("torch, but the full-res cells' raw gates AND raw candidate from HIP", run(set(), "hip_gates_cand"))
 show("HIP: full-resolution cells only (three-pass)", run({"cells_full"}))
+if a.variants == "repr":
+    show("torch, full-res cells' conv inputs + weights as f16 hi + lo pairs (scale 32)", run(set(), "repr"))
+    show("torch, same with the scale 32 + 2 (t mod 8) changing every frame", run(set(), "repr_dither"))
+if a.variants == "weights":
+    keep = {k: v.clone() for k, v in pt.items()}
+    for label, keys in (("candidate conv (W2) of enc1 / dec1", ["encoder.rnn1.conv2.0.weight", "decoder.rnn1.conv2.0.weight"]),
+                        ("gate conv (W1) of enc1 / dec1", ["encoder.rnn1.conv1.0.weight", "decoder.rnn1.conv1.0.weight"]),
+                        ("every conv / deconv weight of the network", [k for k in pt if k.endswith(".weight") and pt[k].dim() == 4 and not k.startswith("head.")])):
+        for k in keys:
+            pt[k] = f16_pair_weights(keep[k])
+        rel = max(float(((pt[k] - keep[k]).abs().max() / keep[k].abs().max())) for k in keys)
+        show(f"all torch-fp32, weights as hi + lo f16: {label} (max rel change {rel:.1e})", run(set()))
+        for k in keys:
+            pt[k] = keep[k]
 if a.variants == "gn":
     for mode in ("fold", "fold_consistent", "centred"):
         show(f"all torch-fp32, full-res cells' GroupNorm affine: {mode}", run(set(), mode))

@@ -75,7 +75,8 @@ def torch_run(seed):
 
 
 def hip_run(seed):
-    eng = RolloutEngine(net, H, W, NUMS, RAIN_MAX, CUM_MAX, max_frames=T_EVENT, keep_raw=True, overlap=True, use_graph=True)
+    # one kernel chain: eng.states are then the live buffers of the next frame (the two-chain schedule ping-pongs the encoder states)
+    eng = RolloutEngine(net, H, W, NUMS, RAIN_MAX, CUM_MAX, max_frames=T_EVENT, keep_raw=True, overlap=False, use_graph=True)
     eng.load_event(ev)
     eng.reset()
     eng.run(1)

@@ -1279,7 +1279,7 @@ static int tune_ring()
 static std::atomic<int> g_matrix_mode{0};
 extern "C" int urnn_set_matrix_mode(int mode)
 {
-    if (mode != URNN_MATRIX_FP32 && mode != URNN_MATRIX_BF16) return URNN_EINVAL;
+    if (mode != URNN_MATRIX_FP32 && mode != URNN_MATRIX_BF16 && mode != URNN_MATRIX_FP32_MFMA) return URNN_EINVAL;
     g_matrix_mode.store(mode, std::memory_order_relaxed);
     return URNN_OK;
 }
@@ -1317,7 +1317,7 @@ static int split_mode(const ConvGemmParams &p)
     // accumulators + pieces: <= 128 accumulators in a 256-register wave (8-wave blocks); the deconv's 6-block tile runs one
     // wave per SIMD (4-wave blocks, 512 registers) and takes its 192
     if constexpr (EPI == EPI_DECONV ? NB * PB * 16 > 192 : NB * PB * 16 > 128) return 0;
-    if (!tune_split()) return 0;
+    if (!tune_split() || g_matrix_mode.load(std::memory_order_relaxed) == URNN_MATRIX_FP32_MFMA) return 0;
     if (p.KT % 8 != 0 || p.kpBegin % 8 != 0 || p.KT <= p.kpBegin) return 0;      // whole 16-k groups, aligned with the packed ones
     if constexpr (EPI == EPI_CAND) {
         const int kpe = p.hKp0 < p.KT ? p.hKp0 : p.KT;
@@ -1500,7 +1500,7 @@ static void set_tile_means(ConvGemmParams &p, int tile_pix)
 static bool gate_grouped(const ConvGemmParams &p)
 {
     if (p.NBf == 2 || !p.wf16 || p.fDwords <= 0 || !p.biasf) return false;
-    if (g_matrix_mode.load(std::memory_order_relaxed) == URNN_MATRIX_BF16 || !tune_split() || !tune_f16()) return false;
+    if (g_matrix_mode.load(std::memory_order_relaxed) != URNN_MATRIX_FP32 || !tune_split() || !tune_f16()) return false;
     if (p.KT % 8 != 0 || p.kpBegin % 8 != 0 || p.KT <= p.kpBegin) return false;
     return true;
 }
@@ -1561,7 +1561,7 @@ hipError_t urnn_launch_cand(ConvGemmParams p, int B, int PB, int map, hipStream_
 int urnn_cand_fused_plan(const ConvGemmParams &p, int B)
 {
     if (p.F != 64 || !p.wfused || p.fu1Dwords <= 0 || p.P % 4 != 0) return 0;
-    if (g_matrix_mode.load(std::memory_order_relaxed) == URNN_MATRIX_BF16 || !tune_split() || !tune_f16()) return 0;
+    if (g_matrix_mode.load(std::memory_order_relaxed) != URNN_MATRIX_FP32 || !tune_split() || !tune_f16()) return 0;
     static const int on = [] { const char *e = getenv("URNN_TUNE_FUSED_R"); return e ? atoi(e) : 1; }();   // development knob (A/B)
     if (!on) return 0;
     if (p.KT % 8 != 0 || p.kpBegin % 8 != 0 || p.hKp0 % 8 != 0 || p.hKp0 >= p.KT || p.kpBegin > p.hKp0) return 0;

@@ -284,6 +284,7 @@ size_t urnn_small_lds_bytes(const ConvGemmParams &p, int nblk_total, int gated)
 bool urnn_small_ok(const ConvGemmParams &p, int nblk_total, int gated)
 {
     if (p.sDwords <= 0 || !p.wsplit) return false;
+    if (urnn_get_matrix_mode() == URNN_MATRIX_FP32_MFMA) return false;      // these kernels have no fp32-MFMA form: the weights-stationary ones run
     if (p.KT % 8 != 0 || p.kpBegin % 8 != 0 || p.KT <= p.kpBegin) return false;
     if (gated) {
         const int kpe = p.hKp0 < p.KT ? p.hKp0 : p.KT;

@@ -11,12 +11,13 @@ LRELU_SLOPE = 0.2   # get_activation("lrelu"), utils.py:63
 NORM_EPS = 1e-5     # nn.GroupNorm / nn.LayerNorm default eps
 
 
-MATRIX_MODES = {"fp32": 0, "bf16": 1}
+MATRIX_MODES = {"fp32": 0, "bf16": 1, "fp32_mfma": 2}
 
 
 class matrix_mode:
     """``with ops.matrix_mode("bf16"):`` -- GEMM arithmetic of the launches enqueued inside (include/urnn_hip.h
-    urnn_set_matrix_mode): "fp32" = the reference's semantics (default), "bf16" = bf16 compute with fp32 accumulation."""
+    urnn_set_matrix_mode): "fp32" = the reference's semantics on the 16-bit matrix pipe (default), "bf16" = bf16 compute with fp32
+    accumulation, "fp32_mfma" = the exact fp32 matrix instructions everywhere (slower; the tightest long-rollout parity)."""
 
     def __init__(self, mode):
         self.mode = MATRIX_MODES[mode]

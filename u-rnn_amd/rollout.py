@@ -365,7 +365,8 @@ class RolloutEngine:
         """A captured timestep holds raw pointers to the PACKED copies of the weights (and to the head's stacked affines), so a
         weight change must drop the graphs: ``load_state_dict`` / in-place edits bump the tensors' version counters, an
         optimizer that re-homes or rewrites parameters behind torch's back (``Trainer``) bumps ``net._urnn_generation``."""
-        stamp = (getattr(self.net, "_urnn_generation", 0),) + tuple((p.data_ptr(), p._version) for p in self.net.parameters())
+        # ... and the launches inside a graph keep the GEMM arithmetic (urnn_set_matrix_mode) they were captured with
+        stamp = (getattr(self.net, "_urnn_generation", 0), lib().urnn_get_matrix_mode()) + tuple((p.data_ptr(), p._version) for p in self.net.parameters())
         if stamp != self._param_stamp:
             if self._param_stamp is not None:
                 self._graph = None
