@@ -84,6 +84,11 @@ def check(name, mod, xx, ee, hh, prefix):
     got = views["cx"].reshape(F, P).double()
     d = (got - ref)
     print(f"   candidate GEMM vs float64: max |err| {float(d.abs().max()):.2e}, rms {float(d.pow(2).mean().sqrt()):.2e}, mean signed {float(d.mean()):+.2e}; |ref| rms {float(ref.pow(2).mean().sqrt()):.2e}")
+    sg = torch.sign(ref)
+    ul = torch.pow(2.0, torch.floor(torch.log2(ref.abs().clamp_min(1e-30))) - 23)          # ulp of the float32 result
+    print(f"   candidate GEMM: mean of err * sign(ref) {float((d * sg).mean()):+.2e} (toward-zero truncation would be negative), in ulps of the result {float((d * sg / ul).mean()):+.3f}; rms in ulps {float((d / ul).pow(2).mean().sqrt()):.2f}")
+    t32 = torch.nn.functional.conv2d(torch.cat(cat, dim=1).float(), W2.float(), b2.float())[0].reshape(F, P).double() - ref
+    print(f"   torch fp32 conv:  mean of err * sign(ref) {float((t32 * sg).mean()):+.2e}, in ulps {float((t32 * sg / ul).mean()):+.3f}; rms in ulps {float((t32 / ul).pow(2).mean().sqrt()):.2f}")
     per_ch = d.mean(dim=1)
     print(f"   per-channel mean signed error: max |.| {float(per_ch.abs().max()):.2e} (a plane-wide offset would show here); rms of the per-channel means {float(per_ch.pow(2).mean().sqrt()):.2e}")
     worst = int(d.abs().max(dim=0).values.argmax())

@@ -145,6 +145,33 @@ def f16_pair_act(x, scale):
     return ((hi.double() + lo.double()) / scale).float()
 
 
+def conv_f16x3(x, w, b, scale, drop=True):
+    """what the f16 x 3 k-loop computes, in float64: (w_hi + w_lo)(x_hi + x_lo) WITHOUT the lo * lo products (three MFMAs per 16 k: lo*hi,
+    hi*lo, hi*hi), then one float32 rounding (the accumulate's own roundings are left out: this isolates the dropped term)"""
+    xs = (x * scale)
+    xh = xs.to(torch.float16)
+    xl = (xs - xh.float()).to(torch.float16)
+    ws_ = w.double() * 1024.0
+    wh = ws_.to(torch.float16)
+    wl = (ws_ - wh.double()).to(torch.float16)
+    xh, xl, wh, wl = xh.double(), xl.double(), wh.double(), wl.double()
+    acc = Fn.conv2d(xh, wh) + Fn.conv2d(xh, wl) + Fn.conv2d(xl, wh)
+    if not drop:
+        acc = acc + Fn.conv2d(xl, wl)
+    return (acc / (scale * 1024.0) + b.double()[None, :, None, None]).float()
+
+
+def cell_f16x3(prefix, x, e, h, drop):
+    F = h.shape[1]
+    W1, b1, g1, be1 = (pt[f"{prefix}.conv1.{k}"] for k in ("0.weight", "0.bias", "1.weight", "1.bias"))
+    W2, b2, g2, be2 = (pt[f"{prefix}.conv2.{k}"] for k in ("0.weight", "0.bias", "1.weight", "1.bias"))
+    cat = lambda *t: torch.cat([u for u in t if u is not None], dim=1)
+    gates = Fn.group_norm(conv_f16x3(cat(x, e, h), W1, b1, 32.0, drop), 2 * F // 32, g1, be1, torch_ref.EPS)
+    z, r = torch.sigmoid(gates[:, :F]), torch.sigmoid(gates[:, F:])
+    n = torch.tanh(Fn.group_norm(conv_f16x3(cat(x, e, r * h), W2, b2, 32.0, drop), F // 32, g2, be2, torch_ref.EPS))
+    return (1 - z) * h + z * n
+
+
 def cell_repr(prefix, x, e, h, scale):
     """torch cell whose two convs see the f16-pair representation of their inputs (and weights)"""
     F = h.shape[1]
@@ -171,7 +198,7 @@ def run(which, gn_mode=None):
             x = preprocess_inputs(t, ev, dev, nums=NUMS, rain_max=RAIN_MAX, cumsum_rain_max=CUM_MAX)[:, 0].contiguous()
             e1, e2, e3, d1, d2, d3 = st
             FRAME[0] = t
-            hc = lambda key, mod, name, xx, ee, hh: (cell_repr(name, xx, ee, hh, 32.0) if (gn_mode == "repr" and key == "cells_full") else cell_repr(name, xx, ee, hh, 32.0 + 2.0 * (FRAME[0] & 7)) if (gn_mode == "repr_dither" and key == "cells_full") else cell_hip_gates(mod, name, xx.contiguous(), None if ee is None else ee.contiguous(), hh.contiguous()) if (gn_mode == "hip_gates" and key == "cells_full") else cell_hip_gates_cand(mod, name, xx.contiguous(), None if ee is None else ee.contiguous(), hh.contiguous()) if (gn_mode == "hip_gates_cand" and key == "cells_full") else mod.step(xx, ee, hh) if key in which else
+            hc = lambda key, mod, name, xx, ee, hh: (cell_f16x3(name, xx, ee, hh, True) if (gn_mode == "x3_drop" and key == "cells_full") else cell_f16x3(name, xx, ee, hh, False) if (gn_mode == "x3_full" and key == "cells_full") else cell_repr(name, xx, ee, hh, 32.0) if (gn_mode == "repr" and key == "cells_full") else cell_repr(name, xx, ee, hh, 32.0 + 2.0 * (FRAME[0] & 7)) if (gn_mode == "repr_dither" and key == "cells_full") else cell_hip_gates(mod, name, xx.contiguous(), None if ee is None else ee.contiguous(), hh.contiguous()) if (gn_mode == "hip_gates" and key == "cells_full") else cell_hip_gates_cand(mod, name, xx.contiguous(), None if ee is None else ee.contiguous(), hh.contiguous()) if (gn_mode == "hip_gates_cand" and key == "cells_full") else mod.step(xx, ee, hh) if key in which else
                                                      (cell_custom(name, xx, ee, hh, gn_mode) if (gn_mode and key == "cells_full") else torch_ref.cell(pt, name, xx, ee, hh)))
             a1 = enc.stage1(x) if "stage1" in which else conv_t("encoder.stage1.conv1_leaky_1", x)
             e1n = hc("cells_full", enc.rnn1, "encoder.rnn1", a1, None, e1)
@@ -218,6 +245,9 @@ variants = [("all torch-fp32", set()), ("all HIP modules (generic stage 1, three
             ("HIP: everything but the cells", ALL - {"cells_full", "cells_rest"})]
 show("torch, but the full-res cells' raw gates AND raw candidate from HIP", run(set(), "hip_gates_cand"))
 show("HIP: full-resolution cells only (three-pass)", run({"cells_full"}))
+if a.variants == "x3":
+    show("torch, full-res cells' convs = float64 sum of hi*hi + hi*lo + lo*hi (lo*lo DROPPED)", run(set(), "x3_drop"))
+    show("torch, full-res cells' convs = float64 sum of all four piece products", run(set(), "x3_full"))
 if a.variants == "repr":
     show("torch, full-res cells' conv inputs + weights as f16 hi + lo pairs (scale 32)", run(set(), "repr"))
     show("torch, same with the scale 32 + 2 (t mod 8) changing every frame", run(set(), "repr_dither"))
