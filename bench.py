@@ -403,7 +403,7 @@ def main():
     ap.add_argument("--seq-num", type=int, default=4, help="train mode: timesteps per SWP window")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
                     help="train mode: GEMM arithmetic (bf16 = BASELINE configs[3]'s variant; inference always runs the fp32-exact path)")
-    ap.add_argument("--matrix-mode", default="fp32", choices=["fp32", "fp32_mfma"],
+    ap.add_argument("--matrix-mode", default="fp32", choices=["fp32", "fp32_mfma", "fp32_cand"],
                     help="infer mode: fp32 = fp32 operands as f16 pieces on the 16-bit matrix pipe (the product default); fp32_mfma = the exact "
                          "fp32 matrix instructions everywhere (include/urnn_hip.h URNN_MATRIX_FP32_MFMA: slower, tightest long-rollout parity)")
     args = ap.parse_args()

@@ -57,6 +57,12 @@ const char *urnn_last_error(void);
 #define URNN_MATRIX_FP32 0
 #define URNN_MATRIX_BF16 1
 #define URNN_MATRIX_FP32_MFMA 2
+/*   URNN_MATRIX_FP32_CAND: the default mode, except that the candidate GEMM of a cell on a plane of >= 100 000 pixels per sample (the
+ *     two full-resolution cells of the published network) runs on v_mfma_f32_32x32x2_f32 and the cell takes its three-pass form
+ *     (URNN_PHASE_FUSED_R is ignored).  That one launch is where the 16-bit k-loop's contribution to a long rollout's error comes
+ *     from (measured by exchanging the arithmetic of one GEMM at a time): with it on the fp32 instruction the trajectory is at
+ *     plain-fp32 torch's distance from the float64 trajectory, at about 0.96x the default mode's frames/s. */
+#define URNN_MATRIX_FP32_CAND 3
 int urnn_set_matrix_mode(int mode);
 int urnn_get_matrix_mode(void);
 

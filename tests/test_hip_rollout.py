@@ -294,10 +294,12 @@ def test_full_size_rollout_vs_oracle(dev, overlap):
     assert np.array_equal(frames, again)
 
 
-def test_fp32_mfma_matrix_mode_rollout_vs_oracle(dev):
-    """urnn_set_matrix_mode(URNN_MATRIX_FP32_MFMA): every GEMM on the exact fp32 matrix instructions (the mode for digit-by-digit
-    comparisons of long rollouts) -- the location1 rollout of test_full_size_rollout_vs_oracle under it: same
-    bars; the engine re-captures its graphs when the process-wide mode changes and goes back to the default mode's bits afterwards."""
+@pytest.mark.parametrize("mode", ["fp32_mfma", "fp32_cand"])
+def test_fp32_mfma_matrix_mode_rollout_vs_oracle(dev, mode):
+    """urnn_set_matrix_mode(URNN_MATRIX_FP32_MFMA): every GEMM on the exact fp32 matrix instructions; URNN_MATRIX_FP32_CAND: only the
+    full-resolution cells' candidate GEMM (the modes for digit-by-digit comparisons of long rollouts) -- the
+    location1 rollout of test_full_size_rollout_vs_oracle under each: same bars; the engine re-captures its graphs when the
+    process-wide mode changes and goes back to the default mode's bits afterwards."""
     import urnn_amd.weights as uw
     from urnn_amd import ops
     from urnn_amd.rollout import RolloutEngine
@@ -309,9 +311,9 @@ def test_fp32_mfma_matrix_mode_rollout_vs_oracle(dev):
     default = eng.rollout(ev).cpu().numpy()
     ref = _oracle_rollout(sd, ev, T, nums, 6.0, 250.0, ("location1", T))
     yard = _torch_fp32_state_errors(sd, ev, T, nums, 6.0, 250.0, dev, ref[1], ("location1", T))
-    with ops.matrix_mode("fp32_mfma"):
+    with ops.matrix_mode(mode):
         frames = eng.rollout(ev).cpu().numpy()
-        _check_rollout_vs_oracle(eng, frames, T, ref, "500x500 fp32_mfma", state_yardstick=yard)
+        _check_rollout_vs_oracle(eng, frames, T, ref, f"500x500 {mode}", state_yardstick=yard)
     assert not np.array_equal(frames, default)          # (another arithmetic: equal to rounding, not to the bit)
     assert np.array_equal(eng.rollout(ev).cpu().numpy(), default)
 

@@ -22,6 +22,7 @@ ap.add_argument("--n", type=int, default=100)
 ap.add_argument("--k", type=int, default=3)
 ap.add_argument("--event-seed", type=int, default=42)
 ap.add_argument("--skip-torch", action="store_true")
+ap.add_argument("--matrix-mode", default="fp32")
 a = ap.parse_args()
 
 import torch_ref  # noqa: E402
@@ -35,6 +36,10 @@ from urnn_amd.rollout import RolloutEngine  # noqa: E402
 H = W = 500
 NUMS, RAIN_MAX, CUM_MAX, T_EVENT = 30, 6.0, 250.0, 360
 dev = torch.device("cuda:0")
+from urnn_amd import ops as _ops  # noqa: E402
+from urnn_amd._lib import check as _check, lib as _lib  # noqa: E402
+_check(_lib().urnn_set_matrix_mode(_ops.MATRIX_MODES[a.matrix_mode]), "urnn_set_matrix_mode")
+print(f"# matrix mode {a.matrix_mode}")
 C = 2 * NUMS + 3
 sd = uw.make_state_dict(H, W, C, seed=0)
 ep, dp = get_network_params(False, H, W, C, load_net_config())

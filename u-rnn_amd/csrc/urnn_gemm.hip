@@ -1279,7 +1279,7 @@ static int tune_ring()
 static std::atomic<int> g_matrix_mode{0};
 extern "C" int urnn_set_matrix_mode(int mode)
 {
-    if (mode != URNN_MATRIX_FP32 && mode != URNN_MATRIX_BF16 && mode != URNN_MATRIX_FP32_MFMA) return URNN_EINVAL;
+    if (mode != URNN_MATRIX_FP32 && mode != URNN_MATRIX_BF16 && mode != URNN_MATRIX_FP32_MFMA && mode != URNN_MATRIX_FP32_CAND) return URNN_EINVAL;
     g_matrix_mode.store(mode, std::memory_order_relaxed);
     return URNN_OK;
 }
@@ -1318,6 +1318,11 @@ static int split_mode(const ConvGemmParams &p)
     // wave per SIMD (4-wave blocks, 512 registers) and takes its 192
     if constexpr (EPI == EPI_DECONV ? NB * PB * 16 > 192 : NB * PB * 16 > 128) return 0;
     if (!tune_split() || g_matrix_mode.load(std::memory_order_relaxed) == URNN_MATRIX_FP32_MFMA) return 0;
+    if constexpr (EPI == EPI_CAND) {
+        // URNN_MATRIX_FP32_CAND: the candidate GEMM of a full-resolution cell is the one launch whose 16-bit k-loop shows in a long
+        // rollout's error (profiles/r03_noise_floor_cell_gemm_arithmetic.txt): exact fp32 MFMA for it, everything else as the default mode
+        if (g_matrix_mode.load(std::memory_order_relaxed) == URNN_MATRIX_FP32_CAND && p.P >= URNN_FULL_RES_PIXELS) return 0;
+    }
     if (p.KT % 8 != 0 || p.kpBegin % 8 != 0 || p.KT <= p.kpBegin) return 0;      // whole 16-k groups, aligned with the packed ones
     if constexpr (EPI == EPI_CAND) {
         const int kpe = p.hKp0 < p.KT ? p.hKp0 : p.KT;
@@ -1500,7 +1505,7 @@ static void set_tile_means(ConvGemmParams &p, int tile_pix)
 static bool gate_grouped(const ConvGemmParams &p)
 {
     if (p.NBf == 2 || !p.wf16 || p.fDwords <= 0 || !p.biasf) return false;
-    if (g_matrix_mode.load(std::memory_order_relaxed) != URNN_MATRIX_FP32 || !tune_split() || !tune_f16()) return false;
+    { const int mm_ = g_matrix_mode.load(std::memory_order_relaxed); if ((mm_ != URNN_MATRIX_FP32 && mm_ != URNN_MATRIX_FP32_CAND) || !tune_split() || !tune_f16()) return false; }
     if (p.KT % 8 != 0 || p.kpBegin % 8 != 0 || p.KT <= p.kpBegin) return false;
     return true;
 }

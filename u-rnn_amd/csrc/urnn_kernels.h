@@ -4,6 +4,7 @@
 #include <stddef.h>
 #include "../../include/urnn_hip.h"
 
+#define URNN_FULL_RES_PIXELS 100000   // URNN_MATRIX_FP32_CAND: planes at least this large per sample count as full resolution
 enum { MAP_VEC = 0, MAP_PAIR = 1, MAP_STRIDED = 2, MAP_POOL = 3, MAP_PAIR16 = 4 };   // pixel geometry of a wave tile (urnn_gemm.hip)
 enum { EPI_LRELU = 0, EPI_POOL = 1, EPI_DECONV = 2, EPI_GRU1 = 3, EPI_CAND = 4 };   // epilogue of conv_gemm_kernel
 

@@ -11,13 +11,14 @@ LRELU_SLOPE = 0.2   # get_activation("lrelu"), utils.py:63
 NORM_EPS = 1e-5     # nn.GroupNorm / nn.LayerNorm default eps
 
 
-MATRIX_MODES = {"fp32": 0, "bf16": 1, "fp32_mfma": 2}
+MATRIX_MODES = {"fp32": 0, "bf16": 1, "fp32_mfma": 2, "fp32_cand": 3}
 
 
 class matrix_mode:
     """``with ops.matrix_mode("bf16"):`` -- GEMM arithmetic of the launches enqueued inside (include/urnn_hip.h
     urnn_set_matrix_mode): "fp32" = the reference's semantics on the 16-bit matrix pipe (default), "bf16" = bf16 compute with fp32
-    accumulation, "fp32_mfma" = the exact fp32 matrix instructions everywhere (slower; the tightest long-rollout parity)."""
+    accumulation, "fp32_mfma" = the exact fp32 matrix instructions everywhere (slower), "fp32_cand" = the default except for the
+    full-resolution cells' candidate GEMM on the fp32 instruction (a few per cent slower; plain-fp32 torch's long-rollout error)."""
 
     def __init__(self, mode):
         self.mode = MATRIX_MODES[mode]
