@@ -375,7 +375,11 @@ def test_whole_event_rollout_vs_oracle(dev):
     net, sd = make_net(H, W, 2 * nums + 3, 0, dev)
     ev = uw.make_event(T, H, W, 6.0, seed=42)
     eng = RolloutEngine(net, H, W, nums, 6.0, 250.0, max_frames=T, keep_raw=True, overlap=True, use_graph=True)
-    eng.rollout(ev)
+    from urnn_amd import ops
+    mode = os.environ.get("URNN_LONG_MODE", "fp32")          # the GEMM arithmetic of the record (include/urnn_hip.h urnn_set_matrix_mode)
+    print(f"matrix mode {mode}")
+    with ops.matrix_mode(mode):
+        eng.rollout(ev)
     hip_raw, hip_cls = eng.out_raw[:T].cpu().numpy(), eng.out_cls[:T].cpu().numpy()
     onet = orc.OracleNet(sd)
     pt = {k: torch.from_numpy(v).to(dev) for k, v in sd.items()}
