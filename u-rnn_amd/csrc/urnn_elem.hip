@@ -967,14 +967,12 @@ __global__ void pack_gru_kernel(const float *__restrict__ W1, const float *__res
         }
         q -= fu.dw1;
         if (q < fu.dw2) {
-            // group (rb, qq): the 16 hidden channels a lane of accumulator block rb holds in rows 8 qq .. 8 qq + 7 of its two halves;
-            // element i of lane half hf <-> channel 32 rb + 16 qq + 8 (i >> 2) + 4 hf + (i & 3)
-            const int grp = q / (NBF * 512), rr = q - grp * (NBF * 512);
-            const int rb = grp >> 1, qq = grp & 1;
-            const int nb = rr / 512, piece = (rr - nb * 512) / 256, l = (rr & 255) >> 2, dd = rr & 3;
-            const int ch0 = 32 * rb + 16 * qq + 8 * (dd >> 1) + 4 * (l >> 5) + 2 * (dd & 1);
-            const size_t row = (size_t)(nb * 32 + (l & 31)) * Ksrc + (size_t)(I + Fe);
-            reinterpret_cast<unsigned *>(packed)[idx] = f16_pair(W2[row + ch0], W2[row + ch0 + 1], piece);
+            // W2[:, h] for the fp32 matrix instruction of phase 2, x 2^15 (the scale of the f16 products it is added to): row (rb, r) of
+            // the accumulator layout = hidden channels 32 rb + row_c(r) (lane half 0) and + 4 (lane half 1), NBF candidate blocks each
+            const int l = q & 63, nb = (q >> 6) % NBF, rr = (q >> 6) / NBF;
+            const int rb = rr >> 4, r = rr & 15;
+            const int ch = 32 * rb + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+            packed[idx] = W2[(size_t)(nb * 32 + (l & 31)) * Ksrc + (size_t)(I + Fe) + ch] * (URNN_F16_ASCALE * URNN_F16_WSCALE);
             return;
         }
         q -= fu.dw2;

@@ -1094,7 +1094,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void cand_fused_kernel(const Con
         {
             const float *hbase = prm.seg[2] + ((size_t)b * prm.F + 4 * half) * prm.P;
             const float *ssb = ssm + ((size_t)b * prm.F + 4 * half) * 2;
-            const char *A2 = urnn_smem + (size_t)prm.fu1Dwords * 4 + lane * 16;
+            const float *A2f = reinterpret_cast<const float *>(urnn_smem + (size_t)prm.fu1Dwords * 4) + lane;
             // h first (every row of the tile's hidden state: 16 x NBF loads of 8 B per lane), then the sigmoids -- which do not need h
             // -- while the loads are in flight; r replaces the accumulator it came from
             float hv[NBF][16][PB];
@@ -1111,21 +1111,20 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void cand_fused_kernel(const Con
 #pragma unroll
                     for (int pb = 0; pb < PB; ++pb) acc[rb][pb][r] = sigmoidf_fast(fin(acc[rb][pb][r], bv) * sc.x + sc.y);
                 }
+                // W2[:, h] . (r (.) h) on the fp32 matrix instruction: of the cell's products this is the one whose 16-bit form shows in a
+                // long rollout, and here it costs little -- the operand is already in registers as fp32 (no split),
+                // K = 2 per instruction pairs the two lane halves' rows (channels c and c + 4), the weights sit in LDS as fp32 x 2^15
+                // (the accumulators' scale) in exactly that order, 64 x 64 of them
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    unsigned ph[PB][4], pl[PB][4];
+                for (int r = 0; r < 16; ++r) {
+                    float v[PB];
 #pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        const int r0 = 8 * q + 2 * d, r1 = r0 + 1;
-#pragma unroll
-                        for (int pb = 0; pb < PB; ++pb)
-                            split2_pair(acc[rb][pb][r0] * hv[rb][r0][pb], acc[rb][pb][r1] * hv[rb][r1][pb], asc, ph[pb][d], pl[pb][d]);
-                    }
-                    const char *ag = A2 + (size_t)((rb * 2 + q) * NBF) * 2048;
+                    for (int pb = 0; pb < PB; ++pb) v[pb] = acc[rb][pb][r] * hv[rb][r][pb];
 #pragma unroll
                     for (int nb = 0; nb < NBF; ++nb) {
-                        mfma3(ag, nb, acc[NBF + nb], ph, pl);
-                        __builtin_amdgcn_sched_barrier(0);
+                        const float wa = A2f[((rb * 16 + r) * NBF + nb) * 64];
+#pragma unroll
+                        for (int pb = 0; pb < PB; ++pb) acc[NBF + nb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa, v[pb], acc[NBF + nb][pb], 0, 0, 0);
                     }
                 }
             }
