@@ -49,19 +49,20 @@ const char *urnn_last_error(void);
  *     norms, statistics, states, loss and the optimizer stay fp32.  Applies to every forward GEMM, the input-gradient GEMMs AND
  *     the weight-gradient GEMMs (dY and X rounded to bf16, fp32 accumulate); gradients are stored in fp32. */
 /*   URNN_MATRIX_FP32_MFMA: every GEMM on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation: the k-loop the other modes
- *     keep for channel counts that do not form 16-k groups), the cells on their three-pass kernels.  About 0.75x the default
- *     mode's frames/s.  Per step the default mode is the MORE accurate one (cell output vs float64: 5e-8 against plain fp32
- *     torch's 1.2e-7 rms at 500x500), but over hundreds of recurrent steps its trajectory ends up 1.3-1.8x further from the
- *     float64 trajectory than plain fp32 torch's in the heavy-rain part of an event, while this mode's stays at torch's level or
- *     below (profiles/r03_noise_floor*.txt) -- for callers that compare long rollouts digit by digit. */
+ *     keep for channel counts that do not form 16-k groups), the cells on their three-pass kernels.  About 0.8x the default
+ *     mode's frames/s.  Background: per step the 16-bit k-loops are the MORE accurate ones (cell output vs
+ *     float64: 5e-8 against plain fp32 torch's 1.2e-7 rms at 500x500), but over hundreds of recurrent steps ONE product of the
+ *     cell in that form -- W2[:, h] . (r * h) of the full-resolution cells -- moves the trajectory 1.3-1.8x further from the float64
+ *     trajectory than plain fp32 torch's.  The default mode therefore computes that product on the fp32 instruction wherever the
+ *     fused candidate kernel runs (URNN_PHASE_FUSED_R); this mode and the next exist for the cells that cannot take that kernel
+ *     and for callers that compare long rollouts digit by digit. */
 #define URNN_MATRIX_FP32 0
 #define URNN_MATRIX_BF16 1
 #define URNN_MATRIX_FP32_MFMA 2
 /*   URNN_MATRIX_FP32_CAND: the default mode, except that the candidate GEMM of a cell on a plane of >= 100 000 pixels per sample (the
- *     two full-resolution cells of the published network) runs on v_mfma_f32_32x32x2_f32 and the cell takes its three-pass form
- *     (URNN_PHASE_FUSED_R is ignored).  That one launch is where the 16-bit k-loop's contribution to a long rollout's error comes
- *     from (measured by exchanging the arithmetic of one GEMM at a time): with it on the fp32 instruction the trajectory is at
- *     plain-fp32 torch's distance from the float64 trajectory, at about 0.96x the default mode's frames/s. */
+ *     two full-resolution cells of the published network) runs on v_mfma_f32_32x32x2_f32 as a whole and the cell takes its
+ *     three-pass form (URNN_PHASE_FUSED_R is ignored): the long-rollout behaviour of URNN_MATRIX_FP32_MFMA for the one launch that
+ *     needs it, whatever the plane's shape, at a few per cent of the frames/s. */
 #define URNN_MATRIX_FP32_CAND 3
 int urnn_set_matrix_mode(int mode);
 int urnn_get_matrix_mode(void);
