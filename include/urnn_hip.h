@@ -119,7 +119,9 @@ int urnn_gru_cell_f32(const float *x, const float *e, const float *h, const floa
  * being written as F raw planes by the gate GEMM and read back; the gate GEMM keeps r's GroupNorm statistics and stores z only.
  * Same arithmetic for r (bit-identical accumulators); two plane passes of F channels less per cell (ConvRNN.py:165-180).  Applies
  * where the cell has that form (F = 64, P % 4 == 0, >= 65 536 pixels per launch, fp32 matrix mode, slabs within the LDS) and is
- * ignored elsewhere; pass it to every phase-split call of a cell or to none.  The workspace's raw reset-gate planes are then
+ * ignored elsewhere -- except that a cell on a plane of >= 100 000 pixels that cannot take this form (P % 4 != 0, F != 64) then runs its
+ * candidate GEMM on the fp32 matrix instruction, so that a long rollout behaves the same whatever the grid's shape; pass the flag to
+ * every phase-split call of a cell or to none.  The workspace's raw reset-gate planes are then
  * undefined: the backward pass (urnn_gru_cell_backward_f32) needs a forward WITHOUT this flag. */
 #define URNN_PHASE_FUSED_R 32
 /* 1 when URNN_PHASE_FUSED_R takes effect for a cell of this shape under the current matrix mode (x present; skip: an e input of F

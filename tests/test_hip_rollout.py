@@ -215,6 +215,29 @@ def test_fused_reset_gate_cell_vs_three_pass_and_oracle(dev, which):
     assert torch.equal(again, fused)
 
 
+def test_rollout_cell_on_an_odd_full_resolution_plane(dev):
+    """A full-resolution cell whose plane is not a multiple of four pixels (501 x 499) cannot take the fused candidate kernel; called the
+    way the rollout engine calls it (URNN_PHASE_FUSED_R) its candidate GEMM then runs on the fp32 matrix instruction (include/urnn_hip.h)
+    -- another arithmetic than the plain call's f16 pieces, both within 1e-4 of the oracle (ConvRNN.py:111-194)."""
+    from oracle import oracle as orc
+    from urnn_amd import ops
+    H, W = 501, 499
+    net, sd = make_net(H, W, 63, 0, dev)
+    rs = np.random.RandomState(13)
+    x = (0.5 * rs.standard_normal((1, 16, H, W))).astype(np.float32)
+    h = (0.5 * rs.standard_normal((1, 64, H, W))).astype(np.float32)
+    tx, th = torch.from_numpy(x).to(dev), torch.from_numpy(h).to(dev)
+    cell = net.encoder.rnn1
+    plain = cell.step(tx, None, th)
+    flagged = cell.step(tx, None, th, phases=ops.PHASE_ALL | ops.PHASE_FUSED_R)
+    ref = orc.gru_cell(x, None, h, orc.OracleNet(sd).enc[0])
+    assert_close(plain.cpu().numpy(), ref, 1e-4, "enc1 cell at 501x499, plain call")
+    assert_close(flagged.cpu().numpy(), ref, 1e-4, "enc1 cell at 501x499, rollout call")
+    d = float((plain - flagged).abs().max())
+    print(f"501x499: rollout call vs plain call max |dh'| = {d:.2e}")
+    assert 0.0 < d <= 3e-6
+
+
 _ORACLE_CACHE = {}
 
 

@@ -380,6 +380,11 @@ static int gru_cell_impl(const float *x, const float *e, const float *h, const f
     c.Cout = F;
     c.out0 = ws.cx;
     c.partial = ws.part2;
+    // a rollout's full-resolution cell that cannot take the fused kernel (P % 4 != 0, too few tiles, F != 64): the candidate GEMM on the
+    // fp32 instruction, so that the long-rollout behaviour does not depend on the grid's shape
+    if ((phase_mask & URNN_PHASE_FUSED_R) && !fused_r && global_pixels <= 0 && P >= URNN_FULL_RES_PIXELS &&
+        urnn_get_matrix_mode() == URNN_MATRIX_FP32)
+        c.candExact = 1;
     int pb2, map2;
     int tiles2 = gru_tiles(B, F, P, 2, &pb2, &map2);
     if (fused_r) {

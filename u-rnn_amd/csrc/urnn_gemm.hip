@@ -1321,6 +1321,7 @@ static int split_mode(const ConvGemmParams &p)
         // URNN_MATRIX_FP32_CAND: the candidate GEMM of a full-resolution cell is the one launch whose 16-bit k-loop shows in a long
         // rollout's error (profiles/r03_noise_floor_cell_gemm_arithmetic.txt): exact fp32 MFMA for it, everything else as the default mode
         if (g_matrix_mode.load(std::memory_order_relaxed) == URNN_MATRIX_FP32_CAND && p.P >= URNN_FULL_RES_PIXELS) return 0;
+        if (p.candExact) return 0;
     }
     if (p.KT % 8 != 0 || p.kpBegin % 8 != 0 || p.KT <= p.kpBegin) return 0;      // whole 16-k groups, aligned with the packed ones
     if constexpr (EPI == EPI_CAND) {

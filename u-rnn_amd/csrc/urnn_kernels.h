@@ -51,6 +51,7 @@ struct ConvGemmParams {
     // (zOnly), cand_fused_kernel recomputes it from its own slab: phase-1 [W1 r rows | W2 x,e columns], phase-2 W2[:, h] in the
     // accumulator-row channel order (urnn_fused_cand_layout), bias [b1 r | b2]
     int zOnly;
+    int candExact;        // EPI_CAND: run the exact fp32 MFMA k-loop whatever the mode (a full-resolution cell of a rollout that cannot take the fused kernel)
     const unsigned *wfused;
     int fu1Dwords, fu2Dwords;
     const float *biasfu;
