@@ -10,9 +10,12 @@ T=360, one event per GPU, fp32, synthetic event + seeded random weights (no data
 N>1: one process per GPU (torchrun), one independent event per rank, no data-path collective (events are
 independent: test.py:741-746) -> weak scaling; value = total frames of all ranks / max-over-ranks time.
 
-Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel = the gate GEMM of the ConvGRU cells,
-timed live with events on the launch streams while the rollout runs in the same scheduling mode as the timed
-region; HBM-bound since the bf16-split k-loop) and "cpu_baseline" (the C oracle on the host cores, bounded sample,
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" -- the kernel FAMILY with the most time per frame among the cells'
+three (candidate GEMMs / gate GEMMs / blend; the candidate GEMMs since round 3), each launch timed with HIP events on its launch
+stream: `avg_launch_us` on ONE kernel chain, where an event pair spans the kernel alone (the figure profiles/r04_kernel_stats_
+overlap0.txt -- rocprofv3 --kernel-trace --stats of `bench.py --overlap 0` -- must agree with), `live_two_chain` in the
+benchmarked two-chain schedule (kernel + what it queued behind: profiles/r04_kernel_stats.txt holds the kernels' own
+durations there); every family under "roofline.kernels" -- and "cpu_baseline" (the C oracle on the host cores, bounded sample,
 rank 0 at N=1 only).  `python bench.py --gpus N` without a launcher re-runs itself as N ranks (torch.distributed.run).
 """
 import argparse
@@ -41,7 +44,7 @@ MIXED = ("futian", "ukea")     # BASELINE configs[4]: mixed-resolution events on
 
 PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X fp32 matrix peak (MI355X_MICROARCH.md)
 PEAK_MFMA_BF16_TFLOPS = 2517.0  # dense bf16 matrix peak (MI355X_MICROARCH.md: ~2.5 PF; 16x the fp32 matrix rate)
-SPLIT_MFMAS = 3                 # f16 MFMAs per fp32-equivalent 16-k step of the forward k-loop (urnn_gemm.hip, SPLIT = 3)
+SPLIT_MFMAS = 3                 # v_mfma_f32_32x32x16_f16 per fp32-equivalent 16-k step of the forward k-loop (f16 hi/lo pieces, urnn_gemm.hip SPLIT = 3)
 PEAK_HBM_TBS = 8.0
 
 
@@ -69,12 +72,9 @@ def a_stage_bytes(H, W, C):
     return 4.0 * (rd + wr + par)
 
 
-def gate_gemm_flops(H, W, B=1):
-    """Algorithmic FLOP of the four launches per frame of conv_gemm_kernel<NB=2,PB=4,MAP_VEC,EPI_GRU1,D=4,WPB=8>
-    (the z|r gates: 2F output channels x K input channels, two FLOP per MAC):
-    enc1 (I=16,F=64) and dec1 (I=96,F=64, skip) at full resolution, enc2 (I=64,F=96) and dec2 (I=96,F=96, skip) at half."""
-    P1, P2 = B * H * W, B * (H // 2) * (W // 2)
-    return {"enc1": P1 * 128 * 80 * 2.0, "dec1": P1 * 128 * 224 * 2.0, "enc2": P2 * 192 * 160 * 2.0, "dec2": P2 * 192 * 288 * 2.0}
+CELLS = {   # the four cells whose kernels are timed: (I, F, skip, plane divisor)
+    "enc1": (16, 64, 0, 1), "dec1": (96, 64, 1, 1), "enc2": (64, 96, 0, 2), "dec2": (96, 96, 1, 2),
+}
 
 
 def fused_reset_gate_cells(H, W, B=1):
@@ -82,21 +82,37 @@ def fused_reset_gate_cells(H, W, B=1):
     GEMM then writes the F update-gate planes only) -- asked of the library, which decides by the same rule at launch."""
     from urnn_amd._lib import lib
     L = lib()
-    return {"enc1": bool(L.urnn_gru_cell_fused_reset_gate_applies(B, 16, 64, H, W, 0)),
-            "dec1": bool(L.urnn_gru_cell_fused_reset_gate_applies(B, 96, 64, H, W, 1)),
-            "enc2": bool(L.urnn_gru_cell_fused_reset_gate_applies(B, 64, 96, H // 2, W // 2, 0)),
-            "dec2": bool(L.urnn_gru_cell_fused_reset_gate_applies(B, 96, 96, H // 2, W // 2, 1))}
+    return {name: bool(L.urnn_gru_cell_fused_reset_gate_applies(B, I, F, H // div, W // div, skip)) for name, (I, F, skip, div) in CELLS.items()}
 
 
-def gate_gemm_bytes(H, W, B=1, fused=None):
-    """Algorithmic HBM bytes of the same four launches (SURVEY 8d's per-stage figure: every input plane read once, every
-    output plane written once, fp32): K input channels + 2F raw gate channels per pixel (weights: < 0.3 MB, not counted) -- F
-    output channels where the cell runs fused (``fused``: fused_reset_gate_cells), whose gate GEMM stores the update gate only."""
-    P1, P2 = B * H * W, B * (H // 2) * (W // 2)
+def cell_kernel_work(H, W, B=1, fused=None):
+    """Algorithmic HBM bytes and FLOP per launch of a cell's three kernels (SURVEY 8d's per-stage accounting: every input plane
+    read once, every output plane written once, fp32; weights < 0.3 MB not counted), K = I + [F] + F input channels:
+      gates      reads K planes, writes the 2F raw gate planes -- F where the cell runs fused (the reset gate leaves only its statistics)
+      candidate  fused (cand_fused_kernel): reads K, writes F (h's second pass comes from L2 / MALL: not counted; FLOP include the
+                 recomputed reset gate);  three-pass (conv_gemm_kernel EPI_CAND): reads K - F plain planes + F raw r + F h, writes F
+      blend      reads z, c, h (3F), writes h' (F)
+    -> {family: {cell: (bytes, flop)}}"""
     fused = fused or {}
-    out = lambda name, F: F if fused.get(name) else 2 * F
-    return {"enc1": 4.0 * P1 * (80 + out("enc1", 64)), "dec1": 4.0 * P1 * (224 + out("dec1", 64)),
-            "enc2": 4.0 * P2 * (160 + out("enc2", 96)), "dec2": 4.0 * P2 * (288 + out("dec2", 96))}
+    out = {"gates": {}, "candidate": {}, "blend": {}}
+    for name, (I, F, skip, div) in CELLS.items():
+        P = B * (H // div) * (W // div)
+        K = I + (F if skip else 0) + F
+        fu = bool(fused.get(name))
+        out["gates"][name] = (4.0 * P * (K + (F if fu else 2 * F)), 2.0 * P * 2 * F * K)
+        out["candidate"][name] = (4.0 * P * (K + F if fu else K + 2 * F), 2.0 * P * F * K * (2 if fu else 1))
+        out["blend"][name] = (4.0 * P * 4 * F, 0.0)
+    return out
+
+
+FAMILY_KERNELS = {
+    "candidate": "cand_fused_kernel<2,8,8> (full-resolution cells: W2.[x;e] on f16 pieces + the reset gate recomputed from the same input stream + "
+                 "W2[:,h].(r*h) on v_mfma_f32_32x32x2_f32) and conv_gemm_kernel<NB,PB,MAP,EPI_CAND,8,WPB,SPLIT=3> (half resolution: hidden rows gated "
+                 "on the fly from the stored raw r); 4 launches per frame: enc1, dec1, enc2, dec2",
+    "gates": "conv_gemm_kernel<NB,2,MAP_PAIR16,EPI_GRU1,8,8,SPLIT=3> (gate GEMM z|r: all 2F columns of a 64-pixel tile per wave -- NB = 4 at F = 64, "
+             "the z / r halves with NB = 3 at F = 96; two scaled f16 pieces per fp32 operand, 3 x v_mfma_f32_32x32x16_f16 per 16 k); 4 launches per frame",
+    "blend": "gru_blend_kernel<V,FIN=true,ITER> (candidate GroupNorm finalize in the prologue, h' = (1 - z) h + z tanh(GN(c))); the same 4 cells",
+}
 
 
 def build_net(H, W, C, dev, seed=0):
@@ -217,11 +233,27 @@ def train_roofline(dev, H, W, B, dtype):
         achieved = tot_b / tot_t / 1e9
         return {"bound": "hbm", "kernel": "wgrad_kernel<NP> + wgrad_finalize (1x1-conv weight gradient over the pixels: dW = dY . X^T; fp32 operands as three "
                                           "bf16 pieces on v_mfma_f32_32x32x16_bf16 in fp32 mode, one rounded piece in bf16 mode), the 12 cell launches of a timestep",
-                "achieved": achieved, "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s", "frac": achieved / (PEAK_HBM_TBS * 1e3), "traffic": None,
-                "traffic_source": "not collected for the training step (profiles/ holds the per-kernel rocprofv3 times of the same command)",
+                "achieved": achieved, "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s", "frac": achieved / (PEAK_HBM_TBS * 1e3),
+                **train_traffic(H, W, B, dtype),
                 "bytes_per_timestep": tot_b, "us_per_timestep": tot_t * 1e6, "launches": per}
     except Exception as exc:  # keep the headline number
         return {"error": repr(exc)}
+
+
+def train_traffic(H, W, B, dtype):
+    """Counter traffic per launch of the weight-gradient GEMM (FETCH_SIZE doubled + WRITE_SIZE passes of `bench.py --mode train`,
+    tools/collect_profiles.sh -> profiles/pmc_train.json), only when the record belongs to the kernel sources loaded here and to
+    this workload."""
+    rec, why = load_pmc_record("pmc_train.json")
+    if rec is None:
+        return {"traffic": None, "traffic_source": why}
+    if (H, W, B, dtype) != (500, 500, 1, "fp32") or "wgrad" not in rec.get("families", {}):
+        return {"traffic": None, "traffic_source": "profiles/pmc_train.json holds the 500x500, one event, fp32 training step"}
+    f = rec["families"]["wgrad"]
+    return {"traffic": f["hbm_bytes_per_launch"], "traffic_source": rec.get("source"),
+            "traffic_note": f"dispatch-weighted average over the {f['dispatches']} wgrad_kernel launches of the profiled windows (all layers, not only "
+                            "the 12 cell launches timed here)",
+            "step_hbm_bytes_per_timestep_counters": rec.get("whole_step", {}).get("hbm_bytes_per_frame")}
 
 
 def bench_train(args, dev, dist, world, rank):
@@ -361,19 +393,19 @@ def kernel_source_hash():
     return h.hexdigest()
 
 
-def load_pmc_record():
-    """profiles/pmc_gate_gemm.json (tools/make_pmc_json.py) if it was measured with THIS build's kernels, else (None, why): the
+def load_pmc_record(name="pmc_kernels.json"):
+    """profiles/pmc_kernels.json (tools/make_pmc_json.py) if it was measured with THIS build's kernels, else (None, why): the
     record carries the hash of the kernel sources the counters were collected with; a stale file must not pass as a measurement."""
-    path = os.path.join(REPO, "profiles", "pmc_gate_gemm.json")
+    path = os.path.join(REPO, "profiles", name)
     if not os.path.isfile(path):
-        return None, "no profiles/pmc_gate_gemm.json"
+        return None, f"no profiles/{name}"
     with open(path) as fh:
         rec = json.load(fh)
     if os.environ.get("URNN_LIB"):
         return None, "URNN_LIB override (tuning variant): counter traffic of the product build not reported"
     now = kernel_source_hash()
     if rec.get("kernel_source_sha256") != now:
-        return None, (f"profiles/pmc_gate_gemm.json was collected with kernel sources {str(rec.get('kernel_source_sha256'))[:12]}, this tree is "
+        return None, (f"profiles/{name} was collected with kernel sources {str(rec.get('kernel_source_sha256'))[:12]}, this tree is "
                       f"{now[:12]}: counter traffic not reported (re-run tools/collect_profiles.sh)")
     return rec, None
 
@@ -540,10 +572,10 @@ def main():
         "long_run": long_run,
         "gflop_per_frame": gflop,
         "step_mfma_frac": fps / world * gflop / 1e3 / PEAK_MFMA_F32_TFLOPS,                          # of the fp32 matrix peak (round 1's pipe)
-        "step_mfma_frac_split_pipe": fps / world * gflop / 1e3 / (PEAK_MFMA_BF16_TFLOPS / SPLIT_MFMAS),  # of 2517 / 6: the pipe the GEMMs run on
+        "step_mfma_frac_split_pipe": fps / world * gflop / 1e3 / (PEAK_MFMA_BF16_TFLOPS / SPLIT_MFMAS),  # of 2517 / 3 TFLOP/s: the f16 x 3 pipe the GEMMs run on
         # frames/s x A_stage / 8 TB/s -- the unfused per-stage traffic model (algorithmic bytes)
         "step_hbm_frac_a_stage": (fps / world * a_stage_bytes(H, W, C) / (PEAK_HBM_TBS * 1e12)) if len(names) == 1 else None,
-        # the same with the bytes the counters saw (FETCH_SIZE / WRITE_SIZE passes of this build, profiles/pmc_gate_gemm.json)
+        # the same with the bytes the counters saw (FETCH_SIZE / WRITE_SIZE passes of this build, profiles/pmc_kernels.json)
         "step_hbm_frac_measured_traffic": None,
     }
     pmc_rec, pmc_why = load_pmc_record()       # counter figures of a profiled run: only if they belong to the library loaded here
@@ -554,35 +586,50 @@ def main():
             result["step_hbm_bytes_per_frame_counters"] = ws["hbm_bytes_per_frame"]
 
     if rank == 0:
-        # dominant kernel: the ConvGRU gate GEMM (4 launches per frame).  With the bf16 x 6 split k-loop its arithmetic
-        # intensity (39 FLOP/B) sits below the ridge of the matrix pipe it runs on (2517 / 6 = 420 TFLOP/s fp32-equivalent
-        # over 8 TB/s = 52 FLOP/B): HBM is the binding roof.  The MFMA view is reported next to it.
+        # The cells' three kernel families, each launch timed with events on its launch stream.  All are HBM-bound: their arithmetic
+        # intensity (<= 40 FLOP/B) sits below the ridge of the pipe they run on (2517 / 3 = 839 TFLOP/s fp32-equivalent over
+        # 8 TB/s = 105 FLOP/B).  `roofline` = the family with the most time per frame; the others under roofline.kernels.
         try:
-            dur = eng.probe_gate_gemm()          # live, events on the launch streams, same scheduling mode as the timed region
             fused_cells = fused_reset_gate_cells(H, W, B)
-            fl, by = gate_gemm_flops(H, W, B), gate_gemm_bytes(H, W, B, fused_cells)
-            flops_per_launch = sum(fl.values()) / len(fl)
-            bytes_per_launch = sum(by.values()) / len(by)
-            avg = sum(dur[k] for k in fl) / len(fl)
-            achieved = bytes_per_launch / avg / 1e9
-            traffic, tsrc = None, pmc_why
-            if pmc_rec is not None and args.config == "location1" and B == 1:
-                traffic, tsrc = pmc_rec.get("hbm_bytes_per_launch"), pmc_rec.get("source")
+            work = cell_kernel_work(H, W, B, fused_cells)
+            live = eng.probe_cell_kernels()       # the timed region's scheduling mode (two chains unless --overlap 0)
+            if args.overlap:                      # one chain: an event pair spans the kernel alone -- what rocprofv3 calls its duration
+                iso_eng = RolloutEngine(eng.net, H, W, nums, rain_max, cum_max, batch=B, max_frames=T, spatial_rain=spatial, net_cfg=cfg,
+                                        use_graph=False, device=dev, overlap=False)
+                iso_eng.load_event(uw.make_event(T, H, W, rain_max, seed=42 + rank, spatial_rain=spatial, batch=B))
+                iso = iso_eng.probe_cell_kernels()
+                del iso_eng
+            else:
+                iso = live
             split = os.environ.get("URNN_TUNE_SPLIT", "1") != "0"
             mfma_peak = PEAK_MFMA_BF16_TFLOPS / SPLIT_MFMAS if split else PEAK_MFMA_F32_TFLOPS
-            result["roofline"] = {
-                "bound": "hbm",
-                "kernel": ("conv_gemm_kernel<NB,PB=2,MAP_PAIR16,EPI_GRU1,D=8,WPB=8,SPLIT=3> (ConvGRU gate GEMM z|r: all 2F gate columns of a 64-pixel "
-                           "tile per wave -- NB = 4 at F = 64, the z / r halves with NB = 3 at F = 96 --; fp32 operands as two scaled f16 pieces, "
-                           "3 x v_mfma_f32_32x32x16_f16 per 16 k, fp32 accumulate; 4 launches per frame: enc1, dec1 at full and enc2, dec2 at half "
-                           "resolution)") if split else "conv_gemm_kernel<2,4,0,3,4,8,0> (fp32 MFMA 32x32x2 k-loop)",
-                "achieved": achieved, "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s", "frac": achieved / (PEAK_HBM_TBS * 1e3),
-                "traffic": traffic, "traffic_source": tsrc,
-                "bytes_per_launch": bytes_per_launch, "avg_launch_us": avg * 1e6, "launch_us": {k: v * 1e6 for k, v in dur.items()},
-                "bytes_per_launch_by_cell": by, "reset_gate_recomputed_in_candidate_kernel": fused_cells,
-                "mfma": {"flops_per_launch": flops_per_launch, "achieved_tflops": flops_per_launch / avg / 1e12,
-                         "peak_tflops_fp32_equivalent": mfma_peak, "frac": flops_per_launch / avg / 1e12 / mfma_peak},
-            }
+            fams = []
+            for fam in ("candidate", "gates", "blend"):
+                by = {c: work[fam][c][0] for c in CELLS}
+                fl = {c: work[fam][c][1] for c in CELLS}
+                us = {c: iso[c][fam] * 1e6 for c in CELLS}
+                us_live = {c: live[c][fam] * 1e6 for c in CELLS}
+                bpl, avg, avg_live = sum(by.values()) / 4, sum(us.values()) / 4, sum(us_live.values()) / 4
+                traffic, tsrc = None, pmc_why
+                if pmc_rec is not None and args.config == "location1" and B == 1 and fam in pmc_rec.get("families", {}):
+                    traffic, tsrc = pmc_rec["families"][fam]["hbm_bytes_per_launch"], pmc_rec.get("source")
+                entry = {"family": fam, "kernel": FAMILY_KERNELS[fam], "bound": "hbm", "launches_per_frame": 4,
+                         "achieved": bpl / avg / 1e3, "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s", "frac": bpl / avg / 1e3 / (PEAK_HBM_TBS * 1e3),
+                         "traffic": traffic, "traffic_source": tsrc, "bytes_per_launch": bpl, "avg_launch_us": avg,
+                         "avg_launch_us_is": "one kernel chain (an event pair on the launch stream spans the kernel alone): compare with rocprofv3 "
+                                             "--kernel-trace --stats of `bench.py --overlap 0` (profiles/*_kernel_stats_overlap0.txt)",
+                         "us_per_frame": sum(us.values()), "launch_us": us, "bytes_per_launch_by_cell": by,
+                         "live_two_chain": {"avg_launch_us": avg_live, "launch_us": us_live, "frac": bpl / avg_live / 1e3 / (PEAK_HBM_TBS * 1e3),
+                                            "note": "the benchmarked schedule: kernel + what it queued behind on its stream while the other chain holds the CUs"}
+                         if args.overlap else None}
+                if sum(fl.values()) > 0:
+                    entry["mfma"] = {"flops_per_launch": sum(fl.values()) / 4, "achieved_tflops": sum(fl.values()) / 4 / avg / 1e6,
+                                     "peak_tflops_fp32_equivalent": mfma_peak, "frac": sum(fl.values()) / 4 / avg / 1e6 / mfma_peak}
+                fams.append(entry)
+            top = max(fams, key=lambda e: e["us_per_frame"])
+            result["roofline"] = dict(top, reset_gate_recomputed_in_candidate_kernel=fused_cells,
+                                      dominant_by="largest sum of launch durations per frame among the cells' kernel families (one chain)",
+                                      kernels=fams)
         except Exception as exc:  # keep the headline number even if the side measurement fails
             result["roofline"] = {"error": repr(exc)}
         if world == 1 and not args.no_cpu_baseline and len(names) == 1:

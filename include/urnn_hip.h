@@ -88,6 +88,23 @@ int urnn_pack_gru_f32(const float *W1, const float *b1, const float *W2, const f
 size_t urnn_packed_deconv_floats(int Cin, int Cout);
 int urnn_pack_deconv_f32(const float *weight, const float *bias, float *packed, int Cin, int Cout, void *stream);
 
+/* Operand range of the default matrix mode.  The f16 pieces of URNN_MATRIX_FP32 are finite for |weight| < 64 and
+ * |activation| < 2047; the published network (O(1) weights, normalised activations) sits far inside.  Two guards for a checkpoint
+ * that does not:
+ *   - weights: max |w[i]| of a device tensor -> *max_abs_out (device float; enqueue-only like everything else).  A layer whose
+ *     weights reach 64 must be launched under URNN_MATRIX_FP32_MFMA (exact fp32 matrix instruction, no range limit); the Python
+ *     host does exactly that per layer (u-rnn_amd/networks/_packing.py, ops.exact_matrix_if) -- reference checkpoint path:
+ *     test.py:380-408.
+ *   - activations: the FIRST 256 BYTES of every cell / head workspace are status words.  Kernels only ever atomically OR into
+ *     word 0: URNN_STATUS_GATES / _CAND when the GroupNorm sums of a cell's gates / candidate are not finite, URNN_STATUS_HEAD
+ *     for a LayerNorm of the head -- which is where an overflowed operand (inf out of the matrix pipe) surfaces, one norm later
+ *     at most.  The owner zeroes the workspace once and reads the word wherever it synchronises anyway (RolloutEngine: once per
+ *     event, raising FloatingPointError and naming the first layer with non-finite output). */
+#define URNN_STATUS_GATES 1
+#define URNN_STATUS_CAND 2
+#define URNN_STATUS_HEAD 4
+int urnn_max_abs_f32(const float *values, long n, float *max_abs_out, void *stream);
+
 /* ---- per-module forwards -------------------------------------------------------------------------- */
 
 /* Encoder/decoder stage conv: out = [AvgPool2d(2,2)](LeakyReLU_slope(W.in + b)).

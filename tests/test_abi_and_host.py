@@ -167,3 +167,35 @@ def test_exp_config_keys_match_the_benchmarked_workloads(tmp_path):
         assert workload(cfg, bench.CONFIGS[name][6]) == bench.CONFIGS[name], name
         assert cfg["lr"] == 0.01 and isinstance(cfg["seq_num"], int)          # unknown keys kept, defaults typed
     assert load_exp_config(str(tmp_path / "location1.yaml"), duration=None, test_list_file="x.txt")["test_list_file"] == "x.txt"
+
+
+def test_exp_config_location_key(tmp_path):
+    """`location` (config.py:121, test.py:738; set in lite.yaml / location2_scratch.yaml): the YAML's catchment reaches the loader,
+    the CLI flag overrides it, the default is "" = every location under data_root."""
+    import yaml
+    from urnn_amd.exp_config import load_exp_config
+    path = tmp_path / "loc.yaml"
+    path.write_text(yaml.safe_dump({"location": "location2", "input_height": 64}))
+    assert load_exp_config(str(path))["location"] == "location2"
+    assert load_exp_config(str(path), location="location16")["location"] == "location16"
+    assert load_exp_config(str(path), location=None)["location"] == "location2"
+    (tmp_path / "none.yaml").write_text("input_height: 64\n")
+    assert load_exp_config(str(tmp_path / "none.yaml"))["location"] == ""
+    import inspect
+    import urnn_amd.evaluate as ev
+    src = inspect.getsource(ev.main)
+    assert "--location" in src and 'location=cfg["location"]' in src
+
+
+def test_bench_cell_kernel_work_matches_the_stage_accounting():
+    """bench.py's per-launch algorithmic bytes (SURVEY 8d accounting) at 500x500: gates K + F (fused) / K + 2F planes, candidate K + F
+    (fused) / K + 2F (three-pass), blend 4F -- the figures DESIGN.md section 6 and the VERDICT's table quote (144 / 288 MB ...)."""
+    import bench
+    w = bench.cell_kernel_work(500, 500, 1, {"enc1": True, "dec1": True, "enc2": False, "dec2": False})
+    MB = 1e6
+    assert w["gates"]["enc1"][0] == 144 * MB and w["gates"]["dec1"][0] == 288 * MB
+    assert w["gates"]["enc2"][0] == 4.0 * 62500 * (160 + 192) and w["gates"]["dec2"][0] == 4.0 * 62500 * (288 + 192)
+    assert w["candidate"]["enc1"][0] == 144 * MB and w["candidate"]["dec1"][0] == 288 * MB
+    assert w["candidate"]["dec2"][0] == 4.0 * 62500 * (288 + 192)
+    assert w["blend"]["dec1"][0] == 256 * MB and w["blend"]["enc2"][0] == 4.0 * 62500 * 384
+    assert w["gates"]["dec1"][1] == 2.0 * 250000 * 128 * 224

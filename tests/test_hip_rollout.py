@@ -433,8 +433,58 @@ def test_whole_event_rollout_vs_oracle(dev):
     assert worst <= 1.0
 
 
+def _sub_err(got, want, plane_max):
+    """conftest.rel_err restricted to a subset of a tensor: the floor is 0.1 x the max |.| of the WHOLE reference tensor."""
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    return float((np.abs(got - want) / np.maximum(np.abs(want), 0.1 * max(float(plane_max), 1e-30))).max())
+
+
+@pytest.mark.parametrize("trace", ["whole_event_500x500_T360.npz", "whole_event_128x128_T360.npz"])
+def test_whole_event_vs_committed_oracle_trace(dev, trace):
+    """The headline parity claim in the DEFAULT suite (reference loop test.py:326-377): the benchmarked
+    schedule (hipGraph, two chains) over ALL 360 frames of the event, against a sparse trace of the CPU oracle committed under
+    tests/golden (every 4th frame x 4096 fixed pixels + a subset of every final state; tests/golden/make_whole_event_trace.py
+    generated it with oracle/ on the GPU box's host cores).  Bar per sampled frame: max(1e-4, 3 x what the reference's own
+    arithmetic -- plain float32 torch, recorded in the trace on the same pixels -- is away from the oracle on that frame).
+    500x500: BASELINE configs[1], the full-resolution cells on the fused candidate kernel (recurrent product on the fp32
+    instruction); 128x128: every cell on the small-plane kernels, whose recurrent product stays on f16 pieces."""
+    import urnn_amd.weights as uw
+    from urnn_amd.rollout import RolloutEngine
+    path = os.path.join(os.path.dirname(__file__), "golden", trace)
+    if not os.path.isfile(path):
+        pytest.fail(f"{trace} missing: generate it with tests/golden/make_whole_event_trace.py")
+    g = np.load(path)
+    H, W, nums, T = int(g["H"]), int(g["W"]), int(g["nums"]), int(g["T"])
+    rain_max, cum_max = float(g["rain_max"]), float(g["cumsum_max"])
+    net, sd = make_net(H, W, 2 * nums + 3, int(g["weights_seed"]), dev)
+    ev = uw.make_event(T, H, W, rain_max, seed=int(g["event_seed"]))
+    eng = RolloutEngine(net, H, W, nums, rain_max, cum_max, max_frames=T, keep_raw=True, overlap=True, use_graph=True)
+    eng.rollout(ev)
+    fr, pix = g["frames"], g["pixels"]
+    raw = eng.out_raw[:T, 0].reshape(T, -1)[torch.from_numpy(fr).long().to(dev)][:, torch.from_numpy(pix).long().to(dev)].cpu().numpy()
+    cls = eng.out_cls[:T, 0].reshape(T, -1)[torch.from_numpy(fr).long().to(dev)][:, torch.from_numpy(pix).long().to(dev)].cpu().numpy()
+    worst, wr, wc, wtr = 0.0, 0.0, 0.0, 0.0
+    for i, t in enumerate(fr):
+        er = _sub_err(raw[i], g["oracle_raw"][i], g["oracle_raw_plane_max"][i])
+        ec = _sub_err(cls[i], g["oracle_cls"][i], g["oracle_cls_plane_max"][i])
+        tr, tc = float(g["torch32_reg_err"][i]), float(g["torch32_cls_err"][i])
+        worst = max(worst, er / max(1e-4, 3 * tr), ec / max(1e-4, 3 * tc))
+        wr, wc, wtr = max(wr, er), max(wc, ec), max(wtr, tr)
+        if i % 15 == 0 or i == len(fr) - 1:
+            print(f"frame {int(t):4d}: reg HIP {er:.2e} torch-fp32 {tr:.2e} | cls HIP {ec:.2e} torch-fp32 {tc:.2e}")
+    srep = []
+    for k, st in enumerate(eng.final_states()):
+        es = _sub_err(st.reshape(-1)[torch.from_numpy(g[f"state{k}_idx"]).to(dev)].cpu().numpy(), g[f"state{k}_oracle"], g["state_plane_max"][k])
+        et = float(g["torch32_state_err"][k])
+        srep.append((k, f"{es:.2e}", f"{et:.2e}"))
+        worst = max(worst, es / max(1e-4, 3 * et))
+    print(f"{trace}: {len(fr)} of {T} frames x {len(pix)} pixels: worst frame reg HIP {wr:.2e} (torch-fp32 {wtr:.2e}), cls {wc:.2e}; "
+          f"final states (state, HIP, torch-fp32) {srep}; worst error / bar = {worst:.2f}")
+    assert worst <= 1.0
+
+
 @pytest.mark.parametrize("name,H,W,nums,T,B,rain_max,cum_max,spatial", [
-    ("futian", 400, 560, 6, 4, 1, 5.0, 100.0, True),       # BASELINE configs[4], futian_scratch.yaml:41-51,66-68
+    ("futian", 400, 560, 6, 72, 1, 5.0, 100.0, True),      # BASELINE configs[4] at its own T (futian_scratch.yaml:41-51,66-68: duration 72)
     ("ukea", 52, 120, 6, 36, 1, 10.0, 150.0, True),        # BASELINE configs[4], ukea_scratch.yaml:43-53,68-70
     ("lite128xB8", 128, 128, 3, 6, 8, 60.0, 250.0, False),  # BASELINE configs[2] grid, 8 events per GPU (lite.yaml:31-36)
 ])
@@ -686,3 +736,56 @@ def test_scalar_rain_engine_keeps_its_graph_across_dem_ranges(dev):
     assert eng._graphs2 is graphs and graphs is not None
     fresh = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T, overlap=True)
     assert torch.equal(b, fresh.rollout(ev_b)) and not torch.equal(a, b)
+
+
+def test_weight_beyond_the_f16_range_runs_on_the_exact_instruction(dev):
+    """Operand range of the default matrix mode (include/urnn_hip.h; reference checkpoint path test.py:380-408): a layer with a
+    weight >= 64 cannot be carried as f16 pieces of w * 2^10 -- the host notices when it packs the layer and launches THAT layer
+    under URNN_MATRIX_FP32_MFMA; the rollout stays finite and within 1e-4 of the oracle (which has no range limit)."""
+    import urnn_amd.weights as uw
+    from oracle import oracle as orc
+    from urnn_amd.rollout import RolloutEngine
+    H, W, nums, T = 32, 48, 3, 3
+    net, sd = make_net(H, W, 2 * nums + 3, 5, dev)
+    sd = {k: v.copy() for k, v in sd.items()}
+    big = {"decoder.stage2.deconv2_leaky_1.weight": 100.0, "encoder.rnn2.conv1.0.weight": -80.0}
+    for k, v in big.items():
+        sd[k].reshape(-1)[3] = v
+        # keep the activations themselves in range: the big weight multiplies one input channel of one output channel
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    ev = uw.make_event(T, H, W, 60.0, seed=9)
+    eng = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T, keep_raw=True, overlap=True, use_graph=True)
+    frames = eng.rollout(ev).cpu().numpy()
+    assert net.decoder.stage2._cache.wide and net.encoder.rnn2._cache.wide and not net.encoder.rnn1._cache.wide
+    assert np.isfinite(frames).all()
+    ref_frames, ref_states, aux = orc.rollout(orc.OracleNet(sd), ev, T, nums, 60.0, 250.0, want_aux=True)
+    assert_close(eng.out_raw[:T].cpu().numpy(), np.stack([a["reg_raw"] for a in aux]), 1e-4, "pre-mask reg with out-of-range weights")
+    for k, (got, want) in enumerate(zip(eng.final_states(), ref_states)):
+        assert_close(got.cpu().numpy(), want, 1e-4, f"state {k} with out-of-range weights")
+
+
+def test_activation_beyond_the_f16_range_raises(dev):
+    """... and an ACTIVATION beyond the pieces' range (|x| >= 2047: here encoder stage 1 is made to output ~3000) turns into inf
+    in the next matrix product.  The kernels that fold norm statistics flag it in their workspace's status word; the engine
+    reads the word once per event and raises, naming the first layer whose output is not finite -- never NaN maps with rc = 0.
+    Under ops.matrix_mode("fp32_mfma") the same net and event roll out finite."""
+    import urnn_amd.weights as uw
+    from urnn_amd import ops
+    from urnn_amd.inference import Inference
+    from urnn_amd.rollout import RolloutEngine
+    H, W, nums, T = 32, 48, 3, 2
+    net, sd = make_net(H, W, 2 * nums + 3, 5, dev)
+    sd = {k: v.copy() for k, v in sd.items()}
+    sd["encoder.stage1.conv1_leaky_1.bias"][:] = 3000.0
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    ev = uw.make_event(T, H, W, 60.0, seed=9)
+    for overlap in (False, True):
+        eng = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T, overlap=overlap, use_graph=True)
+        with pytest.raises(FloatingPointError, match="encoder.rnn1"):
+            eng.rollout(ev)
+    with pytest.raises(FloatingPointError):
+        Inference(net, {k: torch.from_numpy(np.asarray(v)) for k, v in ev.items()}, dev, historical_nums=nums, rain_max=60.0,
+                  cumsum_rain_max=250.0, input_height=H, input_width=W)
+    with ops.matrix_mode("fp32_mfma"):
+        eng = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T, overlap=True, use_graph=True)
+        assert torch.isfinite(eng.rollout(ev)).all()

@@ -424,6 +424,64 @@ def test_two_rank_ddp_graph_capture_equals_eager(dev, tmp_path):
     _check_ddp_against_reference(dirs[True])
 
 
+def _ddp_uneven_worker(rank, world, port, out_dir, use_graph):
+    """DistributedSampler hands every rank its own catchments: rank 0 alternates between two events with different DEM bounds
+    (its captured window changes key -> it captures while rank 1 merely replays), rank 1 stays on one event."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    import urnn_amd.weights as uw
+    from urnn_amd.training import Trainer
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "train_loop_16x16.npz"))
+    net, sd = _loop_net(g, dev)
+    H, W, nums = int(g["loop_H"]), int(g["loop_W"]), int(g["loop_nums"])
+    tr = Trainer(net, H, W, nums, 60.0, 250.0, lr=1e-3, grad_clip=1.0, distributed=True, use_graph=use_graph)
+    S, nwin = 2, 5
+    events = [uw.make_event(S * nwin, H, W, 60.0, seed=300 + k) for k in range(3)]
+    assert events[0]["max_DEM"][0] != events[1]["max_DEM"][0]
+    label = torch.from_numpy(g["loop_label"][:, :S]).to(dev) * (1.0 + 0.5 * rank)
+    captures = []
+    for w in range(nwin):
+        ev = events[w % 2] if rank == 0 else events[2]      # rank 0: A B A B A -- captures at windows 0 and 1, replays afterwards
+        tr.train_window(ev, label, w * S, S, None)
+        torch.cuda.synchronize()
+        captures.append(len(tr._graphs))
+        np.save(os.path.join(out_dir, f"grad_w{w}_rank{rank}.npy"), tr.gflat.cpu().numpy())
+    np.save(os.path.join(out_dir, f"flat_rank{rank}.npy"), tr.flat.cpu().numpy())
+    if use_graph:
+        assert captures == ([1, 2, 2, 2, 2] if rank == 0 else [1, 1, 1, 1, 1]), captures   # alternating catchments are cached, not re-captured
+    dist.destroy_process_group()
+
+
+def test_two_rank_ddp_capture_is_a_per_rank_decision(dev, tmp_path):
+    """a rank that (re)captures its window while the other only replays must not issue a collective of its
+    own -- the eager warm-up inside the capture branch used to run the real gradient reduce, which paired with the other rank's
+    reduce of the NEXT window.  Rank 0 alternates between two catchments (different DEM bounds -> different graph keys), rank 1
+    stays on one: the captured run equals the eager run bit for bit in every window, and the replicas stay identical."""
+    import socket
+    import torch.multiprocessing as mp
+    dirs = {}
+    for graph in (False, True):
+        d = tmp_path / ("graph" if graph else "eager")
+        d.mkdir()
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        mp.spawn(_ddp_uneven_worker, args=(2, port, str(d), graph), nprocs=2, join=True)
+        dirs[graph] = d
+    names = sorted(p.name for p in dirs[False].iterdir() if p.name.endswith(".npy"))
+    assert len(names) == 12
+    for f in names:
+        a, b = np.load(dirs[False] / f), np.load(dirs[True] / f)
+        assert np.isfinite(a).all() and np.array_equal(a, b), f"{f}: captured DDP run differs from the eager one"
+    for d in dirs.values():
+        assert np.array_equal(np.load(d / "flat_rank0.npy"), np.load(d / "flat_rank1.npy")), "replicas diverged"
+        for w in range(5):
+            assert np.array_equal(np.load(d / f"grad_w{w}_rank0.npy"), np.load(d / f"grad_w{w}_rank1.npy"))
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank (the 1-GPU test box cannot host two)")
 def test_two_rank_ddp_matches_the_reference_gradient_mean_over_rccl(tmp_path):
     import socket

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence on the GPU box: raw databases stay in /tmp, text summaries go to gpurun_out/$1.
-# usage (through gpurun): bash tools/collect_profiles.sh r03   (then copy gpurun_out/r03/pmc_gate_gemm.json to profiles/)
+# usage (through gpurun): bash tools/collect_profiles.sh r04   (then copy gpurun_out/r04/pmc_kernels.json + pmc_train.json to profiles/)
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=${1:-r03}
+TAG=${1:-r04}
 O=$R/gpurun_out/$TAG; P=/tmp/prof_$TAG
 mkdir -p $O $P; cd /tmp; export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 14 --warmup 2 --no-cpu-baseline --no-long-run --overlap 0 --no-graph"
@@ -12,7 +12,14 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES S
   timeout 420 rocprofv3 --kernel-trace --pmc $pass -d $P/pmc_$name -o p -- $CMD > $P/pmc_$name.log 2>&1
   { echo "# rocprofv3 --kernel-trace --pmc $pass -- $CMD"; python $R/tools/pmc_summary.py $P/pmc_$name/p_results.db "" --frames=-1; } > $O/pmc_$name.txt 2>&1
 done
-python $R/tools/make_pmc_json.py $O/pmc_FETCH_SIZE.txt $O/pmc_WRITE_SIZE.txt $O/pmc_gate_gemm.json "$TAG" > /dev/null 2>$O/make_pmc_json.err
+python $R/tools/make_pmc_json.py $O/pmc_FETCH_SIZE.txt $O/pmc_WRITE_SIZE.txt $O/pmc_kernels.json "$TAG" > /dev/null 2>$O/make_pmc_json.err
+# the training step's byte counters (two windows of 4 timesteps, eager so that every dispatch is attributed)
+TCMD="python $R/bench.py --mode train --steps 4 --warmup 4 --no-graph"
+for name in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --kernel-trace --pmc $name -d $P/pmct_$name -o p -- $TCMD > $P/pmct_$name.log 2>&1
+  { echo "# rocprofv3 --kernel-trace --pmc $name -- $TCMD   (8 training timesteps: per-'frame' totals below are per timestep)"; python $R/tools/pmc_summary.py $P/pmct_$name/p_results.db "" --frames=8 --all-kernels; } > $O/pmc_train_$name.txt 2>&1
+done
+python $R/tools/make_pmc_json.py $O/pmc_train_FETCH_SIZE.txt $O/pmc_train_WRITE_SIZE.txt $O/pmc_train.json "$TAG train" > /dev/null 2>>$O/make_pmc_json.err
 timeout 420 rocprofv3 --kernel-trace --stats -d $P/stats_default -o d -- python $R/bench.py --no-cpu-baseline > $O/bench_default_under_rocprof.log 2>&1
 python $R/tools/prof_summary.py $P/stats_default/d_results.db > $O/kernel_stats.txt 2>&1
 timeout 420 rocprofv3 --kernel-trace --stats -d $P/stats_ov0 -o o -- python $R/bench.py --no-cpu-baseline --overlap 0 > $O/bench_overlap0_under_rocprof.log 2>&1

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
-"""profiles/pmc_gate_gemm.json from the FETCH_SIZE / WRITE_SIZE summaries of tools/collect_profiles.sh (tools/pmc_summary.py text),
-stamped with the hash of the kernel sources (and of the .so, and the box) that produced them: bench.py prints `traffic` only
-when the source hash matches its own tree.
+"""profiles/pmc_kernels.json (inference step) / profiles/pmc_train.json (training step) from the FETCH_SIZE / WRITE_SIZE summaries of
+tools/collect_profiles.sh (tools/pmc_summary.py text): counter traffic per launch of every kernel family bench.py reports a roofline
+for, stamped with the hash of the kernel sources (and of the .so, and the box) that produced them -- bench.py prints `traffic`
+only when the source hash matches its own tree.
 usage (on the GPU box, from collect_profiles.sh): python tools/make_pmc_json.py <pmc_FETCH_SIZE.txt> <pmc_WRITE_SIZE.txt> <out.json> [tag]"""
 import hashlib
 import json
@@ -13,7 +14,14 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import bench  # noqa: E402  (kernel_source_hash: the same function bench.py checks the record with)
-GATE = re.compile(r"conv_gemm_kernel<\s*\d+,\s*\d+,\s*\d+,\s*3,")        # EPI_GRU1 = 3: the ConvGRU gate GEMM
+FAMILIES = {   # bench.py's roofline families -> kernel-name pattern (template arguments: NB, PB, MAP, EPI, ...)
+    "gates": re.compile(r"conv_gemm_kernel<\s*\d+,\s*\d+,\s*\d+,\s*3,"),                 # EPI_GRU1 = 3, the >= 24 000-pixel planes
+    "candidate": re.compile(r"cand_fused_kernel<|conv_gemm_kernel<\s*\d+,\s*\d+,\s*\d+,\s*4,"),   # fused / EPI_CAND = 4
+    "blend": re.compile(r"gru_blend_kernel<\s*4,"),                                     # the 16-byte form: full and half resolution at 500x500
+    "head": re.compile(r"head_k[1-4]<"),
+    "small_cells": re.compile(r"small_cell_gemm_kernel<|coop_cell_kernel<"),
+    "wgrad": re.compile(r"wgrad_kernel<"),
+}
 
 
 def lib_hash(path=None):
@@ -46,16 +54,22 @@ def parse(path, counter):
 def main(fetch_txt, write_txt, out, tag=""):
     fe, fe_tot = parse(fetch_txt, "FETCH_SIZE")
     wr, wr_tot = parse(write_txt, "WRITE_SIZE")
-    gates = [k for k in fe if GATE.search(k) and k in wr]
-    nd = sum(fe[k][0] for k in gates)
-    fetch = sum(fe[k][0] * fe[k][1] for k in gates) / max(nd, 1)
-    write = sum(wr[k][0] * wr[k][1] for k in gates) / max(sum(wr[k][0] for k in gates), 1)
+    fams = {}
+    for fam, pat in FAMILIES.items():
+        ks = [k for k in fe if pat.search(k) and k in wr]
+        if not ks:
+            continue
+        nd = sum(fe[k][0] for k in ks)
+        fetch = sum(fe[k][0] * fe[k][1] for k in ks) / max(nd, 1)
+        write = sum(wr[k][0] * wr[k][1] for k in ks) / max(sum(wr[k][0] for k in ks), 1)
+        fams[fam] = {"dispatches": nd, "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
+                     "instantiations": {k: {"dispatches": fe[k][0], "FETCH_SIZE_KiB_raw": fe[k][1], "WRITE_SIZE_KiB_raw": wr[k][1]} for k in ks}}
     rec = {
-        "kernel": "conv_gemm_kernel<.., EPI_GRU1, ..> (ConvGRU gate GEMM z|r): dispatch-weighted average over its launches per frame at 500x500",
-        "instantiations": {k: {"dispatches": fe[k][0], "FETCH_SIZE_KiB_raw": fe[k][1], "WRITE_SIZE_KiB_raw": wr[k][1]} for k in gates},
+        "families": fams,
+        "note": "per family: dispatch-weighted average over its launches in the profiled frames (at 500x500: the full- AND half-resolution "
+                "launches together, like bench.py's bytes_per_launch)",
         "correction": "FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B for wide coalesced reads, MI355X_MICROARCH.md HBM section); "
                       "WRITE_SIZE as reported; counters are KiB (x1024); separate --pmc passes",
-        "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
         "source": f"{os.path.basename(fetch_txt)} + {os.path.basename(write_txt)} ({tag})",
         "kernel_source_sha256": bench.kernel_source_hash(),
         "lib_sha256": lib_hash(),

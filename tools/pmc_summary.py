@@ -6,7 +6,7 @@ import sys
 from collections import defaultdict
 
 
-def main(path, filt="", frames=0):
+def main(path, filt="", frames=0, all_kernels=False):
     con = sqlite3.connect(path)
     tables = [r[0] for r in con.execute("select name from sqlite_master where type='table'")]
     T = lambda p: next(t for t in tables if t.startswith(p))
@@ -38,7 +38,8 @@ def main(path, filt="", frames=0):
         # the rollout loop's kernels run a whole number of times per frame; everything else (torch's zero-fills of the 1.1 GB of
         # output frames and the states at engine construction, the weight packers, the once-per-event static part of stage 1) is
         # setup and is listed apart -- dividing it by the few frames of a counter pass would bill it to the frame
-        is_setup = lambda n: n.startswith("at::native") or "pack_" in n or "stage1_static" in n or len(cnt[n]) % frames != 0
+        # (--all-kernels: a training step, where torch's copies / fills and the packers ARE part of every window)
+        is_setup = lambda n: (not all_kernels) and (n.startswith("at::native") or "pack_" in n or "stage1_static" in n or len(cnt[n]) % frames != 0)
         loop = [n for n in acc if not is_setup(n)]
         setup = [n for n in acc if n not in loop]
         tot, tot_setup = defaultdict(float), defaultdict(float)
@@ -55,6 +56,6 @@ def main(path, filt="", frames=0):
 
 
 if __name__ == "__main__":
-    args = [a for a in sys.argv[1:] if not a.startswith("--frames=")]
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
     frames = next((int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--frames=")), 0)
-    main(args[0], args[1] if len(args) > 1 else "", frames)
+    main(args[0], args[1] if len(args) > 1 else "", frames, "--all-kernels" in sys.argv)

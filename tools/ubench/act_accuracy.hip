@@ -5,6 +5,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <vector>
+#define URNN_ALLOW_PACKED_F32 1   // a probe, not the library: no MFMA next to packed fp32 here
 #include "urnn_common.h"
 __global__ void k(const float *x, float *s, float *t, int n)
 {

@@ -1,6 +1,7 @@
 // act_determinism.hip -- development probe: are the activation functions of urnn_common.h bit-reproducible from launch to launch
 // under load?  Each variant maps a fixed input array through one function 300 times; every output is compared with the first
 // launch's.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DURNN_ACT=0|1] tools/ubench/act_determinism.hip -o act_det
+#define URNN_ALLOW_PACKED_F32 1   // a probe, not the library: no MFMA next to packed fp32 here
 #include "../../u-rnn_amd/csrc/urnn_common.h"
 #include <stdio.h>
 #include <stdlib.h>

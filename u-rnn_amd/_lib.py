@@ -20,6 +20,7 @@ SIGNATURES = {
     "urnn_last_error": (ctypes.c_char_p, []),
     "urnn_set_matrix_mode": (_i, [_i]),
     "urnn_get_matrix_mode": (_i, []),
+    "urnn_max_abs_f32": (_i, [_p, ctypes.c_long, _p, _p]),
     "urnn_packed_conv_floats": (_sz, [_i, _i]),
     "urnn_pack_conv_f32": (_i, [_p, _p, _p, _i, _i, _p]),
     "urnn_packed_gru_floats": (_sz, [_i, _i, _i]),

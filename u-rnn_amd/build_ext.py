@@ -16,7 +16,7 @@ HEADERS = ["urnn_common.h", "urnn_kernels.h", os.path.join("..", "..", "include"
 # every ring slot poisoned with NaN until its DMA landed (no NaN ever appeared: the ring protocol was not the cause).  The same
 # sources without packed instructions: 0 of 8000 launches, 0 of 30 whole-event rollouts, and 1.5 % faster (tools/diag_dec1.py,
 # tools/stress_overlap.py; MI355X_MICROARCH.md prices the packed ops as an anti-lever beside MFMAs anyway).
-NO_PACKED_F32 = ("-fno-slp-vectorize",)
+NO_PACKED_F32 = ("-fno-slp-vectorize", "-DURNN_NO_PACKED_F32=1")   # urnn_common.h refuses to compile without the define
 
 
 def _newest(paths):
@@ -32,6 +32,8 @@ def build(force=False, verbose=False, extra_flags=(), out=None, tag=""):
     if not force and os.path.isfile(LIB) and os.path.getmtime(LIB) >= _newest(deps):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if any(f in ("-fslp-vectorize", "-fvectorize-slp") for f in extra_flags):
+        raise ValueError("liburnn_hip must not be built with SLP vectorisation (packed fp32 next to MFMAs: DESIGN.md section 4.8)")
     objs = []
     procs = []
     for s in srcs:

@@ -65,6 +65,14 @@ static void pick_tile(long pixels_total, int waves_per_tile, long P, int *pb_out
     *map_out = pb == 4 ? MAP_VEC : (pb == 2 && P % 4 == 0 ? MAP_PAIR16 : (pb == 2 && P % 2 == 0 ? MAP_PAIR : MAP_STRIDED));
 }
 
+extern "C" int urnn_max_abs_f32(const float *values, long n, float *max_abs_out, void *stream)
+{
+    if (!values || !max_abs_out) return fail(URNN_ENULL, "urnn_max_abs_f32: NULL argument");
+    if (n < 1) return fail(URNN_EINVAL, "urnn_max_abs_f32: n=%ld", n);
+    CHECK_HIP(urnn_launch_max_abs(values, n, max_abs_out, (hipStream_t)stream), "max_abs");
+    return URNN_OK;
+}
+
 // ---- packing ---------------------------------------------------------------------------------------------------------
 extern "C" size_t urnn_packed_conv_floats(int Cin, int Cout)
 {
@@ -171,6 +179,7 @@ static int stage_conv_impl(const float *in, const float *packed, float *out, int
 
 // ---- GRU cell --------------------------------------------------------------------------------------------------------
 struct GruWs {
+    int *status;        // first URNN_STATUS_BYTES of every cell / head workspace (urnn_common.h): the same word whatever the cell's shape
     float *g1, *cx, *part1, *part2, *ss1, *ss2;
     float *st1, *st2;   // per (sample, norm group) (mean, rstd) of the gates / the candidate: read by the backward pass
     size_t bytes;
@@ -187,6 +196,7 @@ static GruWs carve_gru(void *base, int B, int F, long P)
         return p;
     };
     GruWs w;
+    w.status = reinterpret_cast<int *>(take(URNN_STATUS_BYTES / sizeof(float)));
     w.g1 = take((size_t)B * 2 * F * P);
     w.cx = take((size_t)B * F * P);
     w.part1 = take((size_t)B * (2 * F / 32) * tiles * 2);
@@ -306,6 +316,7 @@ static int gru_cell_impl(const float *x, const float *e, const float *h, const f
     p.Cout = 2 * F;
     p.out0 = ws.g1;
     p.partial = ws.part1;
+    p.status = ws.status;
     int pb1, map1;
     // the gate GEMM prefers 128-pixel tiles (one 1-KiB DMA per 8 MFMAs) even when they only fill half the wave slots; the grouped
     // f16 kernel (4 or 3 n-blocks per wave) takes 64-pixel ones.  Strips keep the F/32-group kernel (their statistics exchange
@@ -349,7 +360,7 @@ static int gru_cell_impl(const float *x, const float *e, const float *h, const f
     // without the candidate phase (profiling)
     if ((phase_mask & URNN_PHASE_GN1) && !(phase_mask & URNN_PHASE_CAND))
         CHECK_HIP(urnn_launch_gn_finalize(ws.part1, ftiles1, global_pixels > 0 ? 0 : 32 * pb1, (int)P, count, gn1_w, gn1_b, eps, ws.ss1, ws.st1, B,
-                                          2 * F, st), "gn finalize 1");
+                                          2 * F, ws.status, URNN_STATUS_GATES, st), "gn finalize 1");
 
     // K2: candidate (pre-norm) = W2 . [x; e; sigmoid(GN(r)) * h] + b2, GroupNorm partials.  The hidden-state rows are gated
     // on the fly from the raw reset gate and K1's folded (scale, shift).
@@ -385,6 +396,9 @@ static int gru_cell_impl(const float *x, const float *e, const float *h, const f
     if ((phase_mask & URNN_PHASE_FUSED_R) && !fused_r && global_pixels <= 0 && P >= URNN_FULL_RES_PIXELS &&
         urnn_get_matrix_mode() == URNN_MATRIX_FP32)
         c.candExact = 1;
+    // ... and a STRIP of a full-resolution plane (inference only): the same arithmetic for that product as the single-chip
+    // rollout of the same grid, so that the multi-chip and the single-chip trajectories agree over a long event
+    if (global_pixels >= URNN_FULL_RES_PIXELS && urnn_get_matrix_mode() == URNN_MATRIX_FP32) c.candExact = 1;
     int pb2, map2;
     int tiles2 = gru_tiles(B, F, P, 2, &pb2, &map2);
     if (fused_r) {
@@ -406,12 +420,12 @@ static int gru_cell_impl(const float *x, const float *e, const float *h, const f
     const bool fused = fuse_on && (phase_mask & URNN_PHASE_GN2) && (phase_mask & URNN_PHASE_BLEND) && global_pixels <= 0;
     if (fused) {
         CHECK_HIP(urnn_launch_blend_fin(ws.g1, ws.cx, h, ws.ss1, h_out, B, F, (int)P, ws.part2, tiles2, 32 * pb2, count, gn2_w, gn2_b, eps, ws.ss2,
-                                        ws.st2, st), "gru finalize + blend");
+                                        ws.st2, ws.status, st), "gru finalize + blend");
         return URNN_OK;
     }
     if (phase_mask & URNN_PHASE_GN2)
         CHECK_HIP(urnn_launch_gn_finalize(ws.part2, global_pixels > 0 ? 2 : tiles2, global_pixels > 0 ? 0 : 32 * pb2, (int)P, count, gn2_w, gn2_b,
-                                          eps, ws.ss2, ws.st2, B, F, st), "gn finalize 2");
+                                          eps, ws.ss2, ws.st2, B, F, ws.status, URNN_STATUS_CAND, st), "gn finalize 2");
     if (phase_mask & URNN_PHASE_BLEND) CHECK_HIP(urnn_launch_blend(ws.g1, ws.cx, h, ws.ss1, ws.ss2, h_out, B, F, (int)P, st), "gru blend");
     return URNN_OK;
 }
@@ -852,6 +866,7 @@ extern "C" int urnn_weight_gradient_f32(const float *dy, const float *seg0, int 
 
 // ---- head ------------------------------------------------------------------------------------------------------------
 struct HeadWs {
+    int *status;
     float *u1, *u2, *partial, *stats;
     size_t bytes;
 };
@@ -865,6 +880,7 @@ static HeadWs carve_head(void *base, int B, int C, long P)
         return p;
     };
     HeadWs w;
+    w.status = reinterpret_cast<int *>(take(URNN_STATUS_BYTES / sizeof(float)));
     w.u1 = take((size_t)B * C * P);
     w.u2 = take((size_t)B * C * P);
     w.partial = take((size_t)5 * B * urnn_head_nblk((int)P) * 2);
@@ -910,6 +926,7 @@ static int head_impl(const float *feat, const float *conv_w, const float *ln_w, 
     p.u2 = ws.u2;
     p.partial = ws.partial;
     p.stats = ws.stats;
+    p.status = ws.status;
     p.B = B;
     p.C = C;
     p.P = (int)P;

@@ -4,6 +4,14 @@
 #include <stddef.h>
 #include <stdint.h>
 
+// Every translation unit of the library must be compiled WITHOUT SLP vectorisation: on gfx950 the vectoriser turns pairs of scalar
+// fp32 operations into v_pk_mul_f32 / v_pk_fma_f32, and next to MFMA results those gave -- about once per 10^9 instructions,
+// reproducibly -- a wrong low element in 16 lanes of a wave (tools/stress_overlap.py).  The flag cannot be
+// set from inside a source file, so the build says that it set it: u-rnn_amd/build_ext.py passes both.
+#if !defined(URNN_NO_PACKED_F32) && !defined(URNN_ALLOW_PACKED_F32)
+#error "compile liburnn_hip with -fno-slp-vectorize -DURNN_NO_PACKED_F32=1 (u-rnn_amd/build_ext.py); see DESIGN.md section 4.8"
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -76,6 +84,17 @@ __device__ __forceinline__ int tile_valid(int t, int tile_pix, int P)
 __device__ __forceinline__ double tile_x2(float s1, float y, int n)
 {
     return n > 0 ? (double)y + (double)s1 * (double)s1 / (double)n : (double)y;
+}
+
+// Status words (include/urnn_hip.h): the first 256 bytes of a cell / head workspace.  The kernels that turn partial sums into a
+// norm's (mean, rstd) OR a bit into word 0 when the statistics are not finite -- an operand beyond the f16 pieces' range
+// (|activation| >= 2047 or |weight| >= 64 in the default matrix mode) turns into inf in the matrix pipe and surfaces here, one
+// norm later at most.  The owner of the workspace zeroes it once and reads the word at a synchronisation point of its choice.
+// (bits URNN_STATUS_GATES / _CAND / _HEAD: include/urnn_hip.h)
+#define URNN_STATUS_BYTES 256
+__device__ __forceinline__ void flag_nonfinite(int *status, int bit, double s1, double s2)
+{
+    if (status && !(__builtin_isfinite(s1) && __builtin_isfinite(s2))) atomicOr(status, bit);   // (the sums, before any clamp)
 }
 
 // Activations.  URNN_ACT = 0: hardware exp2 / rcp on x * log2(e) (the argument's rounding costs |x| * 2^-24 relative -- a bias of

@@ -14,7 +14,7 @@
 // (the same fixed order as the fold in the candidate GEMM's prologue).
 __global__ __launch_bounds__(64) void gn_finalize_kernel(const float *__restrict__ partial, int ntiles, int tile_pix, int P, double count,
                                                          const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                         float eps, float *__restrict__ ss, float *__restrict__ stat, int C)
+                                                         float eps, float *__restrict__ ss, float *__restrict__ stat, int C, int *status, int status_bit)
 {
     const int G = C / 32;
     const int b = blockIdx.x / G, g = blockIdx.x - b * G;
@@ -48,6 +48,7 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float *__restrict
         const double sc = (double)gamma[c] * rstd;
         ss[((size_t)b * C + c) * 2] = (float)sc;
         ss[((size_t)b * C + c) * 2 + 1] = (float)((double)beta[c] - mean * sc);
+        if (lane == 0) flag_nonfinite(status, status_bit, s1, s2);
         if (stat && lane == 0) {
             stat[((size_t)b * G + g) * 2] = (float)mean;
             stat[((size_t)b * G + g) * 2 + 1] = (float)rstd;
@@ -56,10 +57,38 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float *__restrict
 }
 
 hipError_t urnn_launch_gn_finalize(const float *partial, int ntiles, int tile_pix, int P, double count, const float *gamma, const float *beta,
-                                   float eps, float *ss, float *stat, int B, int C, hipStream_t st)
+                                   float eps, float *ss, float *stat, int B, int C, int *status, int status_bit, hipStream_t st)
 {
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * (C / 32)), dim3(64), 0, st, partial, ntiles, tile_pix, P, count, gamma, beta, eps, ss,
-                       stat, C);
+                       stat, C, status, status_bit);
+    return hipGetLastError();
+}
+
+// max |v[i]| (the weight-range guard of include/urnn_hip.h): one block, atomicMax on the bits of a non-negative float
+__global__ __launch_bounds__(1024) void max_abs_kernel(const float *__restrict__ v, long n, float *__restrict__ out)
+{
+    float m = 0.f;
+    for (long i = threadIdx.x; i < n; i += 1024) {
+        const float a = fabsf(v[i]);
+        m = (a > m || a != a) ? a : m;              // NaN wins: a NaN weight must not pass as "in range"
+    }
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) {
+        const float o = __shfl_xor(m, k, 64);
+        m = (o > m || o != o) ? o : m;
+    }
+    __shared__ float sh[16];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) m = (sh[w] > m || sh[w] != sh[w]) ? sh[w] : m;
+        *out = m;
+    }
+}
+
+hipError_t urnn_launch_max_abs(const float *v, long n, float *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(max_abs_kernel, dim3(1), dim3(1024), 0, st, v, n, out);
     return hipGetLastError();
 }
 
@@ -78,6 +107,7 @@ struct BlendFin {
     const float *gamma, *beta;
     float eps;
     float *ss2, *stat2;     // out: [B][F][2] (scale, shift), [B][F/32][2] (mean, rstd)
+    int *status;            // the workspace's status word (urnn_common.h flag_nonfinite)
 };
 
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access at 4-byte alignment (planes of odd size)
@@ -125,6 +155,7 @@ __global__ __launch_bounds__(256) void gru_blend_kernel(const float *__restrict_
             st[0] = (float)sc;
             st[1] = (float)((double)fin.beta[f] - mean * sc);
             if (blockIdx.x == 0) {
+                flag_nonfinite(fin.status, URNN_STATUS_CAND, S1, S2);
                 fin.ss2[((size_t)b * F + f) * 2] = st[0];
                 fin.ss2[((size_t)b * F + f) * 2 + 1] = st[1];
                 if ((f & 31) == 0 && fin.stat2) {
@@ -210,7 +241,7 @@ hipError_t urnn_launch_blend(const float *g1, const float *c, const float *h, co
 // GroupNorm finalize of the candidate + blend in one launch (see gru_blend_kernel FIN)
 hipError_t urnn_launch_blend_fin(const float *g1, const float *c, const float *h, const float *ss1, float *out, int B, int F, int P,
                                  const float *partial, int ntiles, int tile_pix, double count, const float *gamma, const float *beta, float eps,
-                                 float *ss2, float *stat2, hipStream_t st)
+                                 float *ss2, float *stat2, int *status, hipStream_t st)
 {
     const bool v4 = (P % 4) == 0, v5 = !v4 && P >= 1024;
     const int vw = (v4 || v5) ? 4 : 1;
@@ -218,7 +249,7 @@ hipError_t urnn_launch_blend_fin(const float *g1, const float *c, const float *h
     const int iter = blocks(8) >= 512 ? 8 : (blocks(2) >= 512 ? 2 : 1);
     const int per_block = 256 * vw * iter;
     dim3 grid((P + per_block - 1) / per_block, B * F);
-    const BlendFin fin = {partial, ntiles, tile_pix, count, gamma, beta, eps, ss2, stat2};
+    const BlendFin fin = {partial, ntiles, tile_pix, count, gamma, beta, eps, ss2, stat2, status};
 #define URNN_BLEND_FIN(V_, I_) hipLaunchKernelGGL((gru_blend_kernel<V_, true, I_>), grid, dim3(256), 0, st, g1, c, h, ss1, nullptr, out, F, P, fin)
 #define URNN_BLEND_FIN_V(V_) do { if (iter == 8) URNN_BLEND_FIN(V_, 8); else if (iter == 2) URNN_BLEND_FIN(V_, 2); else URNN_BLEND_FIN(V_, 1); } while (0)
     if (v4) URNN_BLEND_FIN_V(4);
@@ -427,6 +458,7 @@ __device__ __forceinline__ void head_fold_stats(const HeadParams &prm, int which
     mean_f = (float)mean;
     rstd_f = (float)(1.0 / sqrt(var + (double)prm.eps));
     if (blockIdx.x == 0 && threadIdx.x == 0) {       // the backward pass reads the statistics from prm.stats
+        flag_nonfinite(prm.status, URNN_STATUS_HEAD, s1, s2);
         prm.stats[((size_t)which * prm.B + b) * 2] = mean_f;
         prm.stats[((size_t)which * prm.B + b) * 2 + 1] = rstd_f;
     }
@@ -583,6 +615,7 @@ __global__ __launch_bounds__(64) void ln_finalize_kernel(const HeadParams prm, i
         const double count = (double)HEAD_C * (double)(prm.Pglobal > 0 ? prm.Pglobal : (long)prm.P);
         const double mean = s1 / count;
         double var = s2 / count - mean * mean;
+        flag_nonfinite(prm.status, URNN_STATUS_HEAD, s1, s2);
         var = var > 0.0 ? var : 0.0;
         prm.stats[((size_t)which * prm.B + b) * 2] = (float)mean;
         prm.stats[((size_t)which * prm.B + b) * 2 + 1] = (float)(1.0 / sqrt(var + (double)prm.eps));

@@ -334,6 +334,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
                 if (blockIdx.x == 0) {
                     prm.ss_out[((size_t)b * 2 * F + c) * 2] = fsc;
                     prm.ss_out[((size_t)b * 2 * F + c) * 2 + 1] = fsh;
+                    if (lane == 0) flag_nonfinite(prm.status, URNN_STATUS_GATES, s1, s2);
                     if (lane == 0 && prm.stat_out) {
                         prm.stat_out[((size_t)b * G1 + grp) * 2] = (float)mean;
                         prm.stat_out[((size_t)b * G1 + grp) * 2 + 1] = (float)rstd;
@@ -991,6 +992,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void cand_fused_kernel(const Con
                 if (blockIdx.x == 0) {
                     prm.ss_out[((size_t)b * 2 * F + c) * 2] = fsc;
                     prm.ss_out[((size_t)b * 2 * F + c) * 2 + 1] = fsh;
+                    if (lane == 0) flag_nonfinite(prm.status, URNN_STATUS_GATES, s1, s2);
                     if (lane == 0 && prm.stat_out) {
                         prm.stat_out[((size_t)b * G1 + grp) * 2] = (float)mean;
                         prm.stat_out[((size_t)b * G1 + grp) * 2 + 1] = (float)rstd;
@@ -1333,6 +1335,11 @@ static int split_mode(const ConvGemmParams &p)
     if (g_matrix_mode.load(std::memory_order_relaxed) == URNN_MATRIX_BF16) return bf_ok ? 2 : 0;
     const bool want_bf = p.wide || (URNN_KEEP_BF16X6 && !tune_f16());
     if (want_bf && (EPI == EPI_LRELU || URNN_KEEP_BF16X6)) return bf_ok ? 1 : 0;
+    // the gate GEMM in its F/32 groups of (z_i | r_i) without an f16 slab in that grouping (strips: their statistics exchange is
+    // written against this tile layout): bf16 x 6 instead of dropping to the fp32 matrix instruction
+    if constexpr (EPI == EPI_GRU1 && NB == 2) {
+        if (!f16_ok) return bf_ok ? 1 : 0;
+    }
     return f16_ok ? 3 : 0;
 }
 
@@ -1348,7 +1355,7 @@ static hipError_t launch_conv_cfg(const ConvGemmParams &p, hipStream_t st, int m
         const int sm = split_mode<NB, PB, EPI>(p);
         if (sm == 3) return launch_conv_split<NB, PB, MAP, EPI, D, WPB, 3>(p, st, max_bpc);
         if (sm == 2) return launch_conv_split<NB, PB, MAP, EPI, D, WPB, 2>(p, st, max_bpc);
-        if constexpr (EPI == EPI_LRELU || URNN_KEEP_BF16X6) {
+        if constexpr (EPI == EPI_LRELU || (EPI == EPI_GRU1 && NB == 2) || URNN_KEEP_BF16X6) {
             if (sm == 1) return launch_conv_split<NB, PB, MAP, EPI, D, WPB, 1>(p, st, max_bpc);
         }
     }

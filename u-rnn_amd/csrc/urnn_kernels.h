@@ -55,6 +55,7 @@ struct ConvGemmParams {
     const unsigned *wfused;
     int fu1Dwords, fu2Dwords;
     const float *biasfu;
+    int *status;          // the workspace's status word (urnn_common.h flag_nonfinite); may be NULL
 };
 
 // Packed layout of the fused candidate slab (appended to a cell's packed buffer when ok): nXE 16-k groups of x | e with 2 NBF blocks
@@ -105,12 +106,12 @@ hipError_t urnn_launch_cand(ConvGemmParams p, int B, int PB, int map, hipStream_
 
 // ---- elementwise / reduction kernels (urnn_elem.hip) ----
 hipError_t urnn_launch_gn_finalize(const float *partial, int ntiles, int tile_pix, int P, double count, const float *gamma, const float *beta,
-                                   float eps, float *ss, float *stat, int B, int C, hipStream_t st);
+                                   float eps, float *ss, float *stat, int B, int C, int *status, int status_bit, hipStream_t st);
 hipError_t urnn_launch_blend(const float *g1, const float *c, const float *h, const float *ss1, const float *ss2, float *out,
                              int B, int F, int P, hipStream_t st);
 hipError_t urnn_launch_blend_fin(const float *g1, const float *c, const float *h, const float *ss1, float *out, int B, int F, int P,
                                  const float *partial, int ntiles, int tile_pix, double count, const float *gamma, const float *beta, float eps,
-                                 float *ss2, float *stat2, hipStream_t st);
+                                 float *ss2, float *stat2, int *status, hipStream_t st);
 
 struct HeadParams {
     const float *feat;
@@ -125,6 +126,7 @@ struct HeadParams {
     int B, C, P, nblk;
     long Pglobal;               // > 0: strip mode, LayerNorm statistics over Pglobal pixels from two pseudo-blocks of partials
     float cls_thred, eps, slope;
+    int *status;                // the workspace's status word (urnn_common.h flag_nonfinite)
 };
 hipError_t urnn_launch_head(const HeadParams &p, int phase_mask, hipStream_t st);
 int urnn_head_nblk(int P);        // blocks allocated per (norm, sample) in the partial buffer
@@ -139,6 +141,7 @@ hipError_t urnn_launch_preprocess(const float *rain, const float *cumsum, const 
                                   int B, int T, int nums, int P, int spatial, float rain_max, float cumsum_max,
                                   hipStream_t st);
 hipError_t urnn_launch_advance(int *counter, int delta, hipStream_t st);
+hipError_t urnn_launch_max_abs(const float *v, long n, float *out, hipStream_t st);
 hipError_t urnn_launch_stage1_static(const float *dem, const float *imperv, const float *manhole, float dem_min, float dem_max,
                                      const float *w, float *S, int B, int nums, int Cout, int P, hipStream_t st);
 hipError_t urnn_launch_stage1_scalar(const float *S, const float *rain, const float *cumsum, const float *w, const float *bias,

@@ -80,6 +80,7 @@ __global__ __launch_bounds__(1024) void small_cell_gemm_kernel(const ConvGemmPar
                     ssm[(c - F) * 2 + 1] = fsh;
                 }
                 if (blk == 0) {
+                    if (lane == 0) flag_nonfinite(prm.status, URNN_STATUS_GATES, s1, s2);
                     prm.ss_out[((size_t)b * 2 * F + c) * 2] = fsc;
                     prm.ss_out[((size_t)b * 2 * F + c) * 2 + 1] = fsh;
                     if (lane == 0 && prm.stat_out) {

@@ -52,10 +52,11 @@ def main(argv=None):
     ap.add_argument("--device", default="0")
     ap.add_argument("--test_list_file", default=None)
     ap.add_argument("--data_root", default=None)
+    ap.add_argument("--location", default=None, help="evaluate one catchment only (config.py:121; overrides the YAML's `location`)")
     ap.add_argument("--timestamp", default=None, help="experiment folder name of the reference (only echoed)")
     ap.add_argument("--checkpoint", default=None, help="reference checkpoint (.pth.tar with 'state_dict'); seeded weights if omitted")
     a = ap.parse_args(argv)
-    cfg = load_exp_config(a.exp_config, test_list_file=a.test_list_file, data_root=a.data_root)
+    cfg = load_exp_config(a.exp_config, test_list_file=a.test_list_file, data_root=a.data_root, location=a.location)
     dev = torch.device("cuda", int(str(a.device).split(",")[0]))
     H, W, C = cfg["input_height"], cfg["input_width"], 2 * cfg["historical_nums"] + 3
     ep, dp = get_network_params(False, H, W, C, load_net_config())
@@ -67,7 +68,8 @@ def main(argv=None):
         from . import weights as uw
         net.load_state_dict({k: torch.from_numpy(v) for k, v in uw.make_state_dict(H, W, C, seed=0).items()})
     net = net.to(dev).eval()
-    ds = Dynamic2DFlood(cfg["data_root"], "test", event_list_file=cfg["test_list_file"] or None, duration=cfg["duration"])
+    ds = Dynamic2DFlood(cfg["data_root"], "test", event_list_file=cfg["test_list_file"] or None, duration=cfg["duration"],
+                        location=cfg["location"])
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     metrics, summary, _ = evaluate_events(net, ds, dev, historical_nums=cfg["historical_nums"], rain_max=cfg["rain_max"],
                                           cumsum_rain_max=cfg["cumsum_rain_max"], flood_max=cfg["flood_max"],

@@ -5,6 +5,7 @@ import yaml
 # key: (type, default) -- defaults of the reference's argparse (config.py:70-160) for the keys this build reads
 KEYS = {
     "data_root": (str, "../data/urbanflood24"), "test_list_file": (str, ""), "train_list_file": (str, ""),
+    "location": (str, ""),      # config.py:121: one catchment ("" = every location under data_root), test.py:738
     "input_height": (int, 500), "input_width": (int, 500), "historical_nums": (int, 30),
     "flood_max": (float, 5000.0), "rain_max": (float, 6.0), "cumsum_rain_max": (float, 250.0), "flood_thres": (float, 150.0),
     "duration": (int, 360), "seq_num": (int, 12), "window_size": (int, 36), "batch_size": (int, 1), "cls_thred": (float, 0.5),

@@ -42,6 +42,7 @@ def Inference(net, inputs, device, historical_nums=30, rain_max=6.0, cumsum_rain
         eng.run(Frames)
         torch.cuda.synchronize(eng.device)
         test_duration = time.time() - test_start_time
+        eng.check_status()                         # non-finite norm statistics (operand range): raise, never return NaN maps
         print(f"Test completed in {test_duration:.2f} sec for {Frames} steps, {test_duration / Frames:.2f} sec/step")
         output_data = eng.out_masked[:Frames, 0].cpu().numpy()
     return np.array(output_data)

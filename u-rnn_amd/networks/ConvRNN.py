@@ -41,14 +41,17 @@ class CGRU_cell(nn.Module):
         return self._cache.get(
             (c1.weight, c1.bias, c2.weight, c2.bias),
             lambda: ops.pack_gru(c1.weight.detach(), c1.bias.detach(), c2.weight.detach(), c2.bias.detach(),
-                                 self.input_channels, self.num_features, self.module == "decoder"))
+                                 self.input_channels, self.num_features, self.module == "decoder"),
+            weights=(c1.weight, c2.weight))
 
     def step(self, x, e, h, out=None, phases=ops.PHASE_ALL, ws=None):
         """One timestep on raw (B,C,H,W) tensors.  ``e`` is the encoder skip state (decoder cells) or None.  ``ws``: scratch
         owned by the caller (an engine's buffer); None allocates one for this call."""
         g1, g2 = self.conv1[1], self.conv2[1]
-        return ops.gru_cell(x, e, h, self._packed(), g1.weight.detach(), g1.bias.detach(), g2.weight.detach(),
-                            g2.bias.detach(), self.input_channels, out=out, eps=g1.eps, phases=phases, ws=ws)
+        packed = self._packed()
+        with ops.exact_matrix_if(self._cache.wide):       # a weight beyond the f16 pieces' range: exact fp32 MFMA for this cell
+            return ops.gru_cell(x, e, h, packed, g1.weight.detach(), g1.bias.detach(), g2.weight.detach(),
+                                g2.bias.detach(), self.input_channels, out=out, eps=g1.eps, phases=phases, ws=ws)
 
     @torch.no_grad()
     def forward(self, inputs=None, hidden_state=None, seq_len=1):

@@ -54,14 +54,16 @@ class StageLayers(nn.Module):
     def _packed(self):
         L = self.layer
         fn = ops.pack_conv if self.kind == "conv" else ops.pack_deconv
-        return self._cache.get((L.weight, L.bias), lambda: fn(L.weight.detach(), L.bias.detach()))
+        return self._cache.get((L.weight, L.bias), lambda: fn(L.weight.detach(), L.bias.detach()), weights=(L.weight,))
 
     @torch.no_grad()
     def forward(self, x, out=None):
         x = x.contiguous()
-        if self.kind == "conv":
-            return ops.stage_conv(x, self._packed(), self.out_channels, self.pool, out=out)
-        return ops.deconv2x2(x, self._packed(), self.out_channels, out=out)
+        packed = self._packed()
+        with ops.exact_matrix_if(self._cache.wide):       # a weight beyond the f16 pieces' range: exact fp32 MFMA for this layer
+            if self.kind == "conv":
+                return ops.stage_conv(x, packed, self.out_channels, self.pool, out=out)
+            return ops.deconv2x2(x, packed, self.out_channels, out=out)
 
 
 def make_layers(block, norm_name="", act="lrelu"):

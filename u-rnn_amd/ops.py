@@ -33,6 +33,37 @@ class matrix_mode:
         return False
 
 
+class _NoGuard:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+class _ExactGuard:
+    """The launches inside run with URNN_MATRIX_FP32_MFMA when the process is in one of the f16-piece modes."""
+
+    def __enter__(self):
+        self.prev = lib().urnn_get_matrix_mode()
+        if self.prev in (MATRIX_MODES["fp32"], MATRIX_MODES["fp32_cand"]):
+            check(lib().urnn_set_matrix_mode(MATRIX_MODES["fp32_mfma"]), "urnn_set_matrix_mode")
+        return self
+
+    def __exit__(self, *exc):
+        lib().urnn_set_matrix_mode(self.prev)
+        return False
+
+
+def exact_matrix_if(flag):
+    """``with ops.exact_matrix_if(layer_has_a_weight_beyond_f16_range): launch(...)`` -- the f16 x 3 forward arithmetic is finite for
+    |weight| < 64 (include/urnn_hip.h); a layer outside that range takes the exact fp32 matrix instruction instead of NaN."""
+    return _ExactGuard() if flag else _NO_GUARD
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -55,7 +86,8 @@ def _ptr(t):
 
 def workspace(nbytes, device):
     """A scratch buffer of ``nbytes`` bytes (caller-owned, as the C ABI requires)."""
-    return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    # zeros: the first 256 bytes of a cell / head workspace are STATUS words that kernels only ever OR into (include/urnn_hip.h)
+    return torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
 
 
 class Arena:
@@ -97,6 +129,24 @@ def gru_cell_workspace_bytes(B, F, H, W):
 
 def head_workspace_bytes(B, C, H, W):
     return lib().urnn_head_workspace_bytes(B, C, H, W)
+
+
+STATUS_GATES, STATUS_CAND, STATUS_HEAD = 1, 2, 4     # include/urnn_hip.h: word 0 of a cell / head workspace
+STATUS_NAMES = {STATUS_GATES: "GroupNorm sums of a cell's gates", STATUS_CAND: "GroupNorm sums of a cell's candidate",
+                STATUS_HEAD: "LayerNorm sums of the head"}
+
+
+def workspace_status(ws):
+    """Word 0 of a workspace's status area (0 = every norm's statistics were finite).  Reads the device: synchronises."""
+    return int(ws[:4].view(torch.int32).item())
+
+
+def max_abs(values):
+    """max |v| of a float32 device tensor as a python float (urnn_max_abs_f32; NaN if any element is NaN)."""
+    _dev_check(values)
+    out = torch.empty(1, dtype=torch.float32, device=values.device)
+    check(lib().urnn_max_abs_f32(_ptr(values), values.numel(), _ptr(out), _stream()), "urnn_max_abs_f32")
+    return float(out.item())
 
 
 # ---- weight packing ----------------------------------------------------------------------------------

@@ -118,31 +118,40 @@ class RolloutEngine:
             self.net.encoder.stage1(self.x_in, out=self.a1)
 
     def _cell(self, name, cell, x, e, h, out, ws):
-        """One GRU cell; when a probe is active the gate GEMM of the named full-resolution cells is launched on its
-        own, bracketed by events on the launch stream (bench.py's live roofline measurement)."""
+        """One GRU cell; when a probe is active the three kernels of the named cells (gate GEMM | candidate GEMM | GroupNorm
+        finalize + blend) are launched one ABI call each, every one bracketed by events on the launch stream (bench.py's live
+        roofline measurement)."""
         if self._probe is not None and name in self._probe:
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            cell.step(x, e, h, out=out, phases=ops.PHASE_GATES | self._cell_flags, ws=ws)
-            b.record()
-            self._probe[name].append((a, b))
-            cell.step(x, e, h, out=out, phases=(ops.PHASE_ALL & ~ops.PHASE_GATES) | self._cell_flags, ws=ws)
+            for kind, mask in (("gates", ops.PHASE_GATES), ("candidate", ops.PHASE_GN1 | ops.PHASE_CAND), ("blend", ops.PHASE_GN2 | ops.PHASE_BLEND)):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                cell.step(x, e, h, out=out, phases=mask | self._cell_flags, ws=ws)
+                b.record()
+                self._probe[name][kind].append((a, b))
         else:
             cell.step(x, e, h, out=out, phases=ops.PHASE_ALL | self._cell_flags, ws=ws)
 
-    def probe_gate_gemm(self, frames=12):
-        """Average duration (seconds) of the full- and half-resolution gate-GEMM launches while the rollout runs in this engine's
-        scheduling mode (eager launches, same streams and co-running kernels as the captured graph)."""
+    PROBED_CELLS = ("enc1", "dec1", "enc2", "dec2")
+
+    def probe_cell_kernels(self, frames=12):
+        """Average duration (seconds) of the gate-GEMM / candidate-GEMM / blend launches of the full- and half-resolution cells
+        while the rollout runs in this engine's scheduling mode (eager launches, same streams and co-running kernels as the
+        captured graph): {cell: {"gates": s, "candidate": s, "blend": s}}.  An event pair on the launch stream spans the kernel
+        plus whatever it waited for on that stream's queue -- with overlap=False that is the kernel itself (+ ~1 us)."""
         saved_graph, self.use_graph = self.use_graph, False
         self.reset()
         self.run(2)
-        self._probe = {"enc1": [], "dec1": [], "enc2": [], "dec2": []}
+        self._probe = {c: {"gates": [], "candidate": [], "blend": []} for c in self.PROBED_CELLS}
         self.run(frames)
         torch.cuda.synchronize(self.device)
         probe, self._probe = self._probe, None
         self.use_graph = saved_graph
         self.reset()
-        return {k: sum(a.elapsed_time(b) for a, b in v) / len(v) / 1e3 for k, v in probe.items()}
+        return {c: {k: sum(a.elapsed_time(b) for a, b in v) / len(v) / 1e3 for k, v in kinds.items()} for c, kinds in probe.items()}
+
+    def probe_gate_gemm(self, frames=12):
+        """(kept for callers of the round-2 interface) gate-GEMM durations only: {cell: seconds}"""
+        return {c: v["gates"] for c, v in self.probe_cell_kernels(frames).items()}
 
     # -- overlap mode: two concurrent chains -------------------------------------------------------------
     def _enc_bufs(self, parity):
@@ -406,8 +415,73 @@ class RolloutEngine:
 
     def rollout(self, event):
         """Full event from zero states: returns the (T,B,H,W) masked-depth frames (a view of the engine's
-        output buffer, on device)."""
+        output buffer, on device).  Raises FloatingPointError when a norm saw non-finite statistics (check_status)."""
         T = self.load_event(event)
         self.reset()
         self.run(T)
+        self.check_status()
         return self.out_masked[:T]
+
+    # -- operand-range guard (include/urnn_hip.h, "Operand range of the default matrix mode") ---------------------------
+    def check_status(self):
+        """Once per event: the kernels that fold norm statistics OR a bit into word 0 of their workspace when the sums are not
+        finite -- an activation beyond the f16 pieces' range (|x| >= 2047) leaves the matrix pipe as inf and shows here.  Reading
+        the word synchronises (the caller is about to fetch the frames anyway).  On a hit: re-run the first frames eagerly with a
+        finiteness check behind every layer and raise naming the first one that fails."""
+        bits = 0
+        for ws in self._ws:
+            bits |= ops.workspace_status(ws)
+        if bits == 0:
+            return
+        for ws in self._ws:
+            ws[:4].zero_()
+        what = "; ".join(name for bit, name in ops.STATUS_NAMES.items() if bits & bit)
+        layer = self._first_nonfinite_layer()
+        raise FloatingPointError(
+            f"U-RNN rollout: non-finite {what}" + (f"; first layer with a non-finite output: {layer}" if layer else "") +
+            ".  The default matrix mode carries operands as f16 pieces (|activation| < 2047, |weight| < 64, include/urnn_hip.h); "
+            "run this checkpoint / event under ops.matrix_mode('fp32_mfma').")
+
+    def _first_nonfinite_layer(self, max_frames=4):
+        """Eager replay of the first frames from zero states with torch.isfinite behind every layer (diagnosis only)."""
+        net = self.net
+        enc, dec = net.encoder, net.decoder
+        saved_t = int(self.t_dev.item())
+        states = [torch.zeros_like(s) for s in self.states]
+        e1, e2, e3, d1, d2, d3 = states
+        t_dev = torch.zeros_like(self.t_dev)
+        ws = ops.workspace(self._ws[0].numel(), self.device)
+        found = None
+
+        def bad(name, t):
+            nonlocal found
+            if found is None and not bool(torch.isfinite(t).all()):
+                found = name
+            return found is not None
+        for _ in range(min(max_frames, self.Tcap)):
+            self._stage1(t_dev)
+            if bad("encoder.stage1", self.a1):
+                break
+            steps = (("encoder.rnn1", lambda: enc.rnn1.step(self.a1, None, e1, out=e1, ws=ws), e1),
+                     ("encoder.stage2", lambda: enc.stage2(e1, out=self.a2), self.a2),
+                     ("encoder.rnn2", lambda: enc.rnn2.step(self.a2, None, e2, out=e2, ws=ws), e2),
+                     ("encoder.stage3", lambda: enc.stage3(e2, out=self.a3), self.a3),
+                     ("encoder.rnn3", lambda: enc.rnn3.step(self.a3, None, e3, out=e3, ws=ws), e3),
+                     ("decoder.rnn3", lambda: dec.rnn3.step(None, e3, d1, out=d1, ws=ws), d1),
+                     ("decoder.stage3", lambda: dec.stage3(d1, out=self.u3), self.u3),
+                     ("decoder.rnn2", lambda: dec.rnn2.step(self.u3, e2, d2, out=d2, ws=ws), d2),
+                     ("decoder.stage2", lambda: dec.stage2(d2, out=self.u2), self.u2),
+                     ("decoder.rnn1", lambda: dec.rnn1.step(self.u2, e1, d3, out=d3, ws=ws), d3),
+                     ("decoder.stage1", lambda: dec.stage1(d3, out=self.feat), self.feat))
+            for name, fn, out in steps:
+                fn()
+                if bad(name, out):
+                    break
+            if found:
+                break
+            masked, cls, _ = net.head.run(self.feat, ws=ws)
+            if bad("head", masked) or bad("head", cls):
+                break
+            ops.advance_counter(t_dev, 1)
+        self.t_dev.fill_(saved_t)
+        return found

@@ -75,8 +75,10 @@ class StripRollout:
 
         def cell(mod, x, e, h, level):
             g1, g2 = mod.conv1[1], mod.conv2[1]
-            return ops.gru_cell_strip(x, e, h, mod._packed(), g1.weight.detach(), g1.bias.detach(), g2.weight.detach(), g2.bias.detach(),
-                                      mod.input_channels, gp // (level * level), self._exchange, eps=g1.eps)
+            packed = mod._packed()
+            with ops.exact_matrix_if(mod._cache.wide):
+                return ops.gru_cell_strip(x, e, h, packed, g1.weight.detach(), g1.bias.detach(), g2.weight.detach(), g2.bias.detach(),
+                                          mod.input_channels, gp // (level * level), self._exchange, eps=g1.eps)
 
         x_in = ops.preprocess(ev["rain"], ev["cumsum"], ev["dem"], ev["imperv"], ev["manhole"], ev["dem_min"], ev["dem_max"], int(t),
                               self.nums, self.rain_max, self.cumsum_max)

@@ -250,7 +250,7 @@ class Trainer:
         # the two halves of the gradient mean enqueued between them (forward + backward up to the point where the head's gradients
         # are final | the rest of the backward | clip + Adam), main.py:384-387,750-762
         self.use_graph = bool(use_graph)
-        self._graph = None
+        self._graphs = {}           # captured windows by key (one per catchment / shape / lr): see _train_window_graph
         self.wg = WindowGradients(net, H, W, nums, rain_max, cumsum_max, cls_thred_train)
         self.lr, self.betas, self.eps, self.grad_clip = float(lr), tuple(betas), float(eps), float(grad_clip)
         self.distributed, self.pg = bool(distributed), process_group
@@ -391,6 +391,8 @@ class Trainer:
         gC.capture_end()
         return (gA, gB, gC), out, clip
 
+    MAX_CACHED_WINDOWS = 4
+
     def _train_window_graph(self, ev, targets, t0, steps, states):
         """hipGraph path: static input buffers (targets, the six states, the per-step frame indices, the Adam step counter) are
         refreshed on the stream, then the captured window -- ~250 launches per timestep -- replays as one graph."""
@@ -401,7 +403,12 @@ class Trainer:
         key = (steps, B, ev["T"], tuple(ev["rain"].shape), ev["dem_min"], ev["dem_max"], self.lr, self.matrix_mode)   # lr: one re-capture per epoch
         # (a scratch buffer that grew since the capture -- an eager call with a larger batch through the same arena -- leaves the
         # graph pointing at freed memory: ops.Arena.generation tells)
-        if self._graph is None or self._graph["key"] != key or self._graph["arena_gen"] != self.wg.arena.generation:
+        G = self._graphs.get(key)
+        if G is not None and G["arena_gen"] != self.wg.arena.generation:
+            # a scratch buffer grew since some capture: EVERY cached graph may point at freed memory
+            self._graphs.clear()
+            G = None
+        if G is None:
             from .general import initialize_states
             zero = [s.to(dev).repeat(B, 1, 1, 1) for s in initialize_states(dev, self.wg.H, self.wg.W)]
             sev = dict(ev)
@@ -416,8 +423,16 @@ class Trainer:
             self._invalidate_packed()
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):                       # eager warm-up: sizes every workspace, packs every weight
-                self._window_body(sev, G["tgt"], 0, steps, G["states"], t_devs=G["t_devs"], step_dev=G["step_dev"])
+            # Eager warm-up (sizes every workspace, packs every weight) and capture are PER RANK decisions -- under DDP each rank
+            # sees its own catchments (DistributedSampler), so one rank may (re)capture while another only replays.  Both must
+            # therefore be collective-free: a reduce issued here would pair with another rank's real gradient reduce and the
+            # sequences would stay out of step from then on.  The only collectives of a window are the two between the replays.
+            was_distributed, self.distributed = self.distributed, False
+            try:
+                with torch.cuda.stream(side):
+                    self._window_body(sev, G["tgt"], 0, steps, G["states"], t_devs=G["t_devs"], step_dev=G["step_dev"])
+            finally:
+                self.distributed = was_distributed
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
             for dst, src in zip((self.flat, self.m, self.v), keep):
@@ -429,14 +444,22 @@ class Trainer:
                 with torch.cuda.stream(cap):
                     graphs, out, clip = self._window_body_ddp_graphs(sev, G, steps)
                 torch.cuda.current_stream(dev).wait_stream(cap)
-                G.update(graph=graphs, out=out, clip=clip, arena_gen=self.wg.arena.generation)
+                G.update(graph=graphs, out=out, clip=clip)
             else:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     out, clip = self._window_body(sev, G["tgt"], 0, steps, G["states"], t_devs=G["t_devs"], step_dev=G["step_dev"])
-                G.update(graph=g, out=out, clip=clip, arena_gen=self.wg.arena.generation)
-            self._graph = G
-        G = self._graph
+                G.update(graph=g, out=out, clip=clip)
+            if any(h["arena_gen"] != self.wg.arena.generation for h in self._graphs.values()):
+                self._graphs.clear()            # the warm-up grew a buffer older graphs point into
+            G["arena_gen"] = self.wg.arena.generation
+            # alternating catchments replay their own graphs instead of re-capturing every window; each entry owns a memory pool
+            # with the window's activations, so the cache is small and least-recently-used entries go first
+            while len(self._graphs) >= self.MAX_CACHED_WINDOWS:
+                self._graphs.pop(next(iter(self._graphs)))
+            self._graphs[key] = G
+        else:
+            self._graphs[key] = self._graphs.pop(key)      # most recently used last
         if ev is not G["ev"]:
             for k in ("rain", "cumsum", "dem", "imperv", "manhole"):
                 if G["ev"][k].data_ptr() != ev[k].data_ptr():
