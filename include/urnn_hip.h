@@ -141,6 +141,19 @@ int urnn_gru_cell_f32(const float *x, const float *e, const float *h, const floa
  * every phase-split call of a cell or to none.  The workspace's raw reset-gate planes are then
  * undefined: the backward pass (urnn_gru_cell_backward_f32) needs a forward WITHOUT this flag. */
 #define URNN_PHASE_FUSED_R 32
+/* Optional modifier (not part of URNN_PHASE_ALL), for the same callers: ONE cooperative launch for the whole cell of a small plane
+ * (<= 256 blocks of 64 pixels, F <= 96, f16-piece matrix modes): gate GEMM -> grid barrier -> candidate GEMM -> grid barrier ->
+ * blend, with the raw gates and the candidate kept in registers; only the partial GroupNorm statistics leave the CU between the
+ * phases (ConvRNN.py:111-194).  Same arithmetic and summation orders as the three kernels: h_out is bit-identical.  Needs every
+ * phase in the mask; ignored where the shape does not qualify.  The workspace's raw gate / candidate planes are then undefined.
+ * Word 16 and 32 of the workspace's status area are the launch's barrier state (zero once, never touch).  A grid barrier that does
+ * not complete within ~1 s gives up and sets URNN_STATUS_BARRIER in the status word instead of hanging the GPU.
+ * urnn_gru_cell_coop_blocks: how many blocks that launch would take for a cell of this shape (0: the flag would be ignored).  Every
+ * block must be resident at once (one per CU): a caller that keeps SEVERAL kernel chains in flight passes the flag only for cells
+ * of at most 128 blocks (any two of those fit side by side; u-rnn_amd/rollout.py), a single chain for any planned cell. */
+#define URNN_PHASE_COOP 64
+#define URNN_STATUS_BARRIER 8
+int urnn_gru_cell_coop_blocks(int B, int I, int F, int H, int W, int skip, int has_x);
 /* 1 when URNN_PHASE_FUSED_R takes effect for a cell of this shape under the current matrix mode (x present; skip: an e input of F
  * channels), else 0 -- for byte accounting (bench.py) and tests; the cell entry decides by the same rule. */
 int urnn_gru_cell_fused_reset_gate_applies(int B, int I, int F, int H, int W, int skip);

@@ -216,3 +216,61 @@ def test_argument_errors(dev):
     packed = ops.pack_conv(torch.zeros(16, 8, 1, 1, device=dev), torch.zeros(16, device=dev))
     with pytest.raises(UrnnError):
         ops.stage_conv(x, packed, 16, True, out=torch.zeros(1, 16, 2, 2, device=dev)[:, :, :, 1:].contiguous()[..., :0].new_zeros(3)[1:])
+
+
+@pytest.mark.parametrize("I,F,skip,H,W,B,with_x", [
+    (96, 96, 0, 125, 125, 1, True),    # encoder stage 3 at 500x500: 245 blocks (needs every CU but eleven), odd plane
+    (96, 96, 1, 125, 125, 1, False),   # decoder stage 3: x == None, skip
+    (16, 64, 0, 64, 64, 1, True),      # the 64x64 config's full-resolution cell: 64 blocks of 8 waves
+    (96, 96, 1, 32, 32, 2, True),      # K = 288 (the largest panel: 72 KB), two samples
+    (64, 96, 0, 13, 15, 3, True),      # ragged: 195 pixels per sample, a partial last tile and an empty pixel block
+    (96, 64, 1, 26, 60, 1, True),      # the 52x120 config's half-resolution... decoder cell shape with F = 64
+])
+def test_cooperative_cell_equals_three_kernels(dev, I, F, skip, H, W, B, with_x):
+    """URNN_PHASE_COOP (ConvRNN.py:111-194): the whole cell of a small plane as one launch -- gate GEMM | grid barrier | candidate GEMM
+    | grid barrier | blend, raw gates and candidate kept in registers -- against the three-kernel cell: bit-identical (same pieces,
+    same MFMA order, same summation orders of the statistics), in place and out of place, over repeated launches (the barrier words
+    are reused), and within 1e-4 of the oracle."""
+    from oracle import oracle as orc
+    from urnn_amd import ops
+    from urnn_amd._lib import lib
+    rs = np.random.RandomState(77 + I + F + H)
+    K = I + (2 * F if skip else F)
+    p = {"W1": rs.normal(0, 1 / np.sqrt(K), (2 * F, K)).astype(np.float32), "b1": rs.normal(0, 0.1, 2 * F).astype(np.float32),
+         "g1": rs.uniform(0.5, 1.5, 2 * F).astype(np.float32), "be1": rs.normal(0, 0.1, 2 * F).astype(np.float32),
+         "W2": rs.normal(0, 1 / np.sqrt(K), (F, K)).astype(np.float32), "b2": rs.normal(0, 0.1, F).astype(np.float32),
+         "g2": rs.uniform(0.5, 1.5, F).astype(np.float32), "be2": rs.normal(0, 0.1, F).astype(np.float32)}
+    x = rs.normal(0, 1, (B, I, H, W)).astype(np.float32) if with_x else None
+    e = rs.normal(0, 1, (B, F, H, W)).astype(np.float32) if skip else None
+    h = rs.normal(0, 1, (B, F, H, W)).astype(np.float32)
+    blocks = lib().urnn_gru_cell_coop_blocks(B, I, F, H, W, int(skip), int(with_x))
+    assert blocks == B * ((H * W + 63) // 64), f"expected a cooperative launch for this shape, the library plans {blocks} blocks"
+    packed = ops.pack_gru(T(p["W1"].reshape(2 * F, K, 1, 1), dev), T(p["b1"], dev), T(p["W2"].reshape(F, K, 1, 1), dev),
+                          T(p["b2"], dev), I, F, bool(skip))
+    args = (None if x is None else T(x, dev), None if e is None else T(e, dev))
+    aff = (T(p["g1"], dev), T(p["be1"], dev), T(p["g2"], dev), T(p["be2"], dev))
+    ws = ops.workspace(ops.gru_cell_workspace_bytes(B, F, H, W), dev)
+    three = ops.gru_cell(*args, T(h, dev), packed, *aff, I, phases=ops.PHASE_ALL, ws=ws)
+    one = ops.gru_cell(*args, T(h, dev), packed, *aff, I, phases=ops.PHASE_ALL | ops.PHASE_COOP, ws=ws)
+    torch.cuda.synchronize()
+    assert ops.workspace_status(ws) == 0
+    assert torch.equal(one, three), f"cooperative cell differs from the three kernels: max {float((one - three).abs().max()):.3e}"
+    assert_close(one.cpu().numpy(), orc.gru_cell(x, e, h, p), TOL, "cooperative cell vs oracle")
+    hh = T(h, dev)
+    for _ in range(25):                                   # in place, barrier state reused launch after launch
+        hh.copy_(T(h, dev))
+        ops.gru_cell(*args, hh, packed, *aff, I, out=hh, phases=ops.PHASE_ALL | ops.PHASE_COOP, ws=ws)
+        assert torch.equal(hh, three)
+    assert ops.workspace_status(ws) == 0
+
+
+def test_cooperative_cell_is_not_planned_for_large_planes_or_other_modes(dev):
+    from urnn_amd import ops
+    from urnn_amd._lib import lib
+    L = lib()
+    assert L.urnn_gru_cell_coop_blocks(1, 64, 96, 250, 250, 0, 1) == 0          # 977 blocks: not co-resident
+    assert L.urnn_gru_cell_coop_blocks(1, 16, 64, 500, 500, 0, 1) == 0
+    assert L.urnn_gru_cell_coop_blocks(1, 16, 128, 64, 64, 0, 1) == 0           # F = 128: sixteen waves of gates
+    assert L.urnn_gru_cell_coop_blocks(1, 96, 96, 125, 125, 0, 1) == 245
+    with ops.matrix_mode("fp32_mfma"):
+        assert L.urnn_gru_cell_coop_blocks(1, 96, 96, 125, 125, 0, 1) == 0      # the exact-fp32 mode keeps its own kernels

@@ -32,6 +32,7 @@ SIGNATURES = {
     "urnn_gru_cell_f32": (_i, [_p] * 10 + [_sz, _i, _i, _i, _i, _i, _f, _p]),
     "urnn_gru_cell_phases_f32": (_i, [_p] * 10 + [_sz, _i, _i, _i, _i, _i, _f, _i, _p]),
     "urnn_gru_cell_fused_reset_gate_applies": (_i, [_i] * 6),
+    "urnn_gru_cell_coop_blocks": (_i, [_i] * 7),
     "urnn_deconv2x2_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "urnn_head_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "urnn_head_f32": (_i, [_p] * 13 + [_sz, _i, _i, _i, _i, _f, _f, _f, _p]),

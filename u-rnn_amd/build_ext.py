@@ -36,9 +36,12 @@ def build(force=False, verbose=False, extra_flags=(), out=None, tag=""):
         raise ValueError("liburnn_hip must not be built with SLP vectorisation (packed fp32 next to MFMAs: DESIGN.md section 4.8)")
     objs = []
     procs = []
+    hdrs = [d for d in deps if d not in srcs]
     for s in srcs:
         o = os.path.join(CSRC, os.path.basename(s).replace(".hip", tag + ".o"))
         objs.append(o)
+        if not force and not extra_flags and os.path.isfile(o) and os.path.getmtime(o) >= _newest([s] + hdrs):
+            continue                                  # this translation unit is up to date (urnn_gemm.hip alone takes minutes)
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *NO_PACKED_F32, *extra_flags, "-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd))

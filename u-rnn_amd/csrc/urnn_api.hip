@@ -255,13 +255,34 @@ extern "C" int urnn_gru_cell_fused_reset_gate_applies(int B, int I, int F, int H
     return urnn_cand_fused_plan(p, B) != 0;
 }
 
+// forward declaration: the cell entry with a "plan only" switch (coop_blocks != nullptr: report, launch nothing)
+static int gru_cell_impl(const float *x, const float *e, const float *h, const float *packed, const float *gn1_w,
+                         const float *gn1_b, const float *gn2_w, const float *gn2_b, float *h_out, void *workspace,
+                         size_t workspace_bytes, int B, int I, int F, int H, int W, float eps, int phase_mask, long global_pixels,
+                         void *stream, int *coop_blocks = nullptr);
+
+// Blocks of the cooperative launch a cell of this shape would take under URNN_PHASE_COOP (0: it would run its three kernels).  More than
+// 128 blocks means the launch needs more than half of the chip's CUs to itself: a caller that keeps SEVERAL kernel chains in flight
+// passes the flag only up to 128 blocks (two larger ones waiting for CUs at their grid barriers could starve each other; up to 128
+// blocks any two fit side by side).
+extern "C" int urnn_gru_cell_coop_blocks(int B, int I, int F, int H, int W, int skip, int has_x)
+{
+    if (B < 1 || I < 1 || F < 32 || F % 32 != 0 || F > 128 || H < 1 || W < 1) return 0;
+    int blocks = 0;
+    alignas(16) static float dummy[4];
+    const float *d = dummy;
+    gru_cell_impl(has_x ? d : nullptr, skip ? d : nullptr, d, d, d, d, d, d, dummy, dummy, (size_t)1 << 62, B, I, F, H, W, 1e-5f,
+                  URNN_PHASE_ALL | URNN_PHASE_COOP, 0, nullptr, &blocks);
+    return blocks;
+}
+
 // global_pixels > 0: this call computes one horizontal STRIP of a plane of global_pixels pixels that is split over ranks
 // (SURVEY 8e); the GroupNorm partials have been replaced by the all-reduced totals (two pseudo-tiles: hi + lo floats of
 // the double sums, urnn_gru_cell_strip_stats_f32) and the statistics are over the whole plane
 static int gru_cell_impl(const float *x, const float *e, const float *h, const float *packed, const float *gn1_w,
                          const float *gn1_b, const float *gn2_w, const float *gn2_b, float *h_out, void *workspace,
                          size_t workspace_bytes, int B, int I, int F, int H, int W, float eps, int phase_mask, long global_pixels,
-                         void *stream)
+                         void *stream, int *coop_blocks)
 {
     if (!h || !packed || !gn1_w || !gn1_b || !gn2_w || !gn2_b || !h_out || !workspace)
         return fail(URNN_ENULL, "urnn_gru_cell_f32: NULL argument");
@@ -352,15 +373,6 @@ static int gru_cell_impl(const float *x, const float *e, const float *h, const f
     // activation-stationary kernels of urnn_small.hip: same outputs, same partial layout (development knob URNN_TUNE_SMALL=0)
     // up to URNN_TUNE_SMALL pixels per launch (default 24 000; 0 disables): at 62 500 pixels the per-block weight stream and
     // prologue cost more than they save (candidate GEMMs 38 -> 49 and 56 -> 110 us)
-    if (phase_mask & URNN_PHASE_GATES) {
-        if (small_gates) CHECK_HIP(urnn_launch_small_gates(p, B, st), "gru gates (small plane)");
-        else CHECK_HIP(urnn_launch_gru1(p, B, pb1, map1, st), "gru gates");
-    }
-    // GroupNorm finalise of the gates: folded into the candidate GEMM's prologue; launched on its own only when asked for
-    // without the candidate phase (profiling)
-    if ((phase_mask & URNN_PHASE_GN1) && !(phase_mask & URNN_PHASE_CAND))
-        CHECK_HIP(urnn_launch_gn_finalize(ws.part1, ftiles1, global_pixels > 0 ? 0 : 32 * pb1, (int)P, count, gn1_w, gn1_b, eps, ws.ss1, ws.st1, B,
-                                          2 * F, ws.status, URNN_STATUS_GATES, st), "gn finalize 1");
 
     // K2: candidate (pre-norm) = W2 . [x; e; sigmoid(GN(r)) * h] + b2, GroupNorm partials.  The hidden-state rows are gated
     // on the fly from the raw reset gate and K1's folded (scale, shift).
@@ -401,6 +413,27 @@ static int gru_cell_impl(const float *x, const float *e, const float *h, const f
     if (global_pixels >= URNN_FULL_RES_PIXELS && urnn_get_matrix_mode() == URNN_MATRIX_FP32) c.candExact = 1;
     int pb2, map2;
     int tiles2 = gru_tiles(B, F, P, 2, &pb2, &map2);
+    // URNN_PHASE_COOP: the whole cell of a small plane as ONE cooperative launch (urnn_small.hip coop_cell_kernel) -- when the caller
+    // asked for every phase and the shape qualifies; otherwise the flag is ignored and the three kernels run
+    if ((phase_mask & URNN_PHASE_COOP) && (phase_mask & URNN_PHASE_ALL) == URNN_PHASE_ALL && global_pixels <= 0 && !fused_r && small_gates &&
+        small_on && pb2 == 1 && urnn_coop_cell_ok(p, c, B)) {
+        if (coop_blocks) {                                          // plan only (urnn_gru_cell_coop_blocks)
+            *coop_blocks = B * (int)((P + 63) / 64);
+            return URNN_OK;
+        }
+        CHECK_HIP(urnn_launch_coop_cell(p, c, gn2_w, gn2_b, h_out, reinterpret_cast<unsigned *>(ws.status) + 16, B, st), "gru cell (one cooperative launch)");
+        return URNN_OK;
+    }
+    if (coop_blocks) return URNN_OK;                                // plan only: not a cooperative launch (*coop_blocks stays 0)
+    if (phase_mask & URNN_PHASE_GATES) {
+        if (small_gates) CHECK_HIP(urnn_launch_small_gates(p, B, st), "gru gates (small plane)");
+        else CHECK_HIP(urnn_launch_gru1(p, B, pb1, map1, st), "gru gates");
+    }
+    // GroupNorm finalise of the gates: folded into the candidate GEMM's prologue; launched on its own only when asked for
+    // without the candidate phase (profiling)
+    if ((phase_mask & URNN_PHASE_GN1) && !(phase_mask & URNN_PHASE_CAND))
+        CHECK_HIP(urnn_launch_gn_finalize(ws.part1, ftiles1, global_pixels > 0 ? 0 : 32 * pb1, (int)P, count, gn1_w, gn1_b, eps, ws.ss1, ws.st1, B,
+                                          2 * F, ws.status, URNN_STATUS_GATES, st), "gn finalize 1");
     if (fused_r) {
         pb2 = 2;                                                    // the fused kernel's 64-pixel tiles carry the candidate's partials
         tiles2 = (int)((P + 63) / 64);

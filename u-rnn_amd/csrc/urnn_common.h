@@ -179,6 +179,11 @@ __device__ __forceinline__ unsigned bf16_piece(float x, int piece)
     return __float_as_uint(r) >> 16;
 }
 
+// The GRU blend h' = (1 - z) h + z n (ConvRNN.py:189) with every operation rounded on its own, as the reference's eager torch ops
+// round them -- and so that every kernel that blends (gru_blend_kernel in all its vector forms, coop_cell_kernel) produces the same
+// bits: left to the compiler, one form contracts (1 - z) * h into an fma and another z * n.
+__device__ __forceinline__ float gru_blend(float z, float n, float h) { return __fadd_rn(__fmul_rn(1.f - z, h), __fmul_rn(z, n)); }
+
 __device__ __forceinline__ float lrelu(float v, float slope) { return v >= 0.f ? v : v * slope; }
 __device__ __forceinline__ float siluf_fast(float v) { return v * sigmoidf_fast(v); }
 

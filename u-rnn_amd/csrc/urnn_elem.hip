@@ -184,9 +184,9 @@ __global__ __launch_bounds__(256) void gru_blend_kernel(const float *__restrict_
     if constexpr (V == 5) {                // the last P & 3 pixels of the plane: one thread each, first block
         if (blockIdx.x == 0 && (int)threadIdx.x < P - Pv) {
             const int p = Pv + threadIdx.x;
-            const float z = sigmoidf_fast(gz[p] * s1 + t1);
-            const float n = tanhf_fast(cc[p] * s2 + t2);
-            oo[p] = (1.f - z) * hh[p] + z * n;
+            const float z = sigmoidf_fast(fmaf(gz[p], s1, t1));
+            const float n = tanhf_fast(fmaf(cc[p], s2, t2));
+            oo[p] = gru_blend(z, n, hh[p]);
         }
     }
 #pragma unroll
@@ -200,9 +200,9 @@ __global__ __launch_bounds__(256) void gru_blend_kernel(const float *__restrict_
             f32x4 o;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float z = sigmoidf_fast(g[k] * s1 + t1);
-                const float n = tanhf_fast(cv[k] * s2 + t2);
-                o[k] = (1.f - z) * hv[k] + z * n;
+                const float z = sigmoidf_fast(fmaf(g[k], s1, t1));
+                const float n = tanhf_fast(fmaf(cv[k], s2, t2));
+                o[k] = gru_blend(z, n, hv[k]);
             }
             *reinterpret_cast<f32x4u *>(oo + p) = o;
         } else if constexpr (V == 4) {
@@ -212,15 +212,15 @@ __global__ __launch_bounds__(256) void gru_blend_kernel(const float *__restrict_
             f32x4 o;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float z = sigmoidf_fast(g[k] * s1 + t1);
-                const float n = tanhf_fast(cv[k] * s2 + t2);
-                o[k] = (1.f - z) * hv[k] + z * n;
+                const float z = sigmoidf_fast(fmaf(g[k], s1, t1));
+                const float n = tanhf_fast(fmaf(cv[k], s2, t2));
+                o[k] = gru_blend(z, n, hv[k]);
             }
             *reinterpret_cast<f32x4 *>(oo + p) = o;           // (the state is re-read soon: non-temporal stores cost 1 %)
         } else {
-            const float z = sigmoidf_fast(gz[p] * s1 + t1);
-            const float n = tanhf_fast(cc[p] * s2 + t2);
-            oo[p] = (1.f - z) * hh[p] + z * n;
+            const float z = sigmoidf_fast(fmaf(gz[p], s1, t1));
+            const float n = tanhf_fast(fmaf(cc[p], s2, t2));
+            oo[p] = gru_blend(z, n, hh[p]);
         }
     }
 }

@@ -101,6 +101,10 @@ hipError_t urnn_launch_gru1(ConvGemmParams p, int B, int PB, int map, hipStream_
 bool urnn_small_ok(const ConvGemmParams &p, int nblk_total, int gated);
 hipError_t urnn_launch_small_gates(ConvGemmParams p, int B, hipStream_t st);
 hipError_t urnn_launch_small_cand(ConvGemmParams p, int B, hipStream_t st);
+// the whole cell of a small plane as one cooperative launch (urnn_small.hip coop_cell_kernel); p / c = the gate / candidate blocks
+bool urnn_coop_cell_ok(const ConvGemmParams &p, const ConvGemmParams &c, int B);
+hipError_t urnn_launch_coop_cell(ConvGemmParams p, const ConvGemmParams &c, const float *gn2_w, const float *gn2_b, float *h_out, unsigned *bar,
+                                 int B, hipStream_t st);
 int urnn_cand_nb(int F);      // n-blocks per group of the candidate GEMM
 hipError_t urnn_launch_cand(ConvGemmParams p, int B, int PB, int map, hipStream_t st);
 

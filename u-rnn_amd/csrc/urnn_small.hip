@@ -158,8 +158,8 @@ __global__ __launch_bounds__(1024) void small_cell_gemm_kernel(const ConvGemmPar
                         const int kp0 = 8 * (kg0 + gq) + 2 * d;
                         if (kp0 >= prm.hKp0) {                               // (whole 16-k groups are gated or plain: hKp0 % 8 == 0)
                             const int ch = 2 * (kp0 - prm.hKp0) + hf;
-                            v0[q] *= sigmoidf_fast(g0[q] * ssm[2 * ch] + ssm[2 * ch + 1]);
-                            v1[q] *= sigmoidf_fast(g1[q] * ssm[2 * ch + 4] + ssm[2 * ch + 5]);
+                            v0[q] *= sigmoidf_fast(fmaf(g0[q], ssm[2 * ch], ssm[2 * ch + 1]));
+                            v1[q] *= sigmoidf_fast(fmaf(g1[q], ssm[2 * ch + 4], ssm[2 * ch + 5]));
                         }
                     }
                     unsigned ph, pm, pl;
@@ -341,4 +341,451 @@ hipError_t urnn_launch_small_cand(ConvGemmParams p, int B, hipStream_t st)
     p.tilesPerSample = (p.P + 31) / 32;
     p.totalTiles = B * p.tilesPerSample;
     return launch_small<1>(p, B, p.F / 32, NB, small_mode(p), st);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// coop_cell_kernel -- a WHOLE cell of a small plane in one launch (URNN_PHASE_COOP; ConvRNN.py:111-194): gates -> grid barrier ->
+// candidate -> grid barrier -> blend.  A plane of <= 16 384 pixels per launch is at most 256 blocks of 64 pixels: every block is
+// resident at once (one or two per CU), so the two whole-plane GroupNorm reductions can be barriers between phases instead of
+// kernel boundaries, and nothing but the partial statistics ever leaves the CU between the three phases:
+//   phase A  small_cell_gemm_kernel<0, 3>'s body: the tile's input rows -> f16 pieces in LDS, gate GEMM; the raw gates stay in the
+//            accumulators, their centred tile statistics go to partial1;                                        | grid barrier 1
+//   phase B  every wave folds the statistics of ITS 32-channel group (the order of the GATED prologue above: identical bits);
+//            update-gate waves turn their accumulators into z, reset-gate waves into r (.) h, split it into pieces and overwrite the
+//            hidden-state rows of the panel (a lane's 16 accumulator rows are channels {0-3, 8-11, ...} + 4 half of its block: eight
+//            dwords of the panel per piece); candidate GEMM on the reset-gate waves (same weights, pieces and MFMA order as
+//            small_cell_gemm_kernel<1, 3>: identical accumulators); statistics to partial2;                      | grid barrier 2
+//   phase C  candidate waves fold their group (gru_blend_kernel<FIN>'s order), take z through LDS from the partner wave, blend, store h'.
+// HBM traffic = K input planes + F planes of h a second time (L2) + F planes out: the three-kernel cell moved 2F + F raw planes
+// out and back and read the inputs twice.  Arithmetic and summation orders are those of the three kernels: h' is bit-identical.
+// Residency: blocks <= 256 = one per CU (<= 12 waves, ~130 registers, <= 150 KB LDS).  A stream's kernels run in order, so on ONE
+// kernel chain every block is resident as soon as the predecessor drains.  A rollout with TWO chains passes the flag only for
+// cells of at most 128 blocks (rollout.py: two such launches fit side by side, and kernels without a grid barrier always finish
+// and free their CUs).  Spins are bounded: a barrier that cannot complete in ~1 s raises a status bit
+// instead of hanging the chip.
+// ------------------------------------------------------------------------------------------------------------------------------------
+struct CoopCellParams {
+    ConvGemmParams g;            // the gate GEMM as urnn_launch_small_gates takes it (f16 slab in the grouped order, partial = partial1)
+    const unsigned *cwf16;       // candidate f16 slab [NG2][KT/8][NB2][2][64][4]
+    int cfDwords, cNB;           // dwords per candidate n-group, blocks per group
+    const float *cbias;          // candidate bias [F]
+    const float *gn2_w, *gn2_b;
+    float *partial2;             // [B][F/32][tiles][2]
+    float *h_out;
+    unsigned *bar;               // [0]: arrivals, [16]: generation (two cache lines of the workspace's status area)
+    int nblocks;
+    int zbufDwords;              // LDS dwords the z hand-over needs (aliases the panel)
+};
+
+
+// One monotonic generation word + an arrival counter the last arriver resets (MI355X_MICROARCH.md "barrier-counter" with the
+// hand-off protocol of cdna_hip_programming.md section 6 G16: every wave drains its stores, one lane releases at agent scope, polls
+// relaxed, acquires once).  <= 256 arrivals.
+__device__ __forceinline__ void coop_grid_barrier(unsigned *bar, unsigned nblocks, int *status)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned gen = __hip_atomic_load(&bar[16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == nblocks - 1) {
+            __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&bar[16], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            int spins = 0;
+            while (__hip_atomic_load(&bar[16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > (1 << 22)) {               // ~1 s: something else holds the chip; give up loudly instead of hanging it
+                    if (status) atomicOr(status, URNN_STATUS_BARRIER);
+                    break;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(768) void coop_cell_kernel(const CoopCellParams cp, int nblk_total, int NBG)
+{
+    const ConvGemmParams &prm = cp.g;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int j = lane & 31, half = lane >> 5;
+    const int blocksPerSample = (prm.P + 63) >> 6;
+    const int b = blockIdx.x / blocksPerSample, blk = blockIdx.x - b * blocksPerSample;
+    const int P = prm.P, F = prm.F, G = F / 32;
+    const int kg0 = prm.kpBegin >> 3, KG = (prm.KT - prm.kpBegin) >> 3;
+    constexpr int NPC = 2;
+
+    unsigned *Bp = reinterpret_cast<unsigned *>(urnn_small_smem);       // [KG][2][2][64][4] dwords
+    const int panelDw = KG * 2 * NPC * 256;
+    float *zbuf = reinterpret_cast<float *>(Bp + panelDw);               // [F/32][2][16][64]: z from the update-gate waves to their partners
+    float *bias = zbuf + cp.zbufDwords;
+    float *cbias = bias + nblk_total * 32;                              // [F]
+    float *sstab = cbias + F;                                           // [nwaves][32][2] (scale, shift) of a wave's own channels
+    if (threadIdx.x < nblk_total * 32) bias[threadIdx.x] = prm.biasf[threadIdx.x];
+    if (threadIdx.x < F) cbias[threadIdx.x] = cp.cbias[threadIdx.x];
+
+    const int nbg = wave >> 1, pbw = wave & 1;
+    const int g = nbg / NBG, nb = nbg - g * NBG;
+    const int cb = urnn_gate_cb(prm.gHalves, prm.gGS, G, g, nb);         // canonical block of [z_0 .. z_{G-1} | r_0 .. r_{G-1}]
+    const bool is_r = cb >= G;
+    const int ci = is_r ? cb - G : cb;                                    // channel block of z / r / c this wave works on
+    const u32x4 *Aw = reinterpret_cast<const u32x4 *>(prm.wf16 + (size_t)g * prm.fDwords) + lane;
+    auto a_ptr = [&](int gq, int piece) { return Aw + ((size_t)((kg0 + gq) * NBG + nb) * NPC + piece) * 64; };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    constexpr int PF = 4;
+    u32x4 ah[PF], am[PF];
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+        const int gq = q < KG ? q : KG - 1;
+        ah[q] = *a_ptr(gq, 0);
+        am[q] = *a_ptr(gq, 1);
+    }
+    // ---- phase A prologue: the tile's input rows -> f16 pieces in LDS (small_cell_gemm_kernel<0, 3>) -------------------------------
+    {
+        const int px = blk * 64 + lane;
+        const bool pix_ok = px < P;
+        const int pb = lane >> 5;
+        const int k1 = prm.segKp0[1], k2 = prm.segKp0[2];
+        auto act = [&](int kp, int hf) -> float {
+            if (!pix_ok) return 0.f;
+            const int sg = kp >= k2 ? 2 : (kp >= k1 ? 1 : 0);
+            const int ch = 2 * (kp - (sg == 2 ? k2 : (sg == 1 ? k1 : 0))) + hf;
+            return ch < prm.segC[sg] ? prm.seg[sg][((size_t)b * prm.segC[sg] + ch) * P + px] : 0.f;
+        };
+        const int nunits = KG * 8;
+        constexpr int UB = 8;
+        for (int u0 = wave; u0 < nunits; u0 += UB * nwaves) {
+            float v0[UB], v1[UB];
+#pragma unroll
+            for (int q = 0; q < UB; ++q) {
+                const int u = u0 + q * nwaves;
+                if (u < nunits) {
+                    const int gq = u >> 3, d = (u >> 1) & 3, hf = u & 1;
+                    const int kp0 = 8 * (kg0 + gq) + 2 * d;
+                    v0[q] = act(kp0, hf);
+                    v1[q] = act(kp0 + 1, hf);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < UB; ++q) {
+                const int u = u0 + q * nwaves;
+                if (u < nunits) {
+                    const int gq = u >> 3, d = (u >> 1) & 3, hf = u & 1;
+                    unsigned ph, pm;
+                    split2_pair(v0[q], v1[q], URNN_F16_ASCALE, ph, pm);
+                    unsigned *dst = Bp + ((((size_t)gq * 2 + pb) * NPC) * 64 + ((lane & 31) + 32 * hf)) * 4 + d;
+                    dst[0] = ph;
+                    dst[256] = pm;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    const u32x4 *Bw = reinterpret_cast<const u32x4 *>(Bp) + (size_t)pbw * NPC * 64 + lane;
+    auto mfma3 = [&](const u32x4 &wh, const u32x4 &wl, int gq) {
+        const u32x4 bh = Bw[(size_t)gq * 2 * NPC * 64], bm = Bw[(size_t)gq * 2 * NPC * 64 + 64];
+        const f16x8 fwh = __builtin_bit_cast(f16x8, wh), fwl = __builtin_bit_cast(f16x8, wl);
+        const f16x8 fxh = __builtin_bit_cast(f16x8, bh), fxl = __builtin_bit_cast(f16x8, bm);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwl, fxh, acc, 0, 0, 0);           // small terms first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwh, fxl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwh, fxh, acc, 0, 0, 0);
+    };
+    for (int gq0 = 0; gq0 < KG; gq0 += PF) {
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const int gq = gq0 + q;
+            if (gq < KG) {
+                mfma3(ah[q], am[q], gq);
+                const int gn = gq + PF < KG ? gq + PF : KG - 1;
+                ah[q] = *a_ptr(gn, 0);
+                am[q] = *a_ptr(gn, 1);
+            }
+        }
+    }
+
+    // ---- phase A epilogue: raw gates stay in registers, centred statistics of the 32 x 32 tile -> partial1 ---------------------------
+    const int tile = blk * 2 + pbw;
+    const int px = tile * 32 + j;
+    const bool ok = px < P;
+    const int nvalid = tile_valid(tile, 32, P);
+    auto row_c = [](int r) { return (r & 3) + 8 * (r >> 2); };
+    auto fin = [](float a, float bv) { return fmaf(a, URNN_F16_DESCALE, bv); };
+    const float inv_n = nvalid == 32 ? prm.invFull : prm.invTail;
+    {
+        const float *bias_h = bias + nbg * 32 + 4 * half;
+        float s1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc[r] = fin(acc[r], bias_h[row_c(r)]);
+            if (ok) s1 += acc[r];
+        }
+        s1 = wave_sum(s1);
+        const float mt = s1 * inv_n;
+        float s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float d = acc[r] - mt;
+            if (ok) s2 = fmaf(d, d, s2);
+        }
+        s2 = wave_sum(s2);
+        if (lane == 0 && nvalid > 0) {
+            float *pp = prm.partial + (((size_t)b * 2 * G + cb) * prm.tilesPerSample + tile) * 2;
+            pp[0] = s1;
+            pp[1] = s2;
+        }
+    }
+    const int cg = ci / cp.cNB, cnb = ci - cg * cp.cNB;
+    const u32x4 *Cw = reinterpret_cast<const u32x4 *>(cp.cwf16 + (size_t)cg * cp.cfDwords) + lane;
+    auto c_ptr = [&](int gq, int piece) { return Cw + ((size_t)((kg0 + gq) * cp.cNB + cnb) * NPC + piece) * 64; };
+    // h at this lane's 16 (channel, pixel) positions: the reset-gate waves need it for r (.) h and again for the blend
+    const float *hrow = prm.seg[prm.segKp0[2] != INT_MAX ? 2 : 1] + ((size_t)b * F + ci * 32 + 4 * half) * P + (ok ? px : 0);
+    float hv[16];
+    if (is_r) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hv[r] = ok ? hrow[(size_t)row_c(r) * P] : 0.f;
+    }
+
+    coop_grid_barrier(cp.bar, (unsigned)cp.nblocks, prm.status);
+
+    // ---- phase B: GroupNorm of this wave's gate block (the GATED prologue's fold: 8 loads in flight, lane-strided, xor butterfly) --
+    float *sst = sstab + wave * 64;
+    {
+        const float *pp = prm.partial + ((size_t)b * 2 * G + cb) * prm.tilesPerSample * 2;
+        const int gtiles = prm.tilesPerSample;
+        double s1 = 0.0, s2 = 0.0;
+        for (int t0 = 0; t0 < gtiles; t0 += 64 * 8) {
+            f32x2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + u * 64 + lane;
+                v[u] = t < gtiles ? *reinterpret_cast<const f32x2 *>(pp + 2 * t) : f32x2{0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                s1 += (double)v[u].x;
+                s2 += tile_x2(v[u].x, v[u].y, 32 * tile_valid(t0 + u * 64 + lane, 32, P));
+            }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            s1 += __shfl_xor(s1, m, 64);
+            s2 += __shfl_xor(s2, m, 64);
+        }
+        const double count = 32.0 * (double)P;
+        const double mean = s1 / count;
+        double var = s2 / count - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)prm.eps);
+        if (lane < 32) {
+            const int c = cb * 32 + lane;
+            const double sc = (double)prm.gn_w[c] * rstd;
+            sst[2 * lane] = (float)sc;
+            sst[2 * lane + 1] = (float)((double)prm.gn_b[c] - mean * sc);
+        }
+        if (blk == 0 && pbw == 0 && lane == 0) flag_nonfinite(prm.status, URNN_STATUS_GATES, s1, s2);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the table is this wave's own: no block barrier)
+    if (is_r) {                                              // the candidate's first weight pieces (L2) travel during the gating
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const int gq = q < KG ? q : KG - 1;
+            ah[q] = *c_ptr(gq, 0);
+            am[q] = *c_ptr(gq, 1);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const f32x2 st = *reinterpret_cast<const f32x2 *>(sst + 2 * (row_c(r) + 4 * half));
+        acc[r] = sigmoidf_fast(fmaf(acc[r], st.x, st.y));          // z (update-gate waves) / r (reset-gate waves)
+    }
+    if (is_r) {
+        // r (.) h -> the hidden-state rows of the panel.  Accumulator row r = 4 q + i is hidden channel 32 ci + 8 q + 4 half + i:
+        // k-pair 16 ci + 4 q + 2 half + (i >> 1), row parity i & 1  =>  16-k group gqH + 2 ci + (q >> 1), dword 2 (q & 1) + half,
+        // (i = 0, 2) / (i = 1, 3) the low / high halves of the dword of row parity 0 / 1 (the prologue's unit layout above)
+        const int gqH = (prm.hKp0 - prm.kpBegin) >> 3;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const float v0 = hv[4 * q + hf] * acc[4 * q + hf], v1 = hv[4 * q + hf + 2] * acc[4 * q + hf + 2];
+                unsigned ph, pm;
+                split2_pair(v0, v1, URNN_F16_ASCALE, ph, pm);
+                unsigned *dst = Bp + ((((size_t)(gqH + 2 * ci + (q >> 1)) * 2 + pbw) * NPC) * 64 + (j + 32 * hf)) * 4 + 2 * (q & 1) + half;
+                dst[0] = ph;
+                dst[256] = pm;
+            }
+        }
+    }
+    float *zb = zbuf + (size_t)(ci * 2 + pbw) * 1024 + lane;
+    if (!is_r) {                                             // update-gate waves are done after handing z over
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zb[r * 64] = acc[r];
+    }
+    __syncthreads();
+    if (is_r) {
+        // candidate GEMM (small_cell_gemm_kernel<1, 3>'s main loop on the panel whose hidden rows now hold r (.) h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int gq0 = 0; gq0 < KG; gq0 += PF) {
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+                const int gq = gq0 + q;
+                if (gq < KG) {
+                    mfma3(ah[q], am[q], gq);
+                    const int gn = gq + PF < KG ? gq + PF : KG - 1;
+                    ah[q] = *c_ptr(gn, 0);
+                    am[q] = *c_ptr(gn, 1);
+                }
+            }
+        }
+        const float *cb_h = cbias + ci * 32 + 4 * half;
+        float s1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc[r] = fin(acc[r], cb_h[row_c(r)]);
+            if (ok) s1 += acc[r];
+        }
+        s1 = wave_sum(s1);
+        const float mt = s1 * inv_n;
+        float s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float d = acc[r] - mt;
+            if (ok) s2 = fmaf(d, d, s2);
+        }
+        s2 = wave_sum(s2);
+        if (lane == 0 && nvalid > 0) {
+            float *pp = cp.partial2 + (((size_t)b * G + ci) * prm.tilesPerSample + tile) * 2;
+            pp[0] = s1;
+            pp[1] = s2;
+        }
+    }
+
+    coop_grid_barrier(cp.bar, (unsigned)cp.nblocks, prm.status);
+
+    // ---- phase C: candidate GroupNorm (gru_blend_kernel<FIN>'s order), z from the partner wave's hand-over, blend ----------------------
+    if (is_r) {
+        // 256 threads stride the tiles, xor butterfly per wave, waves combined as (w0 + w1) + (w2 + w3): the same additions, one wave
+        const float *pp = cp.partial2 + ((size_t)b * G + ci) * prm.tilesPerSample * 2;
+        auto sub = [&](int w, double &o1, double &o2) {
+            double a1 = 0.0, a2 = 0.0;
+            for (int t = w * 64 + lane; t < prm.tilesPerSample; t += 256) {
+                const f32x2 v = *reinterpret_cast<const f32x2 *>(pp + 2 * t);
+                a1 += (double)v.x;
+                a2 += tile_x2(v.x, v.y, 32 * tile_valid(t, 32, P));
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                a1 += __shfl_xor(a1, m, 64);
+                a2 += __shfl_xor(a2, m, 64);
+            }
+            o1 = a1;
+            o2 = a2;
+        };
+        double p0, q0, p1, q1;
+        sub(0, p0, q0);
+        sub(1, p1, q1);
+        const double S1a = p0 + p1, S2a = q0 + q1;
+        sub(2, p0, q0);
+        sub(3, p1, q1);
+        const double S1 = S1a + (p0 + p1), S2 = S2a + (q0 + q1);
+        const double count = 32.0 * (double)P;
+        const double mean = S1 / count;
+        double var = S2 / count - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)prm.eps);
+        if (lane < 32) {
+            const int c = ci * 32 + lane;
+            const double sc = (double)cp.gn2_w[c] * rstd;
+            sst[2 * lane] = (float)sc;
+            sst[2 * lane + 1] = (float)((double)cp.gn2_b[c] - mean * sc);
+        }
+        if (blk == 0 && pbw == 0 && lane == 0) flag_nonfinite(prm.status, URNN_STATUS_CAND, S1, S2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (is_r && ok) {
+        float *orow = cp.h_out + ((size_t)b * F + ci * 32 + 4 * half) * P + px;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const f32x2 st = *reinterpret_cast<const f32x2 *>(sst + 2 * (row_c(r) + 4 * half));
+            const float z = zb[r * 64];
+            const float n = tanhf_fast(fmaf(acc[r], st.x, st.y));
+            orow[(size_t)row_c(r) * P] = gru_blend(z, n, hv[r]);
+        }
+    }
+}
+
+// LDS of a cooperative cell launch: panel (or the z hand-over, whichever is larger) + gate bias + candidate bias + per-wave tables
+static size_t coop_lds_bytes(const ConvGemmParams &p, int nblk_total)
+{
+    const size_t KG = (size_t)(p.KT - p.kpBegin) / 8;
+    const size_t panel = KG * 2 * 2 * 1024, zbuf = (size_t)(p.F / 32) * 2 * 4096;
+    return panel + zbuf + (size_t)nblk_total * 128 + (size_t)p.F * 4 + (size_t)nblk_total * 2 * 256;
+}
+
+// Can this cell run as ONE cooperative launch?  p / c: the gate / candidate parameter blocks as gru_cell_impl builds them.
+bool urnn_coop_cell_ok(const ConvGemmParams &p, const ConvGemmParams &c, int B)
+{
+    static const int on = [] { const char *e = getenv("URNN_TUNE_COOP"); return e ? atoi(e) : 1; }();   // development knob (A/B)
+    if (!on) return false;
+    const int mm = urnn_get_matrix_mode();
+    if (mm != URNN_MATRIX_FP32 && mm != URNN_MATRIX_FP32_CAND) return false;           // the f16-piece arithmetic only
+    if (small_mode(p) != 3 || small_mode(c) != 3 || !p.biasf) return false;
+    const int nblk = 2 * p.F / 32;
+    if (!urnn_small_ok(p, nblk, 0) || !urnn_small_ok(c, p.F / 32, 1)) return false;
+    if (c.hKp0 % 8 != 0 || c.hKp0 >= c.KT || (c.KT - c.hKp0) * 2 != p.F) return false;
+    if (nblk * 2 * 64 > 768) return false;                                               // F <= 96: twelve waves
+    const long blocks = (long)B * ((p.P + 63) / 64);
+    const size_t lds = coop_lds_bytes(p, nblk);
+    // every block must be resident at once: one per CU.  (A caller with two kernel chains in flight passes the flag up to 128 blocks
+    // only -- urnn_gru_cell_coop_blocks, include/urnn_hip.h.)
+    return blocks <= 256 && lds <= 150 * 1024;
+}
+
+hipError_t urnn_launch_coop_cell(ConvGemmParams p, const ConvGemmParams &c, const float *gn2_w, const float *gn2_b, float *h_out, unsigned *bar,
+                                 int B, hipStream_t st)
+{
+    p.tilesPerSample = (p.P + 31) / 32;
+    p.totalTiles = B * p.tilesPerSample;
+    {
+        const int tail = p.P - (p.tilesPerSample - 1) * 32;
+        p.invFull = 1.0f / 1024.0f;
+        p.invTail = 1.0f / (32.0f * (float)(tail > 0 ? tail : 32));
+    }
+    const int nblk = 2 * p.F / 32;
+    CoopCellParams cp;
+    cp.g = p;
+    cp.g.NG = p.NGf;
+    cp.cwf16 = c.wf16;
+    cp.cfDwords = c.fDwords;
+    cp.cNB = urnn_cand_nb(p.F);
+    cp.cbias = c.bias;
+    cp.g.hKp0 = c.hKp0;
+    cp.g.gn_w = c.gn_w;
+    cp.g.gn_b = c.gn_b;
+    cp.g.eps = c.eps;
+    cp.gn2_w = gn2_w;
+    cp.gn2_b = gn2_b;
+    cp.partial2 = c.partial;
+    cp.h_out = h_out;
+    cp.bar = bar;
+    cp.nblocks = B * ((p.P + 63) / 64);
+    cp.zbufDwords = (p.F / 32) * 2 * 1024;
+    const size_t lds = coop_lds_bytes(p, nblk);
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(coop_cell_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
+    hipLaunchKernelGGL(coop_cell_kernel, dim3(cp.nblocks), dim3(64 * nblk * 2), lds, st, cp, nblk, p.NBf);
+    return hipGetLastError();
 }

@@ -131,7 +131,7 @@ def head_workspace_bytes(B, C, H, W):
     return lib().urnn_head_workspace_bytes(B, C, H, W)
 
 
-STATUS_GATES, STATUS_CAND, STATUS_HEAD = 1, 2, 4     # include/urnn_hip.h: word 0 of a cell / head workspace
+STATUS_GATES, STATUS_CAND, STATUS_HEAD, STATUS_BARRIER = 1, 2, 4, 8     # include/urnn_hip.h: word 0 of a cell / head workspace
 STATUS_NAMES = {STATUS_GATES: "GroupNorm sums of a cell's gates", STATUS_CAND: "GroupNorm sums of a cell's candidate",
                 STATUS_HEAD: "LayerNorm sums of the head"}
 
@@ -192,6 +192,7 @@ def stage_conv(x, packed, Cout, pool, out=None, slope=LRELU_SLOPE):
 
 
 PHASE_GATES, PHASE_GN1, PHASE_CAND, PHASE_GN2, PHASE_BLEND, PHASE_ALL = 1, 2, 4, 8, 16, 31
+PHASE_COOP = 64        # modifier: the whole cell of a small plane as one cooperative launch (include/urnn_hip.h URNN_PHASE_COOP)
 PHASE_FUSED_R = 32     # modifier: reset gate recomputed inside the candidate kernel (include/urnn_hip.h URNN_PHASE_FUSED_R)
 
 

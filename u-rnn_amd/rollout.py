@@ -15,10 +15,13 @@ from .general import initialize_states
 class RolloutEngine:
     def __init__(self, net, input_height, input_width, historical_nums, rain_max, cumsum_rain_max, batch=1,
                  max_frames=360, spatial_rain=False, net_cfg=None, use_graph=True, keep_raw=False,
-                 device=None, overlap=False, fused_reset_gate=True):
+                 device=None, overlap=False, fused_reset_gate=True, coop_cells=True):
         self.net = net
         # cells whose shape has the form recompute the reset gate inside the candidate kernel instead of round-tripping its raw
         # planes through HBM (include/urnn_hip.h URNN_PHASE_FUSED_R); the engine never reads a cell's workspace
+        # ... and cells on small planes run as ONE cooperative launch (URNN_PHASE_COOP: gates | grid barrier | candidate | grid
+        # barrier | blend, nothing but statistics leaving the CU in between)
+        # barrier | blend, nothing but statistics leaving the CU in between): per cell, self._coop below
         self._cell_flags = ops.PHASE_FUSED_R if fused_reset_gate else 0
         self.H, self.W = int(input_height), int(input_width)
         self.nums = int(historical_nums)
@@ -82,6 +85,16 @@ class RolloutEngine:
         self._graph = None
         self._graphs2 = None
         self._side = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)) if self.overlap else None
+        # A cooperative cell launch needs ALL its blocks resident (one per CU).  With two kernel chains in flight, two such launches
+        # of at most 128 blocks each always fit side by side; a larger one could wait at its grid barrier for CUs the other chain's
+        # cooperative launch holds while that one waits for CUs of ours.  So with overlap=True only cells of <= 128 blocks take the
+        # flag (measured at 500x500, 245 blocks: ordering the two chains' launches instead costs more than the launch saves,
+        # profiles/r04_coop_cells.txt); one chain takes it wherever the library plans it.
+        def coop_flag(cell, has_x, skip):
+            n = L.urnn_gru_cell_coop_blocks(B, cell.input_channels, cell.num_features, cell.shape[0], cell.shape[1], int(skip), int(has_x))
+            return ops.PHASE_COOP if (coop_cells and n > 0 and (n <= 128 or not self.overlap)) else 0
+        self._coop = {"enc1": coop_flag(enc.rnn1, 1, 0), "enc2": coop_flag(enc.rnn2, 1, 0), "enc3": coop_flag(enc.rnn3, 1, 0),
+                      "dec3": coop_flag(dec.rnn3, 0, 1), "dec2": coop_flag(dec.rnn2, 1, 1), "dec1": coop_flag(dec.rnn1, 1, 1)}
         self._dem_stamp = None
 
     # -- one timestep, all launches on the current stream ----------------------------------------------
@@ -95,8 +108,8 @@ class RolloutEngine:
         enc.stage2(e1, out=self.a2)
         self._cell("enc2", enc.rnn2, self.a2, None, e2, e2, ws)
         enc.stage3(e2, out=self.a3)
-        enc.rnn3.step(self.a3, None, e3, out=e3, ws=ws)
-        dec.rnn3.step(None, e3, d1, out=d1, ws=ws)
+        self._cell("enc3", enc.rnn3, self.a3, None, e3, e3, ws)
+        self._cell("dec3", dec.rnn3, None, e3, d1, d1, ws)
         dec.stage3(d1, out=self.u3)
         self._cell("dec2", dec.rnn2, self.u3, e2, d2, d2, ws)
         dec.stage2(d2, out=self.u2)
@@ -129,7 +142,7 @@ class RolloutEngine:
                 b.record()
                 self._probe[name][kind].append((a, b))
         else:
-            cell.step(x, e, h, out=out, phases=ops.PHASE_ALL | self._cell_flags, ws=ws)
+            cell.step(x, e, h, out=out, phases=ops.PHASE_ALL | self._cell_flags | self._coop[name], ws=ws)
 
     PROBED_CELLS = ("enc1", "dec1", "enc2", "dec2")
 
@@ -178,7 +191,7 @@ class RolloutEngine:
 
         def e3():
             enc.stage3(n2, out=self.a3)
-            enc.rnn3.step(self.a3, None, p3, out=n3, ws=ws)
+            self._cell("enc3", enc.rnn3, self.a3, None, p3, n3, ws)
             ops.advance_counter(self.te_dev, 1)
         return [e1, e2, e3]
 
@@ -191,7 +204,7 @@ class RolloutEngine:
         ws = self._ws[1]                       # chain 2 (decoder) scratch
 
         def s3():
-            dec.rnn3.step(None, e3, d1, out=d1, ws=ws)
+            self._cell("dec3", dec.rnn3, None, e3, d1, d1, ws)
             dec.stage3(d1, out=self.u3)
 
         def s2():
