@@ -154,6 +154,26 @@ int urnn_gru_cell_f32(const float *x, const float *e, const float *h, const floa
 #define URNN_PHASE_COOP 64
 #define URNN_STATUS_BARRIER 8
 int urnn_gru_cell_coop_blocks(int B, int I, int F, int H, int W, int skip, int has_x);
+/* The END of a cell fused with the layer that consumes its new state (encoder.py:170-185, decoder.py:150-164: every cell's output
+ * goes straight into a stage's 1x1 conv): the phases in phase_mask run as in urnn_gru_cell_phases_f32, except that GN2 | BLEND and
+ * the conv  conv_out = [AvgPool2](LeakyReLU_slope(Wc . h_out + bc))  (conv_packed: urnn_pack_conv_f32 of a conv with Cin = F) are ONE
+ * launch -- h_out is written as always, but the stage conv no longer reads it back and is no launch of its own.  h_out is
+ * bit-identical to the unfused cell's, conv_out to urnn_stage_conv_f32(h_out).  With head_conv_w (the head's stem conv, 16 x 16; flat
+ * Cout = 16 only) the launch also takes the statistics of the head's first LayerNorm into head_partial0
+ * (urnn_head_tail_partial_floats floats) and urnn_head_after_tail_f32 runs the head without its first pass over feat
+ * (flood_head.py:131-140).  Shapes: urnn_gru_cell_tail_applies (F = 64 / 96, Cout <= F, even H and W when pooling, f16-piece matrix
+ * modes); other shapes return URNN_EINVAL -- call the unfused entries. */
+int urnn_gru_cell_tail_applies(int B, int F, int H, int W, int Cout, int pool);
+size_t urnn_head_tail_partial_floats(int B, int H, int W);
+int urnn_gru_cell_tail_f32(const float *x, const float *e, const float *h, const float *packed, const float *gn1_w,
+                           const float *gn1_b, const float *gn2_w, const float *gn2_b, float *h_out, void *workspace,
+                           size_t workspace_bytes, int B, int I, int F, int H, int W, float eps, int phase_mask,
+                           const float *conv_packed, int Cout, int pool, float slope, float *conv_out,
+                           const float *head_conv_w, float *head_partial0, void *stream);
+int urnn_head_after_tail_f32(const float *feat, const float *conv_w, const float *ln_w, const float *ln_b, const float *cls_w,
+                             const float *cls_b, const float *reg_w, const float *reg_b, float *out_masked, float *out_cls,
+                             float *out_raw, const int *frame_index, void *workspace, size_t workspace_bytes, int B, int C, int H,
+                             int W, float cls_thred, float eps, float slope, const float *head_partial0, void *stream);
 /* 1 when URNN_PHASE_FUSED_R takes effect for a cell of this shape under the current matrix mode (x present; skip: an e input of F
  * channels), else 0 -- for byte accounting (bench.py) and tests; the cell entry decides by the same rule. */
 int urnn_gru_cell_fused_reset_gate_applies(int B, int I, int F, int H, int W, int skip);

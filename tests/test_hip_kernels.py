@@ -254,7 +254,13 @@ def test_cooperative_cell_equals_three_kernels(dev, I, F, skip, H, W, B, with_x)
     one = ops.gru_cell(*args, T(h, dev), packed, *aff, I, phases=ops.PHASE_ALL | ops.PHASE_COOP, ws=ws)
     torch.cuda.synchronize()
     assert ops.workspace_status(ws) == 0
-    assert torch.equal(one, three), f"cooperative cell differs from the three kernels: max {float((one - three).abs().max()):.3e}"
+    if not torch.equal(one, three):
+        d = (one - three).abs()
+        idx = [int(v) for v in np.unravel_index(int(d.argmax()), d.shape)]
+        nbad = int((d > 0).sum())
+        bad_bc = sorted({(int(a), int(c)) for a, c in torch.nonzero(d.amax(dim=(2, 3)) > 0).tolist()})[:12]
+        pytest.fail(f"cooperative cell differs from the three kernels: max {float(d.max()):.3e} at (b, ch, y, x) = {idx}, {nbad} of {d.numel()} "
+                    f"values differ; (sample, channel) pairs with differences: {bad_bc}")
     assert_close(one.cpu().numpy(), orc.gru_cell(x, e, h, p), TOL, "cooperative cell vs oracle")
     hh = T(h, dev)
     for _ in range(25):                                   # in place, barrier state reused launch after launch
@@ -274,3 +280,59 @@ def test_cooperative_cell_is_not_planned_for_large_planes_or_other_modes(dev):
     assert L.urnn_gru_cell_coop_blocks(1, 96, 96, 125, 125, 0, 1) == 245
     with ops.matrix_mode("fp32_mfma"):
         assert L.urnn_gru_cell_coop_blocks(1, 96, 96, 125, 125, 0, 1) == 0      # the exact-fp32 mode keeps its own kernels
+
+
+@pytest.mark.parametrize("I,F,skip,H,W,B,Cout,pool,with_head", [
+    (16, 64, 0, 64, 66, 2, 64, True, False),     # encoder stage 1 -> stage-2 conv + pool (the pooled plane's last block is partial)
+    (64, 96, 0, 30, 34, 1, 96, True, False),     # encoder stage 2 -> stage-3 conv + pool: three output blocks, twelve waves
+    (96, 64, 1, 37, 41, 2, 16, False, True),     # decoder stage 1 -> final conv + the head's first LayerNorm statistics, odd plane
+    (96, 64, 1, 256, 260, 1, 16, False, True),   # ... on a plane large enough for the fused-reset-gate cell (66 560 pixels)
+])
+def test_cell_tail_equals_blend_then_conv(dev, I, F, skip, H, W, B, Cout, pool, with_head):
+    """urnn_gru_cell_tail_f32 (encoder.py:170-185, decoder.py:150-164, flood_head.py:131-140): GroupNorm finalize + blend + the stage
+    conv that consumes the new state in ONE launch, against the cell followed by urnn_stage_conv_f32: the new state and the conv
+    output bit-identical; with the head's statistics taken in the same launch, the head's outputs within 1e-5 of the four-pass head
+    (its first LayerNorm's sums are grouped differently) and both within 1e-4 of the oracle."""
+    from oracle import oracle as orc
+    from urnn_amd import ops
+    rs = np.random.RandomState(500 + I + F + H)
+    K = I + (2 * F if skip else F)
+    p = {"W1": rs.normal(0, 1 / np.sqrt(K), (2 * F, K)).astype(np.float32), "b1": rs.normal(0, 0.1, 2 * F).astype(np.float32),
+         "g1": rs.uniform(0.5, 1.5, 2 * F).astype(np.float32), "be1": rs.normal(0, 0.1, 2 * F).astype(np.float32),
+         "W2": rs.normal(0, 1 / np.sqrt(K), (F, K)).astype(np.float32), "b2": rs.normal(0, 0.1, F).astype(np.float32),
+         "g2": rs.uniform(0.5, 1.5, F).astype(np.float32), "be2": rs.normal(0, 0.1, F).astype(np.float32)}
+    x = rs.normal(0, 1, (B, I, H, W)).astype(np.float32)
+    e = rs.normal(0, 1, (B, F, H, W)).astype(np.float32) if skip else None
+    h = rs.normal(0, 1, (B, F, H, W)).astype(np.float32)
+    wc = rs.normal(0, 1 / np.sqrt(F), (Cout, F, 1, 1)).astype(np.float32)
+    bc = rs.normal(0, 0.1, Cout).astype(np.float32)
+    assert ops.gru_cell_tail_applies(B, F, H, W, Cout, pool)
+    packed = ops.pack_gru(T(p["W1"].reshape(2 * F, K, 1, 1), dev), T(p["b1"], dev), T(p["W2"].reshape(F, K, 1, 1), dev),
+                          T(p["b2"], dev), I, F, bool(skip))
+    cpk = ops.pack_conv(T(wc, dev), T(bc, dev))
+    args = (T(x, dev), None if e is None else T(e, dev))
+    aff = (T(p["g1"], dev), T(p["be1"], dev), T(p["g2"], dev), T(p["be2"], dev))
+    for flags in (0, ops.PHASE_FUSED_R):
+        want_h = ops.gru_cell(*args, T(h, dev), packed, *aff, I, phases=ops.PHASE_ALL | flags)
+        want_c = ops.stage_conv(want_h, cpk, Cout, pool)
+        hw = T(rs.normal(0, 0.25, (16, 16)).astype(np.float32), dev) if with_head else None
+        part0 = ops.head_tail_partial(B, H, W, dev) if with_head else None
+        hh = T(h, dev)
+        got_h, got_c = ops.gru_cell_tail(*args, hh, packed, *aff, I, cpk, Cout, pool, out=hh, phases=ops.PHASE_ALL | flags,
+                                         head_w=hw, head_partial0=part0)                  # in place, like the rollout engine
+        assert torch.equal(got_h, want_h), f"new state differs: max {float((got_h - want_h).abs().max()):.3e}"
+        assert torch.equal(got_c, want_c), f"conv output differs: max {float((got_c - want_c).abs().max()):.3e}"
+    ref_h = orc.gru_cell(x, e, h, p)
+    assert_close(got_h.cpu().numpy(), ref_h, TOL, "tail: new state vs oracle")
+    assert_close(got_c.cpu().numpy(), orc.stage_conv(ref_h, wc.reshape(Cout, F), bc, pool), TOL, "tail: conv output vs oracle")
+    if with_head:
+        P = H * W
+        conv_w = torch.cat([hw[None], T(rs.normal(0, 0.25, (4, 16, 16)).astype(np.float32), dev)])
+        ln_w = T(rs.uniform(0.5, 1.5, (5, 16, H, W)).astype(np.float32), dev)
+        ln_b = T(rs.normal(0, 0.1, (5, 16, H, W)).astype(np.float32), dev)
+        cw, cb_, rw, rb = (T(rs.normal(0, 0.3, 16).astype(np.float32), dev), T(np.zeros(1, np.float32), dev),
+                           T(rs.normal(0, 0.3, 16).astype(np.float32), dev), T(np.full(1, 0.1, np.float32), dev))
+        four = ops.head(got_c, conv_w, ln_w, ln_b, cw, cb_, rw, rb, 0.5, want_raw=True)
+        three = ops.head(got_c, conv_w, ln_w, ln_b, cw, cb_, rw, rb, 0.5, want_raw=True, partial0=part0)
+        for a_, b_, what in ((three[1], four[1], "cls"), (three[2], four[2], "pre-mask reg")):
+            assert_close(a_.cpu().numpy(), b_.cpu().numpy(), 1e-5, f"three-pass head vs four-pass head, {what}")

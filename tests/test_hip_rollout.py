@@ -789,3 +789,24 @@ def test_activation_beyond_the_f16_range_raises(dev):
     with ops.matrix_mode("fp32_mfma"):
         eng = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T, overlap=True, use_graph=True)
         assert torch.isfinite(eng.rollout(ev)).all()
+
+
+def test_fused_tails_rollout_matches_the_default_schedule(dev):
+    """RolloutEngine(fused_tails=True): the end of enc1 / enc2 / dec1 runs together with the stage conv behind it (and dec1's with the
+    head's first LayerNorm statistics) -- encoder.py:170-185, decoder.py:150-164, flood_head.py:131-140.  On a grid whose cells do not
+    take the cooperative launch (160x200: 500 / 125 blocks at full / half resolution with two chains) the six states stay bit-identical
+    to the default schedule over a rollout, the frames within 1e-5 (the head's first statistics are grouped differently)."""
+    import urnn_amd.weights as uw
+    from urnn_amd.rollout import RolloutEngine
+    H, W, nums, T = 160, 200, 3, 4
+    net, _ = make_net(H, W, 2 * nums + 3, 21, dev)
+    ev = uw.make_event(T, H, W, 60.0, seed=4)
+    base = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T, keep_raw=True, overlap=True, use_graph=True)
+    base.rollout(ev)
+    tails = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T, keep_raw=True, overlap=True, use_graph=True, fused_tails=True)
+    tails.rollout(ev)
+    assert tails._tail_of("enc1") is not None and tails._tail_of("dec1") is not None and base._tail_of("dec1") is None
+    for k, (a, b) in enumerate(zip(tails.final_states(), base.final_states())):
+        assert torch.equal(a, b), f"state {k} differs with fused tails"
+    assert_close(tails.out_raw[:T].cpu().numpy(), base.out_raw[:T].cpu().numpy(), 1e-5, "pre-mask reg with fused tails")
+    assert_close(tails.out_cls[:T].cpu().numpy(), base.out_cls[:T].cpu().numpy(), 1e-5, "cls with fused tails")

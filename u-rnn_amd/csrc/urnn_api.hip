@@ -255,11 +255,21 @@ extern "C" int urnn_gru_cell_fused_reset_gate_applies(int B, int I, int F, int H
     return urnn_cand_fused_plan(p, B) != 0;
 }
 
+// the consumer of the cell's new state, fused with the cell's last kernel (urnn_gru_cell_tail_f32)
+struct TailArgs {
+    const float *conv_packed;
+    int Cout, pool;
+    float slope;
+    float *conv_out;
+    const float *head_w;
+    float *head_partial0;
+};
+
 // forward declaration: the cell entry with a "plan only" switch (coop_blocks != nullptr: report, launch nothing)
 static int gru_cell_impl(const float *x, const float *e, const float *h, const float *packed, const float *gn1_w,
                          const float *gn1_b, const float *gn2_w, const float *gn2_b, float *h_out, void *workspace,
                          size_t workspace_bytes, int B, int I, int F, int H, int W, float eps, int phase_mask, long global_pixels,
-                         void *stream, int *coop_blocks = nullptr);
+                         void *stream, int *coop_blocks = nullptr, const TailArgs *tail = nullptr);
 
 // Blocks of the cooperative launch a cell of this shape would take under URNN_PHASE_COOP (0: it would run its three kernels).  More than
 // 128 blocks means the launch needs more than half of the chip's CUs to itself: a caller that keeps SEVERAL kernel chains in flight
@@ -282,7 +292,7 @@ extern "C" int urnn_gru_cell_coop_blocks(int B, int I, int F, int H, int W, int 
 static int gru_cell_impl(const float *x, const float *e, const float *h, const float *packed, const float *gn1_w,
                          const float *gn1_b, const float *gn2_w, const float *gn2_b, float *h_out, void *workspace,
                          size_t workspace_bytes, int B, int I, int F, int H, int W, float eps, int phase_mask, long global_pixels,
-                         void *stream, int *coop_blocks)
+                         void *stream, int *coop_blocks, const TailArgs *tail)
 {
     if (!h || !packed || !gn1_w || !gn1_b || !gn2_w || !gn2_b || !h_out || !workspace)
         return fail(URNN_ENULL, "urnn_gru_cell_f32: NULL argument");
@@ -415,13 +425,13 @@ static int gru_cell_impl(const float *x, const float *e, const float *h, const f
     int tiles2 = gru_tiles(B, F, P, 2, &pb2, &map2);
     // URNN_PHASE_COOP: the whole cell of a small plane as ONE cooperative launch (urnn_small.hip coop_cell_kernel) -- when the caller
     // asked for every phase and the shape qualifies; otherwise the flag is ignored and the three kernels run
-    if ((phase_mask & URNN_PHASE_COOP) && (phase_mask & URNN_PHASE_ALL) == URNN_PHASE_ALL && global_pixels <= 0 && !fused_r && small_gates &&
+    if ((phase_mask & URNN_PHASE_COOP) && !tail && (phase_mask & URNN_PHASE_ALL) == URNN_PHASE_ALL && global_pixels <= 0 && !fused_r && small_gates &&
         small_on && pb2 == 1 && urnn_coop_cell_ok(p, c, B)) {
         if (coop_blocks) {                                          // plan only (urnn_gru_cell_coop_blocks)
             *coop_blocks = B * (int)((P + 63) / 64);
             return URNN_OK;
         }
-        CHECK_HIP(urnn_launch_coop_cell(p, c, gn2_w, gn2_b, h_out, reinterpret_cast<unsigned *>(ws.status) + 16, B, st), "gru cell (one cooperative launch)");
+        CHECK_HIP(urnn_launch_coop_cell(p, c, gn2_w, gn2_b, ws.ss2, h_out, reinterpret_cast<unsigned *>(ws.status) + 16, B, st), "gru cell (one cooperative launch)");
         return URNN_OK;
     }
     if (coop_blocks) return URNN_OK;                                // plan only: not a cooperative launch (*coop_blocks stays 0)
@@ -451,6 +461,25 @@ static int gru_cell_impl(const float *x, const float *e, const float *h, const f
     // launches for phase-split callers (profiling, strips: the statistics are exchanged in between)
     static const bool fuse_on = !getenv("URNN_TUNE_FUSE_BLEND") || atoi(getenv("URNN_TUNE_FUSE_BLEND")) != 0;   // development knob
     const bool fused = fuse_on && (phase_mask & URNN_PHASE_GN2) && (phase_mask & URNN_PHASE_BLEND) && global_pixels <= 0;
+    if (tail && (phase_mask & URNN_PHASE_GN2) && (phase_mask & URNN_PHASE_BLEND)) {
+        // finalize + blend + the consumer's 1x1 conv in one launch (urnn_tail.hip); the caller checked urnn_gru_cell_tail_applies
+        const int Cout = tail->Cout;
+        const int NBc = urnn_conv_nb(Cout), NGc = urnn_conv_ng(Cout), KTc = (F + 1) / 2;
+        const float *cb = tail->conv_packed + (size_t)NGc * slab_floats(KTc, NBc);
+        TailParams tp = {};
+        tp.g1 = ws.g1; tp.cx = ws.cx; tp.h = h; tp.h_out = h_out; tp.ss1 = ws.ss1;
+        tp.partial2 = ws.part2; tp.ntiles2 = tiles2; tp.tile_pix2 = 32 * pb2; tp.count = count;
+        tp.gn2_w = gn2_w; tp.gn2_b = gn2_b; tp.eps = eps; tp.ss2_out = ws.ss2; tp.stat2_out = ws.st2; tp.status = ws.status;
+        tp.B = B; tp.F = F; tp.P = (int)P; tp.W = W;
+        tp.wf16 = reinterpret_cast<const unsigned *>(cb + (size_t)NGc * NBc * 32) + (size_t)NGc * urnn_split_slab_dwords(KTc, NBc);
+        tp.fDwords = urnn_f16_slab_dwords(KTc, NBc);
+        tp.wDwords = NGc * tp.fDwords;
+        tp.NBc = NBc; tp.Cout = Cout; tp.bias = cb; tp.slope = tail->slope; tp.out = tail->conv_out;
+        tp.head_w = tail->pool ? nullptr : tail->head_w;
+        tp.partial0 = tail->head_partial0;
+        CHECK_HIP(urnn_launch_tail(tp, H, tail->pool, st), "gru finalize + blend + consumer conv");
+        return URNN_OK;
+    }
     if (fused) {
         CHECK_HIP(urnn_launch_blend_fin(ws.g1, ws.cx, h, ws.ss1, h_out, B, F, (int)P, ws.part2, tiles2, 32 * pb2, count, gn2_w, gn2_b, eps, ws.ss2,
                                         ws.st2, ws.status, st), "gru finalize + blend");
@@ -470,6 +499,36 @@ extern "C" int urnn_gru_cell_phases_f32(const float *x, const float *e, const fl
 {
     return gru_cell_impl(x, e, h, packed, gn1_w, gn1_b, gn2_w, gn2_b, h_out, workspace, workspace_bytes, B, I, F, H, W, eps, phase_mask, 0,
                          stream);
+}
+
+// 1 when the end of a cell on (B, F, H, W) can be fused with a 1x1 conv F -> Cout (pool: + AvgPool2) under the current matrix mode
+extern "C" int urnn_gru_cell_tail_applies(int B, int F, int H, int W, int Cout, int pool)
+{
+    if (B < 1 || F < 32 || H < 1 || W < 1 || Cout < 1) return 0;
+    return urnn_tail_ok(B, F, H, W, F, Cout, pool) ? 1 : 0;
+}
+
+extern "C" size_t urnn_head_tail_partial_floats(int B, int H, int W)
+{
+    if (B < 1 || H < 1 || W < 1) return 0;
+    return (size_t)B * (((size_t)H * W + 127) / 128) * 2;
+}
+
+extern "C" int urnn_gru_cell_tail_f32(const float *x, const float *e, const float *h, const float *packed, const float *gn1_w,
+                                      const float *gn1_b, const float *gn2_w, const float *gn2_b, float *h_out, void *workspace,
+                                      size_t workspace_bytes, int B, int I, int F, int H, int W, float eps, int phase_mask,
+                                      const float *conv_packed, int Cout, int pool, float slope, float *conv_out,
+                                      const float *head_conv_w, float *head_partial0, void *stream)
+{
+    if (!conv_packed || !conv_out) return fail(URNN_ENULL, "urnn_gru_cell_tail_f32: NULL consumer conv");
+    if ((head_conv_w != nullptr) != (head_partial0 != nullptr)) return fail(URNN_EINVAL, "urnn_gru_cell_tail_f32: head_conv_w and head_partial0 go together");
+    if (head_conv_w && (pool || Cout != 16)) return fail(URNN_EINVAL, "urnn_gru_cell_tail_f32: the head statistics need the flat 16-channel feature map");
+    if (!aligned16(conv_packed)) return fail(URNN_EALIGN, "urnn_gru_cell_tail_f32: conv_packed must be 16-byte aligned");
+    if (!urnn_tail_ok(B, F, H, W, F, Cout, pool))
+        return fail(URNN_EINVAL, "urnn_gru_cell_tail_f32: no fused form for F=%d -> %d (pool=%d) on %dx%d in this matrix mode (urnn_gru_cell_tail_applies)", F, Cout, pool, H, W);
+    const TailArgs t = {conv_packed, Cout, pool, slope, conv_out, head_conv_w, head_partial0};
+    return gru_cell_impl(x, e, h, packed, gn1_w, gn1_b, gn2_w, gn2_b, h_out, workspace, workspace_bytes, B, I, F, H, W, eps,
+                         phase_mask & ~URNN_PHASE_COOP, 0, stream, nullptr, &t);
 }
 
 extern "C" int urnn_gru_cell_strip_f32(const float *x, const float *e, const float *h, const float *packed, const float *gn1_w,
@@ -931,7 +990,8 @@ extern "C" size_t urnn_head_workspace_bytes(int B, int C, int H, int W)
 static int head_impl(const float *feat, const float *conv_w, const float *ln_w, const float *ln_b, const float *cls_w,
                      const float *cls_b, const float *reg_w, const float *reg_b, float *out_masked, float *out_cls,
                      float *out_raw, const int *frame_index, void *workspace, size_t workspace_bytes, int B, int C,
-                     int H, int W, float cls_thred, float eps, float slope, int phase_mask, long global_pixels, void *stream)
+                     int H, int W, float cls_thred, float eps, float slope, int phase_mask, long global_pixels, void *stream,
+                     const float *partial0 = nullptr)
 {
     if (!feat || !conv_w || !ln_w || !ln_b || !cls_w || !cls_b || !reg_w || !reg_b || !out_masked || !out_cls || !workspace)
         return fail(URNN_ENULL, "urnn_head_f32: NULL argument");
@@ -968,6 +1028,9 @@ static int head_impl(const float *feat, const float *conv_w, const float *ln_w, 
     p.eps = eps;
     p.slope = slope;
     p.Pglobal = global_pixels;
+    p.partial0 = partial0;
+    p.nblk0 = (int)((P + 127) / 128);
+    p.bpix0 = 128;
     CHECK_HIP(urnn_launch_head(p, phase_mask, (hipStream_t)stream), "head");
     return URNN_OK;
 }
@@ -979,6 +1042,18 @@ extern "C" int urnn_head_f32(const float *feat, const float *conv_w, const float
 {
     return head_impl(feat, conv_w, ln_w, ln_b, cls_w, cls_b, reg_w, reg_b, out_masked, out_cls, out_raw, frame_index, workspace,
                      workspace_bytes, B, C, H, W, cls_thred, eps, slope, URNN_HEAD_ALL, 0, stream);
+}
+
+// The head behind urnn_gru_cell_tail_f32(..., head_conv_w, head_partial0): its first pass (the statistics of the stem's LayerNorm) was
+// taken where feat was produced; three passes remain.
+extern "C" int urnn_head_after_tail_f32(const float *feat, const float *conv_w, const float *ln_w, const float *ln_b, const float *cls_w,
+                                        const float *cls_b, const float *reg_w, const float *reg_b, float *out_masked, float *out_cls,
+                                        float *out_raw, const int *frame_index, void *workspace, size_t workspace_bytes, int B, int C,
+                                        int H, int W, float cls_thred, float eps, float slope, const float *head_partial0, void *stream)
+{
+    if (!head_partial0) return fail(URNN_ENULL, "urnn_head_after_tail_f32: NULL head_partial0");
+    return head_impl(feat, conv_w, ln_w, ln_b, cls_w, cls_b, reg_w, reg_b, out_masked, out_cls, out_raw, frame_index, workspace,
+                     workspace_bytes, B, C, H, W, cls_thred, eps, slope, URNN_HEAD_ALL, 0, stream, head_partial0);
 }
 
 extern "C" int urnn_head_strip_f32(const float *feat, const float *conv_w, const float *ln_w, const float *ln_b, const float *cls_w,

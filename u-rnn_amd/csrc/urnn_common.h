@@ -179,10 +179,17 @@ __device__ __forceinline__ unsigned bf16_piece(float x, int piece)
     return __float_as_uint(r) >> 16;
 }
 
+// A value the compiler may not fold into a neighbouring operation: hipcc contracts a * b + c into an fma wherever it likes (and
+// __fmul_rn / __dmul_rn are plain multiplications to it), so the SAME source line can round once in one kernel and twice in another --
+// one ulp in a tile's centred sum of squares was enough to move a GroupNorm scale by a float ulp between the cooperative cell and
+// the three-kernel cell.  Wherever several kernels must produce the same bits, the product is made opaque before it is added.
+__device__ __forceinline__ float nofma(float v) { asm("" : "+v"(v)); return v; }
+__device__ __forceinline__ double nofma(double v) { asm("" : "+v"(v)); return v; }
+
 // The GRU blend h' = (1 - z) h + z n (ConvRNN.py:189) with every operation rounded on its own, as the reference's eager torch ops
-// round them -- and so that every kernel that blends (gru_blend_kernel in all its vector forms, coop_cell_kernel) produces the same
-// bits: left to the compiler, one form contracts (1 - z) * h into an fma and another z * n.
-__device__ __forceinline__ float gru_blend(float z, float n, float h) { return __fadd_rn(__fmul_rn(1.f - z, h), __fmul_rn(z, n)); }
+// round them -- and so that every kernel that blends (gru_blend_kernel in all its vector forms, coop_cell_kernel, blend_conv_kernel)
+// produces the same bits.
+__device__ __forceinline__ float gru_blend(float z, float n, float h) { return nofma((1.f - z) * h) + nofma(z * n); }
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v >= 0.f ? v : v * slope; }
 __device__ __forceinline__ float siluf_fast(float v) { return v * sigmoidf_fast(v); }

@@ -41,13 +41,13 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float *__restrict
     }
     if (lane < 32) {
         const double mean = s1 / count;
-        double var = s2 / count - mean * mean;
+        double var = s2 / count - nofma(mean * mean);   // (no contraction: every finalizer gives the same bits)
         var = var > 0.0 ? var : 0.0;
         const double rstd = 1.0 / sqrt(var + (double)eps);
         const int c = g * 32 + lane;
         const double sc = (double)gamma[c] * rstd;
         ss[((size_t)b * C + c) * 2] = (float)sc;
-        ss[((size_t)b * C + c) * 2 + 1] = (float)((double)beta[c] - mean * sc);
+        ss[((size_t)b * C + c) * 2 + 1] = (float)((double)beta[c] - nofma(mean * sc));
         if (lane == 0) flag_nonfinite(status, status_bit, s1, s2);
         if (stat && lane == 0) {
             stat[((size_t)b * G + g) * 2] = (float)mean;
@@ -148,12 +148,12 @@ __global__ __launch_bounds__(256) void gru_blend_kernel(const float *__restrict_
         if (threadIdx.x == 0) {
             const double S1 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), S2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
             const double mean = S1 / fin.count;
-            double var = S2 / fin.count - mean * mean;
+            double var = S2 / fin.count - nofma(mean * mean);   // (no contraction: every finalizer gives the same bits)
             var = var > 0.0 ? var : 0.0;
             const double rstd = 1.0 / sqrt(var + (double)fin.eps);
             const double sc = (double)fin.gamma[f] * rstd;
             st[0] = (float)sc;
-            st[1] = (float)((double)fin.beta[f] - mean * sc);
+            st[1] = (float)((double)fin.beta[f] - nofma(mean * sc));
             if (blockIdx.x == 0) {
                 flag_nonfinite(fin.status, URNN_STATUS_CAND, S1, S2);
                 fin.ss2[((size_t)b * F + f) * 2] = st[0];
@@ -432,6 +432,11 @@ __device__ __forceinline__ void head_fold_stats(const HeadParams &prm, int which
 {
     const int lane = threadIdx.x & 63;
     const float *pp = prm.partial + (((size_t)which * prm.B + b) * prm.nblk) * 2;
+    if (which == 0 && prm.partial0) {                  // statistics of u0 taken by the producer of feat (urnn_tail.hip): its own block size
+        pp = prm.partial0 + (size_t)b * prm.nblk0 * 2;
+        nblk_used = prm.nblk0;
+        block_pix = prm.bpix0;
+    }
     double s1 = 0.0, s2 = 0.0;
     for (int t0 = 0; t0 < nblk_used; t0 += 64 * 16) {
         f32x2 v[16];
@@ -453,7 +458,7 @@ __device__ __forceinline__ void head_fold_stats(const HeadParams &prm, int which
     }
     const double count = (double)HEAD_C * (double)prm.P;
     const double mean = s1 / count;
-    double var = s2 / count - mean * mean;
+    double var = s2 / count - nofma(mean * mean);   // (no contraction: every finalizer gives the same bits)
     var = var > 0.0 ? var : 0.0;
     mean_f = (float)mean;
     rstd_f = (float)(1.0 / sqrt(var + (double)prm.eps));
@@ -614,7 +619,7 @@ __global__ __launch_bounds__(64) void ln_finalize_kernel(const HeadParams prm, i
     if (lane == 0) {
         const double count = (double)HEAD_C * (double)(prm.Pglobal > 0 ? prm.Pglobal : (long)prm.P);
         const double mean = s1 / count;
-        double var = s2 / count - mean * mean;
+        double var = s2 / count - nofma(mean * mean);   // (no contraction: every finalizer gives the same bits)
         flag_nonfinite(prm.status, URNN_STATUS_HEAD, s1, s2);
         var = var > 0.0 ? var : 0.0;
         prm.stats[((size_t)which * prm.B + b) * 2] = (float)mean;
@@ -640,7 +645,7 @@ static hipError_t launch_head_v(const HeadParams &p, int mask, hipStream_t st)
     static const bool fuse_on = !getenv("URNN_TUNE_FUSE_HEAD") || atoi(getenv("URNN_TUNE_FUSE_HEAD")) != 0;
     const int all = URNN_HEAD_K1 | URNN_HEAD_F1 | URNN_HEAD_K2 | URNN_HEAD_F2 | URNN_HEAD_K3 | URNN_HEAD_F3 | URNN_HEAD_K4;
     if (fuse_on && (mask & all) == all && p.Pglobal <= 0) {
-        hipLaunchKernelGGL(head_k1<V>, grid, blk, 0, st, p);
+        if (!p.partial0) hipLaunchKernelGGL(head_k1<V>, grid, blk, 0, st, p);
         hipLaunchKernelGGL((head_k2<V, true>), grid, blk, 0, st, p);
         hipLaunchKernelGGL((head_k3<V, true>), grid, blk, 0, st, p);
         hipLaunchKernelGGL((head_k4<V, true>), grid, blk, 0, st, p);

@@ -320,13 +320,13 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
                 s2 += __shfl_xor(s2, m, 64);
             }
             const double mean = s1 / prm.gcount;
-            double var = s2 / prm.gcount - mean * mean;
+            double var = s2 / prm.gcount - nofma(mean * mean);   // (no contraction: every finalizer gives the same bits)
             var = var > 0.0 ? var : 0.0;
             const double rstd = 1.0 / sqrt(var + (double)prm.eps);
             if (lane < 32) {
                 const int c = grp * 32 + lane;
                 const double sc = (double)prm.gn_w[c] * rstd;
-                const float fsc = (float)sc, fsh = (float)((double)prm.gn_b[c] - mean * sc);
+                const float fsc = (float)sc, fsh = (float)((double)prm.gn_b[c] - nofma(mean * sc));
                 if (c >= F) {
                     ssm[((size_t)b * F + (c - F)) * 2] = fsc;
                     ssm[((size_t)b * F + (c - F)) * 2 + 1] = fsh;
@@ -775,7 +775,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const int cb = grouped ? urnn_gate_cb(prm.gHalves, prm.gGS, G, g, nb) : urnn_gate_cb(0, 1, G, g, nb);
-                const float mt = s1[nb] * inv_n;
+                const float mt = nofma(s1[nb] * inv_n);     // (rounded on its own: v - mt must not become an fma in one kernel and not in another)
                 s2[nb] = 0.f;
                 const bool keep = !(prm.zOnly && cb >= G);     // fused-reset-gate cell: r leaves only its statistics
                 float *obase = prm.out0 + ((size_t)b * 2 * F + cb * 32 + 4 * half) * prm.P;   // one lane-dependent base, uniform row steps
@@ -824,7 +824,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const int grp = g * NB + nb;
-                const float mt = s1[nb] * inv_n;
+                const float mt = nofma(s1[nb] * inv_n);     // (rounded on its own: v - mt must not become an fma in one kernel and not in another)
                 s2[nb] = 0.f;
                 float *obase = prm.out0 + ((size_t)b * F + grp * 32 + 4 * half) * prm.P;
 #pragma unroll
@@ -978,13 +978,13 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void cand_fused_kernel(const Con
                 s2 += __shfl_xor(s2, m, 64);
             }
             const double mean = s1 / prm.gcount;
-            double var = s2 / prm.gcount - mean * mean;
+            double var = s2 / prm.gcount - nofma(mean * mean);   // (no contraction: every finalizer gives the same bits)
             var = var > 0.0 ? var : 0.0;
             const double rstd = 1.0 / sqrt(var + (double)prm.eps);
             if (lane < 32) {
                 const int c = grp * 32 + lane;
                 const double sc = (double)prm.gn_w[c] * rstd;
-                const float fsc = (float)sc, fsh = (float)((double)prm.gn_b[c] - mean * sc);
+                const float fsc = (float)sc, fsh = (float)((double)prm.gn_b[c] - nofma(mean * sc));
                 if (c >= F) {
                     ssm[((size_t)b * F + (c - F)) * 2] = fsc;
                     ssm[((size_t)b * F + (c - F)) * 2 + 1] = fsh;
@@ -1007,6 +1007,10 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void cand_fused_kernel(const Con
     // The slot stream of the gate GEMM -- one slot per k-pair of x | e | h, all plain (as in conv_gemm_kernel) -- runs ACROSS
     // tiles: the last eight refills of a tile (its last 16-k group) already fetch the first eight k-pairs of the wave's next tile,
     // so that their HBM round trip overlaps with phase 2 and the epilogue instead of opening the next tile.
+    // development knob URNN_TUNE_CAND_STAGGER (prm.stagger units of ~1k cycles): the second wave of every SIMD starts late, so that one
+    // wave's MFMA-only phase 2 meets the other's DMA-bound phase 1 instead of its phase 2
+    if (wave >= 4 && prm.stagger)
+        for (int i = 0; i < prm.stagger; ++i) __builtin_amdgcn_s_sleep(16);
     CandStream st;
     st.si = 0; st.total = 0; st.seg_left = INT_MAX; st.seg_cur = 0; st.soff = 0; st.vo0 = 0; st.csz = 0;
     st.sp1 = st.sp2 = st.cp = nullptr;
@@ -1151,7 +1155,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void cand_fused_kernel(const Con
             wave_sum_n<NBF>(s1);
 #pragma unroll
             for (int nb = 0; nb < NBF; ++nb) {
-                const float mt = s1[nb] * inv_n;
+                const float mt = nofma(s1[nb] * inv_n);     // (rounded on its own: v - mt must not become an fma in one kernel and not in another)
                 s2[nb] = 0.f;
                 float *obase = prm.out0 + ((size_t)b * F + nb * 32 + 4 * half) * prm.P;
 #pragma unroll
@@ -1602,6 +1606,8 @@ hipError_t urnn_launch_cand_fused(ConvGemmParams p, int B, hipStream_t st)
         raised = true;
     }
     const int grid = persistent_grid(lds, 1, p.totalTiles, 8, 2);
+    static const int stag = [] { const char *e = getenv("URNN_TUNE_CAND_STAGGER"); return e ? atoi(e) : 0; }();
+    p.stagger = stag;
     hipLaunchKernelGGL(k8, dim3(grid), dim3(512), lds, st, p);
     return hipGetLastError();
 }

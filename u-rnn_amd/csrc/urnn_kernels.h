@@ -103,8 +103,8 @@ hipError_t urnn_launch_small_gates(ConvGemmParams p, int B, hipStream_t st);
 hipError_t urnn_launch_small_cand(ConvGemmParams p, int B, hipStream_t st);
 // the whole cell of a small plane as one cooperative launch (urnn_small.hip coop_cell_kernel); p / c = the gate / candidate blocks
 bool urnn_coop_cell_ok(const ConvGemmParams &p, const ConvGemmParams &c, int B);
-hipError_t urnn_launch_coop_cell(ConvGemmParams p, const ConvGemmParams &c, const float *gn2_w, const float *gn2_b, float *h_out, unsigned *bar,
-                                 int B, hipStream_t st);
+hipError_t urnn_launch_coop_cell(ConvGemmParams p, const ConvGemmParams &c, const float *gn2_w, const float *gn2_b, float *ss2_out, float *h_out,
+                                 unsigned *bar, int B, hipStream_t st);
 int urnn_cand_nb(int F);      // n-blocks per group of the candidate GEMM
 hipError_t urnn_launch_cand(ConvGemmParams p, int B, int PB, int map, hipStream_t st);
 
@@ -116,6 +116,33 @@ hipError_t urnn_launch_blend(const float *g1, const float *c, const float *h, co
 hipError_t urnn_launch_blend_fin(const float *g1, const float *c, const float *h, const float *ss1, float *out, int B, int F, int P,
                                  const float *partial, int ntiles, int tile_pix, double count, const float *gamma, const float *beta, float eps,
                                  float *ss2, float *stat2, int *status, hipStream_t st);
+
+// The end of a cell fused with the 1x1 conv that consumes the new state (urnn_tail.hip blend_conv_kernel)
+struct TailParams {
+    const float *g1, *cx, *h;          // raw gates (B,2F,P; z = the first F planes), raw candidate (B,F,P), previous state
+    float *h_out;
+    const float *ss1;                  // [B][2F][2] (scale, shift) of the gates, from the candidate kernel's prologue
+    const float *partial2;             // candidate GroupNorm partials [B][F/32][ntiles2][2]
+    int ntiles2, tile_pix2;
+    double count;
+    const float *gn2_w, *gn2_b;
+    float eps;
+    float *ss2_out, *stat2_out;
+    int *status;
+    int B, F, P, W;
+    const unsigned *wf16;              // the consumer conv's packed f16 slab, its group stride, blocks per group, output blocks
+    int fDwords, NBc, NBO, Cout, wDwords;   // wDwords: all groups' dwords
+    const float *bias;
+    float slope;
+    int P2, W2;                        // pooled plane (TAIL_POOL)
+    float *out;
+    const float *head_w;               // TAIL_FLAT: the head's stem conv (16 x 16) -> LayerNorm statistics of u0 = Ws . out; may be NULL
+    float *partial0;                   //            [B][blocksPerSample][2], centred per 128-pixel block
+    int blocksPerSample;
+    int chunk;                         // persistent blocks: consecutive tiles per block (0: tiles strided by the grid)
+};
+bool urnn_tail_ok(int B, int F, int H, int W, int Cin, int Cout, int pool);
+hipError_t urnn_launch_tail(TailParams tp, int H, int pool, hipStream_t st);
 
 struct HeadParams {
     const float *feat;
@@ -131,6 +158,10 @@ struct HeadParams {
     long Pglobal;               // > 0: strip mode, LayerNorm statistics over Pglobal pixels from two pseudo-blocks of partials
     float cls_thred, eps, slope;
     int *status;                // the workspace's status word (urnn_common.h flag_nonfinite)
+    // the first LayerNorm's partial statistics came from the kernel that produced feat (urnn_tail.hip): head_k1 is skipped and head_k2
+    // folds them from here: [B][nblk0][2], centred per block of bpix0 pixels
+    const float *partial0;
+    int nblk0, bpix0;
 };
 hipError_t urnn_launch_head(const HeadParams &p, int phase_mask, hipStream_t st);
 int urnn_head_nblk(int P);        // blocks allocated per (norm, sample) in the partial buffer

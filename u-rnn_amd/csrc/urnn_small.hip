@@ -68,13 +68,13 @@ __global__ __launch_bounds__(1024) void small_cell_gemm_kernel(const ConvGemmPar
                 s2 += __shfl_xor(s2, m, 64);
             }
             const double mean = s1 / prm.gcount;
-            double var = s2 / prm.gcount - mean * mean;
+            double var = s2 / prm.gcount - nofma(mean * mean);   // (no contraction: every finalizer gives the same bits)
             var = var > 0.0 ? var : 0.0;
             const double rstd = 1.0 / sqrt(var + (double)prm.eps);
             if (lane < 32) {
                 const int c = grp * 32 + lane;
                 const double sc = (double)prm.gn_w[c] * rstd;
-                const float fsc = (float)sc, fsh = (float)((double)prm.gn_b[c] - mean * sc);
+                const float fsc = (float)sc, fsh = (float)((double)prm.gn_b[c] - nofma(mean * sc));
                 if (c >= F) {
                     ssm[(c - F) * 2] = fsc;
                     ssm[(c - F) * 2 + 1] = fsh;
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(1024) void small_cell_gemm_kernel(const ConvGemmPar
     for (int r = 0; r < 16; ++r)
         if (ok) s1 += fin(acc[r], bias_h[row_c(r)]);
     s1 = wave_sum(s1);
-    const float mt = s1 * (nvalid == 32 ? prm.invFull : prm.invTail);      // 1 / (32 * valid pixels), from the host: no division here
+    const float mt = nofma(s1 * (nvalid == 32 ? prm.invFull : prm.invTail));      // 1 / (32 * valid pixels), from the host: no division here
     float s2 = 0.f;
     float *obase = prm.out0 + ((size_t)b * Cout + ch0 + 4 * half) * P + px;
 #pragma unroll
@@ -371,6 +371,7 @@ struct CoopCellParams {
     const float *cbias;          // candidate bias [F]
     const float *gn2_w, *gn2_b;
     float *partial2;             // [B][F/32][tiles][2]
+    float *ss2_out;              // [B][F][2] (scale, shift) of the candidate, as gru_blend_kernel<FIN> publishes them
     float *h_out;
     unsigned *bar;               // [0]: arrivals, [16]: generation (two cache lines of the workspace's status area)
     int nblocks;
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(768) void coop_cell_kernel(const CoopCellParams cp,
             if (ok) s1 += acc[r];
         }
         s1 = wave_sum(s1);
-        const float mt = s1 * inv_n;
+        const float mt = nofma(s1 * inv_n);
         float s2 = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -581,14 +582,18 @@ __global__ __launch_bounds__(768) void coop_cell_kernel(const CoopCellParams cp,
         }
         const double count = 32.0 * (double)P;
         const double mean = s1 / count;
-        double var = s2 / count - mean * mean;
+        double var = s2 / count - nofma(mean * mean);   // (no contraction: every finalizer gives the same bits)
         var = var > 0.0 ? var : 0.0;
         const double rstd = 1.0 / sqrt(var + (double)prm.eps);
         if (lane < 32) {
             const int c = cb * 32 + lane;
             const double sc = (double)prm.gn_w[c] * rstd;
             sst[2 * lane] = (float)sc;
-            sst[2 * lane + 1] = (float)((double)prm.gn_b[c] - mean * sc);
+            sst[2 * lane + 1] = (float)((double)prm.gn_b[c] - nofma(mean * sc));
+            if (blk == 0 && pbw == 0 && prm.ss_out) {                      // the tables the three-kernel cell leaves in the workspace
+                prm.ss_out[((size_t)b * 2 * F + c) * 2] = sst[2 * lane];
+                prm.ss_out[((size_t)b * 2 * F + c) * 2 + 1] = sst[2 * lane + 1];
+            }
         }
         if (blk == 0 && pbw == 0 && lane == 0) flag_nonfinite(prm.status, URNN_STATUS_GATES, s1, s2);
     }
@@ -654,7 +659,7 @@ __global__ __launch_bounds__(768) void coop_cell_kernel(const CoopCellParams cp,
             if (ok) s1 += acc[r];
         }
         s1 = wave_sum(s1);
-        const float mt = s1 * inv_n;
+        const float mt = nofma(s1 * inv_n);
         float s2 = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -699,14 +704,18 @@ __global__ __launch_bounds__(768) void coop_cell_kernel(const CoopCellParams cp,
         const double S1 = S1a + (p0 + p1), S2 = S2a + (q0 + q1);
         const double count = 32.0 * (double)P;
         const double mean = S1 / count;
-        double var = S2 / count - mean * mean;
+        double var = S2 / count - nofma(mean * mean);   // (no contraction: every finalizer gives the same bits)
         var = var > 0.0 ? var : 0.0;
         const double rstd = 1.0 / sqrt(var + (double)prm.eps);
         if (lane < 32) {
             const int c = ci * 32 + lane;
             const double sc = (double)cp.gn2_w[c] * rstd;
             sst[2 * lane] = (float)sc;
-            sst[2 * lane + 1] = (float)((double)cp.gn2_b[c] - mean * sc);
+            sst[2 * lane + 1] = (float)((double)cp.gn2_b[c] - nofma(mean * sc));
+            if (blk == 0 && pbw == 0 && cp.ss2_out) {
+                cp.ss2_out[((size_t)b * F + c) * 2] = sst[2 * lane];
+                cp.ss2_out[((size_t)b * F + c) * 2 + 1] = sst[2 * lane + 1];
+            }
         }
         if (blk == 0 && pbw == 0 && lane == 0) flag_nonfinite(prm.status, URNN_STATUS_CAND, S1, S2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -750,8 +759,8 @@ bool urnn_coop_cell_ok(const ConvGemmParams &p, const ConvGemmParams &c, int B)
     return blocks <= 256 && lds <= 150 * 1024;
 }
 
-hipError_t urnn_launch_coop_cell(ConvGemmParams p, const ConvGemmParams &c, const float *gn2_w, const float *gn2_b, float *h_out, unsigned *bar,
-                                 int B, hipStream_t st)
+hipError_t urnn_launch_coop_cell(ConvGemmParams p, const ConvGemmParams &c, const float *gn2_w, const float *gn2_b, float *ss2_out, float *h_out,
+                                 unsigned *bar, int B, hipStream_t st)
 {
     p.tilesPerSample = (p.P + 31) / 32;
     p.totalTiles = B * p.tilesPerSample;
@@ -775,6 +784,8 @@ hipError_t urnn_launch_coop_cell(ConvGemmParams p, const ConvGemmParams &c, cons
     cp.gn2_w = gn2_w;
     cp.gn2_b = gn2_b;
     cp.partial2 = c.partial;
+    cp.ss2_out = ss2_out;
+    cp.g.ss_out = c.ss_out;
     cp.h_out = h_out;
     cp.bar = bar;
     cp.nblocks = B * ((p.P + 63) / 64);

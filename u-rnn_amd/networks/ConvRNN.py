@@ -53,6 +53,14 @@ class CGRU_cell(nn.Module):
             return ops.gru_cell(x, e, h, packed, g1.weight.detach(), g1.bias.detach(), g2.weight.detach(),
                                 g2.bias.detach(), self.input_channels, out=out, eps=g1.eps, phases=phases, ws=ws)
 
+    def step_tail(self, x, e, h, stage, conv_out, out=None, phases=ops.PHASE_ALL, ws=None, head_w=None, head_partial0=None):
+        """``step`` with the stage conv that consumes the new state (a ``StageLayers`` of kind "conv") fused into the cell's last
+        kernel (ops.gru_cell_tail); the caller checked ``ops.gru_cell_tail_applies`` and that neither layer is ``wide``."""
+        g1, g2 = self.conv1[1], self.conv2[1]
+        return ops.gru_cell_tail(x, e, h, self._packed(), g1.weight.detach(), g1.bias.detach(), g2.weight.detach(), g2.bias.detach(),
+                                 self.input_channels, stage._packed(), stage.out_channels, stage.pool, conv_out=conv_out, out=out,
+                                 eps=g1.eps, phases=phases, ws=ws, head_w=head_w, head_partial0=head_partial0)
+
     @torch.no_grad()
     def forward(self, inputs=None, hidden_state=None, seq_len=1):
         """Reference contract (ConvRNN.py:111-194): ``inputs`` (S,B,I,H,W) or None, ``hidden_state`` (B,F,H,W)

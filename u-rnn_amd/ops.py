@@ -216,6 +216,35 @@ def gru_cell(x, e, h, packed, gn1_w, gn1_b, gn2_w, gn2_b, I, out=None, eps=NORM_
     return out
 
 
+def gru_cell_tail_applies(B, F, H, W, Cout, pool):
+    """Can the end of a cell on (B, F, H, W) be fused with its consumer, a 1x1 conv F -> Cout (pool: + AvgPool2)?"""
+    return bool(lib().urnn_gru_cell_tail_applies(B, F, H, W, Cout, 1 if pool else 0))
+
+
+def head_tail_partial(B, H, W, device):
+    """Buffer for the head's first LayerNorm statistics when the kernel that produces the feature map takes them (gru_cell_tail)."""
+    return torch.zeros(lib().urnn_head_tail_partial_floats(B, H, W), dtype=torch.float32, device=device)
+
+
+def gru_cell_tail(x, e, h, packed, gn1_w, gn1_b, gn2_w, gn2_b, I, conv_packed, Cout, pool, conv_out=None, out=None, eps=NORM_EPS,
+                  phases=PHASE_ALL, ws=None, head_w=None, head_partial0=None, slope=LRELU_SLOPE):
+    """``gru_cell`` whose last kernel (GroupNorm finalize + blend) also runs the 1x1 conv that consumes the new state:
+    returns (h', [AvgPool2](LeakyReLU(conv(h')))).  ``head_w`` (the head's stem conv (16,16)) + ``head_partial0``: the launch also
+    takes the head's first LayerNorm statistics (``head(..., partial0=head_partial0)`` then skips its first pass)."""
+    _dev_check(x, e, h, packed, gn1_w, gn1_b, gn2_w, gn2_b, out, conv_packed, conv_out, head_w, head_partial0)
+    B, F, H, W = h.shape
+    L = lib()
+    ws = _scratch(ws, L.urnn_gru_cell_workspace_bytes(B, F, H, W), h.device)
+    if out is None:
+        out = torch.empty_like(h)
+    if conv_out is None:
+        conv_out = torch.empty((B, Cout, H // 2, W // 2) if pool else (B, Cout, H, W), dtype=torch.float32, device=h.device)
+    check(L.urnn_gru_cell_tail_f32(_ptr(x), _ptr(e), _ptr(h), _ptr(packed), _ptr(gn1_w), _ptr(gn1_b), _ptr(gn2_w), _ptr(gn2_b), _ptr(out),
+                                   _ptr(ws), ws.numel(), B, I, F, H, W, eps, int(phases), _ptr(conv_packed), int(Cout), 1 if pool else 0,
+                                   slope, _ptr(conv_out), _ptr(head_w), _ptr(head_partial0), _stream()), "urnn_gru_cell_tail_f32")
+    return out, conv_out
+
+
 def gru_cell_strip(x, e, h, packed, gn1_w, gn1_b, gn2_w, gn2_b, I, global_pixels, exchange, out=None, eps=NORM_EPS, ws=None):
     """One horizontal strip of a cell step whose plane of ``global_pixels`` pixels is split over ranks (include/urnn_hip.h,
     "Spatial strips").  ``exchange(sums)`` must all-reduce (sum) the float64 device tensor in place; it is called twice."""
@@ -288,7 +317,7 @@ def deconv2x2(x, packed, Cout, out=None, slope=LRELU_SLOPE):
 
 
 def head(feat, conv_w, ln_w, ln_b, cls_w, cls_b, reg_w, reg_b, cls_thred, out_masked=None, out_cls=None, out_raw=None,
-         frame_index=None, want_raw=False, eps=NORM_EPS, slope=LRELU_SLOPE, ws=None):
+         frame_index=None, want_raw=False, eps=NORM_EPS, slope=LRELU_SLOPE, ws=None, partial0=None):
     """Dual head + mask.  Returns (masked, cls, raw|None), each (B,H,W) unless preallocated (T,B,H,W) buffers
     plus a device ``frame_index`` are given."""
     _dev_check(feat, conv_w, ln_w, ln_b, cls_w, cls_b, reg_w, reg_b, out_masked, out_cls, out_raw)
@@ -301,6 +330,13 @@ def head(feat, conv_w, ln_w, ln_b, cls_w, cls_b, reg_w, reg_b, cls_thred, out_ma
         out_cls = torch.empty((B, H, W), dtype=torch.float32, device=feat.device)
     if out_raw is None and want_raw:
         out_raw = torch.empty((B, H, W), dtype=torch.float32, device=feat.device)
+    if partial0 is not None:      # the first LayerNorm's statistics were taken by the kernel that produced feat (gru_cell_tail)
+        _dev_check(partial0)
+        check(L.urnn_head_after_tail_f32(_ptr(feat), _ptr(conv_w), _ptr(ln_w), _ptr(ln_b), _ptr(cls_w), _ptr(cls_b), _ptr(reg_w),
+                                         _ptr(reg_b), _ptr(out_masked), _ptr(out_cls), _ptr(out_raw), _ptr(frame_index), _ptr(ws),
+                                         ws.numel(), B, C, H, W, float(cls_thred), eps, slope, _ptr(partial0), _stream()),
+              "urnn_head_after_tail_f32")
+        return out_masked, out_cls, out_raw
     check(L.urnn_head_f32(_ptr(feat), _ptr(conv_w), _ptr(ln_w), _ptr(ln_b), _ptr(cls_w), _ptr(cls_b), _ptr(reg_w),
                           _ptr(reg_b), _ptr(out_masked), _ptr(out_cls), _ptr(out_raw), _ptr(frame_index), _ptr(ws),
                           ws.numel(), B, C, H, W, float(cls_thred), eps, slope, _stream()), "urnn_head_f32")

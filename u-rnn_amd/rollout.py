@@ -15,7 +15,7 @@ from .general import initialize_states
 class RolloutEngine:
     def __init__(self, net, input_height, input_width, historical_nums, rain_max, cumsum_rain_max, batch=1,
                  max_frames=360, spatial_rain=False, net_cfg=None, use_graph=True, keep_raw=False,
-                 device=None, overlap=False, fused_reset_gate=True, coop_cells=True):
+                 device=None, overlap=False, fused_reset_gate=True, coop_cells=True, fused_tails=False):
         self.net = net
         # cells whose shape has the form recompute the reset gate inside the candidate kernel instead of round-tripping its raw
         # planes through HBM (include/urnn_hip.h URNN_PHASE_FUSED_R); the engine never reads a cell's workspace
@@ -80,6 +80,13 @@ class RolloutEngine:
                    [L.urnn_gru_cell_workspace_bytes(B, c.num_features, c.shape[0], c.shape[1])
                     for c in (enc.rnn1, enc.rnn2, enc.rnn3, dec.rnn3, dec.rnn2, dec.rnn1)])
         self._ws = [ops.workspace(need, dev) for _ in range(2 if self.overlap else 1)]
+        # fused_tails=True: the END of a cell runs together with the stage conv that consumes the new state (ops.gru_cell_tail: blend +
+        # 1x1 conv [+ pool], for the decoder's last cell + the head's first LayerNorm statistics): enc1 -> stage2, enc2 -> stage3,
+        # dec1 -> stage1.  190 MB per frame less through HBM at 500x500, identical bits -- and 3-4 % FEWER frames/s (DESIGN.md section
+        # 4.10: the fused kernel reads 256-byte runs per plane where the blend reads 4 KB ones), hence off by default
+        self._fused_tails = bool(fused_tails)
+        self._tails = None          # decided at the first step (the layers' weight ranges are known once they are packed)
+        self._k1part = [ops.head_tail_partial(B, H, W, dev) for _ in range(2 if self.overlap else 1)]
         self._param_stamp = None    # what the captured graphs' packed weights were made from (see _check_params)
         self._probe = None          # {"enc1": [(start, stop), ...], "dec1": [...]} while probing
         self._graph = None
@@ -104,19 +111,19 @@ class RolloutEngine:
         e1, e2, e3, d1, d2, d3 = self.states
         ws = self._ws[0]
         self._stage1(self.t_dev)
-        self._cell("enc1", enc.rnn1, self.a1, None, e1, e1, ws)
-        enc.stage2(e1, out=self.a2)
-        self._cell("enc2", enc.rnn2, self.a2, None, e2, e2, ws)
-        enc.stage3(e2, out=self.a3)
+        if not self._cell("enc1", enc.rnn1, self.a1, None, e1, e1, ws, conv_out=self.a2):
+            enc.stage2(e1, out=self.a2)
+        if not self._cell("enc2", enc.rnn2, self.a2, None, e2, e2, ws, conv_out=self.a3):
+            enc.stage3(e2, out=self.a3)
         self._cell("enc3", enc.rnn3, self.a3, None, e3, e3, ws)
         self._cell("dec3", dec.rnn3, None, e3, d1, d1, ws)
         dec.stage3(d1, out=self.u3)
         self._cell("dec2", dec.rnn2, self.u3, e2, d2, d2, ws)
         dec.stage2(d2, out=self.u2)
-        self._cell("dec1", dec.rnn1, self.u2, e1, d3, d3, ws)
-        dec.stage1(d3, out=self.feat)
+        if not self._cell("dec1", dec.rnn1, self.u2, e1, d3, d3, ws, conv_out=self.feat, k1part=self._k1part[0]):
+            dec.stage1(d3, out=self.feat)
         net.head.run(self.feat, out_masked=self.out_masked, out_cls=self.out_cls, out_raw=self.out_raw,
-                     frame_index=self.t_dev, ws=ws)
+                     frame_index=self.t_dev, ws=ws, partial0=self._k1part[0] if self._tail_of("dec1") is not None else None)
         ops.advance_counter(self.t_dev, 1)
 
     def _stage1(self, t_dev):
@@ -130,19 +137,43 @@ class RolloutEngine:
                            self.nums, self.rain_max, self.cumsum_max, out=self.x_in, t_dev=t_dev)
             self.net.encoder.stage1(self.x_in, out=self.a1)
 
-    def _cell(self, name, cell, x, e, h, out, ws):
-        """One GRU cell; when a probe is active the three kernels of the named cells (gate GEMM | candidate GEMM | GroupNorm
-        finalize + blend) are launched one ABI call each, every one bracketed by events on the launch stream (bench.py's live
-        roofline measurement)."""
+    def _tail_of(self, name):
+        """The stage conv fused into the named cell's last kernel, or None (decided once per set of weights)."""
+        if self._tails is None:
+            enc, dec = self.net.encoder, self.net.decoder
+            self._tails = {}
+            for cname, cell, stage in (("enc1", enc.rnn1, enc.stage2), ("enc2", enc.rnn2, enc.stage3), ("dec1", dec.rnn1, dec.stage1)):
+                cell._packed(), stage._packed()                      # (sets the layers' `wide` flags)
+                ok = (self._fused_tails and stage.kind == "conv" and not self._coop[cname] and not cell._cache.wide and not stage._cache.wide and
+                      ops.gru_cell_tail_applies(self.B, cell.num_features, cell.shape[0], cell.shape[1], stage.out_channels, stage.pool))
+                self._tails[cname] = stage if ok else None
+        return self._tails.get(name)
+
+    def _cell(self, name, cell, x, e, h, out, ws, conv_out=None, k1part=None):
+        """One GRU cell (+ the stage conv behind it when ``conv_out`` is given: fused into the cell's last kernel where that form
+        exists, its own launch otherwise).  When a probe is active the three kernels of the named cells (gate GEMM | candidate GEMM |
+        GroupNorm finalize + blend [+ conv]) are launched one ABI call each, every one bracketed by events on the launch stream
+        (bench.py's live roofline measurement)."""
+        stage = self._tail_of(name) if conv_out is not None else None
+        head_w = self.net.head.flat_params()["conv_w"][0] if (stage is not None and k1part is not None) else None
+        flags = self._cell_flags | self._coop[name]
+
+        def run(mask):
+            if stage is not None and (mask & ops.PHASE_BLEND):
+                cell.step_tail(x, e, h, stage, conv_out, out=out, phases=mask | self._cell_flags, ws=ws, head_w=head_w,
+                               head_partial0=k1part if head_w is not None else None)
+            else:
+                cell.step(x, e, h, out=out, phases=mask | (flags if mask == ops.PHASE_ALL else self._cell_flags), ws=ws)
         if self._probe is not None and name in self._probe:
             for kind, mask in (("gates", ops.PHASE_GATES), ("candidate", ops.PHASE_GN1 | ops.PHASE_CAND), ("blend", ops.PHASE_GN2 | ops.PHASE_BLEND)):
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
-                cell.step(x, e, h, out=out, phases=mask | self._cell_flags, ws=ws)
+                run(mask)
                 b.record()
                 self._probe[name][kind].append((a, b))
         else:
-            cell.step(x, e, h, out=out, phases=ops.PHASE_ALL | self._cell_flags | self._coop[name], ws=ws)
+            run(ops.PHASE_ALL)
+        return stage is not None          # True: conv_out has been written
 
     PROBED_CELLS = ("enc1", "dec1", "enc2", "dec2")
 
@@ -183,14 +214,14 @@ class RolloutEngine:
 
         def e1():
             self._stage1(self.te_dev)
-            self._cell("enc1", enc.rnn1, self.a1, None, p1, n1, ws)
+            if not self._cell("enc1", enc.rnn1, self.a1, None, p1, n1, ws, conv_out=self.a2):
+                enc.stage2(n1, out=self.a2)
 
         def e2():
-            enc.stage2(n1, out=self.a2)
-            self._cell("enc2", enc.rnn2, self.a2, None, p2, n2, ws)
+            if not self._cell("enc2", enc.rnn2, self.a2, None, p2, n2, ws, conv_out=self.a3):
+                enc.stage3(n2, out=self.a3)
 
         def e3():
-            enc.stage3(n2, out=self.a3)
             self._cell("enc3", enc.rnn3, self.a3, None, p3, n3, ws)
             ops.advance_counter(self.te_dev, 1)
         return [e1, e2, e3]
@@ -212,8 +243,9 @@ class RolloutEngine:
             dec.stage2(d2, out=self.u2)
 
         def s1():
-            self._cell("dec1", dec.rnn1, self.u2, e1, d3, d3, ws)
-            dec.stage1(d3, out=self.feat if parity == 0 else self.feat_alt)
+            feat = self.feat if parity == 0 else self.feat_alt
+            if not self._cell("dec1", dec.rnn1, self.u2, e1, d3, d3, ws, conv_out=feat, k1part=self._k1part[parity]):
+                dec.stage1(d3, out=feat)
         return [s3, s2, s1]
 
     def _enc_chain(self, parity):
@@ -227,7 +259,8 @@ class RolloutEngine:
     def _head_chain(self, parity):
         """head(t) for t % 2 == parity (reads feat[parity]); shares the encoder chain's stream and scratch."""
         self.net.head.run(self.feat if parity == 0 else self.feat_alt, out_masked=self.out_masked, out_cls=self.out_cls,
-                          out_raw=self.out_raw, frame_index=self.t_dev, ws=self._ws[0])
+                          out_raw=self.out_raw, frame_index=self.t_dev, ws=self._ws[0],
+                          partial0=self._k1part[parity] if self._tail_of("dec1") is not None else None)
         ops.advance_counter(self.t_dev, 1)
 
     def _iter_overlap(self, parity, with_head=True):
@@ -390,6 +423,7 @@ class RolloutEngine:
         # ... and the launches inside a graph keep the GEMM arithmetic (urnn_set_matrix_mode) they were captured with
         stamp = (getattr(self.net, "_urnn_generation", 0), lib().urnn_get_matrix_mode()) + tuple((p.data_ptr(), p._version) for p in self.net.parameters())
         if stamp != self._param_stamp:
+            self._tails = None                  # (a layer's `wide` flag may have changed with its weights)
             if self._param_stamp is not None:
                 self._graph = None
                 self._graphs2 = None
