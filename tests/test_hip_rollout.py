@@ -202,7 +202,8 @@ def test_fused_reset_gate_cell_vs_three_pass_and_oracle(dev, which):
     fused = cell.step(tx, te, th, phases=ops.PHASE_ALL | ops.PHASE_FUSED_R, ws=ws_b)
     torch.cuda.synchronize()
     P = H * W
-    g1_a, g1_b = ws_a[:2 * 64 * P * 4].view(torch.float32), ws_b[:2 * 64 * P * 4].view(torch.float32)
+    S0 = 256                                   # the workspace's status area (include/urnn_hip.h), then the raw gate planes
+    g1_a, g1_b = ws_a[S0:S0 + 2 * 64 * P * 4].view(torch.float32), ws_b[S0:S0 + 2 * 64 * P * 4].view(torch.float32)
     assert torch.equal(g1_a[:64 * P], g1_b[:64 * P]), "raw update gate differs"
     assert float(g1_b[64 * P:].abs().max()) == 0.0, "the fused cell wrote reset-gate planes"      # (the workspace was zero-filled)
     assert float(g1_a[64 * P:].abs().max()) > 0.0
