@@ -174,6 +174,15 @@ int urnn_head_after_tail_f32(const float *feat, const float *conv_w, const float
                              const float *cls_b, const float *reg_w, const float *reg_b, float *out_masked, float *out_cls,
                              float *out_raw, const int *frame_index, void *workspace, size_t workspace_bytes, int B, int C, int H,
                              int W, float cls_thred, float eps, float slope, const float *head_partial0, void *stream);
+/* The head of a small plane as ONE cooperative launch: its four passes with three grid barriers between them, every thread keeping its
+ * pixels' branch activations in registers (flood_head.py:131-177).  Bit-identical to urnn_head_f32.  urnn_head_coop_blocks_f32: the
+ * blocks of that launch -- all must be resident at once: at most 256 (URNN_EINVAL beyond), and at most 128 for a caller with several
+ * kernel chains in flight (the rule of URNN_PHASE_COOP).  Barrier state: words 16 and 32 of the workspace's status area. */
+int urnn_head_coop_blocks_f32(int B, int H, int W);
+int urnn_head_coop_f32(const float *feat, const float *conv_w, const float *ln_w, const float *ln_b, const float *cls_w,
+                       const float *cls_b, const float *reg_w, const float *reg_b, float *out_masked, float *out_cls,
+                       float *out_raw, const int *frame_index, void *workspace, size_t workspace_bytes, int B, int C, int H,
+                       int W, float cls_thred, float eps, float slope, void *stream);
 /* 1 when URNN_PHASE_FUSED_R takes effect for a cell of this shape under the current matrix mode (x present; skip: an e input of F
  * channels), else 0 -- for byte accounting (bench.py) and tests; the cell entry decides by the same rule. */
 int urnn_gru_cell_fused_reset_gate_applies(int B, int I, int F, int H, int W, int skip);

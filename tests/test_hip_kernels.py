@@ -336,3 +336,28 @@ def test_cell_tail_equals_blend_then_conv(dev, I, F, skip, H, W, B, Cout, pool, 
         three = ops.head(got_c, conv_w, ln_w, ln_b, cw, cb_, rw, rb, 0.5, want_raw=True, partial0=part0)
         for a_, b_, what in ((three[1], four[1], "cls"), (three[2], four[2], "pre-mask reg")):
             assert_close(a_.cpu().numpy(), b_.cpu().numpy(), 1e-5, f"three-pass head vs four-pass head, {what}")
+
+
+@pytest.mark.parametrize("H,W,B", [(64, 64, 1), (52, 120, 2), (37, 41, 3), (128, 128, 1)])
+def test_cooperative_head_equals_four_passes(dev, H, W, B):
+    """urnn_head_coop_f32 (flood_head.py:131-177): the head of a small plane as ONE launch -- its four passes with three grid barriers,
+    every thread keeping its pixels' branch activations in registers -- against the four-launch head: bit-identical outputs, launch
+    after launch (the barrier words are reused), including an odd plane (4-byte accesses) and several samples."""
+    from urnn_amd import ops
+    from urnn_amd._lib import lib
+    rs = np.random.RandomState(900 + H + W)
+    assert 0 < lib().urnn_head_coop_blocks_f32(B, H, W) <= 128
+    feat = T(rs.normal(0, 1, (B, 16, H, W)).astype(np.float32), dev)
+    conv_w = T(rs.normal(0, 0.25, (5, 16, 16)).astype(np.float32), dev)
+    ln_w = T(rs.uniform(0.5, 1.5, (5, 16, H, W)).astype(np.float32), dev)
+    ln_b = T(rs.normal(0, 0.1, (5, 16, H, W)).astype(np.float32), dev)
+    cw, cb_, rw, rb = (T(rs.normal(0, 0.3, 16).astype(np.float32), dev), T(np.zeros(1, np.float32), dev),
+                       T(rs.normal(0, 0.3, 16).astype(np.float32), dev), T(np.full(1, 0.1, np.float32), dev))
+    ws = ops.workspace(ops.head_workspace_bytes(B, 16, H, W), dev)
+    four = ops.head(feat, conv_w, ln_w, ln_b, cw, cb_, rw, rb, 0.5, want_raw=True, ws=ws)
+    for _ in range(20):
+        one = ops.head(feat, conv_w, ln_w, ln_b, cw, cb_, rw, rb, 0.5, want_raw=True, ws=ws, coop=True)
+        for a_, b_, what in zip(one, four, ("masked", "cls", "pre-mask reg")):
+            assert torch.equal(a_, b_), f"cooperative head differs in {what}: max {float((a_ - b_).abs().max()):.3e}"
+    assert ops.workspace_status(ws) == 0
+    assert lib().urnn_head_coop_blocks_f32(1, 500, 500) == 489       # the 500x500 head stays on its four launches

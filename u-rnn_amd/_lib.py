@@ -36,6 +36,8 @@ SIGNATURES = {
     "urnn_gru_cell_tail_applies": (_i, [_i] * 6),
     "urnn_head_tail_partial_floats": (_sz, [_i, _i, _i]),
     "urnn_gru_cell_tail_f32": (_i, [_p] * 10 + [_sz, _i, _i, _i, _i, _i, _f, _i, _p, _i, _i, _f, _p, _p, _p, _p]),
+    "urnn_head_coop_blocks_f32": (_i, [_i, _i, _i]),
+    "urnn_head_coop_f32": (_i, [_p] * 13 + [_sz, _i, _i, _i, _i, _f, _f, _f, _p]),
     "urnn_head_after_tail_f32": (_i, [_p] * 13 + [_sz, _i, _i, _i, _i, _f, _f, _f, _p, _p]),
     "urnn_deconv2x2_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "urnn_head_workspace_bytes": (_sz, [_i, _i, _i, _i]),

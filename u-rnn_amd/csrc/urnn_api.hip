@@ -991,7 +991,7 @@ static int head_impl(const float *feat, const float *conv_w, const float *ln_w, 
                      const float *cls_b, const float *reg_w, const float *reg_b, float *out_masked, float *out_cls,
                      float *out_raw, const int *frame_index, void *workspace, size_t workspace_bytes, int B, int C,
                      int H, int W, float cls_thred, float eps, float slope, int phase_mask, long global_pixels, void *stream,
-                     const float *partial0 = nullptr)
+                     const float *partial0 = nullptr, int coop = 0)
 {
     if (!feat || !conv_w || !ln_w || !ln_b || !cls_w || !cls_b || !reg_w || !reg_b || !out_masked || !out_cls || !workspace)
         return fail(URNN_ENULL, "urnn_head_f32: NULL argument");
@@ -1031,6 +1031,11 @@ static int head_impl(const float *feat, const float *conv_w, const float *ln_w, 
     p.partial0 = partial0;
     p.nblk0 = (int)((P + 127) / 128);
     p.bpix0 = 128;
+    if (coop) {
+        if (urnn_head_coop_blocks(B, (int)P) > 256) return fail(URNN_EINVAL, "urnn_head_coop_f32: %d blocks cannot all be resident (urnn_head_coop_blocks)", urnn_head_coop_blocks(B, (int)P));
+        CHECK_HIP(urnn_launch_head_coop(p, reinterpret_cast<unsigned *>(ws.status) + 16, (hipStream_t)stream), "head (one cooperative launch)");
+        return URNN_OK;
+    }
     CHECK_HIP(urnn_launch_head(p, phase_mask, (hipStream_t)stream), "head");
     return URNN_OK;
 }
@@ -1042,6 +1047,22 @@ extern "C" int urnn_head_f32(const float *feat, const float *conv_w, const float
 {
     return head_impl(feat, conv_w, ln_w, ln_b, cls_w, cls_b, reg_w, reg_b, out_masked, out_cls, out_raw, frame_index, workspace,
                      workspace_bytes, B, C, H, W, cls_thred, eps, slope, URNN_HEAD_ALL, 0, stream);
+}
+
+// The head of a small plane as ONE cooperative launch (urnn_elem.hip head_coop_kernel): the four passes with grid barriers between them
+extern "C" int urnn_head_coop_blocks_f32(int B, int H, int W)
+{
+    if (B < 1 || H < 1 || W < 1) return 0;
+    return urnn_head_coop_blocks(B, H * W);
+}
+
+extern "C" int urnn_head_coop_f32(const float *feat, const float *conv_w, const float *ln_w, const float *ln_b, const float *cls_w,
+                                  const float *cls_b, const float *reg_w, const float *reg_b, float *out_masked, float *out_cls,
+                                  float *out_raw, const int *frame_index, void *workspace, size_t workspace_bytes, int B, int C,
+                                  int H, int W, float cls_thred, float eps, float slope, void *stream)
+{
+    return head_impl(feat, conv_w, ln_w, ln_b, cls_w, cls_b, reg_w, reg_b, out_masked, out_cls, out_raw, frame_index, workspace,
+                     workspace_bytes, B, C, H, W, cls_thred, eps, slope, URNN_HEAD_ALL, 0, stream, nullptr, 1);
 }
 
 // The head behind urnn_gru_cell_tail_f32(..., head_conv_w, head_partial0): its first pass (the statistics of the stem's LayerNorm) was

@@ -92,6 +92,9 @@ __device__ __forceinline__ double tile_x2(float s1, float y, int n)
 // norm later at most.  The owner of the workspace zeroes it once and reads the word at a synchronisation point of its choice.
 // (bits URNN_STATUS_GATES / _CAND / _HEAD: include/urnn_hip.h)
 #define URNN_STATUS_BYTES 256
+#ifndef URNN_STATUS_BARRIER
+#define URNN_STATUS_BARRIER 8     // a grid barrier gave up (include/urnn_hip.h)
+#endif
 __device__ __forceinline__ void flag_nonfinite(int *status, int bit, double s1, double s2)
 {
     if (status && !(__builtin_isfinite(s1) && __builtin_isfinite(s2))) atomicOr(status, bit);   // (the sums, before any clamp)
@@ -177,6 +180,37 @@ __device__ __forceinline__ unsigned bf16_piece(float x, int piece)
     if (piece == 1) return u >> 16;
     r = r - __uint_as_float(u & 0xffff0000u);
     return __float_as_uint(r) >> 16;
+}
+
+// ---- grid barrier of the cooperative launches (urnn_small.hip coop_cell_kernel, urnn_elem.hip head_coop_kernel) -------------------------
+// One monotonic generation word + an arrival counter the last arriver resets (MI355X_MICROARCH.md "barrier-counter" with the
+// hand-off protocol of cdna_hip_programming.md section 6 G16: every wave drains its stores, one lane releases at agent scope, polls
+// relaxed, acquires once).  <= 256 arrivals.
+__device__ __forceinline__ void coop_grid_barrier(unsigned *bar, unsigned nblocks, int *status)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned gen = __hip_atomic_load(&bar[16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == nblocks - 1) {
+            __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&bar[16], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            int spins = 0;
+            while (__hip_atomic_load(&bar[16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > (1 << 22)) {               // ~1 s: something else holds the chip; give up loudly instead of hanging it
+                    if (status) atomicOr(status, URNN_STATUS_BARRIER);
+                    break;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
 }
 
 // A value the compiler may not fold into a neighbouring operation: hipcc contracts a * b + c into an fma wherever it likes (and

@@ -590,6 +590,112 @@ __global__ __launch_bounds__(256) void head_k4(const HeadParams prm)
     }
 }
 
+// The whole head of a SMALL plane in one cooperative launch (URNN head of the 64x64 / 52x120 / 128x128 configs: four launches of 5-18 us
+// for microseconds of work): head_k1 | grid barrier | head_k2 | grid barrier | head_k3 | grid barrier | head_k4, a thread keeping its
+// pixels' 2 x 16 branch activations in registers from pass to pass -- nothing but the partial LayerNorm statistics leaves the CU.
+// Same device functions, same block geometry and summation orders as the four kernels: identical bits.  Every block must be
+// resident (<= 256 blocks; with two kernel chains in flight the caller passes <= 128, as for the cooperative cells).
+template <int V>
+__global__ __launch_bounds__(256) void head_coop_kernel(const HeadParams prm, unsigned *bar, int nblocks)
+{
+    const int b = blockIdx.y;
+    const int p = (blockIdx.x * 256 + threadIdx.x) * V;
+    const bool live = p < prm.P;
+    const size_t CP = (size_t)HEAD_C * prm.P;
+    const int nvalid = HEAD_C * tile_valid(blockIdx.x, 256 * V, prm.P);
+    float u1[HEAD_C][V], u2[HEAD_C][V];
+    // ---- pass 1 (head_k1): u0 = Ws . f and its statistics; u0 stays in u1
+    {
+        float s = 0.f, q = 0.f;
+        if (live) {
+            float f[HEAD_C][V];
+            head_load<V>(prm.feat + b * CP, prm.P, p, f);
+            head_conv<V>(prm.conv_w, f, u1);
+            head_thread_stats<V>(u1, s, q);
+        }
+        head_block_stats2(s, q, 0.f, 0.f, live ? HEAD_C * V : 0, false, nvalid, head_partial(prm, 0, b, blockIdx.x), nullptr);
+    }
+    coop_grid_barrier(bar, (unsigned)nblocks, prm.status);
+    // ---- pass 2 (head_k2): t = SiLU(LN0(u0)); u1 = Wc1 . t, u2 = Wq1 . t
+    {
+        float m0, r0;
+        head_stats<true, V>(prm, 0, b, m0, r0);
+        float sc = 0.f, qc = 0.f, sq = 0.f, qq = 0.f;
+        if (live) {
+            float t[HEAD_C][V];
+#pragma unroll
+            for (int c = 0; c < HEAD_C; ++c)
+#pragma unroll
+                for (int k = 0; k < V; ++k) t[c][k] = u1[c][k];
+            head_ln_silu<V>(t, prm.ln_w, prm.ln_b, prm.P, p, m0, r0);
+            head_conv<V>(prm.conv_w + 1 * HEAD_C * HEAD_C, t, u1);
+            head_thread_stats<V>(u1, sc, qc);
+            head_conv<V>(prm.conv_w + 3 * HEAD_C * HEAD_C, t, u2);
+            head_thread_stats<V>(u2, sq, qq);
+        }
+        head_block_stats2(sc, qc, sq, qq, live ? HEAD_C * V : 0, true, nvalid, head_partial(prm, 1, b, blockIdx.x), head_partial(prm, 3, b, blockIdx.x));
+    }
+    coop_grid_barrier(bar, (unsigned)nblocks, prm.status);
+    // ---- pass 3 (head_k3): u1 <- Wc2 . SiLU(LN1(u1)), u2 <- Wq2 . SiLU(LN3(u2))
+    {
+        float m1, r1, m3, r3;
+        head_stats<true, V>(prm, 1, b, m1, r1);
+        head_stats<true, V>(prm, 3, b, m3, r3);
+        float sc = 0.f, qc = 0.f, sq = 0.f, qq = 0.f;
+        if (live) {
+            float x[HEAD_C][V];
+#pragma unroll
+            for (int c = 0; c < HEAD_C; ++c)
+#pragma unroll
+                for (int k = 0; k < V; ++k) x[c][k] = u1[c][k];
+            head_ln_silu<V>(x, prm.ln_w + 1 * CP, prm.ln_b + 1 * CP, prm.P, p, m1, r1);
+            head_conv<V>(prm.conv_w + 2 * HEAD_C * HEAD_C, x, u1);
+            head_thread_stats<V>(u1, sc, qc);
+#pragma unroll
+            for (int c = 0; c < HEAD_C; ++c)
+#pragma unroll
+                for (int k = 0; k < V; ++k) x[c][k] = u2[c][k];
+            head_ln_silu<V>(x, prm.ln_w + 3 * CP, prm.ln_b + 3 * CP, prm.P, p, m3, r3);
+            head_conv<V>(prm.conv_w + 4 * HEAD_C * HEAD_C, x, u2);
+            head_thread_stats<V>(u2, sq, qq);
+        }
+        head_block_stats2(sc, qc, sq, qq, live ? HEAD_C * V : 0, true, nvalid, head_partial(prm, 2, b, blockIdx.x), head_partial(prm, 4, b, blockIdx.x));
+    }
+    coop_grid_barrier(bar, (unsigned)nblocks, prm.status);
+    // ---- pass 4 (head_k4): predictions + wet / dry mask
+    {
+        float m2, r2, m4, r4;
+        head_stats<true, V>(prm, 2, b, m2, r2);
+        head_stats<true, V>(prm, 4, b, m4, r4);
+        if (!live) return;
+        const int frame = prm.frame_index ? *prm.frame_index : 0;
+        const size_t obase = ((size_t)frame * prm.B + b) * prm.P + p;
+        float cls[V], reg[V];
+        head_ln_silu<V>(u1, prm.ln_w + 2 * CP, prm.ln_b + 2 * CP, prm.P, p, m2, r2);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float a = prm.cls_b[0];
+#pragma unroll
+            for (int c = 0; c < HEAD_C; ++c) a = fmaf(prm.cls_w[c], u1[c][k], a);
+            cls[k] = sigmoidf_fast(a);
+        }
+        head_ln_silu<V>(u2, prm.ln_w + 4 * CP, prm.ln_b + 4 * CP, prm.P, p, m4, r4);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float a = prm.reg_b[0];
+#pragma unroll
+            for (int c = 0; c < HEAD_C; ++c) a = fmaf(prm.reg_w[c], u2[c][k], a);
+            reg[k] = lrelu(a, prm.slope);
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            prm.out_masked[obase + k] = reg[k] * (cls[k] >= prm.cls_thred ? 1.f : 0.f);
+            prm.out_cls[obase + k] = cls[k];
+            if (prm.out_raw) prm.out_raw[obase + k] = reg[k];
+        }
+    }
+}
+
 // LayerNorm finalise: one block per (which, sample); which = first + i * stride for i < n (blockIdx.y).
 __global__ __launch_bounds__(64) void ln_finalize_kernel(const HeadParams prm, int first, int stride, int nblk_used, int block_pix)
 {
@@ -658,6 +764,18 @@ static hipError_t launch_head_v(const HeadParams &p, int mask, hipStream_t st)
     if (mask & URNN_HEAD_K3) hipLaunchKernelGGL((head_k3<V, false>), grid, blk, 0, st, p);
     if (mask & URNN_HEAD_F3) hipLaunchKernelGGL(ln_finalize_kernel, dim3(p.B, 2), dim3(64), 0, st, p, 2, 2, fin, bpix);
     if (mask & URNN_HEAD_K4) hipLaunchKernelGGL((head_k4<V, false>), grid, blk, 0, st, p);
+    return hipGetLastError();
+}
+
+// blocks of the cooperative head launch for a plane of P pixels and B samples (the caller decides whether that many may be resident)
+int urnn_head_coop_blocks(int B, int P) { return B * urnn_head_nblk_used(P); }
+
+hipError_t urnn_launch_head_coop(const HeadParams &p, unsigned *bar, hipStream_t st)
+{
+    const int v = head_vec(p.P), nb = urnn_head_nblk_used(p.P);
+    const dim3 grid(nb, p.B), blk(256);
+    if (v == 2) hipLaunchKernelGGL(head_coop_kernel<2>, grid, blk, 0, st, p, bar, nb * p.B);
+    else hipLaunchKernelGGL(head_coop_kernel<1>, grid, blk, 0, st, p, bar, nb * p.B);
     return hipGetLastError();
 }
 

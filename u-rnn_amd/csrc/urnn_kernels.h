@@ -164,6 +164,8 @@ struct HeadParams {
     int nblk0, bpix0;
 };
 hipError_t urnn_launch_head(const HeadParams &p, int phase_mask, hipStream_t st);
+int urnn_head_coop_blocks(int B, int P);
+hipError_t urnn_launch_head_coop(const HeadParams &p, unsigned *bar, hipStream_t st);
 int urnn_head_nblk(int P);        // blocks allocated per (norm, sample) in the partial buffer
 int urnn_head_nblk_used(int P);   // blocks the head kernels write
 hipError_t urnn_launch_stats_reduce(const float *partial, int rows, int stride, int ntiles, int tile_pix, int P, int chans, double *sums,

@@ -379,36 +379,6 @@ struct CoopCellParams {
 };
 
 
-// One monotonic generation word + an arrival counter the last arriver resets (MI355X_MICROARCH.md "barrier-counter" with the
-// hand-off protocol of cdna_hip_programming.md section 6 G16: every wave drains its stores, one lane releases at agent scope, polls
-// relaxed, acquires once).  <= 256 arrivals.
-__device__ __forceinline__ void coop_grid_barrier(unsigned *bar, unsigned nblocks, int *status)
-{
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned gen = __hip_atomic_load(&bar[16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned t = __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == nblocks - 1) {
-            __hip_atomic_store(&bar[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(&bar[16], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            int spins = 0;
-            while (__hip_atomic_load(&bar[16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
-                __builtin_amdgcn_s_sleep(4);
-                if (++spins > (1 << 22)) {               // ~1 s: something else holds the chip; give up loudly instead of hanging it
-                    if (status) atomicOr(status, URNN_STATUS_BARRIER);
-                    break;
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-}
-
 __global__ __launch_bounds__(768) void coop_cell_kernel(const CoopCellParams cp, int nblk_total, int NBG)
 {
     const ConvGemmParams &prm = cp.g;

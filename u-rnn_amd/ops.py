@@ -317,7 +317,7 @@ def deconv2x2(x, packed, Cout, out=None, slope=LRELU_SLOPE):
 
 
 def head(feat, conv_w, ln_w, ln_b, cls_w, cls_b, reg_w, reg_b, cls_thred, out_masked=None, out_cls=None, out_raw=None,
-         frame_index=None, want_raw=False, eps=NORM_EPS, slope=LRELU_SLOPE, ws=None, partial0=None):
+         frame_index=None, want_raw=False, eps=NORM_EPS, slope=LRELU_SLOPE, ws=None, partial0=None, coop=False):
     """Dual head + mask.  Returns (masked, cls, raw|None), each (B,H,W) unless preallocated (T,B,H,W) buffers
     plus a device ``frame_index`` are given."""
     _dev_check(feat, conv_w, ln_w, ln_b, cls_w, cls_b, reg_w, reg_b, out_masked, out_cls, out_raw)
@@ -337,9 +337,10 @@ def head(feat, conv_w, ln_w, ln_b, cls_w, cls_b, reg_w, reg_b, cls_thred, out_ma
                                          ws.numel(), B, C, H, W, float(cls_thred), eps, slope, _ptr(partial0), _stream()),
               "urnn_head_after_tail_f32")
         return out_masked, out_cls, out_raw
-    check(L.urnn_head_f32(_ptr(feat), _ptr(conv_w), _ptr(ln_w), _ptr(ln_b), _ptr(cls_w), _ptr(cls_b), _ptr(reg_w),
-                          _ptr(reg_b), _ptr(out_masked), _ptr(out_cls), _ptr(out_raw), _ptr(frame_index), _ptr(ws),
-                          ws.numel(), B, C, H, W, float(cls_thred), eps, slope, _stream()), "urnn_head_f32")
+    fn, what = (L.urnn_head_coop_f32, "urnn_head_coop_f32") if coop else (L.urnn_head_f32, "urnn_head_f32")   # coop: one cooperative launch
+    check(fn(_ptr(feat), _ptr(conv_w), _ptr(ln_w), _ptr(ln_b), _ptr(cls_w), _ptr(cls_b), _ptr(reg_w),
+             _ptr(reg_b), _ptr(out_masked), _ptr(out_cls), _ptr(out_raw), _ptr(frame_index), _ptr(ws),
+             ws.numel(), B, C, H, W, float(cls_thred), eps, slope, _stream()), what)
     return out_masked, out_cls, out_raw
 
 

@@ -100,6 +100,8 @@ class RolloutEngine:
         def coop_flag(cell, has_x, skip):
             n = L.urnn_gru_cell_coop_blocks(B, cell.input_channels, cell.num_features, cell.shape[0], cell.shape[1], int(skip), int(has_x))
             return ops.PHASE_COOP if (coop_cells and n > 0 and (n <= 128 or not self.overlap)) else 0
+        nhead = L.urnn_head_coop_blocks_f32(B, H, W)                 # ... and the head likewise (urnn_head_coop_f32)
+        self._head_coop = bool(coop_cells) and (nhead <= 128 or (not self.overlap and nhead <= 256))
         self._coop = {"enc1": coop_flag(enc.rnn1, 1, 0), "enc2": coop_flag(enc.rnn2, 1, 0), "enc3": coop_flag(enc.rnn3, 1, 0),
                       "dec3": coop_flag(dec.rnn3, 0, 1), "dec2": coop_flag(dec.rnn2, 1, 1), "dec1": coop_flag(dec.rnn1, 1, 1)}
         self._dem_stamp = None
@@ -122,8 +124,9 @@ class RolloutEngine:
         dec.stage2(d2, out=self.u2)
         if not self._cell("dec1", dec.rnn1, self.u2, e1, d3, d3, ws, conv_out=self.feat, k1part=self._k1part[0]):
             dec.stage1(d3, out=self.feat)
+        tail = self._tail_of("dec1") is not None
         net.head.run(self.feat, out_masked=self.out_masked, out_cls=self.out_cls, out_raw=self.out_raw,
-                     frame_index=self.t_dev, ws=ws, partial0=self._k1part[0] if self._tail_of("dec1") is not None else None)
+                     frame_index=self.t_dev, ws=ws, partial0=self._k1part[0] if tail else None, coop=self._head_coop and not tail)
         ops.advance_counter(self.t_dev, 1)
 
     def _stage1(self, t_dev):
@@ -260,7 +263,8 @@ class RolloutEngine:
         """head(t) for t % 2 == parity (reads feat[parity]); shares the encoder chain's stream and scratch."""
         self.net.head.run(self.feat if parity == 0 else self.feat_alt, out_masked=self.out_masked, out_cls=self.out_cls,
                           out_raw=self.out_raw, frame_index=self.t_dev, ws=self._ws[0],
-                          partial0=self._k1part[parity] if self._tail_of("dec1") is not None else None)
+                          partial0=self._k1part[parity] if self._tail_of("dec1") is not None else None,
+                          coop=self._head_coop and self._tail_of("dec1") is None)
         ops.advance_counter(self.t_dev, 1)
 
     def _iter_overlap(self, parity, with_head=True):
