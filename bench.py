@@ -428,6 +428,9 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="dry run: every rank uses cuda:0 (needs --dist-backend gloo)")
     ap.add_argument("--overlap", type=int, default=1,
                     help="1 (default): encoder(t+1) || decoder+head(t) as two concurrent kernel chains; 0: one chain")
+    ap.add_argument("--fused-tails", action="store_true",
+                    help="infer mode: RolloutEngine(fused_tails=True) -- the end of enc1 / enc2 / dec1 in one launch with the stage conv behind it "
+                         "(190 MB per frame less through HBM, 3-4 %% fewer frames/s: off by default, DESIGN.md 4.10)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train", "strips"],
                     help="infer (default, the BASELINE metric): rollout frames/s.  train: SWP training timesteps/s (forward + backward + "
                          "clipped Adam, windows of --seq-num steps; N>1: DDP mean all-reduce of the flat gradient buffer over RCCL).  "
@@ -493,7 +496,7 @@ def main():
         H, W, nums, T, rain_max, cum_max, spatial = CONFIGS[name]
         net_i, sd_i, cfg = build_net(H, W, 2 * nums + 3, dev)
         eng_i = RolloutEngine(net_i, H, W, nums, rain_max, cum_max, batch=B, max_frames=T, spatial_rain=spatial, net_cfg=cfg,
-                              use_graph=not args.no_graph, device=dev, overlap=bool(args.overlap))
+                              use_graph=not args.no_graph, device=dev, overlap=bool(args.overlap), fused_tails=args.fused_tails)
         eng_i.load_event(uw.make_event(T, H, W, rain_max, seed=42 + rank + 100 * i, spatial_rain=spatial, batch=B))
         eng_i.reset()
         engines.append((eng_i, T))
@@ -568,7 +571,8 @@ def main():
                                ("mixed: " + " + ".join(f"{n} {CONFIGS[n][0]}x{CONFIGS[n][1]} T={CONFIGS[n][3]}" for n in names) +
                                 f" events alternating, {B} event(s) per GPU, one hipGraph per shape"),
                    "events_per_gpu": B, "parallelism": f"event-parallel x{world} (no collective)",
-                   "graph": not args.no_graph, "overlap_chains": bool(args.overlap), "matrix_mode": args.matrix_mode},
+                   "graph": not args.no_graph, "overlap_chains": bool(args.overlap), "matrix_mode": args.matrix_mode,
+                   "fused_tails": bool(args.fused_tails)},
         "long_run": long_run,
         "gflop_per_frame": gflop,
         "step_mfma_frac": fps / world * gflop / 1e3 / PEAK_MFMA_F32_TFLOPS,                          # of the fp32 matrix peak (round 1's pipe)

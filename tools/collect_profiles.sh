@@ -6,6 +6,8 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=${1:-r04}
 O=$R/gpurun_out/$TAG; P=/tmp/prof_$TAG
 mkdir -p $O $P; cd /tmp; export TMPDIR=/tmp
+# one chain, eager (every dispatch attributed) -- with the kernel selection of the benchmarked two-chain schedule (URNN_TUNE_COOP_BIG=0)
+export URNN_TUNE_COOP_BIG=0
 CMD="python $R/bench.py --steps 14 --warmup 2 --no-cpu-baseline --no-long-run --overlap 0 --no-graph"
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   name=$(echo $pass | cut -d' ' -f1)
@@ -13,6 +15,7 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES S
   { echo "# rocprofv3 --kernel-trace --pmc $pass -- $CMD"; python $R/tools/pmc_summary.py $P/pmc_$name/p_results.db "" --frames=-1; } > $O/pmc_$name.txt 2>&1
 done
 python $R/tools/make_pmc_json.py $O/pmc_FETCH_SIZE.txt $O/pmc_WRITE_SIZE.txt $O/pmc_kernels.json "$TAG" > /dev/null 2>$O/make_pmc_json.err
+unset URNN_TUNE_COOP_BIG
 # the training step's byte counters (two windows of 4 timesteps, eager so that every dispatch is attributed)
 TCMD="python $R/bench.py --mode train --steps 4 --warmup 4 --no-graph"
 for name in FETCH_SIZE WRITE_SIZE; do
@@ -24,13 +27,31 @@ timeout 420 rocprofv3 --kernel-trace --stats -d $P/stats_default -o d -- python 
 python $R/tools/prof_summary.py $P/stats_default/d_results.db > $O/kernel_stats.txt 2>&1
 timeout 420 rocprofv3 --kernel-trace --stats -d $P/stats_ov0 -o o -- python $R/bench.py --no-cpu-baseline --overlap 0 > $O/bench_overlap0_under_rocprof.log 2>&1
 python $R/tools/prof_summary.py $P/stats_ov0/o_results.db > $O/kernel_stats_overlap0.txt 2>&1
-python $R/bench.py > $O/bench_default.log 2>&1
-python $R/bench.py --overlap 0 --no-cpu-baseline > $O/bench_overlap0.log 2>&1
-python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_steps20.log 2>&1
-python $R/tools/kernel_bench.py > $O/kernel_bench.txt 2>&1
-python $R/bench.py --mode train > $O/bench_train.log 2>&1
-python $R/bench.py --mode train --dtype bf16 > $O/bench_train_bf16.log 2>&1
-python $R/bench.py --mode train --seq-num 12 > $O/bench_train_seq12.log 2>&1
+timeout 300 python $R/bench.py > $O/bench_default.log 2>&1
+timeout 200 python $R/bench.py --overlap 0 --no-cpu-baseline > $O/bench_overlap0.log 2>&1
+timeout 200 python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_steps20.log 2>&1
+timeout 200 python $R/bench.py --fused-tails --no-cpu-baseline > $O/bench_fused_tails.log 2>&1
+# the other BASELINE shapes: cooperative small-plane cells + head (default) against the three-kernel cells / four-pass head
+PYP='import sys,json
+for l in sys.stdin:
+    if l.startswith("{"):
+        r=json.loads(l); print(sys.argv[1], round(r["value"],1), "frames/s", round(r["ms_per_step"]*1000,1), "us per frame")'
+{ for c in lite64 ukea lite128 futian; do
+    timeout 200 python $R/bench.py --config $c --no-cpu-baseline 2>/dev/null | python -c "$PYP" "$c (default: cooperative cells + head where <= 128 blocks)"
+    URNN_TUNE_COOP=0 timeout 200 python $R/bench.py --config $c --no-cpu-baseline 2>/dev/null | python -c "$PYP" "$c URNN_TUNE_COOP=0 (three-kernel cells)"
+  done
+  timeout 200 python $R/bench.py --config mixed --no-cpu-baseline 2>/dev/null | python -c "$PYP" "mixed (futian + ukea alternating)"; } > $O/bench_configs.txt 2>&1
+# byte counters with the fused tails (the traffic side of that trade)
+export URNN_TUNE_COOP_BIG=0
+for name in FETCH_SIZE WRITE_SIZE; do
+  timeout 420 rocprofv3 --kernel-trace --pmc $name -d $P/pmcf_$name -o p -- $CMD --fused-tails > $P/pmcf_$name.log 2>&1
+  { echo "# rocprofv3 --kernel-trace --pmc $name -- $CMD --fused-tails"; python $R/tools/pmc_summary.py $P/pmcf_$name/p_results.db "" --frames=-1; } > $O/pmc_fused_tails_$name.txt 2>&1
+done
+unset URNN_TUNE_COOP_BIG
+timeout 300 python $R/tools/kernel_bench.py > $O/kernel_bench.txt 2>&1
+timeout 300 python $R/bench.py --mode train > $O/bench_train.log 2>&1
+timeout 300 python $R/bench.py --mode train --dtype bf16 > $O/bench_train_bf16.log 2>&1
+timeout 300 python $R/bench.py --mode train --seq-num 12 > $O/bench_train_seq12.log 2>&1
 timeout 420 rocprofv3 --kernel-trace --stats -d $P/stats_train -o t -- python $R/bench.py --mode train > /dev/null 2>&1
 python $R/tools/prof_summary.py $P/stats_train/t_results.db > $O/train_kernel_stats.txt 2>&1
 python $R/tools/wgrad_trace.py $P/stats_train/t_results.db > $O/train_wgrad_launches.txt 2>&1

@@ -1108,30 +1108,38 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void cand_fused_kernel(const Con
             for (int rb = 0; rb < NBF; ++rb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) load_row<MAP, PB>(hbase + (size_t)(rb * 32 + row_c(r)) * prm.P, pm, hv[rb][r]);
+            // Software pipeline over the reset-gate blocks: the sigmoids of block rb + 1 (VALU, transcendental pipe) are issued between the fp32
+            // MFMAs of block rb (matrix pipe, 64 cycles each, asynchronous), row by row, instead of all sigmoids of a block in front of all
+            // its MFMAs.  Same products in the same order per accumulator: identical bits.
+            auto gate_row = [&](int rb, int r) __attribute__((always_inline)) {
+                const f32x2 sc = *reinterpret_cast<const f32x2 *>(ssb + 2 * (rb * 32 + row_c(r)));
+                const float bv = bias_h[rb * 32 + row_c(r)];
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb) acc[rb][pb][r] = sigmoidf_fast(fin(acc[rb][pb][r], bv) * sc.x + sc.y);
+            };
+            // W2[:, h] . (r (.) h) on the fp32 matrix instruction: of the cell's products this is the one whose 16-bit form shows in a
+            // long rollout, and here it costs little -- the operand is already in registers as fp32 (no split),
+            // K = 2 per instruction pairs the two lane halves' rows (channels c and c + 4), the weights sit in LDS as fp32 x 2^15
+            // (the accumulators' scale) in exactly that order, 64 x 64 of them
+            auto mfma_row = [&](int rb, int r) __attribute__((always_inline)) {
+                float v[PB];
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb) v[pb] = acc[rb][pb][r] * hv[rb][r][pb];
+#pragma unroll
+                for (int nb = 0; nb < NBF; ++nb) {
+                    const float wa = A2f[((rb * 16 + r) * NBF + nb) * 64];
+#pragma unroll
+                    for (int pb = 0; pb < PB; ++pb) acc[NBF + nb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa, v[pb], acc[NBF + nb][pb], 0, 0, 0);
+                }
+            };
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gate_row(0, r);
 #pragma unroll
             for (int rb = 0; rb < NBF; ++rb) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const f32x2 sc = *reinterpret_cast<const f32x2 *>(ssb + 2 * (rb * 32 + row_c(r)));
-                    const float bv = bias_h[rb * 32 + row_c(r)];
-#pragma unroll
-                    for (int pb = 0; pb < PB; ++pb) acc[rb][pb][r] = sigmoidf_fast(fin(acc[rb][pb][r], bv) * sc.x + sc.y);
-                }
-                // W2[:, h] . (r (.) h) on the fp32 matrix instruction: of the cell's products this is the one whose 16-bit form shows in a
-                // long rollout, and here it costs little -- the operand is already in registers as fp32 (no split),
-                // K = 2 per instruction pairs the two lane halves' rows (channels c and c + 4), the weights sit in LDS as fp32 x 2^15
-                // (the accumulators' scale) in exactly that order, 64 x 64 of them
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v[PB];
-#pragma unroll
-                    for (int pb = 0; pb < PB; ++pb) v[pb] = acc[rb][pb][r] * hv[rb][r][pb];
-#pragma unroll
-                    for (int nb = 0; nb < NBF; ++nb) {
-                        const float wa = A2f[((rb * 16 + r) * NBF + nb) * 64];
-#pragma unroll
-                        for (int pb = 0; pb < PB; ++pb) acc[NBF + nb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa, v[pb], acc[NBF + nb][pb], 0, 0, 0);
-                    }
+                    mfma_row(rb, r);
+                    if (rb + 1 < NBF) gate_row(rb + 1, r);
                 }
             }
         }

@@ -91,6 +91,7 @@ class RolloutEngine:
         self._probe = None          # {"enc1": [(start, stop), ...], "dec1": [...]} while probing
         self._graph = None
         self._graphs2 = None
+        # (equal stream priorities: a high-priority chain starves the other -- 900 instead of 1 250 frames/s either way round)
         self._side = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)) if self.overlap else None
         # A cooperative cell launch needs ALL its blocks resident (one per CU).  With two kernel chains in flight, two such launches
         # of at most 128 blocks each always fit side by side; a larger one could wait at its grid barrier for CUs the other chain's
@@ -99,9 +100,12 @@ class RolloutEngine:
         # profiles/r04_coop_cells.txt); one chain takes it wherever the library plans it.
         def coop_flag(cell, has_x, skip):
             n = L.urnn_gru_cell_coop_blocks(B, cell.input_channels, cell.num_features, cell.shape[0], cell.shape[1], int(skip), int(has_x))
-            return ops.PHASE_COOP if (coop_cells and n > 0 and (n <= 128 or not self.overlap)) else 0
+            # (URNN_TUNE_COOP_BIG=0: a one-chain engine keeps the two-chain policy -- the counter passes of tools/collect_profiles.sh run
+            # eager on one chain and must execute the kernels of the benchmarked schedule)
+            big_ok = not self.overlap and os.environ.get("URNN_TUNE_COOP_BIG", "1") != "0"
+            return ops.PHASE_COOP if (coop_cells and n > 0 and (n <= 128 or big_ok)) else 0
         nhead = L.urnn_head_coop_blocks_f32(B, H, W)                 # ... and the head likewise (urnn_head_coop_f32)
-        self._head_coop = bool(coop_cells) and (nhead <= 128 or (not self.overlap and nhead <= 256))
+        self._head_coop = bool(coop_cells) and (nhead <= 128 or (not self.overlap and nhead <= 256 and os.environ.get("URNN_TUNE_COOP_BIG", "1") != "0"))
         self._coop = {"enc1": coop_flag(enc.rnn1, 1, 0), "enc2": coop_flag(enc.rnn2, 1, 0), "enc3": coop_flag(enc.rnn3, 1, 0),
                       "dec3": coop_flag(dec.rnn3, 0, 1), "dec2": coop_flag(dec.rnn2, 1, 1), "dec1": coop_flag(dec.rnn1, 1, 1)}
         self._dem_stamp = None
