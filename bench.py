@@ -620,8 +620,9 @@ def main():
                 entry = {"family": fam, "kernel": FAMILY_KERNELS[fam], "bound": "hbm", "launches_per_frame": 4,
                          "achieved": bpl / avg / 1e3, "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s", "frac": bpl / avg / 1e3 / (PEAK_HBM_TBS * 1e3),
                          "traffic": traffic, "traffic_source": tsrc, "bytes_per_launch": bpl, "avg_launch_us": avg,
-                         "avg_launch_us_is": "one kernel chain (an event pair on the launch stream spans the kernel alone): compare with rocprofv3 "
-                                             "--kernel-trace --stats of `bench.py --overlap 0` (profiles/*_kernel_stats_overlap0.txt)",
+                         "avg_launch_us_is": "one kernel chain (an event pair on the launch stream spans the kernel alone, plus ~2 us of record path / launch "
+                                             "boundary: 4-6 % above rocprofv3's duration of the same launch): compare with rocprofv3 --kernel-trace --stats of "
+                                             "`bench.py --overlap 0` (profiles/*_kernel_stats_overlap0.txt)",
                          "us_per_frame": sum(us.values()), "launch_us": us, "bytes_per_launch_by_cell": by,
                          "live_two_chain": {"avg_launch_us": avg_live, "launch_us": us_live, "frac": bpl / avg_live / 1e3 / (PEAK_HBM_TBS * 1e3),
                                             "note": "the benchmarked schedule: kernel + what it queued behind on its stream while the other chain holds the CUs"}

@@ -198,6 +198,9 @@ class RolloutEngine:
         probe, self._probe = self._probe, None
         self.use_graph = saved_graph
         self.reset()
+        # (An event pair around one launch reads ~2 us more than the kernel's own begin-to-end time -- the record path and the launch
+        # boundary: bench.py's figures sit 4-6 % above rocprofv3's for the same launches, profiles/r04_kernel_stats_overlap0.txt.  An
+        # empty pair measures 6-8 us here and over-corrects; nothing is subtracted.)
         return {c: {k: sum(a.elapsed_time(b) for a, b in v) / len(v) / 1e3 for k, v in kinds.items()} for c, kinds in probe.items()}
 
     def probe_gate_gemm(self, frames=12):
