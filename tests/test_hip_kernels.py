@@ -361,3 +361,59 @@ def test_cooperative_head_equals_four_passes(dev, H, W, B):
             assert torch.equal(a_, b_), f"cooperative head differs in {what}: max {float((a_ - b_).abs().max()):.3e}"
     assert ops.workspace_status(ws) == 0
     assert lib().urnn_head_coop_blocks_f32(1, 500, 500) == 489       # the 500x500 head stays on its four launches
+
+
+@pytest.mark.parametrize("H,W,B", [(64, 64, 1), (100, 60, 2)])
+def test_frame_loop_forms_advance_the_other_chains_counter(dev, H, W, B):
+    """urnn_head_rollout_f32 / urnn_preprocess_rollout_f32 / urnn_stage1_scalar_rain_rollout_f32 (one iteration of test.py:326-377 as
+    two kernel chains with a device frame counter each): same outputs as the plain entries for the frame *frame_index / *t_dev
+    names, and the OTHER counter advanced by exactly one per call; the launch's own counter is refused."""
+    import urnn_amd.weights as uw
+    from urnn_amd import ops
+    from urnn_amd._lib import UrnnError, lib
+    from urnn_amd.dataset import event_to_device
+    rs = np.random.RandomState(77 + H)
+    nums, Tn = 4, 6
+    ev = event_to_device(uw.make_event(Tn, H, W, 6.0, seed=3, batch=B), dev)
+    own = torch.full((1,), 2, dtype=torch.int32, device=dev)
+    other = torch.full((1,), 40, dtype=torch.int32, device=dev)
+    # input assembly, spatial-agnostic entry
+    plain = ops.preprocess(ev["rain"], ev["cumsum"], ev["dem"], ev["imperv"], ev["manhole"], ev["dem_min"], ev["dem_max"], 0, nums, 6.0,
+                           250.0, t_dev=own)
+    both = ops.preprocess(ev["rain"], ev["cumsum"], ev["dem"], ev["imperv"], ev["manhole"], ev["dem_min"], ev["dem_max"], 0, nums, 6.0,
+                          250.0, t_dev=own, next_counter=other)
+    assert torch.equal(plain, both) and int(other.item()) == 41 and int(own.item()) == 2
+    # scalar-rain stage 1
+    Cout = 32
+    w1 = T(rs.normal(0, 0.3, (Cout, 2 * nums + 3)).astype(np.float32), dev)
+    b1 = T(rs.normal(0, 0.1, Cout).astype(np.float32), dev)
+    S = ops.stage1_static(ev["dem"], ev["imperv"], ev["manhole"], ev["dem_min"], ev["dem_max"], w1, nums)
+    plain = ops.stage1_scalar_rain(S, ev["rain"], ev["cumsum"], w1, b1, 0, nums, 6.0, 250.0, t_dev=own)
+    both = ops.stage1_scalar_rain(S, ev["rain"], ev["cumsum"], w1, b1, 0, nums, 6.0, 250.0, t_dev=own, next_counter=other)
+    assert torch.equal(plain, both) and int(other.item()) == 42 and int(own.item()) == 2
+    with pytest.raises(UrnnError):
+        ops.stage1_scalar_rain(S, ev["rain"], ev["cumsum"], w1, b1, 0, nums, 6.0, 250.0, t_dev=own, next_counter=own)
+    # head: four launches, one cooperative launch
+    feat = T(rs.normal(0, 1, (B, 16, H, W)).astype(np.float32), dev)
+    conv_w = T(rs.normal(0, 0.25, (5, 16, 16)).astype(np.float32), dev)
+    ln_w = T(rs.uniform(0.5, 1.5, (5, 16, H, W)).astype(np.float32), dev)
+    ln_b = T(rs.normal(0, 0.1, (5, 16, H, W)).astype(np.float32), dev)
+    cw, cb_, rw, rb = (T(rs.normal(0, 0.3, 16).astype(np.float32), dev), T(np.zeros(1, np.float32), dev),
+                       T(rs.normal(0, 0.3, 16).astype(np.float32), dev), T(np.full(1, 0.1, np.float32), dev))
+    ws = ops.workspace(ops.head_workspace_bytes(B, 16, H, W), dev)
+    four = ops.head(feat, conv_w, ln_w, ln_b, cw, cb_, rw, rb, 0.5, want_raw=True, ws=ws)
+    for coop in (False, True):
+        if coop and not 0 < lib().urnn_head_coop_blocks_f32(B, H, W) <= 128:
+            continue
+        bufs = [torch.zeros((Tn, B, H, W), device=dev) for _ in range(3)]
+        before = int(other.item())
+        ops.head(feat, conv_w, ln_w, ln_b, cw, cb_, rw, rb, 0.5, out_masked=bufs[0], out_cls=bufs[1], out_raw=bufs[2], frame_index=own,
+                 ws=ws, coop=coop, next_counter=other)
+        assert int(other.item()) == before + 1 and int(own.item()) == 2
+        for buf, ref, what in zip(bufs, four, ("masked", "cls", "pre-mask reg")):
+            assert torch.equal(buf[2], ref), f"frame-loop head (coop={coop}) differs in {what}"
+            assert float(buf[:2].abs().max()) == 0 and float(buf[3:].abs().max()) == 0
+    with pytest.raises(UrnnError):
+        ops.head(feat, conv_w, ln_w, ln_b, cw, cb_, rw, rb, 0.5, out_masked=bufs[0], out_cls=bufs[1], out_raw=bufs[2], frame_index=own,
+                 ws=ws, next_counter=own)
+    assert ops.workspace_status(ws) == 0

@@ -63,6 +63,9 @@ SIGNATURES = {
     "urnn_adam_workspace_bytes": (_sz, [ctypes.c_long]),
     "urnn_adam_step_f32": (_i, [_p, _p, _p, _p, ctypes.c_long, _f, _f, _f, _f, _i, _p, _f, _p, _p, _sz, _p]),
     "urnn_advance_counter": (_i, [_p, _i, _p]),
+    "urnn_head_rollout_f32": (_i, [_p] * 13 + [_sz, _i, _i, _i, _i, _f, _f, _f, _i, _p, _p, _p]),
+    "urnn_preprocess_rollout_f32": (_i, [_p] * 5 + [_f, _f, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _p]),
+    "urnn_stage1_scalar_rain_rollout_f32": (_i, [_p] * 6 + [_p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _f, _p]),
     "urnn_gru_cell_strip_f32": (_i, [_p] * 10 + [_sz, _i, _i, _i, _i, _i, _f, _i, ctypes.c_long, _p]),
     "urnn_gru_cell_strip_stats_f32": (_i, [_p, _sz, _i, _i, _i, _i, _i, _i, _p, _p]),
     "urnn_head_strip_f32": (_i, [_p] * 13 + [_sz, _i, _i, _i, _i, _f, _f, _f, _i, ctypes.c_long, _p]),

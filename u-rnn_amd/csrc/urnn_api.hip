@@ -991,7 +991,7 @@ static int head_impl(const float *feat, const float *conv_w, const float *ln_w, 
                      const float *cls_b, const float *reg_w, const float *reg_b, float *out_masked, float *out_cls,
                      float *out_raw, const int *frame_index, void *workspace, size_t workspace_bytes, int B, int C,
                      int H, int W, float cls_thred, float eps, float slope, int phase_mask, long global_pixels, void *stream,
-                     const float *partial0 = nullptr, int coop = 0)
+                     const float *partial0 = nullptr, int coop = 0, int *bump = nullptr)
 {
     if (!feat || !conv_w || !ln_w || !ln_b || !cls_w || !cls_b || !reg_w || !reg_b || !out_masked || !out_cls || !workspace)
         return fail(URNN_ENULL, "urnn_head_f32: NULL argument");
@@ -1031,6 +1031,9 @@ static int head_impl(const float *feat, const float *conv_w, const float *ln_w, 
     p.partial0 = partial0;
     p.nblk0 = (int)((P + 127) / 128);
     p.bpix0 = 128;
+    p.bump = bump;
+    if (bump && (bump == frame_index || phase_mask != URNN_HEAD_ALL))
+        return fail(URNN_EINVAL, "urnn_head_rollout_f32: next_counter must not be the head's own frame_index");
     if (coop) {
         if (urnn_head_coop_blocks(B, (int)P) > 256) return fail(URNN_EINVAL, "urnn_head_coop_f32: %d blocks cannot all be resident (urnn_head_coop_blocks)", urnn_head_coop_blocks(B, (int)P));
         CHECK_HIP(urnn_launch_head_coop(p, reinterpret_cast<unsigned *>(ws.status) + 16, (hipStream_t)stream), "head (one cooperative launch)");
@@ -1075,6 +1078,22 @@ extern "C" int urnn_head_after_tail_f32(const float *feat, const float *conv_w, 
     if (!head_partial0) return fail(URNN_ENULL, "urnn_head_after_tail_f32: NULL head_partial0");
     return head_impl(feat, conv_w, ln_w, ln_b, cls_w, cls_b, reg_w, reg_b, out_masked, out_cls, out_raw, frame_index, workspace,
                      workspace_bytes, B, C, H, W, cls_thred, eps, slope, URNN_HEAD_ALL, 0, stream, head_partial0);
+}
+
+// The head inside a frame loop whose OTHER kernel chain keeps its own frame counter (rollout.py's two chains): the head's first
+// launch also advances *next_counter by one -- the counter the launches queued BEHIND the head on this stream read (the next frame's
+// input assembly), which nothing in flight reads while the head runs.  Saves the frame loop a one-thread kernel per frame.
+// coop / head_partial0 select urnn_head_coop_f32 / urnn_head_after_tail_f32 (at most one of them).
+extern "C" int urnn_head_rollout_f32(const float *feat, const float *conv_w, const float *ln_w, const float *ln_b, const float *cls_w,
+                                     const float *cls_b, const float *reg_w, const float *reg_b, float *out_masked, float *out_cls,
+                                     float *out_raw, const int *frame_index, void *workspace, size_t workspace_bytes, int B, int C,
+                                     int H, int W, float cls_thred, float eps, float slope, int coop, const float *head_partial0,
+                                     int *next_counter, void *stream)
+{
+    if (coop && head_partial0) return fail(URNN_EINVAL, "urnn_head_rollout_f32: coop and head_partial0 exclude each other");
+    if (next_counter && !frame_index) return fail(URNN_ENULL, "urnn_head_rollout_f32: next_counter without frame_index");
+    return head_impl(feat, conv_w, ln_w, ln_b, cls_w, cls_b, reg_w, reg_b, out_masked, out_cls, out_raw, frame_index, workspace,
+                     workspace_bytes, B, C, H, W, cls_thred, eps, slope, URNN_HEAD_ALL, 0, stream, head_partial0, coop ? 1 : 0, next_counter);
 }
 
 extern "C" int urnn_head_strip_f32(const float *feat, const float *conv_w, const float *ln_w, const float *ln_b, const float *cls_w,
@@ -1246,18 +1265,40 @@ extern "C" int urnn_adam_step_f32(float *params, const float *grads, float *exp_
 }
 
 // ---- input assembly --------------------------------------------------------------------------------------------------
-extern "C" int urnn_preprocess_f32(const float *rain, const float *cumsum, const float *dem, const float *imperv,
-                                   const float *manhole, float dem_min, float dem_max, float *out, int t, const int *t_dev,
-                                   int B, int T, int nums, int H, int W, int spatial, float rain_max, float cumsum_max,
-                                   void *stream)
+static int preprocess_impl(const float *rain, const float *cumsum, const float *dem, const float *imperv,
+                           const float *manhole, float dem_min, float dem_max, float *out, int t, const int *t_dev,
+                           int B, int T, int nums, int H, int W, int spatial, float rain_max, float cumsum_max,
+                           void *stream, int *bump)
 {
     if (!rain || !cumsum || !dem || !imperv || !manhole || !out) return fail(URNN_ENULL, "urnn_preprocess_f32: NULL argument");
     if (B < 1 || T < 1 || nums < 1 || H < 1 || W < 1) return fail(URNN_EINVAL, "urnn_preprocess_f32: bad dims");
     if (!t_dev && t < 0) return fail(URNN_EINVAL, "urnn_preprocess_f32: t=%d", t);
     CHECK_HIP(urnn_launch_preprocess(rain, cumsum, dem, imperv, manhole, dem_min, dem_max, out, t, t_dev, B, T, nums, H * W,
-                                     spatial ? 1 : 0, rain_max, cumsum_max, (hipStream_t)stream),
+                                     spatial ? 1 : 0, rain_max, cumsum_max, (hipStream_t)stream, bump),
               "preprocess");
     return URNN_OK;
+}
+
+extern "C" int urnn_preprocess_f32(const float *rain, const float *cumsum, const float *dem, const float *imperv,
+                                   const float *manhole, float dem_min, float dem_max, float *out, int t, const int *t_dev,
+                                   int B, int T, int nums, int H, int W, int spatial, float rain_max, float cumsum_max,
+                                   void *stream)
+{
+    return preprocess_impl(rain, cumsum, dem, imperv, manhole, dem_min, dem_max, out, t, t_dev, B, T, nums, H, W, spatial, rain_max,
+                           cumsum_max, stream, nullptr);
+}
+
+// Frame-loop forms of the two input-assembly entries (see urnn_head_rollout_f32): the frame comes from *t_dev and the launch also
+// advances *next_counter (another chain's counter, never t_dev itself) by one.
+extern "C" int urnn_preprocess_rollout_f32(const float *rain, const float *cumsum, const float *dem, const float *imperv,
+                                           const float *manhole, float dem_min, float dem_max, float *out, const int *t_dev,
+                                           int *next_counter, int B, int T, int nums, int H, int W, int spatial, float rain_max,
+                                           float cumsum_max, void *stream)
+{
+    if (!t_dev) return fail(URNN_ENULL, "urnn_preprocess_rollout_f32: NULL t_dev");
+    if (next_counter == t_dev) return fail(URNN_EINVAL, "urnn_preprocess_rollout_f32: next_counter must not be t_dev");
+    return preprocess_impl(rain, cumsum, dem, imperv, manhole, dem_min, dem_max, out, 0, t_dev, B, T, nums, H, W, spatial, rain_max,
+                           cumsum_max, stream, next_counter);
 }
 
 extern "C" int urnn_stage1_static_f32(const float *dem, const float *imperv, const float *manhole, float dem_min, float dem_max,
@@ -1270,17 +1311,34 @@ extern "C" int urnn_stage1_static_f32(const float *dem, const float *imperv, con
     return URNN_OK;
 }
 
-extern "C" int urnn_stage1_scalar_rain_f32(const float *S, const float *rain, const float *cumsum, const float *weight,
-                                           const float *bias, float *out, int t, const int *t_dev, int B, int T, int nums, int Cout,
-                                           int H, int W, float rain_max, float cumsum_max, float slope, void *stream)
+static int stage1_scalar_impl(const float *S, const float *rain, const float *cumsum, const float *weight,
+                              const float *bias, float *out, int t, const int *t_dev, int B, int T, int nums, int Cout,
+                              int H, int W, float rain_max, float cumsum_max, float slope, void *stream, int *bump)
 {
     if (!S || !rain || !cumsum || !weight || !bias || !out) return fail(URNN_ENULL, "urnn_stage1_scalar_rain_f32: NULL argument");
     if (B < 1 || T < 1 || nums < 1 || Cout < 1 || H < 1 || W < 1) return fail(URNN_EINVAL, "urnn_stage1_scalar_rain_f32: bad dims");
     if (!aligned16(S) || !aligned16(out)) return fail(URNN_EALIGN, "urnn_stage1_scalar_rain_f32: pointers must be 16-byte aligned");
     CHECK_HIP(urnn_launch_stage1_scalar(S, rain, cumsum, weight, bias, out, t, t_dev, B, T, nums, Cout, H * W, rain_max, cumsum_max,
-                                        slope, (hipStream_t)stream),
+                                        slope, (hipStream_t)stream, bump),
               "stage1_scalar_rain");
     return URNN_OK;
+}
+
+extern "C" int urnn_stage1_scalar_rain_f32(const float *S, const float *rain, const float *cumsum, const float *weight,
+                                           const float *bias, float *out, int t, const int *t_dev, int B, int T, int nums, int Cout,
+                                           int H, int W, float rain_max, float cumsum_max, float slope, void *stream)
+{
+    return stage1_scalar_impl(S, rain, cumsum, weight, bias, out, t, t_dev, B, T, nums, Cout, H, W, rain_max, cumsum_max, slope, stream, nullptr);
+}
+
+extern "C" int urnn_stage1_scalar_rain_rollout_f32(const float *S, const float *rain, const float *cumsum, const float *weight,
+                                                   const float *bias, float *out, const int *t_dev, int *next_counter, int B, int T,
+                                                   int nums, int Cout, int H, int W, float rain_max, float cumsum_max, float slope,
+                                                   void *stream)
+{
+    if (!t_dev) return fail(URNN_ENULL, "urnn_stage1_scalar_rain_rollout_f32: NULL t_dev");
+    if (next_counter == t_dev) return fail(URNN_EINVAL, "urnn_stage1_scalar_rain_rollout_f32: next_counter must not be t_dev");
+    return stage1_scalar_impl(S, rain, cumsum, weight, bias, out, 0, t_dev, B, T, nums, Cout, H, W, rain_max, cumsum_max, slope, stream, next_counter);
 }
 
 extern "C" int urnn_advance_counter(int *counter, int delta, void *stream)

@@ -485,6 +485,7 @@ __global__ __launch_bounds__(256) void head_k1(const HeadParams prm)
     const int b = blockIdx.y;
     const int p = (blockIdx.x * 256 + threadIdx.x) * V;
     const bool live = p < prm.P;
+    if (prm.bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *prm.bump += 1;      // (no kernel of this launch reads it)
     float s = 0.f, q = 0.f;
     if (live) {
         float f[HEAD_C][V], u[HEAD_C][V];
@@ -504,6 +505,7 @@ __global__ __launch_bounds__(256) void head_k2(const HeadParams prm)
     const bool live = p < prm.P;
     float sc = 0.f, qc = 0.f, sq = 0.f, qq = 0.f;
     float m0, r0;
+    if (prm.bump && prm.partial0 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *prm.bump += 1;   // (head_k1 did not run)
     head_stats<FIN, V>(prm, 0, b, m0, r0);
     if (live) {
         const size_t CP = (size_t)HEAD_C * prm.P;
@@ -603,6 +605,7 @@ __global__ __launch_bounds__(256) void head_coop_kernel(const HeadParams prm, un
     const bool live = p < prm.P;
     const size_t CP = (size_t)HEAD_C * prm.P;
     const int nvalid = HEAD_C * tile_valid(blockIdx.x, 256 * V, prm.P);
+    if (prm.bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *prm.bump += 1;
     float u1[HEAD_C][V], u2[HEAD_C][V];
     // ---- pass 1 (head_k1): u0 = Ws . f and its statistics; u0 stays in u1
     {
@@ -844,8 +847,9 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const float *__restrict
                                                          const float *__restrict__ dem, const float *__restrict__ imperv,
                                                          const float *__restrict__ manhole, float dem_min, float dem_max,
                                                          float *__restrict__ out, int t_host, const int *__restrict__ t_dev,
-                                                         int T, int nums, int P, int spatial, float rain_max, float cumsum_max)
+                                                         int T, int nums, int P, int spatial, float rain_max, float cumsum_max, int *bump)
 {
+    if (bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *bump += 1;     // another kernel family's frame counter (never t_dev itself)
     const int C = 2 * nums + 3;
     const int bc = blockIdx.y;
     const int b = bc / C, c = bc - b * C;
@@ -886,12 +890,12 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const float *__restrict
 hipError_t urnn_launch_preprocess(const float *rain, const float *cumsum, const float *dem, const float *imperv,
                                   const float *manhole, float dem_min, float dem_max, float *out, int t, const int *t_dev,
                                   int B, int T, int nums, int P, int spatial, float rain_max, float cumsum_max,
-                                  hipStream_t st)
+                                  hipStream_t st, int *bump)
 {
     const int C = 2 * nums + 3;
     dim3 grid((P + 1023) / 1024, B * C);
     hipLaunchKernelGGL(preprocess_kernel, grid, dim3(256), 0, st, rain, cumsum, dem, imperv, manhole, dem_min, dem_max, out, t,
-                       t_dev, T, nums, P, spatial, rain_max, cumsum_max);
+                       t_dev, T, nums, P, spatial, rain_max, cumsum_max, bump);
     return hipGetLastError();
 }
 
@@ -926,9 +930,10 @@ __global__ __launch_bounds__(256) void stage1_scalar_kernel(const float *__restr
                                                             const float *__restrict__ cumsum, const float *__restrict__ w,
                                                             const float *__restrict__ bias, float *__restrict__ out, int t_host,
                                                             const int *__restrict__ t_dev, int T, int nums, int Cout, int P,
-                                                            float rain_max, float cumsum_max, float slope)
+                                                            float rain_max, float cumsum_max, float slope, int *bump)
 {
     __shared__ float vt[64];
+    if (bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *bump += 1;     // another kernel family's frame counter (never t_dev itself)
     const int bn = blockIdx.y;                    // (sample, output channel)
     const int b = bn / Cout, n = bn - b * Cout;
     const int C = 2 * nums + 3;
@@ -973,13 +978,13 @@ hipError_t urnn_launch_stage1_static(const float *dem, const float *imperv, cons
 
 hipError_t urnn_launch_stage1_scalar(const float *S, const float *rain, const float *cumsum, const float *w, const float *bias,
                                      float *out, int t, const int *t_dev, int B, int T, int nums, int Cout, int P, float rain_max,
-                                     float cumsum_max, float slope, hipStream_t st)
+                                     float cumsum_max, float slope, hipStream_t st, int *bump)
 {
     const bool v4 = (P % 4) == 0;
     const int per = 256 * (v4 ? 4 : 1);
     dim3 grid(min((P + per - 1) / per, 64), B * Cout);
-    if (v4) hipLaunchKernelGGL(stage1_scalar_kernel<4>, grid, dim3(256), 0, st, S, rain, cumsum, w, bias, out, t, t_dev, T, nums, Cout, P, rain_max, cumsum_max, slope);
-    else hipLaunchKernelGGL(stage1_scalar_kernel<1>, grid, dim3(256), 0, st, S, rain, cumsum, w, bias, out, t, t_dev, T, nums, Cout, P, rain_max, cumsum_max, slope);
+    if (v4) hipLaunchKernelGGL(stage1_scalar_kernel<4>, grid, dim3(256), 0, st, S, rain, cumsum, w, bias, out, t, t_dev, T, nums, Cout, P, rain_max, cumsum_max, slope, bump);
+    else hipLaunchKernelGGL(stage1_scalar_kernel<1>, grid, dim3(256), 0, st, S, rain, cumsum, w, bias, out, t, t_dev, T, nums, Cout, P, rain_max, cumsum_max, slope, bump);
     return hipGetLastError();
 }
 

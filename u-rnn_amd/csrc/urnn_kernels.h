@@ -162,6 +162,7 @@ struct HeadParams {
     // folds them from here: [B][nblk0][2], centred per block of bpix0 pixels
     const float *partial0;
     int nblk0, bpix0;
+    int *bump;                  // rollouts: a frame counter of ANOTHER kernel family, advanced by one by the head's first launch (see urnn_head_rollout_f32)
 };
 hipError_t urnn_launch_head(const HeadParams &p, int phase_mask, hipStream_t st);
 int urnn_head_coop_blocks(int B, int P);
@@ -176,14 +177,14 @@ hipError_t urnn_launch_stats_scatter(const double *sums, int rows, int stride, f
 hipError_t urnn_launch_preprocess(const float *rain, const float *cumsum, const float *dem, const float *imperv,
                                   const float *manhole, float dem_min, float dem_max, float *out, int t, const int *t_dev,
                                   int B, int T, int nums, int P, int spatial, float rain_max, float cumsum_max,
-                                  hipStream_t st);
+                                  hipStream_t st, int *bump = nullptr);
 hipError_t urnn_launch_advance(int *counter, int delta, hipStream_t st);
 hipError_t urnn_launch_max_abs(const float *v, long n, float *out, hipStream_t st);
 hipError_t urnn_launch_stage1_static(const float *dem, const float *imperv, const float *manhole, float dem_min, float dem_max,
                                      const float *w, float *S, int B, int nums, int Cout, int P, hipStream_t st);
 hipError_t urnn_launch_stage1_scalar(const float *S, const float *rain, const float *cumsum, const float *w, const float *bias,
                                      float *out, int t, const int *t_dev, int B, int T, int nums, int Cout, int P, float rain_max,
-                                     float cumsum_max, float slope, hipStream_t st);
+                                     float cumsum_max, float slope, hipStream_t st, int *bump = nullptr);
 
 hipError_t urnn_launch_pack_conv(const float *w, const float *bias, float *packed, int Cin, int Cout, hipStream_t st);
 hipError_t urnn_launch_pack_gru(const float *W1, const float *b1, const float *W2, const float *b2, float *packed, int I,

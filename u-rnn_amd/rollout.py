@@ -133,15 +133,16 @@ class RolloutEngine:
                      frame_index=self.t_dev, ws=ws, partial0=self._k1part[0] if tail else None, coop=self._head_coop and not tail)
         ops.advance_counter(self.t_dev, 1)
 
-    def _stage1(self, t_dev):
-        """Frame input assembly + encoder stage-1 conv -> self.a1."""
+    def _stage1(self, t_dev, next_counter=None):
+        """Frame input assembly + encoder stage-1 conv -> self.a1.  ``next_counter``: the other chain's frame counter, advanced by
+        the same launch (ops.preprocess)."""
         conv = self.net.encoder.stage1.layer
         if self.S1 is not None:
             ops.stage1_scalar_rain(self.S1, self.rain, self.cumsum, self._w1, conv.bias.detach(), 0, self.nums, self.rain_max,
-                                   self.cumsum_max, out=self.a1, t_dev=t_dev)
+                                   self.cumsum_max, out=self.a1, t_dev=t_dev, next_counter=next_counter)
         else:
             ops.preprocess(self.rain, self.cumsum, self.dem, self.imperv, self.manhole, self.dem_min, self.dem_max, 0,
-                           self.nums, self.rain_max, self.cumsum_max, out=self.x_in, t_dev=t_dev)
+                           self.nums, self.rain_max, self.cumsum_max, out=self.x_in, t_dev=t_dev, next_counter=next_counter)
             self.net.encoder.stage1(self.x_in, out=self.a1)
 
     def _tail_of(self, name):
@@ -216,14 +217,27 @@ class RolloutEngine:
     # The two chains as lists of segments (closures), so that an overlapped iteration can interleave their ENQUEUE order:
     # a graph replay hands its kernel nodes to the hardware queues in creation order at a few microseconds each, so a chain
     # enqueued entirely after the other starts ~100 us late.
-    def _enc_segments(self, parity):
+    # Frame counters of the two-chain schedule (both device int32, so that a captured iteration replays for any frame):
+    #   te_dev = the frame the NEXT encoder pass assembles, t_dev = the frame the NEXT head writes.
+    # In a steady-state iteration t -- head(t-1), encoder(t+1) on chain 1 -- nobody advances them with a launch of its own: the head's
+    # first kernel bumps te_dev (read only by the input assembly queued behind it), the input assembly bumps t_dev (read only by
+    # the next head; the head before it has completed).  Iterations without a head in front (the first of a run() call) advance
+    # te_dev with the one-thread kernel, the trailing head of a run() call advances t_dev likewise, the prologue E(0) advances
+    # nothing.  Invariant at the start of iteration t: te_dev = t (the frame of the newest encoder pass; advanced to t + 1 before
+    # E(t + 1) reads it), t_dev = number of heads completed (t - 1 in steady state, t at the start of a run() call).
+    def _enc_segments(self, parity, advance="none"):
+        """encoder pass into the buffers of ``parity``.  advance: "none" (prologue E(0): reads te_dev = 0 as it stands), "kernel"
+        (te_dev += 1 with a launch of its own BEFORE the input assembly), "piggyback" (the head in front has advanced te_dev; the
+        input assembly advances t_dev)."""
         enc = self.net.encoder
         (p1, p2, p3), (n1, n2, n3) = self._enc_bufs(parity)
 
         ws = self._ws[0]                       # chain 1 (head + encoder) scratch
 
         def e1():
-            self._stage1(self.te_dev)
+            if advance == "kernel":
+                ops.advance_counter(self.te_dev, 1)
+            self._stage1(self.te_dev, next_counter=self.t_dev if advance == "piggyback" else None)
             if not self._cell("enc1", enc.rnn1, self.a1, None, p1, n1, ws, conv_out=self.a2):
                 enc.stage2(n1, out=self.a2)
 
@@ -233,7 +247,6 @@ class RolloutEngine:
 
         def e3():
             self._cell("enc3", enc.rnn3, self.a3, None, p3, n3, ws)
-            ops.advance_counter(self.te_dev, 1)
         return [e1, e2, e3]
 
     def _dec_segments(self, parity):
@@ -266,13 +279,15 @@ class RolloutEngine:
         for seg in self._dec_segments(parity):
             seg()
 
-    def _head_chain(self, parity):
-        """head(t) for t % 2 == parity (reads feat[parity]); shares the encoder chain's stream and scratch."""
+    def _head_chain(self, parity, piggyback=False):
+        """head(t) for t % 2 == parity (reads feat[parity]); shares the encoder chain's stream and scratch.  piggyback: an encoder
+        pass follows on this stream -- the head advances te_dev for it and leaves t_dev to that pass's input assembly."""
         self.net.head.run(self.feat if parity == 0 else self.feat_alt, out_masked=self.out_masked, out_cls=self.out_cls,
                           out_raw=self.out_raw, frame_index=self.t_dev, ws=self._ws[0],
                           partial0=self._k1part[parity] if self._tail_of("dec1") is not None else None,
-                          coop=self._head_coop and self._tail_of("dec1") is None)
-        ops.advance_counter(self.t_dev, 1)
+                          coop=self._head_coop and self._tail_of("dec1") is None, next_counter=self.te_dev if piggyback else None)
+        if not piggyback:
+            ops.advance_counter(self.t_dev, 1)
 
     def _iter_overlap(self, parity, with_head=True):
         """Iteration t (parity = t % 2): chain 1 = head(t-1) then encoder(t+1); chain 2 = decoder(t); enqueued segment by
@@ -281,15 +296,18 @@ class RolloutEngine:
         s1, s2 = self._side
         s1.wait_stream(cur)
         s2.wait_stream(cur)
-        enc = self._enc_segments(1 - parity)
+        enc = self._enc_segments(1 - parity, advance="piggyback" if with_head else "kernel")
         dec = self._dec_segments(parity)
         order = os.environ.get("URNN_TUNE_CHAIN_ORDER", self.ENQUEUE_ORDER)
+        if sorted(order) != sorted("HEEEDDD") or order.index("H") > order.index("E"):
+            raise RuntimeError("enqueue order must hold one H, three E and three D, H before the first E (the head advances the "
+                               "encoder pass's frame counter)")
         ie = idd = 0
         for ch in order:
             if ch == "H":
                 if with_head:
                     with torch.cuda.stream(s1):
-                        self._head_chain(1 - parity)
+                        self._head_chain(1 - parity, piggyback=True)
             elif ch == "E":
                 with torch.cuda.stream(s1):
                     enc[ie]()
@@ -298,7 +316,7 @@ class RolloutEngine:
                 with torch.cuda.stream(s2):
                     dec[idd]()
                 idd += 1
-        if ie != 3 or idd != 3 or order.count("H") != 1:
+        if ie != 3 or idd != 3:
             raise RuntimeError("enqueue order must hold one H, three E and three D")
         cur.wait_stream(s1)
         cur.wait_stream(s2)
