@@ -117,6 +117,34 @@ def test_overlapped_chains_match_sequential(dev):
         assert torch.equal(a, b2)
 
 
+@pytest.mark.parametrize("group", ["0", "2", "4", "6"])
+def test_grouped_iterations_and_piecewise_runs_match_sequential(dev, monkeypatch, group):
+    """The two-chain graphs hold GROUP steady-state iterations per replay, the head advances the encoder pass's frame counter and the
+    input assembly the head's (urnn_*_rollout_f32): whatever the group size and however an event is cut into run() calls (each call
+    starts without a pending head and ends by flushing one), frames and final states equal the one-chain engine's bit for bit."""
+    import urnn_amd.weights as uw
+    from urnn_amd.rollout import RolloutEngine
+    monkeypatch.setenv("URNN_TUNE_GROUP", group)
+    H, W, nums, T = 32, 48, 3, 23
+    net, _ = make_net(H, W, 9, 3, dev)
+    ev = uw.make_event(T, H, W, 60.0, seed=2)
+    seq = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T)
+    a = seq.rollout(ev).clone()
+    ovl = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T, overlap=True)
+    for pieces in ((23,), (3, 7, 1, 12), (1, 1, 2, 5, 6, 8), (10, 13)):
+        ovl.load_event(ev)
+        ovl.reset()
+        ovl.out_masked.zero_()
+        for n in pieces:
+            ovl.run(n)
+        ovl.check_status()
+        assert int(ovl.t_dev.item()) == T and int(ovl.te_dev.item()) == T
+        assert torch.equal(a, ovl.out_masked[:T]), f"GROUP={group}, run() calls of {pieces} frames"
+        for x, y in zip(seq.final_states(), ovl.final_states()):
+            assert torch.equal(x, y)
+    assert ovl._group == int(group)
+
+
 def test_batched_events_match_single_events(dev):
     """Event batching (a build-side extension): per-sample semantics -- a batch of two events must
     equal the two events rolled out one by one."""

@@ -322,6 +322,7 @@ class RolloutEngine:
         cur.wait_stream(s2)
 
     ENQUEUE_ORDER = "HEEEDDD"
+    GROUP = 4
 
     def _capture_overlap(self):
         self.net.head.flat_params()
@@ -341,6 +342,16 @@ class RolloutEngine:
             with torch.cuda.graph(g):
                 self._iter_overlap(parity, with_head=with_head)
             graphs[key] = g
+        # GROUP steady-state iterations per replay (an even number: parity p, 1 - p, ...): a graph launch costs the frame loop ~5 us of
+        # idle GPU, which is 3 % of a 64x64 frame (profiles/r04_bench_configs.txt)
+        self._group = max(0, int(os.environ.get("URNN_TUNE_GROUP", self.GROUP))) & ~1
+        if self._group:
+            for parity in (0, 1):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for k in range(self._group):
+                        self._iter_overlap((parity + k) % 2)
+                graphs[("group", parity)] = g
         for parity in (0, 1):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
@@ -351,14 +362,18 @@ class RolloutEngine:
             self._enc_chain(0)          # pipeline prologue E(0) of an event
         graphs["prologue"] = g
         # The first launch of an instantiated graph uploads it to the device: pay that here, not in the first frames of the first
-        # event.  Two short valid rollouts touch every graph and write frames 0..2 only (states and counters are restored below).
-        if int(t0.item()) + 3 <= self.Tcap:
-            for seq in (("prologue", ("first", 0), 1, 0, ("tail", 0)), ("prologue", ("first", 0), ("tail", 0), ("first", 1), ("tail", 1))):
+        # event.  Short valid rollouts touch every graph and write the first GROUP + 2 frames only (states and counters are restored below).
+        seqs = [(3, ("prologue", ("first", 0), 1, 0, ("tail", 0))), (2, ("prologue", ("first", 0), ("tail", 0), ("first", 1), ("tail", 1)))]
+        if self._group:
+            seqs += [(self._group + 1, ("prologue", ("first", 0), ("group", 1), ("tail", 0))),
+                     (self._group + 2, ("prologue", ("first", 0), 1, ("group", 0), ("tail", 1)))]
+        for nframes, seq in seqs:
+            if int(t0.item()) + nframes <= self.Tcap:
                 self.t_dev.copy_(t0)
                 self.te_dev.copy_(t1)
                 for key in seq:
                     graphs[key].replay()
-            torch.cuda.synchronize(self.device)
+        torch.cuda.synchronize(self.device)
         self._graphs2 = graphs
         for s, v in zip(self.states + self.enc_alt, saved):
             s.copy_(v)
@@ -372,7 +387,8 @@ class RolloutEngine:
             return
         if self.use_graph and self._graphs2 is None:
             self._capture_overlap()
-        for i in range(frames):
+        i = 0
+        while i < frames:
             t = self._frames_done
             if t == 0:                  # pipeline prologue: E(0)
                 if self.use_graph:
@@ -380,11 +396,17 @@ class RolloutEngine:
                 else:
                     self._enc_chain(0)
             first = i == 0              # no head pending at the start of a run() call
+            if self.use_graph and not first and self._group and i + self._group <= frames:
+                self._graphs2[("group", t % 2)].replay()
+                self._frames_done += self._group
+                i += self._group
+                continue
             if self.use_graph:
                 self._graphs2[("first", t % 2) if first else t % 2].replay()
             else:
                 self._iter_overlap(t % 2, with_head=not first)
             self._frames_done += 1
+            i += 1
         if self.use_graph:
             self._graphs2[("tail", (self._frames_done - 1) % 2)].replay()
         else:
