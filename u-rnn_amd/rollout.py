@@ -279,11 +279,11 @@ class RolloutEngine:
         for seg in self._dec_segments(parity):
             seg()
 
-    def _head_chain(self, parity, piggyback=False):
+    def _head_chain(self, parity, piggyback=False, ws=None):
         """head(t) for t % 2 == parity (reads feat[parity]); shares the encoder chain's stream and scratch.  piggyback: an encoder
         pass follows on this stream -- the head advances te_dev for it and leaves t_dev to that pass's input assembly."""
         self.net.head.run(self.feat if parity == 0 else self.feat_alt, out_masked=self.out_masked, out_cls=self.out_cls,
-                          out_raw=self.out_raw, frame_index=self.t_dev, ws=self._ws[0],
+                          out_raw=self.out_raw, frame_index=self.t_dev, ws=self._ws[0] if ws is None else ws,
                           partial0=self._k1part[parity] if self._tail_of("dec1") is not None else None,
                           coop=self._head_coop and self._tail_of("dec1") is None, next_counter=self.te_dev if piggyback else None)
         if not piggyback:
@@ -293,10 +293,16 @@ class RolloutEngine:
         """Iteration t (parity = t % 2): chain 1 = head(t-1) then encoder(t+1); chain 2 = decoder(t); enqueued segment by
         segment in the order ENQUEUE_ORDER (H head, E encoder segment, D decoder segment)."""
         cur = torch.cuda.current_stream(self.device)
-        s1, s2 = self._side
+        s1, s2 = self._side[:2]
         s1.wait_stream(cur)
         s2.wait_stream(cur)
-        enc = self._enc_segments(1 - parity, advance="piggyback" if with_head else "kernel")
+        three = with_head and os.environ.get("URNN_TUNE_HEAD_CHAIN", "0") == "1"      # experiment: the head as a third chain
+        if three:
+            if len(self._side) == 2:
+                self._side = self._side + (torch.cuda.Stream(device=self.device),)
+                self._ws.append(ops.workspace(self._ws[0].numel(), self.device))
+            self._side[2].wait_stream(cur)
+        enc = self._enc_segments(1 - parity, advance="piggyback" if with_head and not three else "kernel")
         dec = self._dec_segments(parity)
         order = os.environ.get("URNN_TUNE_CHAIN_ORDER", self.ENQUEUE_ORDER)
         if sorted(order) != sorted("HEEEDDD") or order.index("H") > order.index("E"):
@@ -305,7 +311,10 @@ class RolloutEngine:
         ie = idd = 0
         for ch in order:
             if ch == "H":
-                if with_head:
+                if three:
+                    with torch.cuda.stream(self._side[2]):
+                        self._head_chain(1 - parity, ws=self._ws[2])
+                elif with_head:
                     with torch.cuda.stream(s1):
                         self._head_chain(1 - parity, piggyback=True)
             elif ch == "E":
@@ -320,6 +329,8 @@ class RolloutEngine:
             raise RuntimeError("enqueue order must hold one H, three E and three D")
         cur.wait_stream(s1)
         cur.wait_stream(s2)
+        if three:
+            cur.wait_stream(self._side[2])
 
     ENQUEUE_ORDER = "HEEEDDD"
     GROUP = 4
