@@ -351,23 +351,24 @@ int urnn_head_strip_stats_f32(void *workspace, size_t workspace_bytes, int B, in
 /* Device-side frame counter helper for graph-captured rollouts: *counter += delta. */
 int urnn_advance_counter(int *counter, int delta, void *stream);
 
-/* Frame-loop forms (replace the same call sites as urnn_head_f32 / urnn_preprocess_f32 / urnn_stage1_scalar_rain_f32 -- test.py:326-377,
- * one loop iteration -- when the loop runs as two kernel chains with a frame counter each): the launch reads its frame from
- * *frame_index / *t_dev and ALSO advances *next_counter by one.  next_counter is the counter of the OTHER kernel family -- the one
- * read by the launches queued behind this one on the same stream, which nothing in flight reads meanwhile (the head advances the
- * input assembly's counter, the input assembly the head's) -- never the launch's own (URNN_EINVAL), and may be NULL.  What it saves
- * is a one-thread urnn_advance_counter launch per counter per frame (~2 us each: 4 % of a 64x64 frame).
+/* Frame-loop forms (same call sites as urnn_head_f32 / urnn_preprocess_f32 / urnn_stage1_scalar_rain_f32 -- test.py:326-377, one loop
+ * iteration -- for a CAPTURED loop, where the frame index must live on the device): the launch reads its frame from *frame_index /
+ * *t_dev and stores that value + 1 to *frame_next / *t_next, the word the same entry's NEXT call will be given as its index.  Two
+ * words used alternately (even frames read word 0 and write word 1, odd frames the reverse) thus form a frame counter that costs no
+ * kernel of its own (urnn_advance_counter: ~2 us + a kernel boundary per frame and counter: 3 % of a 64x64 frame), and each kernel
+ * family keeps its own pair -- the families run on different streams at different frames.  A launch must not write the word it
+ * reads (its other blocks may not have read it yet): frame_next == frame_index / t_next == t_dev is URNN_EINVAL.  NULL = no store.
  * urnn_head_rollout_f32: coop != 0 = urnn_head_coop_f32's launch form, head_partial0 != NULL = urnn_head_after_tail_f32's. */
 int urnn_head_rollout_f32(const float *feat, const float *conv_w, const float *ln_w, const float *ln_b, const float *cls_w,
                           const float *cls_b, const float *reg_w, const float *reg_b, float *out_masked, float *out_cls,
                           float *out_raw, const int *frame_index, void *workspace, size_t workspace_bytes, int B, int C, int H, int W,
-                          float cls_thred, float eps, float slope, int coop, const float *head_partial0, int *next_counter,
+                          float cls_thred, float eps, float slope, int coop, const float *head_partial0, int *frame_next,
                           void *stream);
 int urnn_preprocess_rollout_f32(const float *rain, const float *cumsum, const float *dem, const float *imperv, const float *manhole,
-                                float dem_min, float dem_max, float *out, const int *t_dev, int *next_counter, int B, int T, int nums,
+                                float dem_min, float dem_max, float *out, const int *t_dev, int *t_next, int B, int T, int nums,
                                 int H, int W, int spatial, float rain_max, float cumsum_max, void *stream);
 int urnn_stage1_scalar_rain_rollout_f32(const float *S, const float *rain, const float *cumsum, const float *weight,
-                                        const float *bias, float *out, const int *t_dev, int *next_counter, int B, int T, int nums,
+                                        const float *bias, float *out, const int *t_dev, int *t_next, int B, int T, int nums,
                                         int Cout, int H, int W, float rain_max, float cumsum_max, float slope, void *stream);
 
 #ifdef __cplusplus

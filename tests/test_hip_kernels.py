@@ -364,10 +364,10 @@ def test_cooperative_head_equals_four_passes(dev, H, W, B):
 
 
 @pytest.mark.parametrize("H,W,B", [(64, 64, 1), (100, 60, 2)])
-def test_frame_loop_forms_advance_the_other_chains_counter(dev, H, W, B):
-    """urnn_head_rollout_f32 / urnn_preprocess_rollout_f32 / urnn_stage1_scalar_rain_rollout_f32 (one iteration of test.py:326-377 as
-    two kernel chains with a device frame counter each): same outputs as the plain entries for the frame *frame_index / *t_dev
-    names, and the OTHER counter advanced by exactly one per call; the launch's own counter is refused."""
+def test_frame_loop_forms_store_the_next_frame_index(dev, H, W, B):
+    """urnn_head_rollout_f32 / urnn_preprocess_rollout_f32 / urnn_stage1_scalar_rain_rollout_f32 (one iteration of test.py:326-377 in a
+    captured loop, frame index on the device): same outputs as the plain entries for the frame *frame_index / *t_dev names, that
+    value + 1 stored to the second word (two words used alternately are a frame counter), the launch's own word refused."""
     import urnn_amd.weights as uw
     from urnn_amd import ops
     from urnn_amd._lib import UrnnError, lib
@@ -375,24 +375,25 @@ def test_frame_loop_forms_advance_the_other_chains_counter(dev, H, W, B):
     rs = np.random.RandomState(77 + H)
     nums, Tn = 4, 6
     ev = event_to_device(uw.make_event(Tn, H, W, 6.0, seed=3, batch=B), dev)
-    own = torch.full((1,), 2, dtype=torch.int32, device=dev)
-    other = torch.full((1,), 40, dtype=torch.int32, device=dev)
-    # input assembly, spatial-agnostic entry
-    plain = ops.preprocess(ev["rain"], ev["cumsum"], ev["dem"], ev["imperv"], ev["manhole"], ev["dem_min"], ev["dem_max"], 0, nums, 6.0,
-                           250.0, t_dev=own)
-    both = ops.preprocess(ev["rain"], ev["cumsum"], ev["dem"], ev["imperv"], ev["manhole"], ev["dem_min"], ev["dem_max"], 0, nums, 6.0,
-                          250.0, t_dev=own, next_counter=other)
-    assert torch.equal(plain, both) and int(other.item()) == 41 and int(own.item()) == 2
+    pair = torch.tensor([2, 40], dtype=torch.int32, device=dev)
+    own, nxt = pair[0:1], pair[1:2]
+    args = (ev["rain"], ev["cumsum"], ev["dem"], ev["imperv"], ev["manhole"], ev["dem_min"], ev["dem_max"], 0, nums, 6.0, 250.0)
+    plain = ops.preprocess(*args, t_dev=own)
+    both = ops.preprocess(*args, t_dev=own, t_next=nxt)
+    assert torch.equal(plain, both) and pair.tolist() == [2, 3]
+    again = ops.preprocess(*args, t_dev=nxt, t_next=own)          # the next frame: the words swap roles
+    assert pair.tolist() == [4, 3] and torch.equal(again, ops.preprocess(*args[:7], 3, *args[8:]))
+    pair.copy_(torch.tensor([2, 40], dtype=torch.int32))
     # scalar-rain stage 1
     Cout = 32
     w1 = T(rs.normal(0, 0.3, (Cout, 2 * nums + 3)).astype(np.float32), dev)
     b1 = T(rs.normal(0, 0.1, Cout).astype(np.float32), dev)
     S = ops.stage1_static(ev["dem"], ev["imperv"], ev["manhole"], ev["dem_min"], ev["dem_max"], w1, nums)
     plain = ops.stage1_scalar_rain(S, ev["rain"], ev["cumsum"], w1, b1, 0, nums, 6.0, 250.0, t_dev=own)
-    both = ops.stage1_scalar_rain(S, ev["rain"], ev["cumsum"], w1, b1, 0, nums, 6.0, 250.0, t_dev=own, next_counter=other)
-    assert torch.equal(plain, both) and int(other.item()) == 42 and int(own.item()) == 2
+    both = ops.stage1_scalar_rain(S, ev["rain"], ev["cumsum"], w1, b1, 0, nums, 6.0, 250.0, t_dev=own, t_next=nxt)
+    assert torch.equal(plain, both) and pair.tolist() == [2, 3]
     with pytest.raises(UrnnError):
-        ops.stage1_scalar_rain(S, ev["rain"], ev["cumsum"], w1, b1, 0, nums, 6.0, 250.0, t_dev=own, next_counter=own)
+        ops.stage1_scalar_rain(S, ev["rain"], ev["cumsum"], w1, b1, 0, nums, 6.0, 250.0, t_dev=own, t_next=own)
     # head: four launches, one cooperative launch
     feat = T(rs.normal(0, 1, (B, 16, H, W)).astype(np.float32), dev)
     conv_w = T(rs.normal(0, 0.25, (5, 16, 16)).astype(np.float32), dev)
@@ -406,14 +407,14 @@ def test_frame_loop_forms_advance_the_other_chains_counter(dev, H, W, B):
         if coop and not 0 < lib().urnn_head_coop_blocks_f32(B, H, W) <= 128:
             continue
         bufs = [torch.zeros((Tn, B, H, W), device=dev) for _ in range(3)]
-        before = int(other.item())
+        pair.copy_(torch.tensor([2, 40], dtype=torch.int32))
         ops.head(feat, conv_w, ln_w, ln_b, cw, cb_, rw, rb, 0.5, out_masked=bufs[0], out_cls=bufs[1], out_raw=bufs[2], frame_index=own,
-                 ws=ws, coop=coop, next_counter=other)
-        assert int(other.item()) == before + 1 and int(own.item()) == 2
+                 ws=ws, coop=coop, frame_next=nxt)
+        assert pair.tolist() == [2, 3]
         for buf, ref, what in zip(bufs, four, ("masked", "cls", "pre-mask reg")):
             assert torch.equal(buf[2], ref), f"frame-loop head (coop={coop}) differs in {what}"
             assert float(buf[:2].abs().max()) == 0 and float(buf[3:].abs().max()) == 0
     with pytest.raises(UrnnError):
         ops.head(feat, conv_w, ln_w, ln_b, cw, cb_, rw, rb, 0.5, out_masked=bufs[0], out_cls=bufs[1], out_raw=bufs[2], frame_index=own,
-                 ws=ws, next_counter=own)
+                 ws=ws, frame_next=own)
     assert ops.workspace_status(ws) == 0

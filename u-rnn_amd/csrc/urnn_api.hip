@@ -1033,7 +1033,7 @@ static int head_impl(const float *feat, const float *conv_w, const float *ln_w, 
     p.bpix0 = 128;
     p.bump = bump;
     if (bump && (bump == frame_index || phase_mask != URNN_HEAD_ALL))
-        return fail(URNN_EINVAL, "urnn_head_rollout_f32: next_counter must not be the head's own frame_index");
+        return fail(URNN_EINVAL, "urnn_head_rollout_f32: frame_next must not be the head's own frame_index");
     if (coop) {
         if (urnn_head_coop_blocks(B, (int)P) > 256) return fail(URNN_EINVAL, "urnn_head_coop_f32: %d blocks cannot all be resident (urnn_head_coop_blocks)", urnn_head_coop_blocks(B, (int)P));
         CHECK_HIP(urnn_launch_head_coop(p, reinterpret_cast<unsigned *>(ws.status) + 16, (hipStream_t)stream), "head (one cooperative launch)");
@@ -1080,20 +1080,20 @@ extern "C" int urnn_head_after_tail_f32(const float *feat, const float *conv_w, 
                      workspace_bytes, B, C, H, W, cls_thred, eps, slope, URNN_HEAD_ALL, 0, stream, head_partial0);
 }
 
-// The head inside a frame loop whose OTHER kernel chain keeps its own frame counter (rollout.py's two chains): the head's first
-// launch also advances *next_counter by one -- the counter the launches queued BEHIND the head on this stream read (the next frame's
-// input assembly), which nothing in flight reads while the head runs.  Saves the frame loop a one-thread kernel per frame.
+// The head inside a captured frame loop: it writes frame *frame_index, and its first launch stores *frame_index + 1 to *frame_next --
+// the word the NEXT head reads.  Two words used alternately (frame parity) are a device frame counter that needs no kernel of its own;
+// a launch never writes the word it reads (other blocks may not have read it yet), hence frame_next != frame_index.
 // coop / head_partial0 select urnn_head_coop_f32 / urnn_head_after_tail_f32 (at most one of them).
 extern "C" int urnn_head_rollout_f32(const float *feat, const float *conv_w, const float *ln_w, const float *ln_b, const float *cls_w,
                                      const float *cls_b, const float *reg_w, const float *reg_b, float *out_masked, float *out_cls,
                                      float *out_raw, const int *frame_index, void *workspace, size_t workspace_bytes, int B, int C,
                                      int H, int W, float cls_thred, float eps, float slope, int coop, const float *head_partial0,
-                                     int *next_counter, void *stream)
+                                     int *frame_next, void *stream)
 {
     if (coop && head_partial0) return fail(URNN_EINVAL, "urnn_head_rollout_f32: coop and head_partial0 exclude each other");
-    if (next_counter && !frame_index) return fail(URNN_ENULL, "urnn_head_rollout_f32: next_counter without frame_index");
+    if (frame_next && !frame_index) return fail(URNN_ENULL, "urnn_head_rollout_f32: frame_next without frame_index");
     return head_impl(feat, conv_w, ln_w, ln_b, cls_w, cls_b, reg_w, reg_b, out_masked, out_cls, out_raw, frame_index, workspace,
-                     workspace_bytes, B, C, H, W, cls_thred, eps, slope, URNN_HEAD_ALL, 0, stream, head_partial0, coop ? 1 : 0, next_counter);
+                     workspace_bytes, B, C, H, W, cls_thred, eps, slope, URNN_HEAD_ALL, 0, stream, head_partial0, coop ? 1 : 0, frame_next);
 }
 
 extern "C" int urnn_head_strip_f32(const float *feat, const float *conv_w, const float *ln_w, const float *ln_b, const float *cls_w,
@@ -1288,17 +1288,17 @@ extern "C" int urnn_preprocess_f32(const float *rain, const float *cumsum, const
                            cumsum_max, stream, nullptr);
 }
 
-// Frame-loop forms of the two input-assembly entries (see urnn_head_rollout_f32): the frame comes from *t_dev and the launch also
-// advances *next_counter (another chain's counter, never t_dev itself) by one.
+// Frame-loop forms of the two input-assembly entries (see urnn_head_rollout_f32): the frame comes from *t_dev and the launch stores
+// *t_dev + 1 to *t_next, the word the next frame's input assembly reads (never t_dev itself).
 extern "C" int urnn_preprocess_rollout_f32(const float *rain, const float *cumsum, const float *dem, const float *imperv,
                                            const float *manhole, float dem_min, float dem_max, float *out, const int *t_dev,
-                                           int *next_counter, int B, int T, int nums, int H, int W, int spatial, float rain_max,
+                                           int *t_next, int B, int T, int nums, int H, int W, int spatial, float rain_max,
                                            float cumsum_max, void *stream)
 {
     if (!t_dev) return fail(URNN_ENULL, "urnn_preprocess_rollout_f32: NULL t_dev");
-    if (next_counter == t_dev) return fail(URNN_EINVAL, "urnn_preprocess_rollout_f32: next_counter must not be t_dev");
+    if (t_next == t_dev) return fail(URNN_EINVAL, "urnn_preprocess_rollout_f32: t_next must not be t_dev");
     return preprocess_impl(rain, cumsum, dem, imperv, manhole, dem_min, dem_max, out, 0, t_dev, B, T, nums, H, W, spatial, rain_max,
-                           cumsum_max, stream, next_counter);
+                           cumsum_max, stream, t_next);
 }
 
 extern "C" int urnn_stage1_static_f32(const float *dem, const float *imperv, const float *manhole, float dem_min, float dem_max,
@@ -1332,13 +1332,13 @@ extern "C" int urnn_stage1_scalar_rain_f32(const float *S, const float *rain, co
 }
 
 extern "C" int urnn_stage1_scalar_rain_rollout_f32(const float *S, const float *rain, const float *cumsum, const float *weight,
-                                                   const float *bias, float *out, const int *t_dev, int *next_counter, int B, int T,
+                                                   const float *bias, float *out, const int *t_dev, int *t_next, int B, int T,
                                                    int nums, int Cout, int H, int W, float rain_max, float cumsum_max, float slope,
                                                    void *stream)
 {
     if (!t_dev) return fail(URNN_ENULL, "urnn_stage1_scalar_rain_rollout_f32: NULL t_dev");
-    if (next_counter == t_dev) return fail(URNN_EINVAL, "urnn_stage1_scalar_rain_rollout_f32: next_counter must not be t_dev");
-    return stage1_scalar_impl(S, rain, cumsum, weight, bias, out, 0, t_dev, B, T, nums, Cout, H, W, rain_max, cumsum_max, slope, stream, next_counter);
+    if (t_next == t_dev) return fail(URNN_EINVAL, "urnn_stage1_scalar_rain_rollout_f32: t_next must not be t_dev");
+    return stage1_scalar_impl(S, rain, cumsum, weight, bias, out, 0, t_dev, B, T, nums, Cout, H, W, rain_max, cumsum_max, slope, stream, t_next);
 }
 
 extern "C" int urnn_advance_counter(int *counter, int delta, void *stream)

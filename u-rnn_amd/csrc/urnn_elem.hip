@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) void head_k1(const HeadParams prm)
     const int b = blockIdx.y;
     const int p = (blockIdx.x * 256 + threadIdx.x) * V;
     const bool live = p < prm.P;
-    if (prm.bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *prm.bump += 1;      // (no kernel of this launch reads it)
+    if (prm.bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *prm.bump = *prm.frame_index + 1;      // the NEXT head's frame word (nothing in flight reads it)
     float s = 0.f, q = 0.f;
     if (live) {
         float f[HEAD_C][V], u[HEAD_C][V];
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256) void head_k2(const HeadParams prm)
     const bool live = p < prm.P;
     float sc = 0.f, qc = 0.f, sq = 0.f, qq = 0.f;
     float m0, r0;
-    if (prm.bump && prm.partial0 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *prm.bump += 1;   // (head_k1 did not run)
+    if (prm.bump && prm.partial0 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *prm.bump = *prm.frame_index + 1;   // (head_k1 did not run)
     head_stats<FIN, V>(prm, 0, b, m0, r0);
     if (live) {
         const size_t CP = (size_t)HEAD_C * prm.P;
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(256) void head_coop_kernel(const HeadParams prm, un
     const bool live = p < prm.P;
     const size_t CP = (size_t)HEAD_C * prm.P;
     const int nvalid = HEAD_C * tile_valid(blockIdx.x, 256 * V, prm.P);
-    if (prm.bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *prm.bump += 1;
+    if (prm.bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *prm.bump = *prm.frame_index + 1;
     float u1[HEAD_C][V], u2[HEAD_C][V];
     // ---- pass 1 (head_k1): u0 = Ws . f and its statistics; u0 stays in u1
     {
@@ -849,11 +849,11 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const float *__restrict
                                                          float *__restrict__ out, int t_host, const int *__restrict__ t_dev,
                                                          int T, int nums, int P, int spatial, float rain_max, float cumsum_max, int *bump)
 {
-    if (bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *bump += 1;     // another kernel family's frame counter (never t_dev itself)
     const int C = 2 * nums + 3;
     const int bc = blockIdx.y;
     const int b = bc / C, c = bc - b * C;
     const int t = t_dev ? *t_dev : t_host;
+    if (bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *bump = t + 1;     // the next frame's word (never t_dev itself: other blocks still read it)
     float *dst = out + (size_t)bc * P;
     const int p0 = blockIdx.x * 1024;
     const int pend = min(P, p0 + 1024);
@@ -933,11 +933,11 @@ __global__ __launch_bounds__(256) void stage1_scalar_kernel(const float *__restr
                                                             float rain_max, float cumsum_max, float slope, int *bump)
 {
     __shared__ float vt[64];
-    if (bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *bump += 1;     // another kernel family's frame counter (never t_dev itself)
     const int bn = blockIdx.y;                    // (sample, output channel)
     const int b = bn / Cout, n = bn - b * Cout;
     const int C = 2 * nums + 3;
     const int t = t_dev ? *t_dev : t_host;
+    if (bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *bump = t + 1;     // the next frame's word (never t_dev itself: other blocks still read it)
     if (threadIdx.x < 64) {
         // rain-history part of channel n, one history slot per lane (get_past_rainfall: left zero padding for t < nums)
         const int start = max(0, t - nums + 1), end = min(t + 1, T), nsteps = end - start;

@@ -162,7 +162,7 @@ struct HeadParams {
     // folds them from here: [B][nblk0][2], centred per block of bpix0 pixels
     const float *partial0;
     int nblk0, bpix0;
-    int *bump;                  // rollouts: a frame counter of ANOTHER kernel family, advanced by one by the head's first launch (see urnn_head_rollout_f32)
+    int *bump;                  // rollouts: where the head's first launch stores *frame_index + 1 (the next head's frame word; see urnn_head_rollout_f32)
 };
 hipError_t urnn_launch_head(const HeadParams &p, int phase_mask, hipStream_t st);
 int urnn_head_coop_blocks(int B, int P);

@@ -73,15 +73,15 @@ class YOLOXHead(nn.Module):
         return self._flat
 
     def run(self, feat, out_masked=None, out_cls=None, out_raw=None, frame_index=None, want_raw=False, ws=None, partial0=None, coop=False,
-            next_counter=None):
-        """feat (B,16,H,W) -> (masked, cls, raw|None).  ``partial0``, ``next_counter``: see ops.head."""
+            frame_next=None):
+        """feat (B,16,H,W) -> (masked, cls, raw|None).  ``partial0``, ``frame_next``: see ops.head."""
         fp = self.flat_params()
         return ops.head(feat, fp["conv_w"], fp["ln_w"], fp["ln_b"],
                         self.cls_preds.conv.weight.detach().reshape(-1), self.cls_preds.conv.bias.detach(),
                         self.reg_preds.conv.weight.detach().reshape(-1), self.reg_preds.conv.bias.detach(),
                         self.cls_thred, out_masked=out_masked, out_cls=out_cls, out_raw=out_raw,
                         frame_index=frame_index, want_raw=want_raw, eps=self.stems.ln.eps, ws=ws, partial0=partial0, coop=coop,
-                        next_counter=next_counter)
+                        frame_next=frame_next)
 
     @torch.no_grad()
     def forward(self, inputs):

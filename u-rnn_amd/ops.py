@@ -323,10 +323,11 @@ def deconv2x2(x, packed, Cout, out=None, slope=LRELU_SLOPE):
 
 
 def head(feat, conv_w, ln_w, ln_b, cls_w, cls_b, reg_w, reg_b, cls_thred, out_masked=None, out_cls=None, out_raw=None,
-         frame_index=None, want_raw=False, eps=NORM_EPS, slope=LRELU_SLOPE, ws=None, partial0=None, coop=False, next_counter=None):
+         frame_index=None, want_raw=False, eps=NORM_EPS, slope=LRELU_SLOPE, ws=None, partial0=None, coop=False, frame_next=None):
     """Dual head + mask.  Returns (masked, cls, raw|None), each (B,H,W) unless preallocated (T,B,H,W) buffers
-    plus a device ``frame_index`` are given.  ``next_counter`` (frame loops): another chain's device frame counter, advanced by
-    one by the head's first launch (urnn_head_rollout_f32)."""
+    plus a device ``frame_index`` are given.  ``frame_next`` (captured frame loops): the int32 device word that receives
+    ``frame_index + 1`` -- the next head's ``frame_index``; two words used alternately are a frame counter without a kernel of its own
+    (urnn_head_rollout_f32)."""
     _dev_check(feat, conv_w, ln_w, ln_b, cls_w, cls_b, reg_w, reg_b, out_masked, out_cls, out_raw)
     B, C, H, W = feat.shape
     L = lib()
@@ -337,13 +338,13 @@ def head(feat, conv_w, ln_w, ln_b, cls_w, cls_b, reg_w, reg_b, cls_thred, out_ma
         out_cls = torch.empty((B, H, W), dtype=torch.float32, device=feat.device)
     if out_raw is None and want_raw:
         out_raw = torch.empty((B, H, W), dtype=torch.float32, device=feat.device)
-    if next_counter is not None:
+    if frame_next is not None:
         _dev_check(partial0)
-        _counter_check(frame_index, next_counter)
+        _counter_check(frame_index, frame_next)
         check(L.urnn_head_rollout_f32(_ptr(feat), _ptr(conv_w), _ptr(ln_w), _ptr(ln_b), _ptr(cls_w), _ptr(cls_b), _ptr(reg_w),
                                       _ptr(reg_b), _ptr(out_masked), _ptr(out_cls), _ptr(out_raw), _ptr(frame_index), _ptr(ws),
                                       ws.numel(), B, C, H, W, float(cls_thred), eps, slope, int(bool(coop) and partial0 is None),
-                                      _ptr(partial0), _ptr(next_counter), _stream()), "urnn_head_rollout_f32")
+                                      _ptr(partial0), _ptr(frame_next), _stream()), "urnn_head_rollout_f32")
         return out_masked, out_cls, out_raw
     if partial0 is not None:      # the first LayerNorm's statistics were taken by the kernel that produced feat (gru_cell_tail)
         _dev_check(partial0)
@@ -359,10 +360,10 @@ def head(feat, conv_w, ln_w, ln_b, cls_w, cls_b, reg_w, reg_b, cls_thred, out_ma
     return out_masked, out_cls, out_raw
 
 
-def preprocess(rain, cumsum, dem, imperv, manhole, dem_min, dem_max, t, nums, rain_max, cumsum_max, out=None, t_dev=None, next_counter=None):
+def preprocess(rain, cumsum, dem, imperv, manhole, dem_min, dem_max, t, nums, rain_max, cumsum_max, out=None, t_dev=None, t_next=None):
     """Per-frame input assembly: returns (B, 2*nums+3, H, W).  rain/cumsum (B,T) scalar or (B,T,H,W) spatial;
-    dem/imperv/manhole (B,H,W).  ``t_dev`` (int32 device scalar) overrides ``t`` for graph replay; ``next_counter``: another
-    chain's device frame counter this launch also advances (urnn_preprocess_rollout_f32)."""
+    dem/imperv/manhole (B,H,W).  ``t_dev`` (int32 device scalar) overrides ``t`` for graph replay; ``t_next``: the device word that
+    receives ``t_dev + 1``, the next frame's ``t_dev`` (urnn_preprocess_rollout_f32)."""
     _dev_check(rain, cumsum, dem, imperv, manhole, out)
     B, H, W = dem.shape
     T = rain.shape[1]
@@ -370,10 +371,10 @@ def preprocess(rain, cumsum, dem, imperv, manhole, dem_min, dem_max, t, nums, ra
     C = 2 * nums + 3
     if out is None:
         out = torch.empty((B, C, H, W), dtype=torch.float32, device=dem.device)
-    if next_counter is not None:
-        _counter_check(t_dev, next_counter)
+    if t_next is not None:
+        _counter_check(t_dev, t_next)
         check(lib().urnn_preprocess_rollout_f32(_ptr(rain), _ptr(cumsum), _ptr(dem), _ptr(imperv), _ptr(manhole), float(dem_min),
-                                                float(dem_max), _ptr(out), _ptr(t_dev), _ptr(next_counter), B, T, nums, H, W, spatial,
+                                                float(dem_max), _ptr(out), _ptr(t_dev), _ptr(t_next), B, T, nums, H, W, spatial,
                                                 float(rain_max), float(cumsum_max), _stream()), "urnn_preprocess_rollout_f32")
         return out
     check(lib().urnn_preprocess_f32(_ptr(rain), _ptr(cumsum), _ptr(dem), _ptr(imperv), _ptr(manhole), float(dem_min),
@@ -395,16 +396,16 @@ def stage1_static(dem, imperv, manhole, dem_min, dem_max, weight, nums, out=None
 
 
 def stage1_scalar_rain(S, rain, cumsum, weight, bias, t, nums, rain_max, cumsum_max, out=None, t_dev=None, slope=LRELU_SLOPE,
-                       next_counter=None):
-    """preprocess_inputs + Encoder.stage1 for scalar rain: LeakyReLU(S + v_t) -> (B,Cout,H,W).  ``next_counter`` as in preprocess."""
+                       t_next=None):
+    """preprocess_inputs + Encoder.stage1 for scalar rain: LeakyReLU(S + v_t) -> (B,Cout,H,W).  ``t_next`` as in preprocess."""
     _dev_check(S, rain, cumsum, weight, bias, out)
     B, Cout, H, W = S.shape
     if out is None:
         out = torch.empty_like(S)
-    if next_counter is not None:
-        _counter_check(t_dev, next_counter)
+    if t_next is not None:
+        _counter_check(t_dev, t_next)
         check(lib().urnn_stage1_scalar_rain_rollout_f32(_ptr(S), _ptr(rain), _ptr(cumsum), _ptr(weight), _ptr(bias), _ptr(out),
-                                                        _ptr(t_dev), _ptr(next_counter), B, rain.shape[1], int(nums), Cout, H, W,
+                                                        _ptr(t_dev), _ptr(t_next), B, rain.shape[1], int(nums), Cout, H, W,
                                                         float(rain_max), float(cumsum_max), slope, _stream()),
               "urnn_stage1_scalar_rain_rollout_f32")
         return out

@@ -67,11 +67,15 @@ class RolloutEngine:
         self.feat = torch.empty((B, dec.stage1.out_channels, H, W), **f32)
         self.feat_alt = torch.empty_like(self.feat) if self.overlap else None   # overlap mode: head(t-1) || decoder(t)
         # outputs for every frame
-        self.out_masked = torch.zeros((self.Tcap, B, H, W), **f32)
-        self.out_cls = torch.zeros((self.Tcap, B, H, W), **f32)
-        self.out_raw = torch.zeros((self.Tcap, B, H, W), **f32) if keep_raw else None
-        self.t_dev = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.te_dev = torch.zeros(1, dtype=torch.int32, device=dev)   # overlap mode: frame index of the encoder chain
+        rows = max(self.Tcap, 2)                                     # (the capture warm-up of the overlapped schedule writes two frames)
+        self.out_masked = torch.zeros((rows, B, H, W), **f32)
+        self.out_cls = torch.zeros((rows, B, H, W), **f32)
+        self.out_raw = torch.zeros((rows, B, H, W), **f32) if keep_raw else None
+        self.t_dev = torch.zeros(1, dtype=torch.int32, device=dev)    # one chain: the frame index (urnn_advance_counter per frame)
+        # overlap mode: a pair of words per kernel family, used alternately by frame parity -- the head of frame t reads t2[t % 2] and
+        # stores t + 1 to t2[1 - t % 2], the input assembly of frame t likewise with te2 (urnn_*_rollout_f32): no counter kernels
+        self.t2 = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.te2 = torch.zeros(2, dtype=torch.int32, device=dev)
         self.zero_frame = torch.zeros(1, dtype=torch.int32, device=dev)
         # scratch: OWNED by this engine (a captured graph holds raw pointers into it), one buffer per concurrent kernel chain,
         # sized for the largest consumer before any capture
@@ -79,7 +83,7 @@ class RolloutEngine:
         need = max([L.urnn_head_workspace_bytes(B, 16, H, W)] +
                    [L.urnn_gru_cell_workspace_bytes(B, c.num_features, c.shape[0], c.shape[1])
                     for c in (enc.rnn1, enc.rnn2, enc.rnn3, dec.rnn3, dec.rnn2, dec.rnn1)])
-        self._ws = [ops.workspace(need, dev) for _ in range(2 if self.overlap else 1)]
+        self._ws = [ops.workspace(need, dev) for _ in range(3 if self.overlap else 1)]      # (third: the head as a chain of its own)
         # fused_tails=True: the END of a cell runs together with the stage conv that consumes the new state (ops.gru_cell_tail: blend +
         # 1x1 conv [+ pool], for the decoder's last cell + the head's first LayerNorm statistics): enc1 -> stage2, enc2 -> stage3,
         # dec1 -> stage1.  190 MB per frame less through HBM at 500x500, identical bits -- and 3-4 % FEWER frames/s (DESIGN.md section
@@ -92,22 +96,32 @@ class RolloutEngine:
         self._graph = None
         self._graphs2 = None
         # (equal stream priorities: a high-priority chain starves the other -- 900 instead of 1 250 frames/s either way round)
-        self._side = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)) if self.overlap else None
+        self._side = tuple(torch.cuda.Stream(device=dev) for _ in range(3)) if self.overlap else None
         # A cooperative cell launch needs ALL its blocks resident (one per CU).  With two kernel chains in flight, two such launches
         # of at most 128 blocks each always fit side by side; a larger one could wait at its grid barrier for CUs the other chain's
         # cooperative launch holds while that one waits for CUs of ours.  So with overlap=True only cells of <= 128 blocks take the
         # flag (measured at 500x500, 245 blocks: ordering the two chains' launches instead costs more than the launch saves,
         # profiles/r04_coop_cells.txt); one chain takes it wherever the library plans it.
+        resident = {}                                                # blocks of the cooperative launches in use, by layer
+
         def coop_flag(cell, has_x, skip):
             n = L.urnn_gru_cell_coop_blocks(B, cell.input_channels, cell.num_features, cell.shape[0], cell.shape[1], int(skip), int(has_x))
             # (URNN_TUNE_COOP_BIG=0: a one-chain engine keeps the two-chain policy -- the counter passes of tools/collect_profiles.sh run
             # eager on one chain and must execute the kernels of the benchmarked schedule)
             big_ok = not self.overlap and os.environ.get("URNN_TUNE_COOP_BIG", "1") != "0"
-            return ops.PHASE_COOP if (coop_cells and n > 0 and (n <= 128 or big_ok)) else 0
+            use = coop_cells and n > 0 and (n <= 128 or big_ok)
+            resident[len(resident)] = n if use else 0
+            return ops.PHASE_COOP if use else 0
         nhead = L.urnn_head_coop_blocks_f32(B, H, W)                 # ... and the head likewise (urnn_head_coop_f32)
         self._head_coop = bool(coop_cells) and (nhead <= 128 or (not self.overlap and nhead <= 256 and os.environ.get("URNN_TUNE_COOP_BIG", "1") != "0"))
         self._coop = {"enc1": coop_flag(enc.rnn1, 1, 0), "enc2": coop_flag(enc.rnn2, 1, 0), "enc3": coop_flag(enc.rnn3, 1, 0),
                       "dec3": coop_flag(dec.rnn3, 0, 1), "dec2": coop_flag(dec.rnn2, 1, 1), "dec1": coop_flag(dec.rnn1, 1, 1)}
+        # The head as a THIRD chain (own stream and scratch): head(t-1) || encoder(t+1) || decoder(t) -- +2 % at 500x500, +4 % at 400x560
+        # (profiles/r04_three_chains.txt).  With cooperative launches on three streams the residency rule above becomes: the largest
+        # such launch of each chain, together, must fit the chip's 256 CUs (a block each) -- else the head stays in front of the encoder.
+        blocks = list(resident.values())                             # enc1..3, dec3..1 in the order of the dict above
+        together = max(blocks[:3]) + max(blocks[3:]) + (nhead if self._head_coop else 0)
+        self._head_own_chain = self.overlap and os.environ.get("URNN_TUNE_HEAD_CHAIN", "1") != "0" and together <= 256
         self._dem_stamp = None
 
     # -- one timestep, all launches on the current stream ----------------------------------------------
@@ -133,16 +147,15 @@ class RolloutEngine:
                      frame_index=self.t_dev, ws=ws, partial0=self._k1part[0] if tail else None, coop=self._head_coop and not tail)
         ops.advance_counter(self.t_dev, 1)
 
-    def _stage1(self, t_dev, next_counter=None):
-        """Frame input assembly + encoder stage-1 conv -> self.a1.  ``next_counter``: the other chain's frame counter, advanced by
-        the same launch (ops.preprocess)."""
+    def _stage1(self, t_dev, t_next=None):
+        """Frame input assembly + encoder stage-1 conv -> self.a1.  ``t_next``: the word that receives t_dev + 1 (ops.preprocess)."""
         conv = self.net.encoder.stage1.layer
         if self.S1 is not None:
             ops.stage1_scalar_rain(self.S1, self.rain, self.cumsum, self._w1, conv.bias.detach(), 0, self.nums, self.rain_max,
-                                   self.cumsum_max, out=self.a1, t_dev=t_dev, next_counter=next_counter)
+                                   self.cumsum_max, out=self.a1, t_dev=t_dev, t_next=t_next)
         else:
             ops.preprocess(self.rain, self.cumsum, self.dem, self.imperv, self.manhole, self.dem_min, self.dem_max, 0,
-                           self.nums, self.rain_max, self.cumsum_max, out=self.x_in, t_dev=t_dev, next_counter=next_counter)
+                           self.nums, self.rain_max, self.cumsum_max, out=self.x_in, t_dev=t_dev, t_next=t_next)
             self.net.encoder.stage1(self.x_in, out=self.a1)
 
     def _tail_of(self, name):
@@ -217,27 +230,15 @@ class RolloutEngine:
     # The two chains as lists of segments (closures), so that an overlapped iteration can interleave their ENQUEUE order:
     # a graph replay hands its kernel nodes to the hardware queues in creation order at a few microseconds each, so a chain
     # enqueued entirely after the other starts ~100 us late.
-    # Frame counters of the two-chain schedule (both device int32, so that a captured iteration replays for any frame):
-    #   te_dev = the frame the NEXT encoder pass assembles, t_dev = the frame the NEXT head writes.
-    # In a steady-state iteration t -- head(t-1), encoder(t+1) on chain 1 -- nobody advances them with a launch of its own: the head's
-    # first kernel bumps te_dev (read only by the input assembly queued behind it), the input assembly bumps t_dev (read only by
-    # the next head; the head before it has completed).  Iterations without a head in front (the first of a run() call) advance
-    # te_dev with the one-thread kernel, the trailing head of a run() call advances t_dev likewise, the prologue E(0) advances
-    # nothing.  Invariant at the start of iteration t: te_dev = t (the frame of the newest encoder pass; advanced to t + 1 before
-    # E(t + 1) reads it), t_dev = number of heads completed (t - 1 in steady state, t at the start of a run() call).
-    def _enc_segments(self, parity, advance="none"):
-        """encoder pass into the buffers of ``parity``.  advance: "none" (prologue E(0): reads te_dev = 0 as it stands), "kernel"
-        (te_dev += 1 with a launch of its own BEFORE the input assembly), "piggyback" (the head in front has advanced te_dev; the
-        input assembly advances t_dev)."""
+    def _enc_segments(self, parity):
+        """encoder pass of a frame of ``parity`` into the buffers of that parity (frame index: te2[parity], see __init__)."""
         enc = self.net.encoder
         (p1, p2, p3), (n1, n2, n3) = self._enc_bufs(parity)
 
         ws = self._ws[0]                       # chain 1 (head + encoder) scratch
 
         def e1():
-            if advance == "kernel":
-                ops.advance_counter(self.te_dev, 1)
-            self._stage1(self.te_dev, next_counter=self.t_dev if advance == "piggyback" else None)
+            self._stage1(self.te2[parity:parity + 1], t_next=self.te2[1 - parity:2 - parity])
             if not self._cell("enc1", enc.rnn1, self.a1, None, p1, n1, ws, conv_out=self.a2):
                 enc.stage2(n1, out=self.a2)
 
@@ -279,15 +280,14 @@ class RolloutEngine:
         for seg in self._dec_segments(parity):
             seg()
 
-    def _head_chain(self, parity, piggyback=False, ws=None):
-        """head(t) for t % 2 == parity (reads feat[parity]); shares the encoder chain's stream and scratch.  piggyback: an encoder
-        pass follows on this stream -- the head advances te_dev for it and leaves t_dev to that pass's input assembly."""
+    def _head_chain(self, parity):
+        """head(t) for t % 2 == parity (reads feat[parity], frame index t2[parity]).  On a chain of its own (stream, scratch) when
+        ``_head_own_chain``, else in front of the encoder pass on chain 1."""
+        tail = self._tail_of("dec1") is not None
         self.net.head.run(self.feat if parity == 0 else self.feat_alt, out_masked=self.out_masked, out_cls=self.out_cls,
-                          out_raw=self.out_raw, frame_index=self.t_dev, ws=self._ws[0] if ws is None else ws,
-                          partial0=self._k1part[parity] if self._tail_of("dec1") is not None else None,
-                          coop=self._head_coop and self._tail_of("dec1") is None, next_counter=self.te_dev if piggyback else None)
-        if not piggyback:
-            ops.advance_counter(self.t_dev, 1)
+                          out_raw=self.out_raw, frame_index=self.t2[parity:parity + 1], ws=self._ws[2 if self._head_own_chain else 0],
+                          partial0=self._k1part[parity] if tail else None, coop=self._head_coop and not tail,
+                          frame_next=self.t2[1 - parity:2 - parity])
 
     def _iter_overlap(self, parity, with_head=True):
         """Iteration t (parity = t % 2): chain 1 = head(t-1) then encoder(t+1); chain 2 = decoder(t); enqueued segment by
@@ -296,27 +296,20 @@ class RolloutEngine:
         s1, s2 = self._side[:2]
         s1.wait_stream(cur)
         s2.wait_stream(cur)
-        three = with_head and os.environ.get("URNN_TUNE_HEAD_CHAIN", "0") == "1"      # experiment: the head as a third chain
-        if three:
-            if len(self._side) == 2:
-                self._side = self._side + (torch.cuda.Stream(device=self.device),)
-                self._ws.append(ops.workspace(self._ws[0].numel(), self.device))
-            self._side[2].wait_stream(cur)
-        enc = self._enc_segments(1 - parity, advance="piggyback" if with_head and not three else "kernel")
+        s3 = self._side[2] if self._head_own_chain else s1
+        if with_head and s3 is not s1:
+            s3.wait_stream(cur)
+        enc = self._enc_segments(1 - parity)
         dec = self._dec_segments(parity)
         order = os.environ.get("URNN_TUNE_CHAIN_ORDER", self.ENQUEUE_ORDER)
-        if sorted(order) != sorted("HEEEDDD") or order.index("H") > order.index("E"):
-            raise RuntimeError("enqueue order must hold one H, three E and three D, H before the first E (the head advances the "
-                               "encoder pass's frame counter)")
+        if sorted(order) != sorted("HEEEDDD"):
+            raise RuntimeError("enqueue order must hold one H, three E and three D")
         ie = idd = 0
         for ch in order:
             if ch == "H":
-                if three:
-                    with torch.cuda.stream(self._side[2]):
-                        self._head_chain(1 - parity, ws=self._ws[2])
-                elif with_head:
-                    with torch.cuda.stream(s1):
-                        self._head_chain(1 - parity, piggyback=True)
+                if with_head:
+                    with torch.cuda.stream(s3):
+                        self._head_chain(1 - parity)
             elif ch == "E":
                 with torch.cuda.stream(s1):
                     enc[ie]()
@@ -329,8 +322,8 @@ class RolloutEngine:
             raise RuntimeError("enqueue order must hold one H, three E and three D")
         cur.wait_stream(s1)
         cur.wait_stream(s2)
-        if three:
-            cur.wait_stream(self._side[2])
+        if with_head and s3 is not s1:
+            cur.wait_stream(s3)
 
     ENQUEUE_ORDER = "HEEEDDD"
     GROUP = 4
@@ -338,7 +331,20 @@ class RolloutEngine:
     def _capture_overlap(self):
         self.net.head.flat_params()
         saved = [s.clone() for s in self.states] + [s.clone() for s in self.enc_alt]
-        t0, t1 = self.t_dev.clone(), self.te_dev.clone()
+        t0, t1 = self.t2.clone(), self.te2.clone()
+        # Warm-up and first replays run a few frames for real.  They start at an EVEN frame b (the graphs are per frame parity and
+        # "prologue" / "first 0" are an even frame's), as close behind the frames done as the buffers allow; the output rows they
+        # write are saved and restored (after a mid-event re-capture near the end of an event they may be finished frames).
+        self._group = max(0, int(os.environ.get("URNN_TUNE_GROUP", self.GROUP))) & ~1
+        rows = self.out_masked.shape[0]
+        b = max(0, min(self._frames_done + (self._frames_done & 1), (rows - self._group - 2) & ~1, (rows - 2) & ~1))
+        outs = [o for o in (self.out_masked, self.out_cls, self.out_raw) if o is not None]
+        kept = [o[b:b + self._group + 2].clone() for o in outs]
+
+        def set_counters():
+            self.t2.copy_(torch.tensor([b, b + 1], dtype=torch.int32))
+            self.te2.copy_(torch.tensor([b, b + 1], dtype=torch.int32))
+        set_counters()
         self._enc_chain(0)              # warm-up (packs weights), eager
         self._iter_overlap(0, with_head=False)
         self._iter_overlap(1)
@@ -355,7 +361,6 @@ class RolloutEngine:
             graphs[key] = g
         # GROUP steady-state iterations per replay (an even number: parity p, 1 - p, ...): a graph launch costs the frame loop ~5 us of
         # idle GPU, which is 3 % of a 64x64 frame (profiles/r04_bench_configs.txt)
-        self._group = max(0, int(os.environ.get("URNN_TUNE_GROUP", self.GROUP))) & ~1
         if self._group:
             for parity in (0, 1):
                 g = torch.cuda.CUDAGraph()
@@ -373,23 +378,24 @@ class RolloutEngine:
             self._enc_chain(0)          # pipeline prologue E(0) of an event
         graphs["prologue"] = g
         # The first launch of an instantiated graph uploads it to the device: pay that here, not in the first frames of the first
-        # event.  Short valid rollouts touch every graph and write the first GROUP + 2 frames only (states and counters are restored below).
+        # event.  Short valid rollouts touch every graph and write frames b .. b + GROUP + 1 only (states, counters, outputs restored below).
         seqs = [(3, ("prologue", ("first", 0), 1, 0, ("tail", 0))), (2, ("prologue", ("first", 0), ("tail", 0), ("first", 1), ("tail", 1)))]
         if self._group:
             seqs += [(self._group + 1, ("prologue", ("first", 0), ("group", 1), ("tail", 0))),
                      (self._group + 2, ("prologue", ("first", 0), 1, ("group", 0), ("tail", 1)))]
         for nframes, seq in seqs:
-            if int(t0.item()) + nframes <= self.Tcap:
-                self.t_dev.copy_(t0)
-                self.te_dev.copy_(t1)
+            if b + nframes <= rows:
+                set_counters()
                 for key in seq:
                     graphs[key].replay()
         torch.cuda.synchronize(self.device)
         self._graphs2 = graphs
         for s, v in zip(self.states + self.enc_alt, saved):
             s.copy_(v)
-        self.t_dev.copy_(t0)
-        self.te_dev.copy_(t1)
+        for o, v in zip(outs, kept):
+            o[b:b + self._group + 2].copy_(v)
+        self.t2.copy_(t0)
+        self.te2.copy_(t1)
 
     def _run_overlap(self, frames):
         """Software pipeline over frames: E(0) | {D(0) || E(1)} | {H(0),E(2) || D(1)} | ... | H(last).  The trailing head is
@@ -499,7 +505,9 @@ class RolloutEngine:
             for s in self.enc_alt:
                 s.zero_()
         self.t_dev.zero_()
-        self.te_dev.zero_()
+        if self.overlap:
+            self.t2.zero_()
+            self.te2.zero_()
         self._frames_done = 0
 
     def run(self, frames):
