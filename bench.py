@@ -571,7 +571,8 @@ def main():
                                ("mixed: " + " + ".join(f"{n} {CONFIGS[n][0]}x{CONFIGS[n][1]} T={CONFIGS[n][3]}" for n in names) +
                                 f" events alternating, {B} event(s) per GPU, one hipGraph per shape"),
                    "events_per_gpu": B, "parallelism": f"event-parallel x{world} (no collective)",
-                   "graph": not args.no_graph, "overlap_chains": bool(args.overlap), "matrix_mode": args.matrix_mode,
+                   "graph": not args.no_graph, "overlap_chains": bool(args.overlap),
+                   "kernel_chains": (3 if eng._head_own_chain else 2) if args.overlap else 1, "matrix_mode": args.matrix_mode,
                    "fused_tails": bool(args.fused_tails)},
         "long_run": long_run,
         "gflop_per_frame": gflop,
