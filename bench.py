@@ -13,8 +13,8 @@ independent: test.py:741-746) -> weak scaling; value = total frames of all ranks
 Prints ONE JSON line (rank 0).  Extra objects: "roofline" -- the kernel FAMILY with the most time per frame among the cells'
 three (candidate GEMMs / gate GEMMs / blend; the candidate GEMMs since round 3), each launch timed with HIP events on its launch
 stream: `avg_launch_us` on ONE kernel chain, where an event pair spans the kernel alone (the figure profiles/r04_kernel_stats_
-overlap0.txt -- rocprofv3 --kernel-trace --stats of `bench.py --overlap 0` -- must agree with), `live_two_chain` in the
-benchmarked two-chain schedule (kernel + what it queued behind: profiles/r04_kernel_stats.txt holds the kernels' own
+overlap0.txt -- rocprofv3 --kernel-trace --stats of `bench.py --overlap 0` -- must agree with), `live_overlapped` in the
+benchmarked schedule of concurrent chains (kernel + what it queued behind: profiles/r04_kernel_stats.txt holds the kernels' own
 durations there); every family under "roofline.kernels" -- and "cpu_baseline" (the C oracle on the host cores, bounded sample,
 rank 0 at N=1 only).  `python bench.py --gpus N` without a launcher re-runs itself as N ranks (torch.distributed.run).
 """
@@ -597,7 +597,7 @@ def main():
         try:
             fused_cells = fused_reset_gate_cells(H, W, B)
             work = cell_kernel_work(H, W, B, fused_cells)
-            live = eng.probe_cell_kernels()       # the timed region's scheduling mode (two chains unless --overlap 0)
+            live = eng.probe_cell_kernels()       # the timed region's scheduling mode (concurrent chains unless --overlap 0)
             if args.overlap:                      # one chain: an event pair spans the kernel alone -- what rocprofv3 calls its duration
                 iso_eng = RolloutEngine(eng.net, H, W, nums, rain_max, cum_max, batch=B, max_frames=T, spatial_rain=spatial, net_cfg=cfg,
                                         use_graph=False, device=dev, overlap=False)
@@ -625,7 +625,7 @@ def main():
                                              "boundary: 4-6 % above rocprofv3's duration of the same launch): compare with rocprofv3 --kernel-trace --stats of "
                                              "`bench.py --overlap 0` (profiles/*_kernel_stats_overlap0.txt)",
                          "us_per_frame": sum(us.values()), "launch_us": us, "bytes_per_launch_by_cell": by,
-                         "live_two_chain": {"avg_launch_us": avg_live, "launch_us": us_live, "frac": bpl / avg_live / 1e3 / (PEAK_HBM_TBS * 1e3),
+                         "live_overlapped": {"chains": (3 if eng._head_own_chain else 2) if args.overlap else 1, "avg_launch_us": avg_live, "launch_us": us_live, "frac": bpl / avg_live / 1e3 / (PEAK_HBM_TBS * 1e3),
                                             "note": "the benchmarked schedule: kernel + what it queued behind on its stream while the other chain holds the CUs"}
                          if args.overlap else None}
                 if sum(fl.values()) > 0:

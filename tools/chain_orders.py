@@ -1,5 +1,6 @@
-"""Development aid: whole-rollout frames/s for every enqueue order of the two kernel chains (URNN_TUNE_CHAIN_ORDER).
-Result (round 2): every order with the head first is within noise (1 275-1 283); orders that start with the decoder lose 4-11 %."""
+"""Development aid: whole-rollout frames/s for every enqueue order of the kernel chains' segments (URNN_TUNE_CHAIN_ORDER).
+Result (round 2, two chains -- the head in front of the encoder pass): every order with the head first within noise (1 275-1 283), orders
+that start with the decoder lose 4-11 %.  Round 4, the head on a chain of its own: decoder first is the best (profiles/r04_enqueue_order.txt)."""
 import itertools, subprocess, os, re, sys
 orders=set()
 for pos in itertools.combinations(range(6),3):

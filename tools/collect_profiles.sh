@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=${1:-r04}
 O=$R/gpurun_out/$TAG; P=/tmp/prof_$TAG
 mkdir -p $O $P; cd /tmp; export TMPDIR=/tmp
-# one chain, eager (every dispatch attributed) -- with the kernel selection of the benchmarked two-chain schedule (URNN_TUNE_COOP_BIG=0)
+# one chain, eager (every dispatch attributed) -- with the kernel selection of the benchmarked overlapped schedule (URNN_TUNE_COOP_BIG=0)
 export URNN_TUNE_COOP_BIG=0
 CMD="python $R/bench.py --steps 14 --warmup 2 --no-cpu-baseline --no-long-run --overlap 0 --no-graph"
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do

@@ -20,7 +20,6 @@ class RolloutEngine:
         # cells whose shape has the form recompute the reset gate inside the candidate kernel instead of round-tripping its raw
         # planes through HBM (include/urnn_hip.h URNN_PHASE_FUSED_R); the engine never reads a cell's workspace
         # ... and cells on small planes run as ONE cooperative launch (URNN_PHASE_COOP: gates | grid barrier | candidate | grid
-        # barrier | blend, nothing but statistics leaving the CU in between)
         # barrier | blend, nothing but statistics leaving the CU in between): per cell, self._coop below
         self._cell_flags = ops.PHASE_FUSED_R if fused_reset_gate else 0
         self.H, self.W = int(input_height), int(input_width)
@@ -31,8 +30,9 @@ class RolloutEngine:
         self.Tcap = int(max_frames)
         self.spatial = bool(spatial_rain)
         self.use_graph = bool(use_graph)
-        # overlap=True: encoder(t+1) and decoder+head(t) run as two concurrent kernel chains (two streams forked
-        # inside the captured graph); needs ping-pong encoder states.  Same arithmetic, same results.
+        # overlap=True: head(t-1), encoder(t+1) and decoder(t) run as concurrent kernel chains (streams forked inside the
+        # captured graph: three, or two with the head in front of the encoder -- _head_own_chain); needs ping-pong encoder
+        # states and feature maps.  Same arithmetic, same results.
         self.overlap = bool(overlap)
         self.device = torch.device(device) if device is not None else next(net.parameters()).device
         if self.device.type != "cuda":
@@ -97,8 +97,8 @@ class RolloutEngine:
         self._graphs2 = None
         # (equal stream priorities: a high-priority chain starves the other -- 900 instead of 1 250 frames/s either way round)
         self._side = tuple(torch.cuda.Stream(device=dev) for _ in range(3)) if self.overlap else None
-        # A cooperative cell launch needs ALL its blocks resident (one per CU).  With two kernel chains in flight, two such launches
-        # of at most 128 blocks each always fit side by side; a larger one could wait at its grid barrier for CUs the other chain's
+        # A cooperative cell launch needs ALL its blocks resident (one per CU).  With the encoder and decoder chains in flight, two such
+        # launches of at most 128 blocks each always fit side by side (the head's: further below); a larger one could wait at its grid barrier for CUs the other chain's
         # cooperative launch holds while that one waits for CUs of ours.  So with overlap=True only cells of <= 128 blocks take the
         # flag (measured at 500x500, 245 blocks: ordering the two chains' launches instead costs more than the launch saves,
         # profiles/r04_coop_cells.txt); one chain takes it wherever the library plans it.
@@ -227,7 +227,7 @@ class RolloutEngine:
         bufs = (self.states[:3], self.enc_alt)
         return bufs[1 - parity], bufs[parity]
 
-    # The two chains as lists of segments (closures), so that an overlapped iteration can interleave their ENQUEUE order:
+    # The encoder and decoder chains as lists of segments (closures), so that an overlapped iteration can interleave their ENQUEUE order:
     # a graph replay hands its kernel nodes to the hardware queues in creation order at a few microseconds each, so a chain
     # enqueued entirely after the other starts ~100 us late.
     def _enc_segments(self, parity):
