@@ -157,6 +157,25 @@ def test_grouped_iterations_and_piecewise_runs_match_sequential(dev, monkeypatch
         assert torch.equal(a, ovl.out_masked[:T]), f"re-capture after {cut} frames"
 
 
+@pytest.mark.parametrize("T", [1, 2, 3, 5])
+def test_very_short_events_on_the_overlapped_schedule(dev, T):
+    """Events shorter than a group of iterations (and than the capture warm-up's frames): prologue + first iteration + trailing head
+    only, output buffers of one to five rows -- same frames and states as the one-chain engine, twice through the same graphs."""
+    import urnn_amd.weights as uw
+    from urnn_amd.rollout import RolloutEngine
+    H, W, nums = 32, 48, 3
+    net, _ = make_net(H, W, 9, 3, dev)
+    ev = uw.make_event(T, H, W, 60.0, seed=4)
+    seq = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T)
+    a = seq.rollout(ev).clone()
+    ovl = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T, overlap=True)
+    for _ in range(2):
+        b = ovl.rollout(ev)
+        assert b.shape == a.shape and torch.equal(a, b)
+        for x, y in zip(seq.final_states(), ovl.final_states()):
+            assert torch.equal(x, y)
+
+
 def test_batched_events_match_single_events(dev):
     """Event batching (a build-side extension): per-sample semantics -- a batch of two events must
     equal the two events rolled out one by one."""
