@@ -4,6 +4,8 @@ back-propagation through the steps and through the six recurrent states, giving 
 
 `Trainer` adds global-norm clipping + Adam on flat buffers, the SWP loop (fast mode and pre-warming) and the DDP gradient mean
 (RCCL, overlapped with the backward pass)."""
+import os
+
 import torch
 
 from . import ops, train_ops
@@ -28,55 +30,97 @@ class WindowGradients:
         # scratch owned by this object: ("fwd", step, layer) keeps the forward scratch of layer `layer` of window step `step`
         # until its backward ran, "bwd" is the backward kernels' scratch
         self.arena = ops.Arena(self.device)
+        self._fwd_streams = None
+        self.forward_chains = os.environ.get("URNN_TUNE_TRAIN_CHAINS", "1") != "0"      # _forward_window instead of step by step
+        self.backward_chains = os.environ.get("URNN_TUNE_TRAIN_BWD_CHAINS", "1") != "0"  # _backward_window likewise
+        self._arena_d, self._arena_e = ops.Arena(self.device), ops.Arena(self.device)    # scratch of the decoder / encoder backward chains
 
     # -- forward of one timestep, keeping what the backward reads ---------------------------------------------------
-    def _forward_step(self, ev, t, states, step, t_dev=None):
-        net = self.net
-        enc, dec, head = net.encoder, net.decoder, net.head
-        e1, e2, e3, d1, d2, d3 = states
-        S = {"prev": list(states), "ws": {}}
-        x_in = ops.preprocess(ev["rain"], ev["cumsum"], ev["dem"], ev["imperv"], ev["manhole"], ev["dem_min"], ev["dem_max"], int(t),
-                              self.nums, self.rain_max, self.cumsum_max, t_dev=t_dev)
+    # The forward of a timestep in the three parts that only meet through the tensors they hand on (model.py:65-121): encoder(s + 1)
+    # reads the encoder states of step s, decoder(s) the encoder outputs of step s and its own states, head(s) the decoder's last
+    # feature map.  _forward_step runs them in order; _forward_window runs them as three kernel chains.
+    def _cell_fwd(self, S, step, k, mod, x, e, h):
+        S["ws"][k] = self.arena.get(("fwd", step, k), ops.gru_cell_workspace_bytes(h.shape[0], h.shape[1], h.shape[2], h.shape[3]))
+        return mod.step(x, e, h, ws=S["ws"][k])
 
-        def cell(k, mod, x, e, h):
-            S["ws"][k] = self.arena.get(("fwd", step, k), ops.gru_cell_workspace_bytes(h.shape[0], h.shape[1], h.shape[2], h.shape[3]))
-            return mod.step(x, e, h, ws=S["ws"][k])
-        S["x_in"] = x_in
-        S["a1"] = enc.stage1(x_in)
-        S["e1"] = cell(0, enc.rnn1, S["a1"], None, e1)
+    def _forward_enc(self, ev, t, enc_states, step, t_dev=None):
+        enc = self.net.encoder
+        e1, e2, e3 = enc_states
+        S = {"prev": list(enc_states) + [None] * 3, "ws": {}}
+        S["x_in"] = ops.preprocess(ev["rain"], ev["cumsum"], ev["dem"], ev["imperv"], ev["manhole"], ev["dem_min"], ev["dem_max"], int(t),
+                                   self.nums, self.rain_max, self.cumsum_max, t_dev=t_dev)
+        S["a1"] = enc.stage1(S["x_in"])
+        S["e1"] = self._cell_fwd(S, step, 0, enc.rnn1, S["a1"], None, e1)
         S["a2"] = enc.stage2(S["e1"])
-        S["e2"] = cell(1, enc.rnn2, S["a2"], None, e2)
+        S["e2"] = self._cell_fwd(S, step, 1, enc.rnn2, S["a2"], None, e2)
         S["a3"] = enc.stage3(S["e2"])
-        S["e3"] = cell(2, enc.rnn3, S["a3"], None, e3)
-        S["d1"] = cell(3, dec.rnn3, None, S["e3"], d1)
+        S["e3"] = self._cell_fwd(S, step, 2, enc.rnn3, S["a3"], None, e3)
+        return S
+
+    def _forward_dec(self, S, dec_states, step):
+        dec = self.net.decoder
+        d1, d2, d3 = dec_states
+        S["prev"][3:] = list(dec_states)
+        S["d1"] = self._cell_fwd(S, step, 3, dec.rnn3, None, S["e3"], d1)
         S["u3"] = dec.stage3(S["d1"])
-        S["d2"] = cell(4, dec.rnn2, S["u3"], S["e2"], d2)
+        S["d2"] = self._cell_fwd(S, step, 4, dec.rnn2, S["u3"], S["e2"], d2)
         S["u2"] = dec.stage2(S["d2"])
-        S["d3"] = cell(5, dec.rnn1, S["u2"], S["e1"], d3)
+        S["d3"] = self._cell_fwd(S, step, 5, dec.rnn1, S["u2"], S["e1"], d3)
         S["feat"] = dec.stage1(S["d3"])
+
+    def _forward_head(self, S, step):
         f = S["feat"]
         S["ws"][6] = self.arena.get(("fwd", step, 6), ops.head_workspace_bytes(f.shape[0], f.shape[1], f.shape[2], f.shape[3]))
-        S["masked"], S["cls"], S["raw"] = head.run(f, want_raw=True, ws=S["ws"][6])
+        S["masked"], S["cls"], S["raw"] = self.net.head.run(f, want_raw=True, ws=S["ws"][6])
+
+    def _forward_step(self, ev, t, states, step, t_dev=None):
+        S = self._forward_enc(ev, t, states[:3], step, t_dev)
+        self._forward_dec(S, states[3:], step)
+        self._forward_head(S, step)
         return S, [S["e1"], S["e2"], S["e3"], S["d1"], S["d2"], S["d3"]]
 
-    # -- backward of one timestep -----------------------------------------------------------------------------------------
-    def _backward_step(self, S, step, dout, dstate, G, acc, after_head=None):
-        """dout: d loss / d masked output of this step (B,H,W); dstate: gradients arriving at this step's six NEW states from
-        the following step (or None); returns the gradients w.r.t. the six states this step STARTED from."""
-        net = self.net
-        enc, dec, head = net.encoder, net.decoder, net.head
-        e1p, e2p, e3p, d1p, d2p, d3p = S["prev"]
-        # a state's gradient arrives as a TUPLE of terms (None entries dropped): the layer above in this timestep, the skip
-        # connection's reader, and the same cell in the next timestep -- which itself hands over two (blend / reset-gate part, and the
-        # gates' GEMM output).  The cell backward sums up to four terms on the fly; nothing is added by a pass of its own.
-        dE1, dE2, dE3, dD1, dD2, dD3 = dstate if dstate is not None else [()] * 6
+    def _forward_window(self, ev, t0, steps, states, t_devs=None):
+        """The window's forward as a software pipeline, the rollout engine's schedule (rollout.py): iteration i runs
+        encoder(i + 1) || decoder(i) || head(i - 1) on three streams forked from and joined into the current one.  Same kernels on the
+        same operands as _forward_step step by step, so the same bits; what every part allocates is kept in `saved` until the window's
+        backward has run, and the streams are joined before anything on the current stream reads it."""
+        cur = torch.cuda.current_stream(self.device)
+        if self._fwd_streams is None:
+            self._fwd_streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
+        s1, s2, s3 = self._fwd_streams
+        td = (lambda s: None) if t_devs is None else (lambda s: t_devs[s])
+        saved = [self._forward_enc(ev, t0, states[:3], 0, td(0))]
+        dstates = list(states[3:])
+        for i in range(steps):
+            for s in (s1, s2, s3):
+                s.wait_stream(cur)
+            with torch.cuda.stream(s2):
+                self._forward_dec(saved[i], dstates, i)
+            if i + 1 < steps:
+                with torch.cuda.stream(s1):
+                    S = saved[i]
+                    saved.append(self._forward_enc(ev, t0 + i + 1, [S["e1"], S["e2"], S["e3"]], i + 1, td(i + 1)))
+            if i >= 1:
+                with torch.cuda.stream(s3):
+                    self._forward_head(saved[i - 1], i - 1)
+            for s in (s1, s2, s3):
+                cur.wait_stream(s)
+            dstates = [saved[i]["d1"], saved[i]["d2"], saved[i]["d3"]]
+        self._forward_head(saved[steps - 1], steps - 1)
+        S = saved[steps - 1]
+        return saved, [S["e1"], S["e2"], S["e3"], S["d1"], S["d2"], S["d3"]]
 
+    # -- backward of one timestep -----------------------------------------------------------------------------------------
+    # The backward of a timestep in the three parts that only meet through the gradients they hand on: head (d loss / d feature map),
+    # decoder (gradients of the decoder's parameters and states + what flows into the encoder states through the skip connections),
+    # encoder.  _backward_step runs them in order on one scratch arena; _backward_window as three kernel chains, an arena each.
+    def _bwd_ops(self, S, G, acc, arena):
         def conv_bwd(name, mod, x, dy):
             L = mod.layer
             key = f"{name}.{mod._pname}"
             dx, dw, db = train_ops.stage_conv_backward(x, L.weight.detach(), L.bias.detach(), dy, mod.pool, dweight=G.get(key + ".weight"),
                                                        dbias=G.get(key + ".bias"), accumulate=acc and (key + ".weight") in G,
-                                                       scratch=self.arena, packed=self._bwd_packed.setdefault(key, []))
+                                                       scratch=arena, packed=self._bwd_packed.setdefault(key, []))
             G[key + ".weight"], G[key + ".bias"] = dw, db
             return dx
 
@@ -85,7 +129,7 @@ class WindowGradients:
             key = f"{name}.{mod._pname}"
             dx, dw, db = train_ops.deconv2x2_backward(x, L.weight.detach(), out, dy, dweight=G.get(key + ".weight"),
                                                       dbias=G.get(key + ".bias"), accumulate=acc and (key + ".weight") in G,
-                                                      scratch=self.arena, packed=self._bwd_packed.setdefault(key, []))
+                                                      scratch=arena, packed=self._bwd_packed.setdefault(key, []))
             G[key + ".weight"], G[key + ".bias"] = dw, db
             return dx
 
@@ -109,31 +153,95 @@ class WindowGradients:
             g = train_ops.gru_cell_backward(x, e, h, c1.weight.detach(), c2.weight.detach(), g1.weight.detach(), g2.weight.detach(),
                                             flat[0], mod.input_channels, S["ws"][k], grads=prev, accumulate=acc and have,
                                             packed=self._bwd_packed.setdefault(name, []), dh_out2=flat[1], dh_out3=flat[2], dh_out4=flat[3],
-                                            split_dh=True, scratch=self.arena)
+                                            split_dh=True, scratch=arena)
             for k_, v in names.items():
                 ref = dict(mod.named_parameters())[v]
                 G[f"{name}.{v}"] = g[k_].reshape(ref.shape)
             return g.get("dx"), g.get("de"), (g["dh"], g["dh2"])
+        return conv_bwd, deconv_bwd, cell_bwd
 
-        # head
+    def _bwd_head(self, S, dout, G, acc, arena, after_head=None):
+        """-> d loss / d feature map of this step; the head's parameter gradients accumulate in G["_head"]."""
+        head = self.net.head
         fp = head.flat_params()
         hg_prev = G.get("_head") if acc else None
         hg = train_ops.head_backward(S["feat"], fp["conv_w"], fp["ln_w"], fp["ln_b"], head.reg_preds.conv.weight.detach().reshape(-1),
                                      S["raw"], S["cls"], dout.contiguous(), head.cls_thred, S["ws"][6], grads=hg_prev,
-                                     accumulate=hg_prev is not None, scratch=self.arena)
+                                     accumulate=hg_prev is not None, scratch=arena)
         G["_head"] = hg
         if after_head is not None:      # the head's gradients of this window are final here (when this is the first timestep)
             after_head(hg)
-        # decoder
-        du2, dE1_dec, dD3n = cell_bwd(5, "decoder.rnn1", dec.rnn1, S["u2"], S["e1"], d3p, conv_bwd("decoder.stage1", dec.stage1, S["d3"], hg["dfeat"]), dD3)
+        return hg["dfeat"]
+
+    def _bwd_dec(self, S, dfeat, dD, G, acc, arena):
+        """dD: the terms arriving at this step's three NEW decoder states from the following step.  -> (the three terms the skip
+        connections send into this step's new encoder states, the terms for the decoder states this step STARTED from)."""
+        dec = self.net.decoder
+        conv_bwd, deconv_bwd, cell_bwd = self._bwd_ops(S, G, acc, arena)
+        d1p, d2p, d3p = S["prev"][3:]
+        dD1, dD2, dD3 = dD
+        du2, dE1_dec, dD3n = cell_bwd(5, "decoder.rnn1", dec.rnn1, S["u2"], S["e1"], d3p, conv_bwd("decoder.stage1", dec.stage1, S["d3"], dfeat), dD3)
         du3, dE2_dec, dD2n = cell_bwd(4, "decoder.rnn2", dec.rnn2, S["u3"], S["e2"], d2p, deconv_bwd("decoder.stage2", dec.stage2, S["d2"], S["u2"], du2), dD2)
         _, dE3_dec, dD1n = cell_bwd(3, "decoder.rnn3", dec.rnn3, None, S["e3"], d1p, deconv_bwd("decoder.stage3", dec.stage3, S["d1"], S["u3"], du3), dD1)
-        # encoder
+        return (dE1_dec, dE2_dec, dE3_dec), (dD1n, dD2n, dD3n)
+
+    def _bwd_enc(self, S, dE_dec, dE, G, acc, arena):
+        """dE_dec: from this step's decoder (skip connections); dE: from the following step's encoder.  -> the terms for the encoder
+        states this step STARTED from."""
+        enc = self.net.encoder
+        conv_bwd, _, cell_bwd = self._bwd_ops(S, G, acc, arena)
+        e1p, e2p, e3p = S["prev"][:3]
+        dE1_dec, dE2_dec, dE3_dec = dE_dec
+        dE1, dE2, dE3 = dE
         da3, _, dE3n = cell_bwd(2, "encoder.rnn3", enc.rnn3, S["a3"], None, e3p, dE3_dec, dE3)
         da2, _, dE2n = cell_bwd(1, "encoder.rnn2", enc.rnn2, S["a2"], None, e2p, conv_bwd("encoder.stage3", enc.stage3, S["e2"], da3), dE2_dec, dE2)
         da1, _, dE1n = cell_bwd(0, "encoder.rnn1", enc.rnn1, S["a1"], None, e1p, conv_bwd("encoder.stage2", enc.stage2, S["e1"], da2), dE1_dec, dE1)
         conv_bwd("encoder.stage1", enc.stage1, S["x_in"], da1)
-        return [dE1n, dE2n, dE3n, dD1n, dD2n, dD3n]
+        return (dE1n, dE2n, dE3n)
+
+    def _backward_step(self, S, step, dout, dstate, G, acc, after_head=None):
+        """dout: d loss / d masked output of this step (B,H,W); dstate: gradients arriving at this step's six NEW states from
+        the following step (or None); returns the gradients w.r.t. the six states this step STARTED from."""
+        # a state's gradient arrives as a TUPLE of terms (None entries dropped): the layer above in this timestep, the skip
+        # connection's reader, and the same cell in the next timestep -- which itself hands over two (blend / reset-gate part, and the
+        # gates' GEMM output).  The cell backward sums up to four terms on the fly; nothing is added by a pass of its own.
+        dE1, dE2, dE3, dD1, dD2, dD3 = dstate if dstate is not None else [()] * 6
+        # (the same scratch arenas as the pipelined form: whichever ran in the eager warm-up has sized them for the other's capture)
+        dfeat = self._bwd_head(S, dout, G, acc, self.arena, after_head)
+        dE_dec, dDn = self._bwd_dec(S, dfeat, (dD1, dD2, dD3), G, acc, self._arena_d)
+        dEn = self._bwd_enc(S, dE_dec, (dE1, dE2, dE3), G, acc, self._arena_e)
+        return list(dEn) + list(dDn)
+
+    def _backward_window(self, saved, dreg, steps, G):
+        """The window's backward as a software pipeline over the timesteps, last to first: iteration k runs head(S-1-k) ||
+        decoder(S-k) || encoder(S+1-k) on three streams forked from and joined into the current one (the forward's schedule,
+        mirrored).  Each chain has its own scratch arena and touches its own parameters' gradients; what a chain hands to another
+        (dfeat, the skip connections' terms) is kept alive until the window's end, so no block is reused while a stream still reads it."""
+        cur = torch.cuda.current_stream(self.device)
+        if self._fwd_streams is None:
+            self._fwd_streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
+        sE, sD, sH = self._fwd_streams
+        dfeat, dE_dec = {}, {}
+        dD, dE = ((), (), ()), ((), (), ())
+        for k in range(steps + 2):
+            sh, sd, se = steps - 1 - k, steps - k, steps + 1 - k
+            for s in (sE, sD, sH):
+                s.wait_stream(cur)
+            if 0 <= sd < steps:
+                with torch.cuda.stream(sD):
+                    dE_dec[sd], dD = self._bwd_dec(saved[sd], dfeat[sd], dD, G, sd != steps - 1, self._arena_d)
+            if 0 <= se < steps:
+                with torch.cuda.stream(sE):
+                    dE = self._bwd_enc(saved[se], dE_dec[se], dE, G, se != steps - 1, self._arena_e)
+            if 0 <= sh < steps:
+                with torch.cuda.stream(sH):
+                    dfeat[sh] = self._bwd_head(saved[sh], dreg[:, sh], G, sh != steps - 1, self.arena)
+            for s in (sE, sD, sH):
+                cur.wait_stream(s)
+        return list(dE) + list(dD)
+
+    def arena_generation(self):
+        return self.arena.generation + self._arena_d.generation + self._arena_e.generation
 
     def head_gradients(self, hg):
         """{reference parameter name: tensor} views of the head backward's stacked buffers."""
@@ -165,16 +273,22 @@ class WindowGradients:
         targets = torch.as_tensor(targets, dtype=torch.float32, device=self.device).contiguous()
         for v in self._bwd_packed.values():      # the parameters may have changed since the last window: re-pack once per window
             v.clear()
-        saved = []
-        for s in range(steps):
-            S, states = self._forward_step(ev, t0 + s, states, s, None if t_devs is None else t_devs[s])
-            saved.append(S)
+        if self.forward_chains and self.device.type == "cuda":
+            saved, states = self._forward_window(ev, t0, steps, states, t_devs)
+        else:
+            saved = []
+            for s in range(steps):
+                S, states = self._forward_step(ev, t0 + s, states, s, None if t_devs is None else t_devs[s])
+                saved.append(S)
         reg = torch.stack([S["masked"] for S in saved], dim=1).contiguous()            # (B,steps,H,W) as main.py concatenates
         comps, dreg = train_ops.loss(reg, targets, cls_thred=self.cls_thred_train, scratch=self.arena)
         G, dstate = ({k: v for k, v in grad_buffers.items() if not k.startswith("head.")} if grad_buffers else {}), None
-        for s in reversed(range(steps)):
-            hook = (lambda hg: on_head_final(self.head_gradients(hg))) if (on_head_final is not None and s == 0) else None
-            dstate = self._backward_step(saved[s], s, dreg[:, s], dstate, G, acc=(s != steps - 1), after_head=hook)
+        if self.backward_chains and on_head_final is None and self.device.type == "cuda":
+            dstate = self._backward_window(saved, dreg, steps, G)
+        else:       # (DDP: the window is cut into graphs where the head's gradients are final -- one chain)
+            for s in reversed(range(steps)):
+                hook = (lambda hg: on_head_final(self.head_gradients(hg))) if (on_head_final is not None and s == 0) else None
+                dstate = self._backward_step(saved[s], s, dreg[:, s], dstate, G, acc=(s != steps - 1), after_head=hook)
         grads = {k: v for k, v in G.items() if not k.startswith("_")}
         grads.update(self.head_gradients(G["_head"]))
         # state_grads: per state the TWO terms of dL/d(initial state) (their sum is the gradient; left unsummed: nobody in the loop reads it)
@@ -404,7 +518,7 @@ class Trainer:
         # (a scratch buffer that grew since the capture -- an eager call with a larger batch through the same arena -- leaves the
         # graph pointing at freed memory: ops.Arena.generation tells)
         G = self._graphs.get(key)
-        if G is not None and G["arena_gen"] != self.wg.arena.generation:
+        if G is not None and G["arena_gen"] != self.wg.arena_generation():
             # a scratch buffer grew since some capture: EVERY cached graph may point at freed memory
             self._graphs.clear()
             G = None
@@ -450,9 +564,9 @@ class Trainer:
                 with torch.cuda.graph(g):
                     out, clip = self._window_body(sev, G["tgt"], 0, steps, G["states"], t_devs=G["t_devs"], step_dev=G["step_dev"])
                 G.update(graph=g, out=out, clip=clip)
-            if any(h["arena_gen"] != self.wg.arena.generation for h in self._graphs.values()):
+            if any(h["arena_gen"] != self.wg.arena_generation() for h in self._graphs.values()):
                 self._graphs.clear()            # the warm-up grew a buffer older graphs point into
-            G["arena_gen"] = self.wg.arena.generation
+            G["arena_gen"] = self.wg.arena_generation()
             # alternating catchments replay their own graphs instead of re-capturing every window; each entry owns a memory pool
             # with the window's activations, so the cache is small and least-recently-used entries go first
             while len(self._graphs) >= self.MAX_CACHED_WINDOWS:
