@@ -212,11 +212,13 @@ class WindowGradients:
         dEn = self._bwd_enc(S, dE_dec, (dE1, dE2, dE3), G, acc, self._arena_e)
         return list(dEn) + list(dDn)
 
-    def _backward_window(self, saved, dreg, steps, G):
+    def _backward_window(self, saved, dreg, steps, G, on_head_final=None):
         """The window's backward as a software pipeline over the timesteps, last to first: iteration k runs head(S-1-k) ||
         decoder(S-k) || encoder(S+1-k) on three streams forked from and joined into the current one (the forward's schedule,
         mirrored).  Each chain has its own scratch arena and touches its own parameters' gradients; what a chain hands to another
-        (dfeat, the skip connections' terms) is kept alive until the window's end, so no block is reused while a stream still reads it."""
+        (dfeat, the skip connections' terms) is kept alive until the window's end, so no block is reused while a stream still reads it.
+        on_head_final(head gradients): called on the current stream once the iteration with the FIRST timestep's head backward is
+        joined -- the head's gradients are final there, with decoder(0), encoder(1) and encoder(0) still to run."""
         cur = torch.cuda.current_stream(self.device)
         if self._fwd_streams is None:
             self._fwd_streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
@@ -227,6 +229,7 @@ class WindowGradients:
             sh, sd, se = steps - 1 - k, steps - k, steps + 1 - k
             for s in (sE, sD, sH):
                 s.wait_stream(cur)
+            # (the enqueue order of the three parts makes no difference here: 4.09-4.12 ms for all of them)
             if 0 <= sd < steps:
                 with torch.cuda.stream(sD):
                     dE_dec[sd], dD = self._bwd_dec(saved[sd], dfeat[sd], dD, G, sd != steps - 1, self._arena_d)
@@ -238,6 +241,8 @@ class WindowGradients:
                     dfeat[sh] = self._bwd_head(saved[sh], dreg[:, sh], G, sh != steps - 1, self.arena)
             for s in (sE, sD, sH):
                 cur.wait_stream(s)
+            if sh == 0 and on_head_final is not None:
+                on_head_final(self.head_gradients(G["_head"]))
         return list(dE) + list(dD)
 
     def arena_generation(self):
@@ -283,9 +288,9 @@ class WindowGradients:
         reg = torch.stack([S["masked"] for S in saved], dim=1).contiguous()            # (B,steps,H,W) as main.py concatenates
         comps, dreg = train_ops.loss(reg, targets, cls_thred=self.cls_thred_train, scratch=self.arena)
         G, dstate = ({k: v for k, v in grad_buffers.items() if not k.startswith("head.")} if grad_buffers else {}), None
-        if self.backward_chains and on_head_final is None and self.device.type == "cuda":
-            dstate = self._backward_window(saved, dreg, steps, G)
-        else:       # (DDP: the window is cut into graphs where the head's gradients are final -- one chain)
+        if self.backward_chains and self.device.type == "cuda":
+            dstate = self._backward_window(saved, dreg, steps, G, on_head_final)
+        else:
             for s in reversed(range(steps)):
                 hook = (lambda hg: on_head_final(self.head_gradients(hg))) if (on_head_final is not None and s == 0) else None
                 dstate = self._backward_step(saved[s], s, dreg[:, s], dstate, G, acc=(s != steps - 1), after_head=hook)
