@@ -52,6 +52,7 @@ timeout 300 python $R/tools/kernel_bench.py > $O/kernel_bench.txt 2>&1
 timeout 300 python $R/bench.py --mode train > $O/bench_train.log 2>&1
 timeout 300 python $R/bench.py --mode train --dtype bf16 > $O/bench_train_bf16.log 2>&1
 timeout 300 python $R/bench.py --mode train --seq-num 12 > $O/bench_train_seq12.log 2>&1
+URNN_TUNE_TRAIN_CHAINS=0 URNN_TUNE_TRAIN_BWD_CHAINS=0 timeout 300 python $R/bench.py --mode train > $O/bench_train_one_chain.log 2>&1   # the window step by step on one stream
 timeout 420 rocprofv3 --kernel-trace --stats -d $P/stats_train -o t -- python $R/bench.py --mode train > /dev/null 2>&1
 python $R/tools/prof_summary.py $P/stats_train/t_results.db > $O/train_kernel_stats.txt 2>&1
 python $R/tools/wgrad_trace.py $P/stats_train/t_results.db > $O/train_wgrad_launches.txt 2>&1
