@@ -5,8 +5,9 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "liburnn_hip.so")
-SOURCES = ["urnn_gemm.hip", "urnn_small.hip", "urnn_tail.hip", "urnn_elem.hip", "urnn_train.hip", "urnn_api.hip"]
-HEADERS = ["urnn_common.h", "urnn_kernels.h", os.path.join("..", "..", "include", "urnn_hip.h")]
+SOURCES = ["urnn_gemm.hip", "urnn_gemm_gates.hip", "urnn_gemm_cand.hip", "urnn_gemm_deconv.hip", "urnn_cand_fused.hip", "urnn_small.hip",
+           "urnn_tail.hip", "urnn_elem.hip", "urnn_train.hip", "urnn_api.hip"]
+HEADERS = ["urnn_common.h", "urnn_kernels.h", "urnn_gemm.h", os.path.join("..", "..", "include", "urnn_hip.h")]
 
 
 # No SLP vectorisation: on gfx950 it turns pairs of scalar fp32 operations into packed v_pk_mul_f32 / v_pk_fma_f32.  In the
@@ -29,8 +30,10 @@ def build(force=False, verbose=False, extra_flags=(), out=None, tag=""):
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
     LIB = out or globals()["LIB"]
-    if not force and os.path.isfile(LIB) and os.path.getmtime(LIB) >= _newest(deps):
+    if not force and not extra_flags and os.path.isfile(LIB) and os.path.getmtime(LIB) >= _newest(deps):
         return LIB
+    if extra_flags and (not out or not tag):
+        raise ValueError("a build with extra flags needs its own library path (out=) and object tag (tag=): it must not replace the product library or its objects")
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if any(f in ("-fslp-vectorize", "-fvectorize-slp") for f in extra_flags):
         raise ValueError("liburnn_hip must not be built with SLP vectorisation (packed fp32 next to MFMAs: DESIGN.md section 4.8)")
@@ -40,15 +43,23 @@ def build(force=False, verbose=False, extra_flags=(), out=None, tag=""):
     for s in srcs:
         o = os.path.join(CSRC, os.path.basename(s).replace(".hip", tag + ".o"))
         objs.append(o)
-        if not force and not extra_flags and os.path.isfile(o) and os.path.getmtime(o) >= _newest([s] + hdrs):
-            continue                                  # this translation unit is up to date (urnn_gemm.hip alone takes minutes)
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *NO_PACKED_F32, *extra_flags, "-c", s, "-o", o]
+        # an object is reused only if it is newer than its sources AND was built by exactly this command line (recorded next to it):
+        # an object left by a build with other flags must never be linked into the product library
+        stamp = o + ".cmd"
+        same_cmd = os.path.isfile(stamp) and open(stamp).read() == " ".join(cmd)
+        if not force and same_cmd and os.path.isfile(o) and os.path.getmtime(o) >= _newest([s] + hdrs):
+            continue                                  # this translation unit is up to date
         if verbose:
             print(" ".join(cmd))
-        procs.append(subprocess.Popen(cmd))
-    for p in procs:
+        if os.path.isfile(stamp):
+            os.remove(stamp)
+        procs.append((subprocess.Popen(cmd), stamp, " ".join(cmd)))
+    for p, stamp, line in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed")
+        with open(stamp, "w") as f:
+            f.write(line)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))

@@ -48,8 +48,7 @@ extern "C" const char *urnn_last_error(void) { return g_err; }
 // aligned fall back to dword DMA (MAP_PAIR / MAP_STRIDED).
 static int tune_env(const char *name)
 {
-    const char *v = getenv(name);
-    return v ? atoi(v) : 0;
+    return (int)urnn_tune(name, 0);
 }
 
 static void pick_tile(long pixels_total, int waves_per_tile, long P, int *pb_out, int *map_out, const char *tune = nullptr,
@@ -230,7 +229,7 @@ static int gru_tiles(int B, int F, long P, int which, int *pb_out = nullptr, int
 // stationary kernels of urnn_small.hip up to URNN_TUNE_SMALL pixels per launch (default 24 000; 0 disables)
 static bool small_on_gates(int B, long P)
 {
-    static const long small_max = getenv("URNN_TUNE_SMALL") ? atol(getenv("URNN_TUNE_SMALL")) : 24000;
+    static const long small_max = urnn_tune("URNN_TUNE_SMALL", 24000);
     return (long)B * P <= small_max;
 }
 
@@ -459,7 +458,7 @@ static int gru_cell_impl(const float *x, const float *e, const float *h, const f
     }
     // K3: GroupNorm finalize of the candidate + blend.  One launch when both are asked for (the product path); separate
     // launches for phase-split callers (profiling, strips: the statistics are exchanged in between)
-    static const bool fuse_on = !getenv("URNN_TUNE_FUSE_BLEND") || atoi(getenv("URNN_TUNE_FUSE_BLEND")) != 0;   // development knob
+    static const bool fuse_on = urnn_tune("URNN_TUNE_FUSE_BLEND", 1) != 0;   // development knob
     const bool fused = fuse_on && (phase_mask & URNN_PHASE_GN2) && (phase_mask & URNN_PHASE_BLEND) && global_pixels <= 0;
     if (tail && (phase_mask & URNN_PHASE_GN2) && (phase_mask & URNN_PHASE_BLEND)) {
         // finalize + blend + the consumer's 1x1 conv in one launch (urnn_tail.hip); the caller checked urnn_gru_cell_tail_applies

@@ -751,7 +751,7 @@ static hipError_t launch_head_v(const HeadParams &p, int mask, hipStream_t st)
     dim3 grid(nb, p.B), blk(256);
     // whole head in one call, one device: the three finalize launches are folded into their consumers (identical bits; development
     // knob URNN_TUNE_FUSE_HEAD=0 keeps them).  Strips / phase-split callers exchange or inspect the statistics in between.
-    static const bool fuse_on = !getenv("URNN_TUNE_FUSE_HEAD") || atoi(getenv("URNN_TUNE_FUSE_HEAD")) != 0;
+    static const bool fuse_on = urnn_tune("URNN_TUNE_FUSE_HEAD", 1) != 0;
     const int all = URNN_HEAD_K1 | URNN_HEAD_F1 | URNN_HEAD_K2 | URNN_HEAD_F2 | URNN_HEAD_K3 | URNN_HEAD_F3 | URNN_HEAD_K4;
     if (fuse_on && (mask & all) == all && p.Pglobal <= 0) {
         if (!p.partial0) hipLaunchKernelGGL(head_k1<V>, grid, blk, 0, st, p);

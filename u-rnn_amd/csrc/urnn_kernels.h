@@ -4,8 +4,23 @@
 #include <stddef.h>
 #include "../../include/urnn_hip.h"
 
+// Development knobs (URNN_TUNE_* environment variables: A/B switches, forced tile shapes, ...) exist in TUNING builds only
+// (-DURNN_TUNING; tools build one next to the product library and select it with URNN_LIB).  The product library reads no
+// environment variable: every knob is its default.
+#include <stdlib.h>
+static inline long urnn_tune(const char *name, long dflt)
+{
+#ifdef URNN_TUNING
+    const char *e = getenv(name);
+    return e ? atol(e) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
+
 #define URNN_FULL_RES_PIXELS 100000   // URNN_MATRIX_FP32_CAND: planes at least this large per sample count as full resolution
-enum { MAP_VEC = 0, MAP_PAIR = 1, MAP_STRIDED = 2, MAP_POOL = 3, MAP_PAIR16 = 4 };   // pixel geometry of a wave tile (urnn_gemm.hip)
+enum { MAP_VEC = 0, MAP_PAIR = 1, MAP_STRIDED = 2, MAP_POOL = 3, MAP_PAIR16 = 4, MAP_QUAD16 = 5 };   // pixel geometry of a wave tile (urnn_gemm.hip)
 enum { EPI_LRELU = 0, EPI_POOL = 1, EPI_DECONV = 2, EPI_GRU1 = 3, EPI_CAND = 4 };   // epilogue of conv_gemm_kernel
 
 struct ConvGemmParams {

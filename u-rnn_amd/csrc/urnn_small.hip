@@ -271,7 +271,7 @@ __global__ __launch_bounds__(1024) void small_cell_gemm_kernel(const ConvGemmPar
 static int small_mode(const ConvGemmParams &p)
 {
     if (urnn_get_matrix_mode() == URNN_MATRIX_BF16) return 2;
-    static const int f16 = [] { const char *e = getenv("URNN_TUNE_F16"); return e ? atoi(e) : 1; }();   // development knob (A/B)
+    static const int f16 = (int)urnn_tune("URNN_TUNE_F16", 1);   // development knob (A/B)
     return (f16 && p.fDwords > 0 && p.wf16) ? 3 : 1;
 }
 
@@ -713,7 +713,7 @@ static size_t coop_lds_bytes(const ConvGemmParams &p, int nblk_total)
 // Can this cell run as ONE cooperative launch?  p / c: the gate / candidate parameter blocks as gru_cell_impl builds them.
 bool urnn_coop_cell_ok(const ConvGemmParams &p, const ConvGemmParams &c, int B)
 {
-    static const int on = [] { const char *e = getenv("URNN_TUNE_COOP"); return e ? atoi(e) : 1; }();   // development knob (A/B)
+    static const int on = (int)urnn_tune("URNN_TUNE_COOP", 1);   // development knob (A/B)
     if (!on) return false;
     const int mm = urnn_get_matrix_mode();
     if (mm != URNN_MATRIX_FP32 && mm != URNN_MATRIX_FP32_CAND) return false;           // the f16-piece arithmetic only

@@ -306,7 +306,7 @@ static size_t tail_lds_bytes(int F, int NBO, int wDwords)
 // Can the end of a cell on (B, F, H, W) be fused with a 1x1 conv to Cout channels (pool: + AvgPool2)?
 bool urnn_tail_ok(int B, int F, int H, int W, int Cin, int Cout, int pool)
 {
-    static const int on = [] { const char *e = getenv("URNN_TUNE_TAIL"); return e ? atoi(e) : 1; }();       // development knob (A/B)
+    static const int on = (int)urnn_tune("URNN_TUNE_TAIL", 1);       // development knob (A/B)
     if (!on || B < 1) return false;
     const int mm = urnn_get_matrix_mode();
     if (mm != URNN_MATRIX_FP32 && mm != URNN_MATRIX_FP32_CAND) return false;          // the f16-piece arithmetic of the stage conv
@@ -343,7 +343,7 @@ hipError_t urnn_launch_tail(TailParams tp, int H, int pool, hipStream_t st)
     const int total = tp.B * tp.blocksPerSample;
     const int per_cu = tp.F == 64 ? 2 : 1;                                         // persistent blocks
     int nblocks = total < 256 * per_cu ? total : 256 * per_cu;
-    static const int chunked = [] { const char *e = getenv("URNN_TUNE_TAIL_CHUNK"); return e ? atoi(e) : 1; }();   // development knob (A/B)
+    static const int chunked = (int)urnn_tune("URNN_TUNE_TAIL_CHUNK", 1);   // development knob (A/B)
     tp.chunk = chunked ? (total + nblocks - 1) / nblocks : 0;
     if (tp.chunk) nblocks = (total + tp.chunk - 1) / tp.chunk;
     const dim3 grid(nblocks), blk(64 * 2 * (tp.F / 16));

@@ -744,7 +744,7 @@ size_t urnn_train_wgrad_partial_floats(int B, int N, int K, int P)
 // at least one 64-pixel stage pair per chunk, at most 512 chunks (their partial tiles are summed afterwards)
 int urnn_train_wgrad_chunks(int B, int N, int K, int P)
 {
-    static const int target = [] { const char *e = getenv("URNN_TUNE_WGRAD_BLOCKS"); return e ? atoi(e) : 512; }();
+    static const int target = (int)urnn_tune("URNN_TUNE_WGRAD_BLOCKS", 512);
     const int tiles = ((N + WG_T - 1) / WG_T) * ((K + WG_T - 1) / WG_T) * B;
     int n = target / tiles;
     const int most = (P + 63) / 64;
@@ -784,7 +784,7 @@ hipError_t urnn_train_wgrad(const float *dy, const float *const seg[3], const in
     }
     w.tilesK = (K + WG_T - 1) / WG_T;
     w.tilesN = (N + WG_T - 1) / WG_T;
-    static const int xcd_map = [] { const char *e = getenv("URNN_TUNE_WGRAD_MAP"); return e ? atoi(e) : 1; }();
+    static const int xcd_map = (int)urnn_tune("URNN_TUNE_WGRAD_MAP", 1);
     w.xcdMap = xcd_map;
     hipLaunchKernelGGL(kern, dim3((unsigned)((chunks + 7) / 8 * 8 * w.tilesK * w.tilesN)), dim3(256), lds, st, w);
     const long cntW = (long)N * K, cntB = db ? N : 0;
