@@ -25,7 +25,9 @@
 extern "C" {
 #endif
 
-#define URNN_ABI_VERSION 1
+/* ABI history.  1: rounds 1-3.  2: the first 256 bytes of every cell / head workspace are status / barrier words (zero them once:
+ * "Operand range of the default matrix mode" and URNN_PHASE_COOP below), the cooperative and frame-loop entry points, the cell tail. */
+#define URNN_ABI_VERSION 2
 
 #define URNN_OK 0
 #define URNN_EINVAL (-1)   /* bad dimension / unsupported shape                     */

@@ -90,7 +90,7 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if handle.urnn_abi_version() != 1:
+        if handle.urnn_abi_version() != 2:
             raise UrnnError("liburnn_hip.so ABI version mismatch")
         _lib = handle
     return _lib

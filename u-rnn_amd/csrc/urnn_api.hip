@@ -1034,7 +1034,7 @@ static int head_impl(const float *feat, const float *conv_w, const float *ln_w, 
     if (bump && (bump == frame_index || phase_mask != URNN_HEAD_ALL))
         return fail(URNN_EINVAL, "urnn_head_rollout_f32: frame_next must not be the head's own frame_index");
     if (coop) {
-        if (urnn_head_coop_blocks(B, (int)P) > 256) return fail(URNN_EINVAL, "urnn_head_coop_f32: %d blocks cannot all be resident (urnn_head_coop_blocks)", urnn_head_coop_blocks(B, (int)P));
+        if (urnn_head_coop_blocks(B, (int)P) <= 0) return fail(URNN_EINVAL, "urnn_head_coop_f32: the launch's blocks cannot all be resident on this device (urnn_head_coop_blocks_f32 returned 0)");
         CHECK_HIP(urnn_launch_head_coop(p, reinterpret_cast<unsigned *>(ws.status) + 16, (hipStream_t)stream), "head (one cooperative launch)");
         return URNN_OK;
     }

@@ -93,28 +93,28 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void cand_fused_kernel(const Con
     auto fin = [](float a, float bv) { return fmaf(a, URNN_F16_DESCALE, bv); };
     const int kp_begin = prm.kpBegin, KT = prm.KT, kH = prm.hKp0;
 
+#ifdef URNN_TRACE
+    if (urnn_trace_buf && lane == 0) urnn_trace_buf[((size_t)(blockIdx.x * WPB + wave) * 8 + 7) * 8 + 0] = __builtin_amdgcn_s_memtime();   // kernel entry
+#endif
     stage_weights(reinterpret_cast<const float *>(prm.wfused), urnn_smem, prm.fu1Dwords + prm.fu2Dwords, wave, WPB, lane);
     if (threadIdx.x < NB1 * 32) bias[threadIdx.x] = prm.biasfu[threadIdx.x];
-    {
+    // hand-over words of the block: [0] folds completed (waves 4-7), [1 + w] "go" for wave 4 + w from its SIMD partner, wave w
+    volatile int *flags = reinterpret_cast<volatile int *>(ssm + (size_t)prm.B * prm.F * 2);
+    if (threadIdx.x < 16) flags[threadIdx.x] = 0;
+    wait_vmcnt<0>();
+    __syncthreads();                                          // slab and bias are in LDS
+    // The gates' GroupNorm is needed in phase 2 only, so the FIRST wave of every SIMD (waves 0-3) starts streaming at once, while the
+    // SECOND one (waves 4-7) folds the statistics and then waits until its partner is prm.stagger 16-k groups into its first tile.
+    // No block waits for a fold before its first byte moves, and the two waves of a SIMD run out of phase: one wave's phase 2 +
+    // epilogue (VALU / MFMA work, no reads) meets the other's k-loop (reads, little arithmetic) instead of its phase 2.
+    if (wave >= WPB / 2) {
         // GroupNorm of the gates from the gate GEMM's partials: the arithmetic of conv_gemm_kernel's EPI_CAND prologue, value for value
         const int F = prm.F, G1 = 2 * F / 32;
-        for (int q = wave; q < prm.B * G1; q += WPB) {
+        for (int q = wave - WPB / 2; q < prm.B * G1; q += WPB / 2) {
             const int b = q / G1, grp = q - b * G1;
             const float *pp = prm.gpart + ((size_t)b * G1 + grp) * prm.gtiles * 2;
-            double s1 = 0.0, s2 = 0.0;
-            for (int t0 = 0; t0 < prm.gtiles; t0 += 64 * 32) {
-                f32x2 v[32];
-#pragma unroll
-                for (int u = 0; u < 32; ++u) {
-                    const int t = t0 + u * 64 + lane;
-                    v[u] = t < prm.gtiles ? *reinterpret_cast<const f32x2 *>(pp + 2 * t) : f32x2{0.f, 0.f};
-                }
-#pragma unroll
-                for (int u = 0; u < 32; ++u) {
-                    s1 += (double)v[u].x;
-                    s2 += tile_x2(v[u].x, v[u].y, 32 * tile_valid(t0 + u * 64 + lane, prm.gtilePix, prm.P));
-                }
-            }
+            double s1, s2;
+            fold_lane_chain<32>(pp, prm.gtiles, prm.gtilePix, 32, prm.P, lane, s1, s2);      // (urnn_common.h: the order every finalizer shares)
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) {
                 s1 += __shfl_xor(s1, m, 64);
@@ -129,8 +129,12 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void cand_fused_kernel(const Con
                 const double sc = (double)prm.gn_w[c] * rstd;
                 const float fsc = (float)sc, fsh = (float)((double)prm.gn_b[c] - nofma(mean * sc));
                 if (c >= F) {
-                    ssm[((size_t)b * F + (c - F)) * 2] = fsc;
-                    ssm[((size_t)b * F + (c - F)) * 2 + 1] = fsh;
+                    // phase 2 evaluates sigmoid(GN(acc * 2^-15 + bias)) as sigmoid_of_log2arg(acc * a + b): the accumulator's scale, the bias,
+                    // the norm's affine and log2(e) folded into one (a, b) per channel, in double, rounded once
+                    const double L2E = 1.4426950408889634074;
+                    const double shd = (double)prm.gn_b[c] - nofma(mean * sc);
+                    ssm[((size_t)b * F + (c - F)) * 2] = (float)(sc * (double)URNN_F16_DESCALE * L2E);
+                    ssm[((size_t)b * F + (c - F)) * 2 + 1] = (float)(((double)prm.biasfu[c - F] * sc + shd) * L2E);
                 }
                 if (blockIdx.x == 0) {
                     prm.ss_out[((size_t)b * 2 * F + c) * 2] = fsc;
@@ -144,29 +148,48 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void cand_fused_kernel(const Con
             }
         }
     }
-    wait_vmcnt<0>();
-    __syncthreads();
+#ifdef URNN_TRACE
+    if (urnn_trace_buf && lane == 0) urnn_trace_buf[((size_t)(blockIdx.x * WPB + wave) * 8 + 7) * 8 + 1] = __builtin_amdgcn_s_memtime();   // own prologue work done
+#endif
+    // hand-over through LDS words instead of a barrier: LDS operations of a wave execute in order, so the table is written before the count
+    // moves and read after it was seen
+    bool synced = wave >= WPB / 2;                            // waves 0-3: has the fold been seen complete?  (needed from phase 2 on)
+    bool gone = false;                                        // waves 0-3: has the partner been released?
+#define RELEASE_PARTNER() do { if (lane == 0) flags[1 + wave] = 1; gone = true; } while (0)   /* (not a closure: see the note on CandStream) */
+    if (wave >= WPB / 2) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) atomicAdd(const_cast<int *>(&flags[0]), 1);
+        while (flags[1 + wave - WPB / 2] == 0) __builtin_amdgcn_s_sleep(8);      // the partner's k-loop is prm.stagger groups ahead
+    }
+    const int gstag = prm.stagger;                            // 16-k groups of its first tile after which a wave 0-3 releases its partner
+    int gdone = 0;
+    if (wave < WPB / 2 && (gstag <= 0 || blockIdx.x * WPB + wave >= prm.totalTiles)) RELEASE_PARTNER();
+#ifdef URNN_TRACE
+    if (urnn_trace_buf && lane == 0) urnn_trace_buf[((size_t)(blockIdx.x * WPB + wave) * 8 + 7) * 8 + 2] = __builtin_amdgcn_s_memtime();   // past the barrier
+#endif
 
     // The slot stream of the gate GEMM -- one slot per k-pair of x | e | h, all plain (as in conv_gemm_kernel) -- runs ACROSS
     // tiles: the last eight refills of a tile (its last 16-k group) already fetch the first eight k-pairs of the wave's next tile,
     // so that their HBM round trip overlaps with phase 2 and the epilogue instead of opening the next tile.
-    // development knob URNN_TUNE_CAND_STAGGER (prm.stagger units of ~1k cycles): the second wave of every SIMD starts late, so that one
-    // wave's MFMA-only phase 2 meets the other's DMA-bound phase 1 instead of its phase 2
-    if (wave >= 4 && prm.stagger)
-        for (int i = 0; i < prm.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+#ifdef URNN_TUNING
+    const int abl = prm.abl;            // 1 no phase 2, 4 no stores, 16 no phase-1 MFMAs, 32 no epilogue, 64 no k-loop
+#else
+    constexpr int abl = 0;
+#endif
+    int tr_n = 0;
+    (void)tr_n;
     CandStream st;
     st.si = 0; st.total = 0; st.seg_left = INT_MAX; st.seg_cur = 0; st.soff = 0; st.vo0 = 0; st.csz = 0;
     st.sp1 = st.sp2 = st.cp = nullptr;
-    auto wrap = [](int s_) { return s_ >= D ? s_ - D : s_; };
     static_assert(D * R::KPS == 8, "the last 16-k group's refills issue exactly the next tile's first D slots (8 k-pairs), and the steps of a group bring the ring back to its first slot");
     const int item0 = blockIdx.x * WPB + wave;
-    int slot = 0;
 
     for (int item = item0; item < prm.totalTiles; item += gridDim.x * WPB) {
         if (item == item0) {                                  // the wave's first tile opens the stream; later ones find it running
             cand_stream_open(st, prm, item0, j, lane);
             for (int i = 0; i < D; ++i) cand_stream_refill(st, prm, ring + i * R::SLOT, scratch, lane);
         }
+        TRACE_STAMP(0);
         const int b = __builtin_amdgcn_readfirstlane(item / prm.tilesPerSample);      // (the division runs in the VALU)
         const int tile = item - b * prm.tilesPerSample;
         PixelMap<MAP, PB> pm;
@@ -179,12 +202,19 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void cand_fused_kernel(const Con
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[nb][pb][r] = 0.f;
 
-        float rbf[2][PB];
+        // The k-loop, one 16-k group at a time.  The ring holds exactly one group (D slots x 2 k-pairs = 8 k-pairs), requested one group
+        // ahead: a group (1) waits for its four slots, (2) reads its eight fragments into registers, (3) hands all four slots back to
+        // the DMA -- the NEXT group's rows -- and only then (4) splits and multiplies.  The requests fly during the ~1 k cycles of (4)
+        // and of the SIMD's other wave's (4).  The step-wise protocol this replaces (one slot refilled every second k-pair, a counted
+        // wait per step) had the look-ahead read at the end of a group wait for a slot requested six steps -- a few hundred cycles --
+        // earlier: every group stalled for most of a DMA round trip (2-4 k cycles against ~1 k of arithmetic), which is where the
+        // "DMA-bound phase 1" of this kernel and of the gate GEMM came from.
         unsigned bh[PB][4], bl[PB][4];
         const float asc = URNN_F16_ASCALE;
         const char *Ap = urnn_smem + lane * 16;
-        wait_vmcnt<(D - 1) * R::NLOAD>();                     // (already landed for every tile but the wave's first)
-        R::read(ring + slot * R::SLOT, lane, rbf[0]);
+#ifdef URNN_TRACE
+        unsigned long long tr_wait = 0;                       // cycles this tile's groups spent waiting for their slots
+#endif
         auto mfma3 = [&](const char *ag, int nb_slab, f32x16 (&a)[PB], const unsigned (&ph)[PB][4], const unsigned (&pl)[PB][4]) __attribute__((always_inline)) {
             const f16x8 fh = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4 *>(ag + (nb_slab * 2 + 0) * 1024));
             const f16x8 fl = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4 *>(ag + (nb_slab * 2 + 1) * 1024));
@@ -195,47 +225,46 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void cand_fused_kernel(const Con
 #pragma unroll
             for (int pb = 0; pb < PB; ++pb) a[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, as_f16x8(ph[pb]), a[pb], 0, 0, 0);
         };
-        auto sstep = [&](const char *ag, auto q_tag, auto hg_tag) __attribute__((always_inline)) {
-            constexpr int Q = decltype(q_tag)::value;
+        auto group = [&](const char *ag, auto hg_tag) __attribute__((always_inline)) {
             constexpr bool HG = decltype(hg_tag)::value;
-            const int nslot = wrap(slot + 1);
-            if constexpr (Q & 1) {
+            float fr[8][PB];
+#ifdef URNN_TRACE
+            const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
+#endif
+            wait_vmcnt<0>();                                  // the group's four slots (and whatever the wave stored before them)
+#ifdef URNN_TRACE
+            tr_wait += __builtin_amdgcn_s_memtime() - tw0;
+#endif
 #pragma unroll
-                for (int pb = 0; pb < PB; ++pb) split2_pair(rbf[0][pb], rbf[1][pb], asc, bh[pb][Q >> 1], bl[pb][Q >> 1]);
-            }
-            if constexpr ((Q & 1) == 0) {
-                R::read(ring + slot * R::SLOT, lane, rbf[1], 1);   // the slot's second k-pair landed with its first
-            } else {
-                wait_vmcnt<(D - 2) * R::NLOAD>();             // the next slot has landed (or is a dummy)
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot about to be refilled has left LDS (conv_gemm_kernel, hazard note)
-                cand_stream_refill(st, prm, ring + slot * R::SLOT, scratch, lane);
-                R::read(ring + nslot * R::SLOT, lane, rbf[0], 0);
-            }
-            if constexpr (Q == 7) {
-                constexpr int NBC = HG ? NBF : NB1;           // hidden-state groups feed the reset gate only
+            for (int q = 0; q < 8; ++q) R::read(ring + (q >> 1) * R::SLOT, lane, fr[q], q & 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the fragments have left LDS: the slots may be overwritten
+#pragma unroll
+            for (int sl = 0; sl < D; ++sl) cand_stream_refill(st, prm, ring + sl * R::SLOT, scratch, lane);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb) split2_pair(fr[2 * q][pb], fr[2 * q + 1][pb], asc, bh[pb][q], bl[pb][q]);
+            constexpr int NBC = HG ? NBF : NB1;               // hidden-state groups feed the reset gate only
+            if (!(abl & 16)) {
 #pragma unroll
                 for (int nb = 0; nb < NBC; ++nb) {
                     mfma3(ag, nb, acc[nb], bh, bl);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if constexpr (Q & 1) slot = nslot;
         };
-        auto group = [&](const char *ag, auto hg_tag) __attribute__((always_inline)) {
-            sstep(ag, std::integral_constant<int, 0>{}, hg_tag);
-            sstep(ag, std::integral_constant<int, 1>{}, hg_tag);
-            sstep(ag, std::integral_constant<int, 2>{}, hg_tag);
-            sstep(ag, std::integral_constant<int, 3>{}, hg_tag);
-            sstep(ag, std::integral_constant<int, 4>{}, hg_tag);
-            sstep(ag, std::integral_constant<int, 5>{}, hg_tag);
-            sstep(ag, std::integral_constant<int, 6>{}, hg_tag);
-            sstep(ag, std::integral_constant<int, 7>{}, hg_tag);
-        };
-        for (int kp = kp_begin; kp < kH; kp += 8) group(Ap + (size_t)(kp >> 3) * (NB1 * 2048), std::false_type{});
+        if (!(abl & 64))
+        for (int kp = kp_begin; kp < kH; kp += 8) {
+            group(Ap + (size_t)(kp >> 3) * (NB1 * 2048), std::false_type{});
+            if (!gone && ++gdone >= gstag) RELEASE_PARTNER();
+        }
         const char *Ah = Ap + (size_t)(kH >> 3) * (NB1 * 2048);
+        if (!(abl & 64))
         for (int kp = kH; kp < KT; kp += 8) {                 // (ONE call site per group flavour: a second one and hipcc stops inlining the
             if (kp + 8 == KT) cand_stream_open(st, prm, item + gridDim.x * WPB, j, lane);   // lambda -- every captured variable moves to the stack.)  The last
             group(Ah + (size_t)((kp - kH) >> 3) * (NBF * 2048), std::true_type{});   // group's refills fetch the next tile's first k-pairs
+            if (!gone && ++gdone >= gstag) RELEASE_PARTNER();
         }
         {
             int tile_e = __builtin_amdgcn_readfirstlane(tile), j_e = j;   // derive the tile's pixel map here instead of carrying it across the k-loop
@@ -243,91 +272,137 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void cand_fused_kernel(const Con
             pm.init(tile_e, j_e, prm.P, prm.W, prm.P2, prm.W2);
         }
 
+        if (!gone) RELEASE_PARTNER();
+        if (!synced) {                                        // waves 0-3, first tile: phase 2 needs the table that waves 4-7 folded
+            while (flags[0] < WPB / 2) __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            synced = true;
+        }
+#ifdef URNN_TRACE
+        if (urnn_trace_buf && lane == 0 && tr_n < 8) urnn_trace_buf[((size_t)(blockIdx.x * WPB + wave) * 8 + tr_n) * 8 + 1] = urnn_trace_buf[((size_t)(blockIdx.x * WPB + wave) * 8 + tr_n) * 8 + 0] + tr_wait;
+#endif
+        TRACE_STAMP(2);
         // ---- phase 2: r (.) h out of the accumulators, W2[:, h] . (r (.) h) ---------------------------------------------------------
-        {
-            const float *hbase = prm.seg[2] + ((size_t)b * prm.F + 4 * half) * prm.P;
+        if (!(abl & 1)) {
             const float *ssb = ssm + ((size_t)b * prm.F + 4 * half) * 2;
             const float *A2f = reinterpret_cast<const float *>(urnn_smem + (size_t)prm.fu1Dwords * 4) + lane;
-            // h first (every row of the tile's hidden state: 16 x NBF loads of 8 B per lane), then the sigmoids -- which do not need h
-            // -- while the loads are in flight; r replaces the accumulator it came from
+            // h first (every row of the tile's hidden state: 16 x NBF loads of 8 B per lane; its rows have just streamed by: L2 / MALL)
             float hv[NBF][16][PB];
+            {
+                const float *hbase = prm.seg[2] + ((size_t)b * prm.F + 4 * half) * prm.P;
 #pragma unroll
-            for (int rb = 0; rb < NBF; ++rb)
+                for (int rb = 0; rb < NBF; ++rb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) load_row<MAP, PB>(hbase + (size_t)(rb * 32 + row_c(r)) * prm.P, pm, hv[rb][r]);
+                    for (int r = 0; r < 16; ++r) load_row<MAP, PB>(hbase + (size_t)(rb * 32 + row_c(r)) * prm.P, pm, hv[rb][r]);
+            }
             // Software pipeline over the reset-gate blocks: the sigmoids of block rb + 1 (VALU, transcendental pipe) are issued between the fp32
             // MFMAs of block rb (matrix pipe, 64 cycles each, asynchronous), row by row, instead of all sigmoids of a block in front of all
             // its MFMAs.  Same products in the same order per accumulator: identical bits.
-            auto gate_row = [&](int rb, int r) __attribute__((always_inline)) {
-                const f32x2 sc = *reinterpret_cast<const f32x2 *>(ssb + 2 * (rb * 32 + row_c(r)));
-                const float bv = bias_h[rb * 32 + row_c(r)];
+            // Every row needs operands from LDS -- the gate's folded affine (a, b), the product's two weight fragments.  Left to the
+            // compiler they are read right in front of their use (it keeps register pressure down), and a wave alone in phase 2 -- its
+            // SIMD partner streaming -- then stalls on ~130 LDS round trips per tile.  They are requested PF rows ahead instead, and a
+            // scheduling barrier per row keeps them there.
+            #ifndef URNN_P2_PF
+#define URNN_P2_PF 4
+#endif
+            constexpr int NROW = NBF * 16, PF = URNN_P2_PF;
+            f32x2 gsc[NROW];
+            float wq[NROW][NBF];
+            auto gate_ops = [&](int i) __attribute__((always_inline)) {        // i = rb * 16 + r
+                gsc[i] = *reinterpret_cast<const f32x2 *>(ssb + 2 * ((i >> 4) * 32 + row_c(i & 15)));
+            };
+            auto mfma_ops = [&](int i) __attribute__((always_inline)) {
 #pragma unroll
-                for (int pb = 0; pb < PB; ++pb) acc[rb][pb][r] = sigmoidf_fast(fin(acc[rb][pb][r], bv) * sc.x + sc.y);
+                for (int nb = 0; nb < NBF; ++nb) wq[i][nb] = A2f[(i * NBF + nb) * 64];
+            };
+            auto gate_row = [&](int i) __attribute__((always_inline)) {
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb) acc[i >> 4][pb][i & 15] = sigmoid_of_log2arg(fmaf(acc[i >> 4][pb][i & 15], gsc[i].x, gsc[i].y));
             };
             // W2[:, h] . (r (.) h) on the fp32 matrix instruction: of the cell's products this is the one whose 16-bit form shows in a
             // long rollout, and here it costs little -- the operand is already in registers as fp32 (no split),
             // K = 2 per instruction pairs the two lane halves' rows (channels c and c + 4), the weights sit in LDS as fp32 x 2^15
             // (the accumulators' scale) in exactly that order, 64 x 64 of them
-            auto mfma_row = [&](int rb, int r) __attribute__((always_inline)) {
+            auto mfma_row = [&](int i) __attribute__((always_inline)) {
                 float v[PB];
 #pragma unroll
-                for (int pb = 0; pb < PB; ++pb) v[pb] = acc[rb][pb][r] * hv[rb][r][pb];
+                for (int pb = 0; pb < PB; ++pb) v[pb] = acc[i >> 4][pb][i & 15] * hv[i >> 4][i & 15][pb];
 #pragma unroll
-                for (int nb = 0; nb < NBF; ++nb) {
-                    const float wa = A2f[((rb * 16 + r) * NBF + nb) * 64];
+                for (int nb = 0; nb < NBF; ++nb)
 #pragma unroll
-                    for (int pb = 0; pb < PB; ++pb) acc[NBF + nb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa, v[pb], acc[NBF + nb][pb], 0, 0, 0);
-                }
+                    for (int pb = 0; pb < PB; ++pb) acc[NBF + nb][pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[i][nb], v[pb], acc[NBF + nb][pb], 0, 0, 0);
             };
+            TRACE_STAMP(3);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) gate_row(0, r);
+            for (int i = 0; i < PF; ++i) gate_ops(i);
 #pragma unroll
-            for (int rb = 0; rb < NBF; ++rb) {
+            for (int i = 0; i < 16; ++i) {                            // the first block's gates: nothing to interleave them with
+                if (i + PF < NROW) gate_ops(i + PF);
+                if (i + PF >= 16 && i + PF - 16 < PF) mfma_ops(i + PF - 16);     // (the product's first PF rows)
+                __builtin_amdgcn_sched_barrier(0);
+                gate_row(i);
+            }
+            TRACE_STAMP(4);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    mfma_row(rb, r);
-                    if (rb + 1 < NBF) gate_row(rb + 1, r);
-                }
+            for (int i = 0; i < NROW; ++i) {
+                if (i + 16 + PF < NROW) gate_ops(i + 16 + PF);
+                if (i + PF < NROW) mfma_ops(i + PF);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_row(i);
+                if (i + 16 < NROW) gate_row(i + 16);
             }
         }
 
+        TRACE_STAMP(5);
         // ---- epilogue: conv_gemm_kernel's EPI_CAND on the candidate blocks ------------------------------------------------------------
-        {
+        if (!(abl & 32)) {
             const int F = prm.F;
             const float inv_n = tile == prm.tilesPerSample - 1 ? prm.invTail : prm.invFull;
             float s1[NBF], s2[NBF];
+            bool allv = true;
 #pragma unroll
-            for (int nb = 0; nb < NBF; ++nb) {
-                s1[nb] = 0.f;
+            for (int pb = 0; pb < PB; ++pb) allv = allv && pm.valid[pb];
+            // (conv_gemm_kernel's epilogue: values finished in place, a select-free copy for tiles whose pixels are all valid)
+            auto stats = [&](auto full_tag) __attribute__((always_inline)) {
+                constexpr bool FULLT = decltype(full_tag)::value;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float bv = bias_h[(NBF + nb) * 32 + row_c(r)];
+                for (int nb = 0; nb < NBF; ++nb) {
+                    s1[nb] = 0.f;
 #pragma unroll
-                    for (int pb = 0; pb < PB; ++pb)
-                        if (pm.valid[pb]) s1[nb] += fin(acc[NBF + nb][pb][r], bv);
-                }
-            }
-            wave_sum_n<NBF>(s1);
+                    for (int r = 0; r < 16; ++r) {
+                        const float bv = bias_h[(NBF + nb) * 32 + row_c(r)];
 #pragma unroll
-            for (int nb = 0; nb < NBF; ++nb) {
-                const float mt = nofma(s1[nb] * inv_n);     // (rounded on its own: v - mt must not become an fma in one kernel and not in another)
-                s2[nb] = 0.f;
-                float *obase = prm.out0 + ((size_t)b * F + nb * 32 + 4 * half) * prm.P;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float bv = bias_h[(NBF + nb) * 32 + row_c(r)];
-                    float *orow = obase + (size_t)row_c(r) * prm.P;
-                    float v[PB];
-#pragma unroll
-                    for (int pb = 0; pb < PB; ++pb) {
-                        v[pb] = fin(acc[NBF + nb][pb][r], bv);
-                        const float dd = v[pb] - mt;
-                        if (pm.valid[pb]) s2[nb] = fmaf(dd, dd, s2[nb]);
+                        for (int pb = 0; pb < PB; ++pb) {
+                            const float v = fin(acc[NBF + nb][pb][r], bv);
+                            acc[NBF + nb][pb][r] = v;
+                            if (FULLT || pm.valid[pb]) s1[nb] += v;
+                        }
                     }
-                    store_row<MAP, PB>(orow, pm, v);
                 }
-            }
-            wave_sum_n<NBF>(s2);
+                wave_sum_n<NBF>(s1);
+                TRACE_STAMP(6);
+#pragma unroll
+                for (int nb = 0; nb < NBF; ++nb) {
+                    const float mt = nofma(s1[nb] * inv_n);     // (rounded on its own: v - mt must not become an fma in one kernel and not in another)
+                    s2[nb] = 0.f;
+                    float *obase = prm.out0 + ((size_t)b * F + nb * 32 + 4 * half) * prm.P;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float *orow = obase + (size_t)row_c(r) * prm.P;
+                        float v[PB];
+#pragma unroll
+                        for (int pb = 0; pb < PB; ++pb) {
+                            v[pb] = acc[NBF + nb][pb][r];
+                            const float dd = v[pb] - mt;
+                            if (FULLT || pm.valid[pb]) s2[nb] = fmaf(dd, dd, s2[nb]);
+                        }
+                        if (!(abl & 4)) store_row<MAP, PB>(orow, pm, v);
+                    }
+                }
+                wave_sum_n<NBF>(s2);
+            };
+            if (__builtin_amdgcn_ballot_w64(!allv) == 0) stats(std::true_type{});
+            else stats(std::false_type{});
             if (lane == 0) {
 #pragma unroll
                 for (int nb = 0; nb < NBF; ++nb) {
@@ -337,6 +412,10 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void cand_fused_kernel(const Con
                 }
             }
         }
+#ifdef URNN_TRACE
+        TRACE_STAMP(7);
+        ++tr_n;
+#endif
     }
 }
 
@@ -355,7 +434,7 @@ int urnn_cand_fused_plan(const ConvGemmParams &p, int B)
     if ((long)B * ((p.P + 63) / 64) < 1024) return 0;              // small planes keep their own kernels
     if ((p.segKp0[1] != INT_MAX && (p.segKp0[1] & 1)) || (p.segKp0[2] != INT_MAX && (p.segKp0[2] & 1))) return 0;   // 4-row slots
     using R = Ring<2, MAP_QUAD16>;
-    const size_t lds = ((size_t)p.fu1Dwords + p.fu2Dwords) * 4 + (size_t)8 * (4 + 1) * R::SLOT + 4 * 32 * 4 + (size_t)B * p.F * 8;
+    const size_t lds = ((size_t)p.fu1Dwords + p.fu2Dwords) * 4 + (size_t)8 * (4 + 1) * R::SLOT + 4 * 32 * 4 + (size_t)B * p.F * 8 + 64;
     return lds <= LDS_PER_CU ? 4 : 0;
 }
 
@@ -369,7 +448,7 @@ hipError_t urnn_launch_cand_fused(ConvGemmParams p, int B, hipStream_t st)
     p.tilesPerSample = (p.P + 63) / 64;
     p.totalTiles = B * p.tilesPerSample;
     set_tile_means(p, 64);
-    const size_t lds = ((size_t)p.fu1Dwords + p.fu2Dwords) * 4 + (size_t)8 * (D + 1) * R::SLOT + 4 * 32 * 4 + (size_t)B * p.F * 8;
+    const size_t lds = ((size_t)p.fu1Dwords + p.fu2Dwords) * 4 + (size_t)8 * (D + 1) * R::SLOT + 4 * 32 * 4 + (size_t)B * p.F * 8 + 64;
     auto k8 = cand_fused_kernel<2, 4, 8>;
     static bool raised = false;
     if (!raised) {
@@ -378,8 +457,8 @@ hipError_t urnn_launch_cand_fused(ConvGemmParams p, int B, hipStream_t st)
         raised = true;
     }
     const int grid = persistent_grid(lds, 1, p.totalTiles, 8, 2);
-    static const int stag = (int)urnn_tune("URNN_TUNE_CAND_STAGGER", 0);
-    p.stagger = stag;
+    p.abl = (int)urnn_tune("URNN_TUNE_ABL", 0);
+    p.stagger = (int)urnn_tune("URNN_TUNE_CAND_STAG", 3);      // 16-k groups a SIMD's first wave runs ahead of its second
     hipLaunchKernelGGL(k8, dim3(grid), dim3(512), lds, st, p);
     return hipGetLastError();
 }

@@ -86,6 +86,66 @@ __device__ __forceinline__ double tile_x2(float s1, float y, int n)
     return n > 0 ? (double)y + (double)s1 * (double)s1 / (double)n : (double)y;
 }
 
+// One lane's share of a fold over a sample's per-tile partials pp[t] = (sum, centred second moment): tiles lane, lane + 64, ... in
+// ascending order, U loads in flight -- the order EVERY finalizer of the library uses (then an xor butterfly over the lanes), so that they
+// all produce the same bits.  chans * tile_pix values per full tile; tile_pix == 0: raw partials (strip mode).
+// A full tile's count is a power of two for every tile shape of the GEMMs (32 channels x 32 / 64 / 128 pixels), and dividing by 2^k
+// is an exact scaling: the product with the exact reciprocal has the same bits as tile_x2's quotient (s * s is exact in double: 48
+// significant bits).  Only a sample's last, partial tile needs the fp64 division; it is the last element of its lane's chain, so it
+// is added after the loop.  The straightforward loop -- tile_valid, an integer -> double conversion and a division per element, each
+// guarded load its own branch -- was 25 k cycles for the 3 907 tiles of a 500 x 500 plane: 13 % of the candidate kernel's launch,
+// spent by every block before its first byte moved.
+// FAST = false: the plain loop only (the head's kernels fold ~8 elements per lane in every wave of ~500 short-lived blocks: there the
+// two-path version measured slower -- head_k3 36 -> 54 us -- although it executes fewer instructions).
+template <int U, bool FAST = true>
+__device__ __forceinline__ void fold_lane_chain(const float *pp, int ntiles, int tile_pix, int chans, int P, int lane, double &s1, double &s2)
+{
+    s1 = 0.0;
+    s2 = 0.0;
+    const int nfull = chans * tile_pix;
+    if (FAST && tile_pix > 0 && (nfull & (nfull - 1)) == 0) {
+        const int k = 31 - __builtin_clz((unsigned)nfull);
+        const double inv = __longlong_as_double((long long)(1023 - k) << 52);   // 2^-k, exact
+        const int tpart = (P % tile_pix) != 0 && P / tile_pix < ntiles ? P / tile_pix : -1;   // the partial tile, if any
+        const int nclean = tpart >= 0 ? tpart : ntiles;                    // tiles [0, nclean) are full
+        const bool mine = tpart >= 0 && (tpart & 63) == lane;              // (requested with the loop's first loads, used after them)
+        const f32x2 ldp = *reinterpret_cast<const f32x2 *>(pp + 2 * (mine ? tpart : 0));
+        for (int t0 = 0; t0 < nclean; t0 += 64 * U) {
+            f32x2 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + u * 64 + lane;
+                const f32x2 ld = *reinterpret_cast<const f32x2 *>(pp + 2 * (t < nclean ? t : 0));   // (clamped: no branch around the load)
+                v[u] = t < nclean ? ld : f32x2{0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double dx = (double)v[u].x;
+                s1 += dx;
+                s2 += (double)v[u].y + dx * dx * inv;                      // = y + x * x / n: both products are exact, fused or not
+            }
+        }
+        if (mine) {
+            s1 += (double)ldp.x;
+            s2 += tile_x2(ldp.x, ldp.y, chans * (P - tpart * tile_pix));
+        }
+        return;
+    }
+    for (int t0 = 0; t0 < ntiles; t0 += 64 * U) {
+        f32x2 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = t0 + u * 64 + lane;
+            v[u] = t < ntiles ? *reinterpret_cast<const f32x2 *>(pp + 2 * t) : f32x2{0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            s1 += (double)v[u].x;
+            s2 += tile_x2(v[u].x, v[u].y, chans * tile_valid(t0 + u * 64 + lane, tile_pix, P));
+        }
+    }
+}
+
 // Status words (include/urnn_hip.h): the first 256 bytes of a cell / head workspace.  The kernels that turn partial sums into a
 // norm's (mean, rstd) OR a bit into word 0 when the statistics are not finite -- an operand beyond the f16 pieces' range
 // (|activation| >= 2047 or |weight| >= 64 in the default matrix mode) turns into inf in the matrix pipe and surfaces here, one
@@ -144,6 +204,16 @@ __device__ __forceinline__ float sigmoidf_fast(float v)
     const float r = rcp_1to2(1.0f + e);
     return v >= 0.f ? r : e * r;
 #endif
+}
+
+// sigmoid(v) from t = v * log2(e), for callers that can fold log2(e) into an affine they evaluate anyway (cand_fused_kernel: the reset
+// gate's GroupNorm).  Nine VALU instead of fifteen: the argument's rounding -- what exp_neg carries along -- perturbs e = 2^-|t| by at
+// most ~|t| * 1e-7 relative, and sigmoid damps that by e / (1 + e): <= 1 ulp of the result, unbiased (a rounding, not a constant).
+__device__ __forceinline__ float sigmoid_of_log2arg(float t)
+{
+    const float e = __builtin_amdgcn_exp2f(-fabsf(t));
+    const float r = rcp_1to2(1.0f + e);
+    return t >= 0.f ? r : e * r;
 }
 
 __device__ __forceinline__ float tanhf_fast(float v)

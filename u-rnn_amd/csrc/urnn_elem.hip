@@ -20,20 +20,8 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float *__restrict
     const int b = blockIdx.x / G, g = blockIdx.x - b * G;
     const int lane = threadIdx.x;
     const float *pp = partial + ((size_t)b * G + g) * ntiles * 2;
-    double s1 = 0.0, s2 = 0.0;
-    for (int t0 = 0; t0 < ntiles; t0 += 64 * 32) {
-        f32x2 v[32];
-#pragma unroll
-        for (int u = 0; u < 32; ++u) {
-            const int t = t0 + u * 64 + lane;
-            v[u] = t < ntiles ? *reinterpret_cast<const f32x2 *>(pp + 2 * t) : f32x2{0.f, 0.f};
-        }
-#pragma unroll
-        for (int u = 0; u < 32; ++u) {
-            s1 += (double)v[u].x;
-            s2 += tile_x2(v[u].x, v[u].y, 32 * tile_valid(t0 + u * 64 + lane, tile_pix, P));
-        }
-    }
+    double s1, s2;
+    fold_lane_chain<32>(pp, ntiles, tile_pix, 32, P, lane, s1, s2);      // (urnn_common.h: the order every finalizer shares)
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         s1 += __shfl_xor(s1, m, 64);
@@ -437,20 +425,8 @@ __device__ __forceinline__ void head_fold_stats(const HeadParams &prm, int which
         nblk_used = prm.nblk0;
         block_pix = prm.bpix0;
     }
-    double s1 = 0.0, s2 = 0.0;
-    for (int t0 = 0; t0 < nblk_used; t0 += 64 * 16) {
-        f32x2 v[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int t = t0 + u * 64 + lane;
-            v[u] = t < nblk_used ? *reinterpret_cast<const f32x2 *>(pp + 2 * t) : f32x2{0.f, 0.f};
-        }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            s1 += (double)v[u].x;
-            s2 += tile_x2(v[u].x, v[u].y, HEAD_C * tile_valid(t0 + u * 64 + lane, block_pix, prm.P));
-        }
-    }
+    double s1, s2;
+    fold_lane_chain<16, false>(pp, nblk_used, block_pix, HEAD_C, prm.P, lane, s1, s2);      // (urnn_common.h: the order every finalizer shares)
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         s1 += __shfl_xor(s1, m, 64);
@@ -706,20 +682,8 @@ __global__ __launch_bounds__(64) void ln_finalize_kernel(const HeadParams prm, i
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
     const float *pp = prm.partial + (((size_t)which * prm.B + b) * prm.nblk) * 2;
-    double s1 = 0.0, s2 = 0.0;
-    for (int t0 = 0; t0 < nblk_used; t0 += 64 * 16) {        // 16 independent loads in flight per lane, summed in order
-        f32x2 v[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int t = t0 + u * 64 + lane;
-            v[u] = t < nblk_used ? *reinterpret_cast<const f32x2 *>(pp + 2 * t) : f32x2{0.f, 0.f};
-        }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            s1 += (double)v[u].x;
-            s2 += tile_x2(v[u].x, v[u].y, HEAD_C * tile_valid(t0 + u * 64 + lane, block_pix, prm.P));   // block_pix 0: raw (strip mode)
-        }
-    }
+    double s1, s2;
+    fold_lane_chain<16, false>(pp, nblk_used, block_pix, HEAD_C, prm.P, lane, s1, s2);      // (urnn_common.h: the order every finalizer shares)
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         s1 += __shfl_xor(s1, m, 64);
@@ -771,7 +735,13 @@ static hipError_t launch_head_v(const HeadParams &p, int mask, hipStream_t st)
 }
 
 // blocks of the cooperative head launch for a plane of P pixels and B samples (the caller decides whether that many may be resident)
-int urnn_head_coop_blocks(int B, int P) { return B * urnn_head_nblk_used(P); }
+// blocks a cooperative head launch takes; 0 when this device could not hold them all at once (one 256-thread block per CU is the
+// residency the callers' rules are written for)
+int urnn_head_coop_blocks(int B, int P)
+{
+    const int n = B * urnn_head_nblk_used(P);
+    return n <= urnn_device_cus() ? n : 0;
+}
 
 hipError_t urnn_launch_head_coop(const HeadParams &p, unsigned *bar, hipStream_t st)
 {

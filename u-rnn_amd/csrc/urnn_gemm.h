@@ -35,13 +35,13 @@
 #define URNN_ABL 0   // tuning builds only: 2 skip activation DMA, 4 skip epilogue stores, 8 skip LDS fragment reads
 #endif
 #ifdef URNN_TRACE
-// tuning builds: [wave slot][item][4] s_memtime stamps.  One buffer pointer and one setter per translation unit (no relocatable
+// tuning builds: [wave slot][item (8)][8] s_memtime stamps.  One buffer pointer and one setter per translation unit (no relocatable
 // device code): urnn_debug_set_trace_<URNN_TU> -- tools/trace_gates.py sets them all.
 static __device__ unsigned long long *urnn_trace_buf = nullptr;
 #define URNN_TRACE_CAT2(a, b) a##b
 #define URNN_TRACE_CAT(a, b) URNN_TRACE_CAT2(a, b)
 extern "C" int URNN_TRACE_CAT(urnn_debug_set_trace_, URNN_TU)(unsigned long long *p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(urnn_trace_buf), &p, sizeof(p)); }
-#define TRACE_STAMP(k) do { if (urnn_trace_buf && lane == 0 && tr_n < 8) urnn_trace_buf[((size_t)(blockIdx.x * WPB + wave) * 8 + tr_n) * 4 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define TRACE_STAMP(k) do { if (urnn_trace_buf && lane == 0 && tr_n < 8) urnn_trace_buf[((size_t)(blockIdx.x * WPB + wave) * 8 + tr_n) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define TRACE_STAMP(k) do { } while (0)
 #endif
@@ -318,20 +318,8 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
         for (int q = wave; q < prm.B * G1; q += WPB) {
             const int b = q / G1, grp = q - b * G1;
             const float *pp = prm.gpart + ((size_t)b * G1 + grp) * prm.gtiles * 2;
-            double s1 = 0.0, s2 = 0.0;
-            for (int t0 = 0; t0 < prm.gtiles; t0 += 64 * 32) {          // 32 independent loads in flight, summed in order
-                f32x2 v[32];
-#pragma unroll
-                for (int u = 0; u < 32; ++u) {
-                    const int t = t0 + u * 64 + lane;
-                    v[u] = t < prm.gtiles ? *reinterpret_cast<const f32x2 *>(pp + 2 * t) : f32x2{0.f, 0.f};
-                }
-#pragma unroll
-                for (int u = 0; u < 32; ++u) {
-                    s1 += (double)v[u].x;
-                    s2 += tile_x2(v[u].x, v[u].y, 32 * tile_valid(t0 + u * 64 + lane, prm.gtilePix, prm.P));
-                }
-            }
+            double s1, s2;
+            fold_lane_chain<32>(pp, prm.gtiles, prm.gtilePix, 32, prm.P, lane, s1, s2);      // (urnn_common.h: the order every finalizer shares)
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) {
                 s1 += __shfl_xor(s1, m, 64);

@@ -19,6 +19,18 @@ static inline long urnn_tune(const char *name, long dflt)
 #endif
 }
 
+// Compute units of the current device (queried once): the cooperative launches need every block resident at once, one per CU, so
+// their block limits are bounded by what THIS device has (256 on an MI355X; fewer on a partitioned or masked one).
+static inline int urnn_device_cus()
+{
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    return cus;
+}
+
 #define URNN_FULL_RES_PIXELS 100000   // URNN_MATRIX_FP32_CAND: planes at least this large per sample count as full resolution
 enum { MAP_VEC = 0, MAP_PAIR = 1, MAP_STRIDED = 2, MAP_POOL = 3, MAP_PAIR16 = 4, MAP_QUAD16 = 5 };   // pixel geometry of a wave tile (urnn_gemm.hip)
 enum { EPI_LRELU = 0, EPI_POOL = 1, EPI_DECONV = 2, EPI_GRU1 = 3, EPI_CAND = 4 };   // epilogue of conv_gemm_kernel
@@ -71,6 +83,7 @@ struct ConvGemmParams {
     int fu1Dwords, fu2Dwords;
     const float *biasfu;
     int *status;          // the workspace's status word (urnn_common.h flag_nonfinite); may be NULL
+    int abl;              // tuning builds (-DURNN_TUNING): ablation mask URNN_TUNE_ABL -- phases of cand_fused_kernel skipped for timing (wrong results)
 };
 
 // Packed layout of the fused candidate slab (appended to a cell's packed buffer when ok): nXE 16-k groups of x | e with 2 NBF blocks

@@ -48,20 +48,8 @@ __global__ __launch_bounds__(1024) void small_cell_gemm_kernel(const ConvGemmPar
         const int G1 = 2 * F / 32;
         for (int grp = wave; grp < G1; grp += nwaves) {
             const float *pp = prm.gpart + ((size_t)b * G1 + grp) * prm.gtiles * 2;
-            double s1 = 0.0, s2 = 0.0;
-            for (int t0 = 0; t0 < prm.gtiles; t0 += 64 * 8) {           // 8 independent loads in flight, summed in tile order
-                f32x2 v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int t = t0 + u * 64 + lane;
-                    v[u] = t < prm.gtiles ? *reinterpret_cast<const f32x2 *>(pp + 2 * t) : f32x2{0.f, 0.f};
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    s1 += (double)v[u].x;
-                    s2 += tile_x2(v[u].x, v[u].y, 32 * tile_valid(t0 + u * 64 + lane, prm.gtilePix, P));
-                }
-            }
+            double s1, s2;
+            fold_lane_chain<8>(pp, prm.gtiles, prm.gtilePix, 32, P, lane, s1, s2);      // (urnn_common.h: the order every finalizer shares)
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) {
                 s1 += __shfl_xor(s1, m, 64);
@@ -531,20 +519,8 @@ __global__ __launch_bounds__(768) void coop_cell_kernel(const CoopCellParams cp,
     {
         const float *pp = prm.partial + ((size_t)b * 2 * G + cb) * prm.tilesPerSample * 2;
         const int gtiles = prm.tilesPerSample;
-        double s1 = 0.0, s2 = 0.0;
-        for (int t0 = 0; t0 < gtiles; t0 += 64 * 8) {
-            f32x2 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int t = t0 + u * 64 + lane;
-                v[u] = t < gtiles ? *reinterpret_cast<const f32x2 *>(pp + 2 * t) : f32x2{0.f, 0.f};
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                s1 += (double)v[u].x;
-                s2 += tile_x2(v[u].x, v[u].y, 32 * tile_valid(t0 + u * 64 + lane, 32, P));
-            }
-        }
+        double s1, s2;
+        fold_lane_chain<8>(pp, gtiles, 32, 32, P, lane, s1, s2);      // (urnn_common.h: the order every finalizer shares)
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {
             s1 += __shfl_xor(s1, m, 64);
@@ -726,7 +702,7 @@ bool urnn_coop_cell_ok(const ConvGemmParams &p, const ConvGemmParams &c, int B)
     const size_t lds = coop_lds_bytes(p, nblk);
     // every block must be resident at once: one per CU.  (A caller with two kernel chains in flight passes the flag up to 128 blocks
     // only -- urnn_gru_cell_coop_blocks, include/urnn_hip.h.)
-    return blocks <= 256 && lds <= 150 * 1024;
+    return blocks <= (urnn_device_cus() < 256 ? urnn_device_cus() : 256) && lds <= 150 * 1024;
 }
 
 hipError_t urnn_launch_coop_cell(ConvGemmParams p, const ConvGemmParams &c, const float *gn2_w, const float *gn2_b, float *ss2_out, float *h_out,

@@ -16,17 +16,19 @@ class PackedCache:
         self._stamp = None
         self._packed = None
         self.wide = False        # some |weight| >= F16_WEIGHT_LIMIT: the layer's launches take URNN_MATRIX_FP32_MFMA
+        self.owner_checks = False    # an owner of all the parameters (training.Trainer) refreshes `wide` itself, once per event
 
     def get(self, params, pack_fn, weights=()):
         """``weights``: the tensors that become f16 pieces; their range is checked when they are (re)packed -- one small
-        reduction and a host read per layer and weight change, skipped under stream capture (a captured training window
-        re-packs inside the graph: ``Trainer`` refreshes the flags once per event instead)."""
+        reduction and a host read per layer and weight change.  Skipped under stream capture and when an owner has taken the
+        check over (``owner_checks``: ``training.Trainer.refresh_weight_ranges`` -- one reduction over its flat parameter
+        buffer per event instead of a host synchronisation per layer and window)."""
         import torch
         stamp = params_stamp(*params)
         if self._packed is None or stamp != self._stamp:
             self._packed = pack_fn()
             self._stamp = stamp
-            if weights and not torch.cuda.is_current_stream_capturing():
+            if weights and not self.owner_checks and not torch.cuda.is_current_stream_capturing():
                 from .. import ops
                 m = max(ops.max_abs(w.detach().contiguous()) for w in weights)
                 self.wide = not (m < F16_WEIGHT_LIMIT)          # (NaN counts as out of range)

@@ -86,8 +86,11 @@ def _ptr(t):
 
 def workspace(nbytes, device):
     """A scratch buffer of ``nbytes`` bytes (caller-owned, as the C ABI requires)."""
-    # zeros: the first 256 bytes of a cell / head workspace are STATUS words that kernels only ever OR into (include/urnn_hip.h)
-    return torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
+    # the first 256 bytes of a cell / head workspace are STATUS words that kernels only ever OR into (include/urnn_hip.h): only
+    # those need to start at zero -- the rest is scratch every kernel writes before it reads (tens of MB per full-resolution cell)
+    buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    buf[:min(256, int(nbytes))].zero_()
+    return buf
 
 
 class Arena:
@@ -139,7 +142,9 @@ def head_workspace_bytes(B, C, H, W):
 
 STATUS_GATES, STATUS_CAND, STATUS_HEAD, STATUS_BARRIER = 1, 2, 4, 8     # include/urnn_hip.h: word 0 of a cell / head workspace
 STATUS_NAMES = {STATUS_GATES: "GroupNorm sums of a cell's gates", STATUS_CAND: "GroupNorm sums of a cell's candidate",
-                STATUS_HEAD: "LayerNorm sums of the head"}
+                STATUS_HEAD: "LayerNorm sums of the head",
+                STATUS_BARRIER: "a cooperative launch's grid barrier gave up (its blocks were not all resident: the GPU is shared, "
+                                "partitioned or masked)"}
 
 
 def workspace_status(ws):

@@ -103,17 +103,18 @@ class RolloutEngine:
         # flag (measured at 500x500, 245 blocks: ordering the two chains' launches instead costs more than the launch saves,
         # profiles/r04_coop_cells.txt); one chain takes it wherever the library plans it.
         resident = {}                                                # blocks of the cooperative launches in use, by layer
+        cus = int(torch.cuda.get_device_properties(self.device).multi_processor_count)   # 256 on an MI355X (the library bounds its plans by the same count)
 
         def coop_flag(cell, has_x, skip):
             n = L.urnn_gru_cell_coop_blocks(B, cell.input_channels, cell.num_features, cell.shape[0], cell.shape[1], int(skip), int(has_x))
             # (URNN_TUNE_COOP_BIG=0: a one-chain engine keeps the two-chain policy -- the counter passes of tools/collect_profiles.sh run
             # eager on one chain and must execute the kernels of the benchmarked schedule)
             big_ok = not self.overlap and os.environ.get("URNN_TUNE_COOP_BIG", "1") != "0"
-            use = coop_cells and n > 0 and (n <= 128 or big_ok)
+            use = coop_cells and n > 0 and (n <= cus // 2 or big_ok)
             resident[len(resident)] = n if use else 0
             return ops.PHASE_COOP if use else 0
         nhead = L.urnn_head_coop_blocks_f32(B, H, W)                 # ... and the head likewise (urnn_head_coop_f32)
-        self._head_coop = bool(coop_cells) and (nhead <= 128 or (not self.overlap and nhead <= 256 and os.environ.get("URNN_TUNE_COOP_BIG", "1") != "0"))
+        self._head_coop = bool(coop_cells) and nhead > 0 and (nhead <= cus // 2 or (not self.overlap and nhead <= cus and os.environ.get("URNN_TUNE_COOP_BIG", "1") != "0"))
         self._coop = {"enc1": coop_flag(enc.rnn1, 1, 0), "enc2": coop_flag(enc.rnn2, 1, 0), "enc3": coop_flag(enc.rnn3, 1, 0),
                       "dec3": coop_flag(dec.rnn3, 0, 1), "dec2": coop_flag(dec.rnn2, 1, 1), "dec1": coop_flag(dec.rnn1, 1, 1)}
         # The head as a THIRD chain (own stream and scratch): head(t-1) || encoder(t+1) || decoder(t) -- +2 % at 500x500, +4 % at 400x560
@@ -121,7 +122,7 @@ class RolloutEngine:
         # such launch of each chain, together, must fit the chip's 256 CUs (a block each) -- else the head stays in front of the encoder.
         blocks = list(resident.values())                             # enc1..3, dec3..1 in the order of the dict above
         together = max(blocks[:3]) + max(blocks[3:]) + (nhead if self._head_coop else 0)
-        self._head_own_chain = self.overlap and os.environ.get("URNN_TUNE_HEAD_CHAIN", "1") != "0" and together <= 256
+        self._head_own_chain = self.overlap and os.environ.get("URNN_TUNE_HEAD_CHAIN", "1") != "0" and together <= cus
         self._dem_stamp = None
 
     # -- one timestep, all launches on the current stream ----------------------------------------------
@@ -554,6 +555,11 @@ class RolloutEngine:
             return
         for ws in self._ws:
             ws[:4].zero_()
+        if bits & ops.STATUS_BARRIER:
+            # not an arithmetic problem: a cooperative launch ran without all of its blocks resident and went on with incomplete
+            # statistics.  The frames of this event are invalid; an engine built with coop_cells=False has no grid barriers.
+            raise RuntimeError("U-RNN rollout: " + ops.STATUS_NAMES[ops.STATUS_BARRIER] + ".  The event's frames are invalid; "
+                               "rebuild the engine with RolloutEngine(..., coop_cells=False) on this device.")
         what = "; ".join(name for bit, name in ops.STATUS_NAMES.items() if bits & bit)
         layer = self._first_nonfinite_layer()
         raise FloatingPointError(

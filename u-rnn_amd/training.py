@@ -408,9 +408,35 @@ class Trainer:
         self.net._urnn_generation = getattr(self.net, "_urnn_generation", 0) + 1
 
 
+    def refresh_weight_ranges(self):
+        """The per-layer choice between the f16-piece k-loops and the exact fp32 matrix instruction (|weight| >= 64: include/urnn_hip.h
+        "Operand range") for the windows that follow -- called once per event, outside any capture.  One reduction over the flat
+        parameter buffer and one host read; only a network that has a large weight somewhere pays the per-layer check.  A captured
+        window bakes the choice in, so a flag that flips drops the captured windows."""
+        from .networks._packing import F16_WEIGHT_LIMIT
+        caches = [(mod, mod._cache) for mod in self.net.modules() if hasattr(getattr(mod, "_cache", None), "owner_checks")]
+        small = ops.max_abs(self.flat) < F16_WEIGHT_LIMIT
+        flipped = False
+        for mod, cache in caches:
+            cache.owner_checks = True
+            wide = False
+            if not small:
+                ws = [p.detach().contiguous() for p in mod.parameters() if p.dim() == 4]     # the conv / deconv weights below this module
+                wide = bool(ws) and not (max(ops.max_abs(w) for w in ws) < F16_WEIGHT_LIMIT)
+            flipped |= wide != cache.wide
+            cache.wide = wide
+        if flipped:
+            self._graphs.clear()
+
     def set_lr(self, lr):
         """Learning rate of the following windows (the epoch loop calls this once per epoch; the captured window is re-captured)."""
-        self.lr = float(lr)
+        lr = float(lr)
+        if lr != self.lr:
+            # a captured window bakes its learning rate in: graphs of another rate can never be replayed again -- release their private
+            # pools (a whole window's activations each) now instead of leaving them to the LRU eviction
+            for key in [k for k in self._graphs if k[6] != lr]:
+                del self._graphs[key]
+        self.lr = lr
 
     # -- checkpoints: the reference's file content (earlystopping.py:40-44) ----------------------------------------------------
     def state_dict(self):
@@ -638,6 +664,7 @@ class Trainer:
         T = label.shape[1]
         window_size = T - loc if window_size is None else window_size
         states, losses = None, []
+        self.refresh_weight_ranges()
         for ind in (window_starts(loc, seq_num, window_size) if starts is None else starts):
             if prewarming:
                 states = self.prewarm(ev, ind) if ind > 0 else None
