@@ -178,8 +178,10 @@ int urnn_head_after_tail_f32(const float *feat, const float *conv_w, const float
                              int W, float cls_thred, float eps, float slope, const float *head_partial0, void *stream);
 /* The head of a small plane as ONE cooperative launch: its four passes with three grid barriers between them, every thread keeping its
  * pixels' branch activations in registers (flood_head.py:131-177).  Bit-identical to urnn_head_f32.  urnn_head_coop_blocks_f32: the
- * blocks of that launch -- all must be resident at once: at most 256 (URNN_EINVAL beyond), and at most 128 for a caller with several
- * kernel chains in flight (the rule of URNN_PHASE_COOP).  Barrier state: words 16 and 32 of the workspace's status area. */
+ * blocks of that launch, or 0 when they could not all be resident at once on THIS device (one block per compute unit: the count is
+ * queried, 256 on an MI355X; urnn_head_coop_f32 then returns URNN_EINVAL) -- and at most half the compute units for a caller with
+ * several kernel chains in flight (the rule of URNN_PHASE_COOP, whose block limit is bounded by the queried count the same way).
+ * Barrier state: words 16 and 32 of the workspace's status area. */
 int urnn_head_coop_blocks_f32(int B, int H, int W);
 int urnn_head_coop_f32(const float *feat, const float *conv_w, const float *ln_w, const float *ln_b, const float *cls_w,
                        const float *cls_b, const float *reg_w, const float *reg_b, float *out_masked, float *out_cls,

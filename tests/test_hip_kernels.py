@@ -360,7 +360,7 @@ def test_cooperative_head_equals_four_passes(dev, H, W, B):
         for a_, b_, what in zip(one, four, ("masked", "cls", "pre-mask reg")):
             assert torch.equal(a_, b_), f"cooperative head differs in {what}: max {float((a_ - b_).abs().max()):.3e}"
     assert ops.workspace_status(ws) == 0
-    assert lib().urnn_head_coop_blocks_f32(1, 500, 500) == 489       # the 500x500 head stays on its four launches
+    assert lib().urnn_head_coop_blocks_f32(1, 500, 500) == 0         # 489 blocks > the device's CUs: the 500x500 head stays on its four launches
 
 
 @pytest.mark.parametrize("H,W,B", [(64, 64, 1), (100, 60, 2)])

@@ -16,6 +16,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// A value the compiler may not fold into a neighbouring operation: hipcc contracts a * b + c into an fma wherever it likes (and
+// __fmul_rn / __dmul_rn are plain multiplications to it), so the SAME source line can round once in one kernel and twice in another --
+// one ulp in a tile's centred sum of squares was enough to move a GroupNorm scale by a float ulp between the cooperative cell and
+// the three-kernel cell.  Wherever several kernels must produce the same bits, the product is made opaque before it is added.
+__device__ __forceinline__ float nofma(float v) { asm("" : "+v"(v)); return v; }
+__device__ __forceinline__ double nofma(double v) { asm("" : "+v"(v)); return v; }
+
 // k-pairs (one v_mfma_f32_32x32x2_f32 consumes a k-pair) per software-pipeline chunk.  Every K segment of a
 // packed weight matrix is padded to a multiple of 2*KU rows.
 #ifndef URNN_KU
@@ -216,6 +223,16 @@ __device__ __forceinline__ float sigmoid_of_log2arg(float t)
     return t >= 0.f ? r : e * r;
 }
 
+// The cell's gate activation  sigmoid(raw * scale + shift)  -- (scale, shift) = a GroupNorm folded per channel -- as every inference
+// kernel that forms z or r evaluates it (blend, two-stream candidate, small-plane and cooperative cells, cell tail): log2(e) goes
+// into the affine (two multiplies per channel, hoisted out of the pixel loops) and the sigmoid works on the exp2 argument directly.
+// One definition, so that kernels which must agree bit for bit do.
+__device__ __forceinline__ float gate_sigmoid(float raw, float scale, float shift)
+{
+    const float L2E = 1.44269502162933349609375f;
+    return sigmoid_of_log2arg(fmaf(raw, nofma(scale * L2E), nofma(shift * L2E)));
+}
+
 __device__ __forceinline__ float tanhf_fast(float v)
 {
 #if URNN_ACT == 0
@@ -252,6 +269,41 @@ __device__ __forceinline__ unsigned bf16_piece(float x, int piece)
     return __float_as_uint(r) >> 16;
 }
 
+// The same for a fold in which thread `tid` of NT walks tiles tid, tid + NT, ... (gru_blend_kernel<FIN>'s order, which the cooperative cell's
+// last phase and the cell tail reproduce): every block of the blend folds its channel group's partials before it streams -- ~2 000
+// blocks x 16 fp64 divisions per thread at 500 x 500 were ~10 us of the chip's VALU per launch.
+template <int NT>
+__device__ __forceinline__ void fold_thread_chain(const float *pp, int ntiles, int tile_pix, int chans, int P, int tid, double &a1, double &a2)
+{
+    a1 = 0.0;
+    a2 = 0.0;
+    const int nfull = chans * tile_pix;
+    if (tile_pix > 0 && (nfull & (nfull - 1)) == 0) {
+        const int k = 31 - __builtin_clz((unsigned)nfull);
+        const double inv = __longlong_as_double((long long)(1023 - k) << 52);   // 2^-k, exact
+        const int tpart = (P % tile_pix) != 0 && P / tile_pix < ntiles ? P / tile_pix : -1;   // the partial tile, if any: the last of its thread's chain
+        const int nclean = tpart >= 0 ? tpart : ntiles;
+        const bool mine = tpart >= 0 && tpart % NT == tid;
+        const f32x2 ldp = *reinterpret_cast<const f32x2 *>(pp + 2 * (mine ? tpart : 0));
+        for (int t = tid; t < nclean; t += NT) {
+            const f32x2 v = *reinterpret_cast<const f32x2 *>(pp + 2 * t);
+            const double dx = (double)v.x;
+            a1 += dx;
+            a2 += (double)v.y + dx * dx * inv;                                   // = tile_x2: both products are exact
+        }
+        if (mine) {
+            a1 += (double)ldp.x;
+            a2 += tile_x2(ldp.x, ldp.y, chans * (P - tpart * tile_pix));
+        }
+        return;
+    }
+    for (int t = tid; t < ntiles; t += NT) {
+        const f32x2 v = *reinterpret_cast<const f32x2 *>(pp + 2 * t);
+        a1 += (double)v.x;
+        a2 += tile_x2(v.x, v.y, chans * tile_valid(t, tile_pix, P));
+    }
+}
+
 // ---- grid barrier of the cooperative launches (urnn_small.hip coop_cell_kernel, urnn_elem.hip head_coop_kernel) -------------------------
 // One monotonic generation word + an arrival counter the last arriver resets (MI355X_MICROARCH.md "barrier-counter" with the
 // hand-off protocol of cdna_hip_programming.md section 6 G16: every wave drains its stores, one lane releases at agent scope, polls
@@ -283,12 +335,6 @@ __device__ __forceinline__ void coop_grid_barrier(unsigned *bar, unsigned nblock
     __syncthreads();
 }
 
-// A value the compiler may not fold into a neighbouring operation: hipcc contracts a * b + c into an fma wherever it likes (and
-// __fmul_rn / __dmul_rn are plain multiplications to it), so the SAME source line can round once in one kernel and twice in another --
-// one ulp in a tile's centred sum of squares was enough to move a GroupNorm scale by a float ulp between the cooperative cell and
-// the three-kernel cell.  Wherever several kernels must produce the same bits, the product is made opaque before it is added.
-__device__ __forceinline__ float nofma(float v) { asm("" : "+v"(v)); return v; }
-__device__ __forceinline__ double nofma(double v) { asm("" : "+v"(v)); return v; }
 
 // The GRU blend h' = (1 - z) h + z n (ConvRNN.py:189) with every operation rounded on its own, as the reference's eager torch ops
 // round them -- and so that every kernel that blends (gru_blend_kernel in all its vector forms, coop_cell_kernel, blend_conv_kernel)

@@ -117,12 +117,8 @@ __global__ __launch_bounds__(256) void gru_blend_kernel(const float *__restrict_
         __shared__ float st[2];
         const int G = F / 32, g = f >> 5;
         const float *pp = fin.partial + ((size_t)b * G + g) * fin.ntiles * 2;
-        double a1 = 0.0, a2 = 0.0;
-        for (int t = threadIdx.x; t < fin.ntiles; t += 256) {
-            const f32x2 v = *reinterpret_cast<const f32x2 *>(pp + 2 * t);
-            a1 += (double)v.x;
-            a2 += tile_x2(v.x, v.y, 32 * tile_valid(t, fin.tile_pix, P));
-        }
+        double a1, a2;
+        fold_thread_chain<256>(pp, fin.ntiles, fin.tile_pix, 32, P, threadIdx.x, a1, a2);
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {
             a1 += __shfl_xor(a1, m, 64);
@@ -172,7 +168,7 @@ __global__ __launch_bounds__(256) void gru_blend_kernel(const float *__restrict_
     if constexpr (V == 5) {                // the last P & 3 pixels of the plane: one thread each, first block
         if (blockIdx.x == 0 && (int)threadIdx.x < P - Pv) {
             const int p = Pv + threadIdx.x;
-            const float z = sigmoidf_fast(fmaf(gz[p], s1, t1));
+            const float z = gate_sigmoid(gz[p], s1, t1);
             const float n = tanhf_fast(fmaf(cc[p], s2, t2));
             oo[p] = gru_blend(z, n, hh[p]);
         }
@@ -188,7 +184,7 @@ __global__ __launch_bounds__(256) void gru_blend_kernel(const float *__restrict_
             f32x4 o;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float z = sigmoidf_fast(fmaf(g[k], s1, t1));
+                const float z = gate_sigmoid(g[k], s1, t1);
                 const float n = tanhf_fast(fmaf(cv[k], s2, t2));
                 o[k] = gru_blend(z, n, hv[k]);
             }
@@ -200,13 +196,13 @@ __global__ __launch_bounds__(256) void gru_blend_kernel(const float *__restrict_
             f32x4 o;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float z = sigmoidf_fast(fmaf(g[k], s1, t1));
+                const float z = gate_sigmoid(g[k], s1, t1);
                 const float n = tanhf_fast(fmaf(cv[k], s2, t2));
                 o[k] = gru_blend(z, n, hv[k]);
             }
             *reinterpret_cast<f32x4 *>(oo + p) = o;           // (the state is re-read soon: non-temporal stores cost 1 %)
         } else {
-            const float z = sigmoidf_fast(fmaf(gz[p], s1, t1));
+            const float z = gate_sigmoid(gz[p], s1, t1);
             const float n = tanhf_fast(fmaf(cc[p], s2, t2));
             oo[p] = gru_blend(z, n, hh[p]);
         }

@@ -449,7 +449,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
             R::read(ring + wrap(slot + 1) * R::SLOT, lane, hh);
             const f32x2 st = *reinterpret_cast<const f32x2 *>(ssb + 2 * (2 * (kp - kpe) + half));
 #pragma unroll
-            for (int pb = 0; pb < PB; ++pb) bv[pb] = sigmoidf_fast(gg[pb] * st.x + st.y) * hh[pb];
+            for (int pb = 0; pb < PB; ++pb) bv[pb] = gate_sigmoid(gg[pb], st.x, st.y) * hh[pb];
         };
 
         if constexpr (SPLIT) {
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
                     R::read(ring + wrap(slot_ + 1) * R::SLOT, lane, hh);
                     const f32x2 st = *reinterpret_cast<const f32x2 *>(ssb + 2 * (2 * (kp - kpe) + half));
 #pragma unroll
-                    for (int pb = 0; pb < PB; ++pb) bv[pb] = sigmoidf_fast(gg[pb] * st.x + st.y) * hh[pb];
+                    for (int pb = 0; pb < PB; ++pb) bv[pb] = gate_sigmoid(gg[pb], st.x, st.y) * hh[pb];
                 }
             };
             wait_vmcnt<(D - 1) * R::NLOAD>();

@@ -146,8 +146,8 @@ __global__ __launch_bounds__(1024) void small_cell_gemm_kernel(const ConvGemmPar
                         const int kp0 = 8 * (kg0 + gq) + 2 * d;
                         if (kp0 >= prm.hKp0) {                               // (whole 16-k groups are gated or plain: hKp0 % 8 == 0)
                             const int ch = 2 * (kp0 - prm.hKp0) + hf;
-                            v0[q] *= sigmoidf_fast(fmaf(g0[q], ssm[2 * ch], ssm[2 * ch + 1]));
-                            v1[q] *= sigmoidf_fast(fmaf(g1[q], ssm[2 * ch + 4], ssm[2 * ch + 5]));
+                            v0[q] *= gate_sigmoid(g0[q], ssm[2 * ch], ssm[2 * ch + 1]);
+                            v1[q] *= gate_sigmoid(g1[q], ssm[2 * ch + 4], ssm[2 * ch + 5]);
                         }
                     }
                     unsigned ph, pm, pl;
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(768) void coop_cell_kernel(const CoopCellParams cp,
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const f32x2 st = *reinterpret_cast<const f32x2 *>(sst + 2 * (row_c(r) + 4 * half));
-        acc[r] = sigmoidf_fast(fmaf(acc[r], st.x, st.y));          // z (update-gate waves) / r (reset-gate waves)
+        acc[r] = gate_sigmoid(acc[r], st.x, st.y);          // z (update-gate waves) / r (reset-gate waves)
     }
     if (is_r) {
         // r (.) h -> the hidden-state rows of the panel.  Accumulator row r = 4 q + i is hidden channel 32 ci + 8 q + 4 half + i:

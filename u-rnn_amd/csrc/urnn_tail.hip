@@ -167,7 +167,7 @@ __global__ __launch_bounds__(128 * KGT, KGT == 4 ? 4 : 3) void blend_conv_kernel
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const int c = 16 * gq1 + k;
-                const float z = sigmoidf_fast(fmaf(zv[k], ss1z[2 * c], ss1z[2 * c + 1]));
+                const float z = gate_sigmoid(zv[k], ss1z[2 * c], ss1z[2 * c + 1]);
                 const float n = tanhf_fast(fmaf(cv[k], ss2[2 * c], ss2[2 * c + 1]));
                 o[k] = okc ? gru_blend(z, n, hv[k]) : 0.f;
             }
