@@ -12,9 +12,9 @@ independent: test.py:741-746) -> weak scaling; value = total frames of all ranks
 
 Prints ONE JSON line (rank 0).  Extra objects: "roofline" -- the kernel FAMILY with the most time per frame among the cells'
 three (candidate GEMMs / gate GEMMs / blend; the candidate GEMMs since round 3), each launch timed with HIP events on its launch
-stream: `avg_launch_us` on ONE kernel chain, where an event pair spans the kernel alone (the figure profiles/r04_kernel_stats_
+stream: `avg_launch_us` on ONE kernel chain, where an event pair spans the kernel alone (the figure profiles/r05_kernel_stats_
 overlap0.txt -- rocprofv3 --kernel-trace --stats of `bench.py --overlap 0` -- must agree with), `live_overlapped` in the
-benchmarked schedule of concurrent chains (kernel + what it queued behind: profiles/r04_kernel_stats.txt holds the kernels' own
+benchmarked schedule of concurrent chains (kernel + what it queued behind: profiles/r05_kernel_stats.txt holds the kernels' own
 durations there); every family under "roofline.kernels" -- and "cpu_baseline" (the C oracle on the host cores, bounded sample,
 rank 0 at N=1 only).  `python bench.py --gpus N` without a launcher re-runs itself as N ranks (torch.distributed.run).
 """
@@ -106,7 +106,7 @@ def cell_kernel_work(H, W, B=1, fused=None):
 
 
 FAMILY_KERNELS = {
-    "candidate": "cand_fused_kernel<2,8,8> (full-resolution cells: W2.[x;e] on f16 pieces + the reset gate recomputed from the same input stream + "
+    "candidate": "cand_fused_kernel<2,4,8> (full-resolution cells: W2.[x;e] on f16 pieces + the reset gate recomputed from the same input stream + "
                  "W2[:,h].(r*h) on v_mfma_f32_32x32x2_f32) and conv_gemm_kernel<NB,PB,MAP,EPI_CAND,8,WPB,SPLIT=3> (half resolution: hidden rows gated "
                  "on the fly from the stored raw r); 4 launches per frame: enc1, dec1, enc2, dec2",
     "gates": "conv_gemm_kernel<NB,2,MAP_PAIR16,EPI_GRU1,8,8,SPLIT=3> (gate GEMM z|r: all 2F columns of a 64-pixel tile per wave -- NB = 4 at F = 64, "

@@ -323,3 +323,33 @@ def test_trainer_graph_equals_eager_full_size(dev):
     for a, b in zip(res[False][0], res[True][0]):
         assert torch.equal(a, b), (a, b)
     assert torch.equal(res[False][1], res[True][1])
+
+
+def test_paper_mode_prewarm_matches_the_inference_engine(dev):
+    """Paper mode (main.py:542-595, 655-672) rolls gradient-free from frame 0 to a window's start THROUGH THE TRAINING FORWARD -- the
+    three-pass cells, whose recurrent product W2[:, h].(r * h) stays on f16 pieces, where the inference engine's fused candidate
+    kernel puts it on the fp32 matrix instruction.  120 frames of BASELINE configs[1] (500x500, C = 63) both ways:
+    the six states must agree to 2e-4 of each state's range -- twice the rollouts' bar against the oracle, since BOTH sides carry
+    amplified float32 roundoff here (plain float32 torch is 1-2e-4 from the oracle through the rain peak: DESIGN.md 5) -- i.e. the
+    16-bit product does not drift a pre-warm of this length away from the states the inference path would hand over."""
+    import urnn_amd.weights as uw
+    from conftest import rel_err
+    from urnn_amd.rollout import RolloutEngine
+    from urnn_amd.training import Trainer
+    H = W = 500
+    nums, rain_max, cum_max, frames = 30, 6.0, 250.0, 120
+    ev = uw.make_event(frames, H, W, rain_max, seed=42)
+    net, _ = _bench_net(dev, H, W, 2 * nums + 3)
+    eng = RolloutEngine(net, H, W, nums, rain_max, cum_max, max_frames=frames, overlap=True, use_graph=True)
+    eng.load_event(ev)
+    eng.reset()
+    eng.run(frames)
+    torch.cuda.synchronize()
+    want = [s.clone() for s in eng.final_states()]
+    del eng
+    tr = Trainer(net, H, W, nums, rain_max, cum_max, lr=1e-4, use_graph=False)
+    got = tr.prewarm(ev, frames)
+    torch.cuda.synchronize()
+    errs = [rel_err(g.cpu().numpy(), w.cpu().numpy()) for g, w in zip(got, want)]
+    print("pre-warm of 120 frames through the training forward vs the inference engine: state errors", ["%.2e" % e for e in errs])
+    assert max(errs) <= 2e-4, errs

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence on the GPU box: raw databases stay in /tmp, text summaries go to gpurun_out/$1.
-# usage (through gpurun): bash tools/collect_profiles.sh r04   (then copy gpurun_out/r04/pmc_kernels.json + pmc_train.json to profiles/)
+# usage (through gpurun): bash tools/collect_profiles.sh r05   (then copy gpurun_out/r05/* to profiles/r05_*, pmc_kernels.json + pmc_train.json to profiles/)
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=${1:-r04}
+TAG=${1:-r05}
 O=$R/gpurun_out/$TAG; P=/tmp/prof_$TAG
 mkdir -p $O $P; cd /tmp; export TMPDIR=/tmp
 # one chain, eager (every dispatch attributed) -- with the kernel selection of the benchmarked overlapped schedule (URNN_TUNE_COOP_BIG=0)
@@ -30,24 +30,19 @@ python $R/tools/prof_summary.py $P/stats_ov0/o_results.db > $O/kernel_stats_over
 timeout 300 python $R/bench.py > $O/bench_default.log 2>&1
 timeout 200 python $R/bench.py --overlap 0 --no-cpu-baseline > $O/bench_overlap0.log 2>&1
 timeout 200 python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_steps20.log 2>&1
-timeout 200 python $R/bench.py --fused-tails --no-cpu-baseline > $O/bench_fused_tails.log 2>&1
-# the other BASELINE shapes: cooperative small-plane cells + head (default) against the three-kernel cells / four-pass head
+# the other BASELINE shapes: one event per GPU and -- configs[4] is BATCHED inference -- eight events per GPU
 PYP='import sys,json
 for l in sys.stdin:
     if l.startswith("{"):
-        r=json.loads(l); print(sys.argv[1], round(r["value"],1), "frames/s", round(r["ms_per_step"]*1000,1), "us per frame")'
-{ for c in lite64 ukea lite128 futian; do
-    timeout 200 python $R/bench.py --config $c --no-cpu-baseline 2>/dev/null | python -c "$PYP" "$c (default: cooperative cells + head where <= 128 blocks)"
-    URNN_TUNE_COOP=0 timeout 200 python $R/bench.py --config $c --no-cpu-baseline 2>/dev/null | python -c "$PYP" "$c URNN_TUNE_COOP=0 (three-kernel cells)"
+        r=json.loads(l); print(sys.argv[1], round(r["value"],1), "frames/s", round(r["ms_per_step"]*1000,1), "us per step (one frame per event)")'
+{ for c in lite64 ukea lite128 futian mixed; do
+    timeout 300 python $R/bench.py --config $c --no-cpu-baseline 2>/dev/null | python -c "$PYP" "$c batch 1"
   done
-  timeout 200 python $R/bench.py --config mixed --no-cpu-baseline 2>/dev/null | python -c "$PYP" "mixed (futian + ukea alternating)"; } > $O/bench_configs.txt 2>&1
-# byte counters with the fused tails (the traffic side of that trade)
-export URNN_TUNE_COOP_BIG=0
-for name in FETCH_SIZE WRITE_SIZE; do
-  timeout 420 rocprofv3 --kernel-trace --pmc $name -d $P/pmcf_$name -o p -- $CMD --fused-tails > $P/pmcf_$name.log 2>&1
-  { echo "# rocprofv3 --kernel-trace --pmc $name -- $CMD --fused-tails"; python $R/tools/pmc_summary.py $P/pmcf_$name/p_results.db "" --frames=-1; } > $O/pmc_fused_tails_$name.txt 2>&1
-done
-unset URNN_TUNE_COOP_BIG
+  for c in lite64 ukea lite128 mixed; do
+    timeout 300 python $R/bench.py --config $c --batch 8 --no-cpu-baseline 2>/dev/null | python -c "$PYP" "$c batch 8"
+  done; } > $O/bench_configs.txt 2>&1
+# the request-shape microbenchmark (tools/ubench/operand_stream.hip)
+( cd $R/tools/ubench && hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -o /tmp/operand_stream operand_stream.hip && /tmp/operand_stream ) > $O/operand_stream.txt 2>&1
 timeout 300 python $R/tools/kernel_bench.py > $O/kernel_bench.txt 2>&1
 timeout 300 python $R/bench.py --mode train > $O/bench_train.log 2>&1
 timeout 300 python $R/bench.py --mode train --dtype bf16 > $O/bench_train_bf16.log 2>&1
