@@ -107,9 +107,9 @@ def cell_kernel_work(H, W, B=1, fused=None):
 
 FAMILY_KERNELS = {
     "candidate": "cand_fused_kernel<2,4,8> (full-resolution cells: W2.[x;e] on f16 pieces + the reset gate recomputed from the same input stream + "
-                 "W2[:,h].(r*h) on v_mfma_f32_32x32x2_f32) and conv_gemm_kernel<NB,PB,MAP,EPI_CAND,8,WPB,SPLIT=3> (half resolution: hidden rows gated "
-                 "on the fly from the stored raw r); 4 launches per frame: enc1, dec1, enc2, dec2",
-    "gates": "conv_gemm_kernel<NB,2,MAP_PAIR16,EPI_GRU1,8,8,SPLIT=3> (gate GEMM z|r: all 2F columns of a 64-pixel tile per wave -- NB = 4 at F = 64, "
+                 "W2[:,h].(r*h) on v_mfma_f32_32x32x2_f32) and cand_gated_kernel<3,4> (half resolution: 64-pixel tiles, one wave per SIMD, hidden rows gated "
+                 "on the fly from the stored raw r, group-wise ring); 4 launches per frame: enc1, dec1, enc2, dec2",
+    "gates": "conv_gemm_kernel<NB,2,MAP_QUAD16,EPI_GRU1,D,8,SPLIT=3> (gate GEMM z|r: all 2F columns of a 64-pixel tile per wave -- NB = 4 at F = 64, "
              "the z / r halves with NB = 3 at F = 96; two scaled f16 pieces per fp32 operand, 3 x v_mfma_f32_32x32x16_f16 per 16 k); 4 launches per frame",
     "blend": "gru_blend_kernel<V,FIN=true,ITER> (candidate GroupNorm finalize in the prologue, h' = (1 - z) h + z tanh(GN(c))); the same 4 cells",
 }

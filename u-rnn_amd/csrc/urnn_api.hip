@@ -422,6 +422,13 @@ static int gru_cell_impl(const float *x, const float *e, const float *h, const f
     if (global_pixels >= URNN_FULL_RES_PIXELS && urnn_get_matrix_mode() == URNN_MATRIX_FP32) c.candExact = 1;
     int pb2, map2;
     int tiles2 = gru_tiles(B, F, P, 2, &pb2, &map2);
+    // half-resolution planes: the two-stream candidate on 64-pixel tiles (urnn_cand_gated.hip).  Decided from the shapes alone, so that
+    // phase-split callers see the same tile size in the candidate and in the blend's fold
+    const bool gated2 = !fused_r && global_pixels <= 0 && !small_on && urnn_cand_gated_plan(c, B) != 0;
+    if (gated2) {
+        pb2 = 2;
+        tiles2 = (int)((P + 63) / 64);
+    }
     // URNN_PHASE_COOP: the whole cell of a small plane as ONE cooperative launch (urnn_small.hip coop_cell_kernel) -- when the caller
     // asked for every phase and the shape qualifies; otherwise the flag is ignored and the three kernels run
     if ((phase_mask & URNN_PHASE_COOP) && !tail && (phase_mask & URNN_PHASE_ALL) == URNN_PHASE_ALL && global_pixels <= 0 && !fused_r && small_gates &&
@@ -453,7 +460,8 @@ static int gru_cell_impl(const float *x, const float *e, const float *h, const f
         if (phase_mask & URNN_PHASE_CAND) CHECK_HIP(urnn_launch_cand_fused(fz, B, st), "gru candidate (reset gate recomputed)");
     } else
     if (phase_mask & URNN_PHASE_CAND) {
-        if (small_on && pb2 == 1 && urnn_small_ok(c, NW, 1)) CHECK_HIP(urnn_launch_small_cand(c, B, st), "gru candidate (small plane)");
+        if (gated2) CHECK_HIP(urnn_launch_cand_gated(c, B, st), "gru candidate (64-pixel tiles, group-wise ring)");
+        else if (small_on && pb2 == 1 && urnn_small_ok(c, NW, 1)) CHECK_HIP(urnn_launch_small_cand(c, B, st), "gru candidate (small plane)");
         else CHECK_HIP(urnn_launch_cand(c, B, pb2, map2, st), "gru candidate");
     }
     // K3: GroupNorm finalize of the candidate + blend.  One launch when both are asked for (the product path); separate

@@ -134,6 +134,10 @@ bool urnn_coop_cell_ok(const ConvGemmParams &p, const ConvGemmParams &c, int B);
 hipError_t urnn_launch_coop_cell(ConvGemmParams p, const ConvGemmParams &c, const float *gn2_w, const float *gn2_b, float *ss2_out, float *h_out,
                                  unsigned *bar, int B, hipStream_t st);
 int urnn_cand_nb(int F);      // n-blocks per group of the candidate GEMM
+// the two-stream candidate of a half-resolution plane on 64-pixel tiles and a group-wise ring (urnn_cand_gated.hip); plan: 1 when it
+// takes the launch -- the candidate's GroupNorm partials are then per 64-pixel tile
+int urnn_cand_gated_plan(const ConvGemmParams &p, int B);
+hipError_t urnn_launch_cand_gated(ConvGemmParams p, int B, hipStream_t st);
 hipError_t urnn_launch_cand(ConvGemmParams p, int B, int PB, int map, hipStream_t st);
 
 // ---- elementwise / reduction kernels (urnn_elem.hip) ----
