@@ -45,27 +45,32 @@ __device__ __forceinline__ void gated_open(GatedStream &gs, const ConvGemmParams
     gs.sh = prm.seg[2] + (size_t)b_ * prm.segC[2] * prm.P;
     gs.sg = prm.gate + ((size_t)b_ * 2 * prm.F + prm.F) * prm.P;
 }
-// request the rows of the group that starts at k-pair kp0 (plain: slots 0-3; gated: raw r rows into 0-3, h rows into 4-7)
-__device__ __forceinline__ void gated_request(const GatedStream &gs, const ConvGemmParams &prm, char *ring, int kp0, int lane)
+// The stream in UNITS of four slots (half a ring): plain group i is unit i; gated group q is units nP + 2 q (its raw reset-gate rows) and
+// nP + 2 q + 1 (its rows of h).  Unit u lives in ring half u & 1.  Two units are in flight at any time, so a plain group's rows were
+// requested two groups before they are needed and a gated group's one group before.
+__device__ __forceinline__ void gated_request_unit(const GatedStream &gs, const ConvGemmParams &prm, char *ring, int u, int nP, int lane)
 {
     using R = Ring<2, MAP_QUAD16>;
     const unsigned qstep = 16u * (unsigned)prm.P;                      // one slot = four rows
     const unsigned vb[R::NV] = {gs.vo};
-    if (kp0 < prm.hKp0) {
-        const bool in_e = kp0 >= prm.segKp0[1];
-        const rsrc_t rs = make_rsrc(gated_uniform_ptr(in_e ? gs.se : gs.sx), 4u * (unsigned)(in_e ? prm.segC[1] : prm.segC[0]) * (unsigned)prm.P);
-        const unsigned base = 8u * (unsigned)prm.P * (unsigned)(kp0 - (in_e ? prm.segKp0[1] : 0));
+    char *half_ring = ring + (u & 1) * 4 * R::SLOT;
+    // (plain selects on scalar values: a pointer picked through an if / else chain made hipcc keep the struct on the stack)
+    const bool plain = u < nP;
+    const int kp0 = prm.kpBegin + 8 * u;
+    const bool in_e = plain && kp0 >= prm.segKp0[1];
+    const int q = (u - nP) >> 1;
+    const bool hrows = !plain && ((u - nP) & 1) != 0;
+    const unsigned long long px = reinterpret_cast<unsigned long long>(gs.sx), pe = reinterpret_cast<unsigned long long>(gs.se),
+                             ph = reinterpret_cast<unsigned long long>(gs.sh), pg = reinterpret_cast<unsigned long long>(gs.sg);
+    const unsigned long long psel = plain ? (in_e ? pe : px) : (hrows ? ph : pg);
+    const float *src = reinterpret_cast<const float *>(psel);
+    const int chans = plain ? (in_e ? prm.segC[1] : prm.segC[0]) : (hrows ? prm.segC[2] : prm.F);
+    const unsigned bytes = 4u * (unsigned)chans * (unsigned)prm.P;
+    const unsigned base = plain ? 8u * (unsigned)prm.P * (unsigned)(kp0 - (in_e ? prm.segKp0[1] : 0))
+                                : 64u * (unsigned)prm.P * (unsigned)q;   // (gated: eight k-pairs = sixteen rows per group)
+    const rsrc_t rs = make_rsrc(gated_uniform_ptr(src), (unsigned)__builtin_amdgcn_readfirstlane((int)bytes));
 #pragma unroll
-        for (int sl = 0; sl < 4; ++sl) R::issue(ring + sl * R::SLOT, rs, vb, base + sl * qstep, lane);
-    } else {
-        const rsrc_t rg = make_rsrc(gated_uniform_ptr(gs.sg), 4u * (unsigned)prm.F * (unsigned)prm.P);
-        const rsrc_t rh = make_rsrc(gated_uniform_ptr(gs.sh), 4u * (unsigned)prm.segC[2] * (unsigned)prm.P);
-        const unsigned base = 8u * (unsigned)prm.P * (unsigned)(kp0 - prm.hKp0);
-#pragma unroll
-        for (int sl = 0; sl < 4; ++sl) R::issue(ring + sl * R::SLOT, rg, vb, base + sl * qstep, lane);
-#pragma unroll
-        for (int sl = 0; sl < 4; ++sl) R::issue(ring + (4 + sl) * R::SLOT, rh, vb, base + sl * qstep, lane);
-    }
+    for (int sl = 0; sl < 4; ++sl) R::issue(half_ring + sl * R::SLOT, rs, vb, base + sl * qstep, lane);
 }
 
 template <int NB, int WPB>
@@ -97,9 +102,11 @@ __global__ __launch_bounds__(64 * WPB, 1) void cand_gated_kernel(const ConvGemmP
     gs.vo = 0; gs.sx = gs.se = gs.sh = gs.sg = nullptr;
     wait_vmcnt<0>();
     __syncthreads();                                                  // slab and bias are in LDS
+    const int nP = (kH - kp_begin) >> 3, nG = (KT - kH) >> 3, U = nP + 2 * nG;      // plain groups, gated groups, units per tile
     if (item0 < prm.totalTiles) {
         gated_open(gs, prm, item0, j, lane);
-        gated_request(gs, prm, ring, kp_begin, lane);                                            // the first group's rows travel while the statistics are folded
+        gated_request_unit(gs, prm, ring, 0, nP, lane);               // the first two units travel while the statistics are folded
+        gated_request_unit(gs, prm, ring, 1, nP, lane);
     }
     {
         // GroupNorm of the gates from the gate GEMM's partials: the arithmetic of conv_gemm_kernel's EPI_CAND prologue, value for value
@@ -154,35 +161,43 @@ __global__ __launch_bounds__(64 * WPB, 1) void cand_gated_kernel(const ConvGemmP
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[nb][pb][r] = 0.f;
         unsigned bh[PB][4], bl[PB][4];
+        if (item != item0) {                                          // (a wave's later tiles open their own stream: one exposed round trip per tile)
+            gated_open(gs, prm, item, j, lane);
+            gated_request_unit(gs, prm, ring, 0, nP, lane);
+            gated_request_unit(gs, prm, ring, 1, nP, lane);
+        }
+        int next = 2;                                                 // the next unit to request
         for (int kp = kp_begin; kp < KT; kp += 8) {
             const bool gated = kp >= kH;                              // uniform
             float fr[8][PB];
-            wait_vmcnt<0>();                                          // this group's slots (requested one group ago)
             if (!gated) {
+                const int u = (kp - kp_begin) >> 3;
+                if (u + 1 < U) wait_vmcnt<4 * R::NLOAD>(); else wait_vmcnt<0>();      // unit u has landed; u + 1 may still travel
+                const char *hr = ring + (u & 1) * 4 * R::SLOT;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) R::read(ring + (q >> 1) * R::SLOT, lane, fr[q], q & 1);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the fragments have left LDS: the slots may be overwritten
+                for (int q = 0; q < 8; ++q) R::read(hr + (q >> 1) * R::SLOT, lane, fr[q], q & 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the fragments have left LDS: the half may be overwritten
+                if (next < U) { gated_request_unit(gs, prm, ring, next, nP, lane); ++next; }
             } else {
+                const int u = nP + 2 * ((kp - kH) >> 3);
+                wait_vmcnt<0>();                                      // both of the group's units
+                const char *rr = ring + (u & 1) * 4 * R::SLOT, *hr = ring + ((u + 1) & 1) * 4 * R::SLOT;
                 float hf[8][PB];
                 f32x2 st[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    R::read(ring + (q >> 1) * R::SLOT, lane, fr[q], q & 1);
-                    R::read(ring + (4 + (q >> 1)) * R::SLOT, lane, hf[q], q & 1);
+                    R::read(rr + (q >> 1) * R::SLOT, lane, fr[q], q & 1);
+                    R::read(hr + (q >> 1) * R::SLOT, lane, hf[q], q & 1);
                     st[q] = *reinterpret_cast<const f32x2 *>(ssb + 2 * (2 * (kp + q - kH) + half));
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 // (the next group's rows are requested before the sigmoids: their round trip overlaps this group's arithmetic)
-                if (kp + 8 < KT) gated_request(gs, prm, ring, kp + 8, lane);
-                else if (item + istep < prm.totalTiles) { gated_open(gs, prm, item + istep, j, lane); gated_request(gs, prm, ring, kp_begin, lane); }
+                if (next < U) { gated_request_unit(gs, prm, ring, next, nP, lane); ++next; }
+                if (next < U) { gated_request_unit(gs, prm, ring, next, nP, lane); ++next; }
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
 #pragma unroll
                     for (int pb = 0; pb < PB; ++pb) fr[q][pb] = gate_sigmoid(fr[q][pb], st[q].x, st[q].y) * hf[q][pb];
-            }
-            if (!gated) {
-                if (kp + 8 < KT) gated_request(gs, prm, ring, kp + 8, lane);
-                else if (item + istep < prm.totalTiles) { gated_open(gs, prm, item + istep, j, lane); gated_request(gs, prm, ring, kp_begin, lane); }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
