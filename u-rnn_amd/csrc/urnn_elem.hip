@@ -245,113 +245,109 @@ hipError_t urnn_launch_blend_fin(const float *g1, const float *c, const float *h
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Head (flood_head.py:131-202).  C = 16 channels; each thread owns V consecutive pixels x 16 channels in registers.
-// LayerNorm([16,H,W]) statistics are whole-sample reductions => four passes separated by finalise kernels:
+// Head (flood_head.py:131-202).  C = 16 channels.  LayerNorm([16,H,W]) statistics are whole-sample reductions => four passes:
 //   k1: stats(u0 = Ws.f)                                   k2: t = SiLU(LN0(u0)); u1 = Wc1.t, u2 = Wq1.t (+stats)
 //   k3: u1 <- Wc2.SiLU(LN1(u1)), u2 <- Wq2.SiLU(LN3(u2)) (+stats)      k4: cls / reg predictions + wet/dry mask
-// The element-wise LayerNorm affine (16,H,W) per block is the dominant HBM stream.
+// The element-wise LayerNorm affines (16,H,W) -- ten planes sets of 16 MB at 500 x 500 -- are the dominant HBM stream.
+//
+// Register layout (round 5; rounds 1-4 kept a pixel's 16 channels in one thread, which allowed 4- / 8-byte accesses only -- 16-byte
+// ones needed 256 registers -- and spent 256 fma per pixel and layer on the VALU): a WAVE owns a 64-pixel tile; lane l = 16 cg + pq
+// holds channels 4 cg .. 4 cg + 3 of pixels 4 pq .. 4 pq + 3 as four f32x4 (x[i][j] = channel 4 cg + i, pixel 4 pq + j).  Every
+// HBM access is 16 bytes per lane, 256 contiguous bytes per channel row, and the 16 x 16 channel mix runs on the matrix pipe:
+// v_mfma_f32_16x16x4_f32 takes B[k = l / 16][n = l % 16] and returns D[m = 4 (l / 16) + r][n = l % 16] in four registers, so with
+// k-block i = the channels {4 kk + i} the B operand of pixel j IS x[i][j] and the result lands in the same layout: 16 MFMAs per
+// tile and layer (exact fp32 products, fp32 accumulation), no data movement.  A block = 4 waves = 256 pixels = one LayerNorm partial.
+// Planes whose size is not a multiple of four (AL = false) use element-wise guarded accesses with the same layout and arithmetic.
 // ------------------------------------------------------------------------------------------------------------------
 #define HEAD_C 16
+#define HEAD_BLOCK_PIX 256
 
-template <int V>
-__device__ __forceinline__ void head_load(const float *__restrict__ src, int P, int p, float (&v)[HEAD_C][V])
+struct HeadLane {
+    int cg, pq;     // channel group, pixel quad of the wave's tile
+    int p;          // the lane's first pixel
+    int npx;        // how many of its four pixels lie inside the plane (AL: 0 or 4)
+};
+
+__device__ __forceinline__ HeadLane head_lane(int blk, int P)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    HeadLane L;
+    L.cg = lane >> 4;
+    L.pq = lane & 15;
+    L.p = (blk * 4 + wave) * 64 + 4 * L.pq;
+    const int left = P - L.p;
+    L.npx = left >= 4 ? 4 : (left > 0 ? left : 0);
+    return L;
+}
+
+__device__ __forceinline__ void head_zero(f32x4 (&x)[4])
 {
 #pragma unroll
-    for (int c = 0; c < HEAD_C; ++c) {
-        if constexpr (V == 4) {
-            const f32x4 t = *reinterpret_cast<const f32x4 *>(src + (size_t)c * P + p);
-            v[c][0] = t.x; v[c][1] = t.y; v[c][2] = t.z; v[c][3] = t.w;
-        } else if constexpr (V == 2) {
-            const f32x2 t = *reinterpret_cast<const f32x2 *>(src + (size_t)c * P + p);
-            v[c][0] = t.x; v[c][1] = t.y;
+    for (int i = 0; i < 4; ++i) x[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// the lane's 4 x 4 values of a (16, P) tensor; lanes / pixels outside the plane read as 0
+template <bool AL>
+__device__ __forceinline__ void head_load(const float *__restrict__ src, int P, const HeadLane &L, f32x4 (&x)[4])
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float *row = src + (size_t)(4 * L.cg + i) * P + L.p;
+        if constexpr (AL) {
+            x[i] = L.npx > 0 ? *reinterpret_cast<const f32x4 *>(row) : f32x4{0.f, 0.f, 0.f, 0.f};
         } else {
-            v[c][0] = src[(size_t)c * P + p];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[i][j] = j < L.npx ? row[j] : 0.f;
         }
     }
 }
 
-template <int V>
-__device__ __forceinline__ void head_store(float *dst, int P, int p, const float (&v)[HEAD_C][V])
+template <bool AL>
+__device__ __forceinline__ void head_store(float *dst, int P, const HeadLane &L, const f32x4 (&x)[4])
 {
 #pragma unroll
-    for (int c = 0; c < HEAD_C; ++c) {
-        if constexpr (V == 4) *reinterpret_cast<f32x4 *>(dst + (size_t)c * P + p) = f32x4{v[c][0], v[c][1], v[c][2], v[c][3]};
-        else if constexpr (V == 2) *reinterpret_cast<f32x2 *>(dst + (size_t)c * P + p) = f32x2{v[c][0], v[c][1]};
-        else dst[(size_t)c * P + p] = v[c][0];
-    }
-}
-
-// u[n] = sum_c w[n][c] * x[c]    (w is block-uniform -> scalar loads)
-template <int V>
-__device__ __forceinline__ void head_conv(const float *__restrict__ w, const float (&x)[HEAD_C][V], float (&u)[HEAD_C][V])
-{
+    for (int i = 0; i < 4; ++i) {
+        float *row = dst + (size_t)(4 * L.cg + i) * P + L.p;
+        if constexpr (AL) {
+            if (L.npx > 0) *reinterpret_cast<f32x4 *>(row) = x[i];
+        } else {
 #pragma unroll
-    for (int n = 0; n < HEAD_C; ++n) {
-#pragma unroll
-        for (int k = 0; k < V; ++k) u[n][k] = 0.f;
-#pragma unroll
-        for (int c = 0; c < HEAD_C; ++c) {
-            const float wv = w[n * HEAD_C + c];
-#pragma unroll
-            for (int k = 0; k < V; ++k) u[n][k] = fmaf(wv, x[c][k], u[n][k]);
+            for (int j = 0; j < 4; ++j)
+                if (j < L.npx) row[j] = x[i][j];
         }
     }
 }
 
-// x <- SiLU((x - mean) * rstd * gamma[c][p] + beta[c][p]); the affines are streamed four channels at a time (8 independent
-// loads in flight per thread without holding all 32 vectors)
-template <int V>
-__device__ __forceinline__ void head_ln_silu(float (&x)[HEAD_C][V], const float *__restrict__ gamma, const float *__restrict__ beta,
-                                             int P, int p, float mean, float rstd)
+// A operand of the four k-blocks: a[i] = W[m = l % 16][4 (l / 16) + i]  (w: 16 x 16 row-major, 16-byte aligned)
+__device__ __forceinline__ f32x4 head_weights(const float *__restrict__ w)
 {
-#pragma unroll
-    for (int c0 = 0; c0 < HEAD_C; c0 += 4) {
-        float g[4][V], bt[4][V];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if constexpr (V == 4) {
-                const f32x4 a = *reinterpret_cast<const f32x4 *>(gamma + (size_t)(c0 + c) * P + p), b = *reinterpret_cast<const f32x4 *>(beta + (size_t)(c0 + c) * P + p);
-                g[c][0] = a.x; g[c][1] = a.y; g[c][2] = a.z; g[c][3] = a.w;
-                bt[c][0] = b.x; bt[c][1] = b.y; bt[c][2] = b.z; bt[c][3] = b.w;
-            } else if constexpr (V == 2) {
-                const f32x2 a = *reinterpret_cast<const f32x2 *>(gamma + (size_t)(c0 + c) * P + p), b = *reinterpret_cast<const f32x2 *>(beta + (size_t)(c0 + c) * P + p);
-                g[c][0] = a.x; g[c][1] = a.y;
-                bt[c][0] = b.x; bt[c][1] = b.y;
-            } else {
-                g[c][0] = gamma[(size_t)(c0 + c) * P + p];
-                bt[c][0] = beta[(size_t)(c0 + c) * P + p];
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int k = 0; k < V; ++k) x[c0 + c][k] = siluf_fast((x[c0 + c][k] - mean) * rstd * g[c][k] + bt[c][k]);
-    }
+    const int lane = threadIdx.x & 63;
+    return *reinterpret_cast<const f32x4u *>(w + (lane & 15) * HEAD_C + 4 * (lane >> 4));   // (a parameter view: 4-byte alignment only)
 }
 
-template <int V>
-__device__ __forceinline__ float head_sum(const float (&u)[HEAD_C][V])
+// u[m][pixel] = sum_c W[m][c] x[c][pixel] on the matrix pipe (whole waves only: never inside a divergent branch)
+__device__ __forceinline__ void head_conv(const f32x4 &a, const f32x4 (&x)[4], f32x4 (&u)[4])
 {
-    float s = 0.f;
+    f32x4 acc[4];
 #pragma unroll
-    for (int c = 0; c < HEAD_C; ++c)
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < V; ++k) s += u[c][k];
-    return s;
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], x[i][j], acc[j], 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) u[r][j] = acc[j][r];
 }
 
-template <int V>
-__device__ __forceinline__ float head_sumsq_about(const float (&u)[HEAD_C][V], float m)
+// x <- SiLU((x - mean) * rstd * gamma + beta); a pixel outside the plane (x = gamma = beta = 0) stays 0
+__device__ __forceinline__ void head_ln_silu(f32x4 (&x)[4], const f32x4 (&g)[4], const f32x4 (&bt)[4], float mean, float rstd)
 {
-    float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < HEAD_C; ++c)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int k = 0; k < V; ++k) {
-            const float d = u[c][k] - m;
-            s = fmaf(d, d, s);
-        }
-    return s;
+        for (int j = 0; j < 4; ++j) x[i][j] = siluf_fast((x[i][j] - mean) * rstd * g[i][j] + bt[i][j]);
 }
 
 // Block-wide sums of two values, returned to every thread (fixed order: xor butterfly per wave, then waves 0..3).
@@ -372,25 +368,53 @@ __device__ __forceinline__ void head_block_sum2(float &a, float &b)
 }
 
 // LayerNorm partial statistics (sum, second moment about the block's own mean -- urnn_common.h tile_x2) of up to two tensors from
-// per-thread scalars: a thread reduces its HEAD_C * V values to (sum s, squares q about its own mean) while they are in
-// registers, so the values can be stored and die before any block-wide step; the block then combines the threads exactly
-// (Chan): Q = sum_threads [ q + n (m_thread - m_block)^2 ].  Threads outside the plane pass n = 0.
-template <int V>
-__device__ __forceinline__ void head_thread_stats(const float (&u)[HEAD_C][V], float &s, float &q)
+// per-lane scalars: a lane reduces its 4 x npx values to (sum s, squares q about its own mean) while they are in registers, so the
+// values can be stored and die before any block-wide step; the block then combines the lanes exactly (Chan):
+// Q = sum_lanes [ q + n (m_lane - m_block)^2 ].  Lanes outside the plane pass n = 0.
+template <bool AL>
+__device__ __forceinline__ void head_lane_stats(const f32x4 (&u)[4], int npx, float &s, float &q)
 {
-    s = head_sum<V>(u);
-    q = head_sumsq_about<V>(u, s * (1.f / (HEAD_C * V)));
+    s = 0.f;
+    q = 0.f;
+    if constexpr (AL) {            // npx = 4, or 0 with u = 0 (a conv of zeros): no predicates
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += u[i][j];
+        const float m = s * (1.f / 16.f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = u[i][j] - m;
+                q = fmaf(d, d, q);
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += j < npx ? u[i][j] : 0.f;
+        const float m = npx > 0 ? s / (float)(4 * npx) : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = j < npx ? u[i][j] - m : 0.f;
+                q = fmaf(d, d, q);
+            }
+    }
 }
 
-__device__ __forceinline__ void head_block_stats2(float sa, float qa, float sb, float qb, int n_thread, bool two, int nvalid, float *dst_a,
+__device__ __forceinline__ void head_block_stats2(float sa, float qa, float sb, float qb, int n_lane, bool two, int nvalid, float *dst_a,
                                                   float *dst_b)
 {
-    const float ma = sa * (1.f / 16.f) / (float)(n_thread > 0 ? n_thread / 16 : 1), mb = sb * (1.f / 16.f) / (float)(n_thread > 0 ? n_thread / 16 : 1);
+    const float fn = (float)n_lane;
+    const float ma = n_lane > 0 ? sa / fn : 0.f, mb = n_lane > 0 ? sb / fn : 0.f;
     float Sa = sa, Sb = sb;
     head_block_sum2(Sa, Sb);
     const float inv = 1.f / (float)nvalid;
     const float da = ma - Sa * inv, db = mb - Sb * inv;
-    float Qa = n_thread > 0 ? fmaf((float)n_thread * da, da, qa) : 0.f, Qb = n_thread > 0 ? fmaf((float)n_thread * db, db, qb) : 0.f;
+    float Qa = n_lane > 0 ? fmaf(fn * da, da, qa) : 0.f, Qb = n_lane > 0 ? fmaf(fn * db, db, qb) : 0.f;
     head_block_sum2(Qa, Qb);
     if (threadIdx.x == 0) {
         dst_a[0] = Sa;
@@ -408,21 +432,27 @@ __device__ __forceinline__ float *head_partial(const HeadParams &p, int which, i
     return p.partial + ((((size_t)which * p.B + b) * p.nblk) + blk) * 2;
 }
 
-// LayerNorm statistics of tensor `which` of sample b folded from the per-block partials by EVERY wave of the consuming kernel
-// (FIN variants of head_k2 .. k4: no finalize launch in between): lane-strided double sums in ascending block order, then the xor
-// butterfly -- the order ln_finalize_kernel uses, so the fused and the separate path give identical bits and every wave of every
-// block holds the same (mean, rstd).  ~8 loads per lane for a 500x500 plane.
-__device__ __forceinline__ void head_fold_stats(const HeadParams &prm, int which, int b, int nblk_used, int block_pix, float &mean_f, float &rstd_f)
+// LayerNorm statistics of tensor `which` of sample b folded from the per-block partials by ONE wave: lane-strided double sums in
+// ascending block order, then the xor butterfly -- the order ln_finalize_kernel uses, so every path gives identical bits.
+// Who folds (round 5): a finalize launch of ONE wave per (norm, sample) between the passes (ln_finalize_kernel); the consumers read
+// two floats.  Rounds 1-4 had every wave of every consuming block fold all partials in front of (or, tried this round, behind) its
+// own loads -- ~1 000 blocks x 4 waves x 8 KB of L2 reads, a dependent round trip and ~60 registers per tile: head_k4 32 -> 20 us
+// without it, the three finalize launches cost 3 x 3-5 us.  (Also tried: the producer's last block to finish folds -- one
+// agent-scope counter and a release fence per block: 17-40 ns per block SERIALISED, head_k3 31 -> 110 us.)
+// The cooperative head folds across its grid barriers (small planes), and a feature map whose producer took the first norm's
+// partials (urnn_tail.hip) is folded by head_k2's waves as before.
+__device__ __forceinline__ void head_fold_stats(const HeadParams &prm, int which, int b, bool publish, float &mean_f, float &rstd_f)
 {
     const int lane = threadIdx.x & 63;
     const float *pp = prm.partial + (((size_t)which * prm.B + b) * prm.nblk) * 2;
+    int nblk_used = (prm.P + HEAD_BLOCK_PIX - 1) / HEAD_BLOCK_PIX, block_pix = HEAD_BLOCK_PIX;
     if (which == 0 && prm.partial0) {                  // statistics of u0 taken by the producer of feat (urnn_tail.hip): its own block size
         pp = prm.partial0 + (size_t)b * prm.nblk0 * 2;
         nblk_used = prm.nblk0;
         block_pix = prm.bpix0;
     }
     double s1, s2;
-    fold_lane_chain<16, false>(pp, nblk_used, block_pix, HEAD_C, prm.P, lane, s1, s2);      // (urnn_common.h: the order every finalizer shares)
+    fold_lane_chain<8>(pp, nblk_used, block_pix, HEAD_C, prm.P, lane, s1, s2);      // (urnn_common.h: the order every finalizer shares)
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         s1 += __shfl_xor(s1, m, 64);
@@ -434,240 +464,249 @@ __device__ __forceinline__ void head_fold_stats(const HeadParams &prm, int which
     var = var > 0.0 ? var : 0.0;
     mean_f = (float)mean;
     rstd_f = (float)(1.0 / sqrt(var + (double)prm.eps));
-    if (blockIdx.x == 0 && threadIdx.x == 0) {       // the backward pass reads the statistics from prm.stats
+    if (publish && lane == 0) {                      // the consumers (and the backward pass) read the statistics from prm.stats
         flag_nonfinite(prm.status, URNN_STATUS_HEAD, s1, s2);
         prm.stats[((size_t)which * prm.B + b) * 2] = mean_f;
         prm.stats[((size_t)which * prm.B + b) * 2 + 1] = rstd_f;
     }
 }
-// (mean, rstd) of tensor `which`: folded here (FIN) or read from prm.stats (a finalize launch ran: strips, phase-split callers)
-template <bool FIN, int V>
+// (mean, rstd) of tensor `which` as its producer's last block (or a finalize launch: strips, phase-split callers) left them
 __device__ __forceinline__ void head_stats(const HeadParams &prm, int which, int b, float &mean, float &rstd)
 {
-    if constexpr (FIN) head_fold_stats(prm, which, b, (prm.P + 256 * V - 1) / (256 * V), 256 * V, mean, rstd);
+    mean = prm.stats[(which * prm.B + b) * 2];
+    rstd = prm.stats[(which * prm.B + b) * 2 + 1];
+}
+
+// prediction layer of one branch: a[j] = sum_c w[c] x[c][pixel j] + bias -- the lane's four channels, then the four channel groups
+// (xor 16, xor 32: every lane of a pixel quad ends with the same bits)
+__device__ __forceinline__ f32x4 head_pred(const float *__restrict__ w, const float *__restrict__ bias, int cg, const f32x4 (&x)[4])
+{
+    f32x4 a;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float wv = w[4 * cg + i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = fmaf(wv, x[i][j], a[j]);
+    }
+    const float bv = bias[0];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        a[j] += __shfl_xor(a[j], 16, 64);
+        a[j] += __shfl_xor(a[j], 32, 64);
+        a[j] += bv;
+    }
+    return a;
+}
+
+// cls / masked reg / raw reg of the lane's four pixels: channel group 0 stores cls, 1 the masked depth, 2 the raw one
+template <bool AL>
+__device__ __forceinline__ void head_outputs(const HeadParams &prm, int b, const HeadLane &L, const f32x4 &acls, const f32x4 &areg)
+{
+    if (L.npx == 0 || L.cg == 3) return;
+    const int frame = prm.frame_index ? *prm.frame_index : 0;
+    const size_t obase = ((size_t)frame * prm.B + b) * prm.P + L.p;
+    f32x4 cls, reg, o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        cls[j] = sigmoidf_fast(acls[j]);
+        reg[j] = lrelu(areg[j], prm.slope);
+    }
+    float *dst;
+    if (L.cg == 0) {
+        dst = prm.out_cls;
+        o = cls;
+    } else if (L.cg == 1) {
+        dst = prm.out_masked;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = reg[j] * (cls[j] >= prm.cls_thred ? 1.f : 0.f);
+    } else {
+        dst = prm.out_raw;
+        o = reg;
+        if (!dst) return;
+    }
+    if constexpr (AL) *reinterpret_cast<f32x4u *>(dst + obase) = o;   // (the caller's frames: 4-byte alignment only)
     else {
-        mean = prm.stats[(which * prm.B + b) * 2];
-        rstd = prm.stats[(which * prm.B + b) * 2 + 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < L.npx) dst[obase + j] = o[j];
     }
 }
 
-template <int V>
+template <bool AL>
 __global__ __launch_bounds__(256) void head_k1(const HeadParams prm)
 {
     const int b = blockIdx.y;
-    const int p = (blockIdx.x * 256 + threadIdx.x) * V;
-    const bool live = p < prm.P;
+    const HeadLane L = head_lane(blockIdx.x, prm.P);
     if (prm.bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *prm.bump = *prm.frame_index + 1;      // the NEXT head's frame word (nothing in flight reads it)
-    float s = 0.f, q = 0.f;
-    if (live) {
-        float f[HEAD_C][V], u[HEAD_C][V];
-        head_load<V>(prm.feat + (size_t)b * HEAD_C * prm.P, prm.P, p, f);
-        head_conv<V>(prm.conv_w, f, u);
-        head_thread_stats<V>(u, s, q);
-    }
-    head_block_stats2(s, q, 0.f, 0.f, live ? HEAD_C * V : 0, false, HEAD_C * tile_valid(blockIdx.x, 256 * V, prm.P), head_partial(prm, 0, b, blockIdx.x),
+    f32x4 f[4], u[4];
+    head_load<AL>(prm.feat + (size_t)b * HEAD_C * prm.P, prm.P, L, f);
+    head_conv(head_weights(prm.conv_w), f, u);
+    float s, q;
+    head_lane_stats<AL>(u, L.npx, s, q);
+    head_block_stats2(s, q, 0.f, 0.f, 4 * L.npx, false, HEAD_C * tile_valid(blockIdx.x, HEAD_BLOCK_PIX, prm.P), head_partial(prm, 0, b, blockIdx.x),
                       nullptr);
 }
 
-template <int V, bool FIN>
+// TAIL: the producer of feat took the first norm's partials (urnn_tail.hip, prm.partial0) and head_k1 did not run: every wave folds them
+template <bool AL, bool TAIL>
 __global__ __launch_bounds__(256) void head_k2(const HeadParams prm)
 {
     const int b = blockIdx.y;
-    const int p = (blockIdx.x * 256 + threadIdx.x) * V;
-    const bool live = p < prm.P;
-    float sc = 0.f, qc = 0.f, sq = 0.f, qq = 0.f;
+    const HeadLane L = head_lane(blockIdx.x, prm.P);
+    const size_t CP = (size_t)HEAD_C * prm.P;
+    if (TAIL && prm.bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *prm.bump = *prm.frame_index + 1;   // (head_k1 did not run)
+    f32x4 f[4], t[4], g[4], bt[4], u[4];
+    head_load<AL>(prm.feat + b * CP, prm.P, L, f);               // the tile's rows travel while the statistics are folded
+    head_load<AL>(prm.ln_w, prm.P, L, g);
+    head_load<AL>(prm.ln_b, prm.P, L, bt);
+    const f32x4 a0 = head_weights(prm.conv_w), a1 = head_weights(prm.conv_w + 1 * HEAD_C * HEAD_C), a3 = head_weights(prm.conv_w + 3 * HEAD_C * HEAD_C);
     float m0, r0;
-    if (prm.bump && prm.partial0 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *prm.bump = *prm.frame_index + 1;   // (head_k1 did not run)
-    head_stats<FIN, V>(prm, 0, b, m0, r0);
-    if (live) {
-        const size_t CP = (size_t)HEAD_C * prm.P;
-        float f[HEAD_C][V], t[HEAD_C][V];
-        head_load<V>(prm.feat + b * CP, prm.P, p, f);
-        head_conv<V>(prm.conv_w, f, t);
-        head_ln_silu<V>(t, prm.ln_w, prm.ln_b, prm.P, p, m0, r0);
-        head_conv<V>(prm.conv_w + 1 * HEAD_C * HEAD_C, t, f);
-        head_thread_stats<V>(f, sc, qc);
-        head_store<V>(prm.u1 + b * CP, prm.P, p, f);
-        head_conv<V>(prm.conv_w + 3 * HEAD_C * HEAD_C, t, f);
-        head_thread_stats<V>(f, sq, qq);
-        head_store<V>(prm.u2 + b * CP, prm.P, p, f);
-    }
-    head_block_stats2(sc, qc, sq, qq, live ? HEAD_C * V : 0, true, HEAD_C * tile_valid(blockIdx.x, 256 * V, prm.P), head_partial(prm, 1, b, blockIdx.x),
+    if constexpr (TAIL) head_fold_stats(prm, 0, b, blockIdx.x == 0 && threadIdx.x < 64, m0, r0);
+    else head_stats(prm, 0, b, m0, r0);
+    head_conv(a0, f, t);
+    head_ln_silu(t, g, bt, m0, r0);
+    float sc, qc, sq, qq;
+    head_conv(a1, t, u);
+    head_lane_stats<AL>(u, L.npx, sc, qc);
+    head_store<AL>(prm.u1 + b * CP, prm.P, L, u);
+    head_conv(a3, t, u);
+    head_lane_stats<AL>(u, L.npx, sq, qq);
+    head_store<AL>(prm.u2 + b * CP, prm.P, L, u);
+    head_block_stats2(sc, qc, sq, qq, 4 * L.npx, true, HEAD_C * tile_valid(blockIdx.x, HEAD_BLOCK_PIX, prm.P), head_partial(prm, 1, b, blockIdx.x),
                       head_partial(prm, 3, b, blockIdx.x));
 }
 
-template <int V, bool FIN>
+// blockIdx.z: the branch (0: cls, norms 1 -> 2 in u1; 1: reg, norms 3 -> 4 in u2) -- twice the blocks at half the registers
+template <bool AL>
 __global__ __launch_bounds__(256) void head_k3(const HeadParams prm)
 {
-    const int b = blockIdx.y;
-    const int p = (blockIdx.x * 256 + threadIdx.x) * V;
-    const bool live = p < prm.P;
-    float sc = 0.f, qc = 0.f, sq = 0.f, qq = 0.f;
-    float m1, r1, m3, r3;
-    head_stats<FIN, V>(prm, 1, b, m1, r1);
-    head_stats<FIN, V>(prm, 3, b, m3, r3);
-    if (live) {
-        const size_t CP = (size_t)HEAD_C * prm.P;
-        float x[HEAD_C][V], u[HEAD_C][V];
-        head_load<V>(prm.u1 + b * CP, prm.P, p, x);
-        head_ln_silu<V>(x, prm.ln_w + 1 * CP, prm.ln_b + 1 * CP, prm.P, p, m1, r1);
-        head_conv<V>(prm.conv_w + 2 * HEAD_C * HEAD_C, x, u);
-        head_thread_stats<V>(u, sc, qc);
-        head_store<V>(prm.u1 + b * CP, prm.P, p, u);
-        head_load<V>(prm.u2 + b * CP, prm.P, p, x);
-        head_ln_silu<V>(x, prm.ln_w + 3 * CP, prm.ln_b + 3 * CP, prm.P, p, m3, r3);
-        head_conv<V>(prm.conv_w + 4 * HEAD_C * HEAD_C, x, u);
-        head_thread_stats<V>(u, sq, qq);
-        head_store<V>(prm.u2 + b * CP, prm.P, p, u);
-    }
-    head_block_stats2(sc, qc, sq, qq, live ? HEAD_C * V : 0, true, HEAD_C * tile_valid(blockIdx.x, 256 * V, prm.P), head_partial(prm, 2, b, blockIdx.x),
-                      head_partial(prm, 4, b, blockIdx.x));
+    const int b = blockIdx.y, br = blockIdx.z;
+    const HeadLane L = head_lane(blockIdx.x, prm.P);
+    const size_t CP = (size_t)HEAD_C * prm.P;
+    const int win = br ? 3 : 1, wout = br ? 4 : 2;
+    float *buf = (br ? prm.u2 : prm.u1) + b * CP;
+    f32x4 x[4], g[4], bt[4], u[4];
+    head_load<AL>(buf, prm.P, L, x);
+    head_load<AL>(prm.ln_w + win * CP, prm.P, L, g);
+    head_load<AL>(prm.ln_b + win * CP, prm.P, L, bt);
+    const f32x4 a = head_weights(prm.conv_w + wout * HEAD_C * HEAD_C);
+    float m, r;
+    head_stats(prm, win, b, m, r);
+    head_ln_silu(x, g, bt, m, r);
+    head_conv(a, x, u);
+    float s, q;
+    head_lane_stats<AL>(u, L.npx, s, q);
+    head_store<AL>(buf, prm.P, L, u);
+    head_block_stats2(s, q, 0.f, 0.f, 4 * L.npx, false, HEAD_C * tile_valid(blockIdx.x, HEAD_BLOCK_PIX, prm.P), head_partial(prm, wout, b, blockIdx.x),
+                      nullptr);
 }
 
-template <int V, bool FIN>
+template <bool AL>
 __global__ __launch_bounds__(256) void head_k4(const HeadParams prm)
 {
     const int b = blockIdx.y;
-    const int p = (blockIdx.x * 256 + threadIdx.x) * V;
-    float m2, r2, m4, r4;
-    head_stats<FIN, V>(prm, 2, b, m2, r2);       // (whole waves: before the tail threads leave)
-    head_stats<FIN, V>(prm, 4, b, m4, r4);
-    if (p >= prm.P) return;
+    const HeadLane L = head_lane(blockIdx.x, prm.P);
     const size_t CP = (size_t)HEAD_C * prm.P;
-    const int frame = prm.frame_index ? *prm.frame_index : 0;
-    const size_t obase = ((size_t)frame * prm.B + b) * prm.P + p;
-    float x[HEAD_C][V];
-    float cls[V], reg[V];
-    head_load<V>(prm.u1 + b * CP, prm.P, p, x);
-    head_ln_silu<V>(x, prm.ln_w + 2 * CP, prm.ln_b + 2 * CP, prm.P, p, m2, r2);
-#pragma unroll
-    for (int k = 0; k < V; ++k) {
-        float a = prm.cls_b[0];
-#pragma unroll
-        for (int c = 0; c < HEAD_C; ++c) a = fmaf(prm.cls_w[c], x[c][k], a);
-        cls[k] = sigmoidf_fast(a);
-    }
-    head_load<V>(prm.u2 + b * CP, prm.P, p, x);
-    head_ln_silu<V>(x, prm.ln_w + 4 * CP, prm.ln_b + 4 * CP, prm.P, p, m4, r4);
-#pragma unroll
-    for (int k = 0; k < V; ++k) {
-        float a = prm.reg_b[0];
-#pragma unroll
-        for (int c = 0; c < HEAD_C; ++c) a = fmaf(prm.reg_w[c], x[c][k], a);
-        reg[k] = lrelu(a, prm.slope);
-    }
-#pragma unroll
-    for (int k = 0; k < V; ++k) {
-        prm.out_masked[obase + k] = reg[k] * (cls[k] >= prm.cls_thred ? 1.f : 0.f);
-        prm.out_cls[obase + k] = cls[k];
-        if (prm.out_raw) prm.out_raw[obase + k] = reg[k];
-    }
+    f32x4 x1[4], g1[4], b1[4], x2[4], g2[4], b2[4];
+    head_load<AL>(prm.u1 + b * CP, prm.P, L, x1);
+    head_load<AL>(prm.ln_w + 2 * CP, prm.P, L, g1);
+    head_load<AL>(prm.ln_b + 2 * CP, prm.P, L, b1);
+    head_load<AL>(prm.u2 + b * CP, prm.P, L, x2);
+    head_load<AL>(prm.ln_w + 4 * CP, prm.P, L, g2);
+    head_load<AL>(prm.ln_b + 4 * CP, prm.P, L, b2);
+    float m2, r2, m4, r4;
+    head_stats(prm, 2, b, m2, r2);
+    head_stats(prm, 4, b, m4, r4);
+    head_ln_silu(x1, g1, b1, m2, r2);
+    const f32x4 acls = head_pred(prm.cls_w, prm.cls_b, L.cg, x1);
+    head_ln_silu(x2, g2, b2, m4, r4);
+    const f32x4 areg = head_pred(prm.reg_w, prm.reg_b, L.cg, x2);
+    head_outputs<AL>(prm, b, L, acls, areg);
 }
 
 // The whole head of a SMALL plane in one cooperative launch (URNN head of the 64x64 / 52x120 / 128x128 configs: four launches of 5-18 us
-// for microseconds of work): head_k1 | grid barrier | head_k2 | grid barrier | head_k3 | grid barrier | head_k4, a thread keeping its
+// for microseconds of work): head_k1 | grid barrier | head_k2 | grid barrier | head_k3 | grid barrier | head_k4, a lane keeping its
 // pixels' 2 x 16 branch activations in registers from pass to pass -- nothing but the partial LayerNorm statistics leaves the CU.
 // Same device functions, same block geometry and summation orders as the four kernels: identical bits.  Every block must be
 // resident (<= 256 blocks; with two kernel chains in flight the caller passes <= 128, as for the cooperative cells).
-template <int V>
+template <bool AL>
 __global__ __launch_bounds__(256) void head_coop_kernel(const HeadParams prm, unsigned *bar, int nblocks)
 {
     const int b = blockIdx.y;
-    const int p = (blockIdx.x * 256 + threadIdx.x) * V;
-    const bool live = p < prm.P;
+    const HeadLane L = head_lane(blockIdx.x, prm.P);
     const size_t CP = (size_t)HEAD_C * prm.P;
-    const int nvalid = HEAD_C * tile_valid(blockIdx.x, 256 * V, prm.P);
+    const int nvalid = HEAD_C * tile_valid(blockIdx.x, HEAD_BLOCK_PIX, prm.P);
     if (prm.bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *prm.bump = *prm.frame_index + 1;
-    float u1[HEAD_C][V], u2[HEAD_C][V];
+    const bool pub = blockIdx.x == 0 && threadIdx.x < 64;           // who leaves (mean, rstd) in prm.stats (the backward pass reads them)
+    f32x4 u1[4], u2[4], g[4], bt[4];
     // ---- pass 1 (head_k1): u0 = Ws . f and its statistics; u0 stays in u1
     {
-        float s = 0.f, q = 0.f;
-        if (live) {
-            float f[HEAD_C][V];
-            head_load<V>(prm.feat + b * CP, prm.P, p, f);
-            head_conv<V>(prm.conv_w, f, u1);
-            head_thread_stats<V>(u1, s, q);
-        }
-        head_block_stats2(s, q, 0.f, 0.f, live ? HEAD_C * V : 0, false, nvalid, head_partial(prm, 0, b, blockIdx.x), nullptr);
+        f32x4 f[4];
+        head_load<AL>(prm.feat + b * CP, prm.P, L, f);
+        head_conv(head_weights(prm.conv_w), f, u1);
+        float s, q;
+        head_lane_stats<AL>(u1, L.npx, s, q);
+        head_block_stats2(s, q, 0.f, 0.f, 4 * L.npx, false, nvalid, head_partial(prm, 0, b, blockIdx.x), nullptr);
     }
+    head_load<AL>(prm.ln_w, prm.P, L, g);                          // (the next pass's affine rows travel across the barrier)
+    head_load<AL>(prm.ln_b, prm.P, L, bt);
     coop_grid_barrier(bar, (unsigned)nblocks, prm.status);
     // ---- pass 2 (head_k2): t = SiLU(LN0(u0)); u1 = Wc1 . t, u2 = Wq1 . t
     {
         float m0, r0;
-        head_stats<true, V>(prm, 0, b, m0, r0);
-        float sc = 0.f, qc = 0.f, sq = 0.f, qq = 0.f;
-        if (live) {
-            float t[HEAD_C][V];
+        head_fold_stats(prm, 0, b, pub, m0, r0);
+        float sc, qc, sq, qq;
+        f32x4 t[4];
 #pragma unroll
-            for (int c = 0; c < HEAD_C; ++c)
-#pragma unroll
-                for (int k = 0; k < V; ++k) t[c][k] = u1[c][k];
-            head_ln_silu<V>(t, prm.ln_w, prm.ln_b, prm.P, p, m0, r0);
-            head_conv<V>(prm.conv_w + 1 * HEAD_C * HEAD_C, t, u1);
-            head_thread_stats<V>(u1, sc, qc);
-            head_conv<V>(prm.conv_w + 3 * HEAD_C * HEAD_C, t, u2);
-            head_thread_stats<V>(u2, sq, qq);
-        }
-        head_block_stats2(sc, qc, sq, qq, live ? HEAD_C * V : 0, true, nvalid, head_partial(prm, 1, b, blockIdx.x), head_partial(prm, 3, b, blockIdx.x));
+        for (int i = 0; i < 4; ++i) t[i] = u1[i];
+        head_ln_silu(t, g, bt, m0, r0);
+        head_conv(head_weights(prm.conv_w + 1 * HEAD_C * HEAD_C), t, u1);
+        head_lane_stats<AL>(u1, L.npx, sc, qc);
+        head_conv(head_weights(prm.conv_w + 3 * HEAD_C * HEAD_C), t, u2);
+        head_lane_stats<AL>(u2, L.npx, sq, qq);
+        head_block_stats2(sc, qc, sq, qq, 4 * L.npx, true, nvalid, head_partial(prm, 1, b, blockIdx.x), head_partial(prm, 3, b, blockIdx.x));
     }
+    head_load<AL>(prm.ln_w + 1 * CP, prm.P, L, g);
+    head_load<AL>(prm.ln_b + 1 * CP, prm.P, L, bt);
     coop_grid_barrier(bar, (unsigned)nblocks, prm.status);
     // ---- pass 3 (head_k3): u1 <- Wc2 . SiLU(LN1(u1)), u2 <- Wq2 . SiLU(LN3(u2))
     {
         float m1, r1, m3, r3;
-        head_stats<true, V>(prm, 1, b, m1, r1);
-        head_stats<true, V>(prm, 3, b, m3, r3);
-        float sc = 0.f, qc = 0.f, sq = 0.f, qq = 0.f;
-        if (live) {
-            float x[HEAD_C][V];
+        head_fold_stats(prm, 1, b, pub, m1, r1);
+        head_fold_stats(prm, 3, b, pub, m3, r3);
+        float sc, qc, sq, qq;
+        f32x4 x[4];
 #pragma unroll
-            for (int c = 0; c < HEAD_C; ++c)
+        for (int i = 0; i < 4; ++i) x[i] = u1[i];
+        head_ln_silu(x, g, bt, m1, r1);
+        head_load<AL>(prm.ln_w + 3 * CP, prm.P, L, g);
+        head_load<AL>(prm.ln_b + 3 * CP, prm.P, L, bt);
+        head_conv(head_weights(prm.conv_w + 2 * HEAD_C * HEAD_C), x, u1);
+        head_lane_stats<AL>(u1, L.npx, sc, qc);
 #pragma unroll
-                for (int k = 0; k < V; ++k) x[c][k] = u1[c][k];
-            head_ln_silu<V>(x, prm.ln_w + 1 * CP, prm.ln_b + 1 * CP, prm.P, p, m1, r1);
-            head_conv<V>(prm.conv_w + 2 * HEAD_C * HEAD_C, x, u1);
-            head_thread_stats<V>(u1, sc, qc);
-#pragma unroll
-            for (int c = 0; c < HEAD_C; ++c)
-#pragma unroll
-                for (int k = 0; k < V; ++k) x[c][k] = u2[c][k];
-            head_ln_silu<V>(x, prm.ln_w + 3 * CP, prm.ln_b + 3 * CP, prm.P, p, m3, r3);
-            head_conv<V>(prm.conv_w + 4 * HEAD_C * HEAD_C, x, u2);
-            head_thread_stats<V>(u2, sq, qq);
-        }
-        head_block_stats2(sc, qc, sq, qq, live ? HEAD_C * V : 0, true, nvalid, head_partial(prm, 2, b, blockIdx.x), head_partial(prm, 4, b, blockIdx.x));
+        for (int i = 0; i < 4; ++i) x[i] = u2[i];
+        head_ln_silu(x, g, bt, m3, r3);
+        head_conv(head_weights(prm.conv_w + 4 * HEAD_C * HEAD_C), x, u2);
+        head_lane_stats<AL>(u2, L.npx, sq, qq);
+        head_block_stats2(sc, qc, sq, qq, 4 * L.npx, true, nvalid, head_partial(prm, 2, b, blockIdx.x), head_partial(prm, 4, b, blockIdx.x));
     }
+    head_load<AL>(prm.ln_w + 2 * CP, prm.P, L, g);
+    head_load<AL>(prm.ln_b + 2 * CP, prm.P, L, bt);
     coop_grid_barrier(bar, (unsigned)nblocks, prm.status);
     // ---- pass 4 (head_k4): predictions + wet / dry mask
     {
         float m2, r2, m4, r4;
-        head_stats<true, V>(prm, 2, b, m2, r2);
-        head_stats<true, V>(prm, 4, b, m4, r4);
-        if (!live) return;
-        const int frame = prm.frame_index ? *prm.frame_index : 0;
-        const size_t obase = ((size_t)frame * prm.B + b) * prm.P + p;
-        float cls[V], reg[V];
-        head_ln_silu<V>(u1, prm.ln_w + 2 * CP, prm.ln_b + 2 * CP, prm.P, p, m2, r2);
-#pragma unroll
-        for (int k = 0; k < V; ++k) {
-            float a = prm.cls_b[0];
-#pragma unroll
-            for (int c = 0; c < HEAD_C; ++c) a = fmaf(prm.cls_w[c], u1[c][k], a);
-            cls[k] = sigmoidf_fast(a);
-        }
-        head_ln_silu<V>(u2, prm.ln_w + 4 * CP, prm.ln_b + 4 * CP, prm.P, p, m4, r4);
-#pragma unroll
-        for (int k = 0; k < V; ++k) {
-            float a = prm.reg_b[0];
-#pragma unroll
-            for (int c = 0; c < HEAD_C; ++c) a = fmaf(prm.reg_w[c], u2[c][k], a);
-            reg[k] = lrelu(a, prm.slope);
-        }
-#pragma unroll
-        for (int k = 0; k < V; ++k) {
-            prm.out_masked[obase + k] = reg[k] * (cls[k] >= prm.cls_thred ? 1.f : 0.f);
-            prm.out_cls[obase + k] = cls[k];
-            if (prm.out_raw) prm.out_raw[obase + k] = reg[k];
-        }
+        head_fold_stats(prm, 2, b, pub, m2, r2);
+        head_fold_stats(prm, 4, b, pub, m4, r4);
+        head_ln_silu(u1, g, bt, m2, r2);
+        head_load<AL>(prm.ln_w + 4 * CP, prm.P, L, g);
+        head_load<AL>(prm.ln_b + 4 * CP, prm.P, L, bt);
+        const f32x4 acls = head_pred(prm.cls_w, prm.cls_b, L.cg, u1);
+        head_ln_silu(u2, g, bt, m4, r4);
+        const f32x4 areg = head_pred(prm.reg_w, prm.reg_b, L.cg, u2);
+        head_outputs<AL>(prm, b, L, acls, areg);
     }
 }
 
@@ -679,7 +718,7 @@ __global__ __launch_bounds__(64) void ln_finalize_kernel(const HeadParams prm, i
     const int lane = threadIdx.x;
     const float *pp = prm.partial + (((size_t)which * prm.B + b) * prm.nblk) * 2;
     double s1, s2;
-    fold_lane_chain<16, false>(pp, nblk_used, block_pix, HEAD_C, prm.P, lane, s1, s2);      // (urnn_common.h: the order every finalizer shares)
+    fold_lane_chain<16>(pp, nblk_used, block_pix, HEAD_C, prm.P, lane, s1, s2);      // (urnn_common.h: the order every finalizer shares)
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         s1 += __shfl_xor(s1, m, 64);
@@ -697,40 +736,30 @@ __global__ __launch_bounds__(64) void ln_finalize_kernel(const HeadParams prm, i
 }
 
 int urnn_head_nblk(int P) { const int n = (P + 255) / 256; return n < 2 ? 2 : n; }   // >= 2: the strip mode's two pseudo-blocks
-// pixels per thread: 8- / 4-byte accesses (16-byte ones put head_k3 / k4 at 256 registers, one wave per SIMD: slower)
-static inline int head_vec(int P) { return P % 2 == 0 ? 2 : 1; }   // (4-byte accesses on even planes measured the same: 1241 vs 1245 frames/s)
-int urnn_head_nblk_used(int P) { const int v = head_vec(P); return (P + 256 * v - 1) / (256 * v); }
-int urnn_head_block_pix(int P) { return 256 * head_vec(P); }
+int urnn_head_nblk_used(int P) { return (P + HEAD_BLOCK_PIX - 1) / HEAD_BLOCK_PIX; }
+int urnn_head_block_pix(int) { return HEAD_BLOCK_PIX; }
 
-template <int V>
+template <bool AL>
 static hipError_t launch_head_v(const HeadParams &p, int mask, hipStream_t st)
 {
-    const int nb = (p.P + 256 * V - 1) / (256 * V);
-    const int fin = p.Pglobal > 0 ? 2 : nb;          // strip mode: the partials hold the all-reduced totals as two pseudo-blocks
-    const int bpix = p.Pglobal > 0 ? 0 : 256 * V;    //             ... which are raw (sum, sum of squares)
-    dim3 grid(nb, p.B), blk(256);
-    // whole head in one call, one device: the three finalize launches are folded into their consumers (identical bits; development
-    // knob URNN_TUNE_FUSE_HEAD=0 keeps them).  Strips / phase-split callers exchange or inspect the statistics in between.
-    static const bool fuse_on = urnn_tune("URNN_TUNE_FUSE_HEAD", 1) != 0;
-    const int all = URNN_HEAD_K1 | URNN_HEAD_F1 | URNN_HEAD_K2 | URNN_HEAD_F2 | URNN_HEAD_K3 | URNN_HEAD_F3 | URNN_HEAD_K4;
-    if (fuse_on && (mask & all) == all && p.Pglobal <= 0) {
-        if (!p.partial0) hipLaunchKernelGGL(head_k1<V>, grid, blk, 0, st, p);
-        hipLaunchKernelGGL((head_k2<V, true>), grid, blk, 0, st, p);
-        hipLaunchKernelGGL((head_k3<V, true>), grid, blk, 0, st, p);
-        hipLaunchKernelGGL((head_k4<V, true>), grid, blk, 0, st, p);
-        return hipGetLastError();
+    const int nb = urnn_head_nblk_used(p.P);
+    const int fin = p.Pglobal > 0 ? 2 : nb;                  // strip mode: the partials hold the all-reduced totals as two pseudo-blocks
+    const int bpix = p.Pglobal > 0 ? 0 : HEAD_BLOCK_PIX;     //             ... which are raw (sum, sum of squares)
+    dim3 grid(nb, p.B), grid3(nb, p.B, 2), blk(256);
+    const bool tail = p.partial0 != nullptr;                 // the producer of feat took norm 0's partials: no head_k1, head_k2 folds them
+    if ((mask & URNN_HEAD_K1) && !tail) hipLaunchKernelGGL(head_k1<AL>, grid, blk, 0, st, p);
+    if ((mask & URNN_HEAD_F1) && !tail) hipLaunchKernelGGL(ln_finalize_kernel, dim3(p.B, 1), dim3(64), 0, st, p, 0, 1, fin, bpix);
+    if (mask & URNN_HEAD_K2) {
+        if (tail) hipLaunchKernelGGL((head_k2<AL, true>), grid, blk, 0, st, p);
+        else hipLaunchKernelGGL((head_k2<AL, false>), grid, blk, 0, st, p);
     }
-    if (mask & URNN_HEAD_K1) hipLaunchKernelGGL(head_k1<V>, grid, blk, 0, st, p);
-    if (mask & URNN_HEAD_F1) hipLaunchKernelGGL(ln_finalize_kernel, dim3(p.B, 1), dim3(64), 0, st, p, 0, 1, fin, bpix);
-    if (mask & URNN_HEAD_K2) hipLaunchKernelGGL((head_k2<V, false>), grid, blk, 0, st, p);
     if (mask & URNN_HEAD_F2) hipLaunchKernelGGL(ln_finalize_kernel, dim3(p.B, 2), dim3(64), 0, st, p, 1, 2, fin, bpix);
-    if (mask & URNN_HEAD_K3) hipLaunchKernelGGL((head_k3<V, false>), grid, blk, 0, st, p);
+    if (mask & URNN_HEAD_K3) hipLaunchKernelGGL(head_k3<AL>, grid3, blk, 0, st, p);
     if (mask & URNN_HEAD_F3) hipLaunchKernelGGL(ln_finalize_kernel, dim3(p.B, 2), dim3(64), 0, st, p, 2, 2, fin, bpix);
-    if (mask & URNN_HEAD_K4) hipLaunchKernelGGL((head_k4<V, false>), grid, blk, 0, st, p);
+    if (mask & URNN_HEAD_K4) hipLaunchKernelGGL(head_k4<AL>, grid, blk, 0, st, p);
     return hipGetLastError();
 }
 
-// blocks of the cooperative head launch for a plane of P pixels and B samples (the caller decides whether that many may be resident)
 // blocks a cooperative head launch takes; 0 when this device could not hold them all at once (one 256-thread block per CU is the
 // residency the callers' rules are written for)
 int urnn_head_coop_blocks(int B, int P)
@@ -741,17 +770,17 @@ int urnn_head_coop_blocks(int B, int P)
 
 hipError_t urnn_launch_head_coop(const HeadParams &p, unsigned *bar, hipStream_t st)
 {
-    const int v = head_vec(p.P), nb = urnn_head_nblk_used(p.P);
+    const int nb = urnn_head_nblk_used(p.P);
     const dim3 grid(nb, p.B), blk(256);
-    if (v == 2) hipLaunchKernelGGL(head_coop_kernel<2>, grid, blk, 0, st, p, bar, nb * p.B);
-    else hipLaunchKernelGGL(head_coop_kernel<1>, grid, blk, 0, st, p, bar, nb * p.B);
+    if (p.P % 4 == 0) hipLaunchKernelGGL(head_coop_kernel<true>, grid, blk, 0, st, p, bar, nb * p.B);
+    else hipLaunchKernelGGL(head_coop_kernel<false>, grid, blk, 0, st, p, bar, nb * p.B);
     return hipGetLastError();
 }
 
 hipError_t urnn_launch_head(const HeadParams &p, int mask, hipStream_t st)
 {
-    if (p.P % 2 == 0) return launch_head_v<2>(p, mask, st);
-    return launch_head_v<1>(p, mask, st);
+    if (p.P % 4 == 0) return launch_head_v<true>(p, mask, st);
+    return launch_head_v<false>(p, mask, st);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
