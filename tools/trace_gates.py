@@ -28,12 +28,17 @@ for _ in range(3):
 nw = 512 * 8
 buf = torch.zeros(nw * 8 * 4, dtype=torch.int64, device=dev)
 L = _lib.lib()
-L.urnn_debug_set_trace.argtypes = [ctypes.c_void_p]
-assert L.urnn_debug_set_trace(buf.data_ptr()) == 0
+setters = [getattr(L, "urnn_debug_set_trace_" + tu, None) for tu in ("urnn_gemm", "urnn_gemm_gates", "urnn_gemm_cand", "urnn_gemm_deconv")]
+setters = [f for f in setters if f is not None]          # one trace pointer per translation unit of the GEMM template
+assert setters, "build the trace library first: python tools/build_variants.py trace; URNN_LIB=u-rnn_amd/liburnn_hip_trace.so"
+for f in setters:
+    f.argtypes = [ctypes.c_void_p]
+    assert f(buf.data_ptr()) == 0
 torch.cuda.synchronize()
 cell.step(x, e, h, out=tmp, phases=phase, ws=ws)
 torch.cuda.synchronize()
-L.urnn_debug_set_trace(0)
+for f in setters:
+    f(0)
 t = buf.cpu().numpy().reshape(nw, 8, 4).astype(np.float64)
 used = t[:, :, 3] > 0
 # s_memtime bases differ across the chip: reference every wave to the earliest stamp of its own block

@@ -1157,7 +1157,7 @@ static HeadBwdWs carve_head_bwd(void *base, int B, long P)
     w.save = takef((size_t)6 * B * 16 * P);
     w.ds = takef((size_t)B * 16 * P);
     w.draw = takef((size_t)B * P);
-    w.partial = takef((size_t)B * ((P + 255) / 256) * 2);
+    w.partial = takef((size_t)B * 16 * urnn_train_head_ln_chunks((int)P) * 2);      // head_ln_bwd_a_kernel: one pair per (sample, channel, 1024-pixel chunk)
     w.coef = takef((size_t)B * 2);
     {
         const size_t a = urnn_train_wgrad_partial_floats(B, 16, 16, (int)P), b = urnn_train_wgrad_partial_floats(B, 1, 16, (int)P);

@@ -255,6 +255,7 @@ hipError_t urnn_train_head_save(const float *feat, const float *conv_w, const fl
                                 int P, float *save, hipStream_t st);
 hipError_t urnn_train_head_pred_bwd(const float *dout, const float *cls, const float *reg, const float *reg_w, float thr, float slope,
                                     int B, int P, float *draw, float *ds, hipStream_t st);
+int urnn_train_head_ln_chunks(int P);   // blocks per channel plane of the head's LayerNorm backward (the size of its partial buffer)
 hipError_t urnn_train_head_ln_bwd(float *ds, const float *u, const float *g, const float *bt, const float *stats, int B, int P, float *dg,
                                   float *dbt, int accumulate, float *partial, float *coef, hipStream_t st);
 int urnn_train_loss_nblk(long n);

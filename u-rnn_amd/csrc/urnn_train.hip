@@ -133,6 +133,34 @@ __global__ __launch_bounds__(64) void gn_bwd_sums_coef_kernel(const float *__res
     }
 }
 
+// The streaming kernels of the backward pass walk a channel plane in QUADS of four consecutive pixels -- 16-byte accesses at 4-byte
+// alignment (the quarter-resolution planes of 125 x 125 pixels start at every 4-byte phase); the last P & 3 pixels go one each to
+// the first threads of the plane's first block.  Rounds 1-4 moved one float per thread and access: 4-byte streams reach 3.4-4.1 TB/s
+// on this chip where 16-byte ones reach 5.2.  URNN_PLANE_WALK(P, BODY): BODY(n_tag, p) handles N = 4 or 1 pixels at p.
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+template <int N>
+__device__ __forceinline__ void ldn(const float *p, float (&v)[N])
+{
+    if constexpr (N == 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4u *>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+        v[0] = p[0];
+    }
+}
+template <int N>
+__device__ __forceinline__ void stn(float *p, const float (&v)[N])
+{
+    if constexpr (N == 4) *reinterpret_cast<f32x4u *>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    else p[0] = v[0];
+}
+#define URNN_PLANE_WALK(P_, BODY)                                                                                       \
+    do {                                                                                                                \
+        const int Pq_ = (P_) & ~3;                                                                                      \
+        for (int p_ = (blockIdx.x * 256 + threadIdx.x) * 4; p_ < Pq_; p_ += gridDim.x * 1024) BODY(std::integral_constant<int, 4>{}, p_); \
+        if (blockIdx.x == 0 && (int)threadIdx.x < (P_) - Pq_) BODY(std::integral_constant<int, 1>{}, Pq_ + (int)threadIdx.x);               \
+    } while (0)
+
 // dv = rstd * (gamma * dy - m1 - xhat * m2), in place over dy.  grid (chunks, B*C)
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(float *dy, const float *__restrict__ v, const float *__restrict__ stat,
                                                            const float *__restrict__ coef, const float *__restrict__ gamma, int C, int P)
@@ -144,10 +172,19 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(float *dy, const floa
     const float gm = gamma[c];
     float *dp = dy + (size_t)bc * P;
     const float *vp = v + (size_t)bc * P;
-    for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += gridDim.x * 256) {
-        const float xh = (vp[p] - mu) * rs;
-        dp[p] = rs * (gm * dp[p] - m1 - xh * m2);
-    }
+    auto body = [&](auto n_tag, int p) {
+        constexpr int N = decltype(n_tag)::value;
+        float d[N], x[N];
+        ldn<N>(dp + p, d);
+        ldn<N>(vp + p, x);
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const float xh = (x[k] - mu) * rs;
+            d[k] = rs * (gm * d[k] - m1 - xh * m2);
+        }
+        stn<N>(dp + p, d);
+    };
+    URNN_PLANE_WALK(P, body);
 }
 
 // Blend backward (h' = (1 - z) h + z n,  z = sigmoid(GN(gz)),  n = tanh(GN(c))):
@@ -196,24 +233,45 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(const float *__restrict_
     const float *dd4 = dout4 ? dout4 + (size_t)bc * P : nullptr;
     float *o2 = dy2 + (size_t)bc * P, *o1 = dy1 + ((size_t)b * 2 * F + f) * P, *oh = dh + (size_t)bc * P;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};       // sum dyz, sum dyz * xhat1, sum dy2, sum dy2 * xhat2
-    for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += gridDim.x * 256) {
-        const float gv = gz[p], cv = cc[p];
-        const float z = 1.0f / (1.0f + expf(-(gv * s1 + t1)));
-        const float n = tanhf(cv * s2 + t2);
-        float d = dd[p];
-        if (dd2) d += dd2[p];
-        if (dd3) d += dd3[p];
-        if (dd4) d += dd4[p];
-        const float a2 = d * z * (1.0f - n * n);
-        const float a1 = d * (n - hh[p]) * z * (1.0f - z);
-        o2[p] = a2;
-        o1[p] = a1;
-        oh[p] = d * (1.0f - z);
-        acc[0] += a1;
-        acc[1] += a1 * ((gv - mu1) * rs1);
-        acc[2] += a2;
-        acc[3] += a2 * ((cv - mu2) * rs2);
-    }
+    auto body = [&](auto n_tag, int p) {
+        constexpr int N = decltype(n_tag)::value;
+        float gv[N], cv[N], d[N], hv[N], t[N], a1[N], a2[N], oh_[N];
+        ldn<N>(gz + p, gv);
+        ldn<N>(cc + p, cv);
+        ldn<N>(dd + p, d);
+        ldn<N>(hh + p, hv);
+        if (dd2) {
+            ldn<N>(dd2 + p, t);
+#pragma unroll
+            for (int k = 0; k < N; ++k) d[k] += t[k];
+        }
+        if (dd3) {
+            ldn<N>(dd3 + p, t);
+#pragma unroll
+            for (int k = 0; k < N; ++k) d[k] += t[k];
+        }
+        if (dd4) {
+            ldn<N>(dd4 + p, t);
+#pragma unroll
+            for (int k = 0; k < N; ++k) d[k] += t[k];
+        }
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const float z = 1.0f / (1.0f + expf(-(gv[k] * s1 + t1)));
+            const float n = tanhf(cv[k] * s2 + t2);
+            a2[k] = d[k] * z * (1.0f - n * n);
+            a1[k] = d[k] * (n - hv[k]) * z * (1.0f - z);
+            oh_[k] = d[k] * (1.0f - z);
+            acc[0] += a1[k];
+            acc[1] += a1[k] * ((gv[k] - mu1) * rs1);
+            acc[2] += a2[k];
+            acc[3] += a2[k] * ((cv[k] - mu2) * rs2);
+        }
+        stn<N>(o2 + p, a2);
+        stn<N>(o1 + p, a1);
+        stn<N>(oh + p, oh_);
+    };
+    URNN_PLANE_WALK(P, body);
     block_partials(acc, 4, part1 + (((size_t)b * 2 * F + f) * gridDim.x + blockIdx.x) * 2, part2 + ((size_t)bc * gridDim.x + blockIdx.x) * 2);
 }
 
@@ -225,7 +283,16 @@ __global__ __launch_bounds__(256) void reset_gate_kernel(const float *__restrict
     const float s = ss1[((size_t)b * 2 * F + F + f) * 2], t = ss1[((size_t)b * 2 * F + F + f) * 2 + 1];
     const float *gr = g1 + ((size_t)b * 2 * F + F + f) * P, *hh = h + (size_t)bc * P;
     float *o = rh + (size_t)bc * P;
-    for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += gridDim.x * 256) o[p] = hh[p] / (1.0f + expf(-(gr[p] * s + t)));
+    auto body = [&](auto n_tag, int p) {
+        constexpr int N = decltype(n_tag)::value;
+        float gv[N], hv[N];
+        ldn<N>(gr + p, gv);
+        ldn<N>(hh + p, hv);
+#pragma unroll
+        for (int k = 0; k < N; ++k) hv[k] = hv[k] / (1.0f + expf(-(gv[k] * s + t)));
+        stn<N>(o + p, hv);
+    };
+    URNN_PLANE_WALK(P, body);
 }
 
 // From d(r*h) (rows K-F.. of dA2, batch stride K*P): dyr = drh * h * r (1 - r) -> dy1[:, F:];  dh += drh * r
@@ -242,16 +309,25 @@ __global__ __launch_bounds__(256) void reset_gate_bwd_kernel(const float *__rest
     const float *dd = drh + (size_t)b * drh_bs + (size_t)f * P;
     float *o1 = dy1 + ((size_t)b * 2 * F + F + f) * P, *oh = dh + (size_t)bc * P;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += gridDim.x * 256) {
-        const float gv = gr[p];
-        const float r = 1.0f / (1.0f + expf(-(gv * s + t)));
-        const float d = dd[p];
-        const float a = d * hh[p] * r * (1.0f - r);
-        o1[p] = a;
-        oh[p] += d * r;
-        acc[0] += a;
-        acc[1] += a * ((gv - mu) * rs);
-    }
+    auto body = [&](auto n_tag, int p) {
+        constexpr int N = decltype(n_tag)::value;
+        float gv[N], d[N], hv[N], a[N], dhv[N];
+        ldn<N>(gr + p, gv);
+        ldn<N>(dd + p, d);
+        ldn<N>(hh + p, hv);
+        ldn<N>(oh + p, dhv);
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const float r = 1.0f / (1.0f + expf(-(gv[k] * s + t)));
+            a[k] = d[k] * hv[k] * r * (1.0f - r);
+            dhv[k] += d[k] * r;
+            acc[0] += a[k];
+            acc[1] += a[k] * ((gv[k] - mu) * rs);
+        }
+        stn<N>(o1 + p, a);
+        stn<N>(oh + p, dhv);
+    };
+    URNN_PLANE_WALK(P, body);
     block_partials(acc, 2, part1 + (((size_t)b * 2 * F + F + f) * gridDim.x + blockIdx.x) * 2, nullptr);
 }
 
@@ -263,10 +339,26 @@ __global__ __launch_bounds__(256) void add_slices_kernel(float *out, long out_bs
     float *o = out + (size_t)b * out_bs + (size_t)c * P;
     const float *pa = a + (size_t)b * a_bs + (size_t)c * P;
     const float *pb = a2 ? a2 + (size_t)b * a2_bs + (size_t)c * P : nullptr;
-    for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += gridDim.x * 256) {
-        float v = pa[p] + (pb ? pb[p] : 0.f);
-        o[p] = accumulate ? o[p] + v : v;
-    }
+    auto body = [&](auto n_tag, int p) {
+        constexpr int N = decltype(n_tag)::value;
+        float v[N], t[N];
+        ldn<N>(pa + p, v);
+        if (pb) {
+            ldn<N>(pb + p, t);
+#pragma unroll
+            for (int k = 0; k < N; ++k) v[k] = v[k] + t[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < N; ++k) v[k] = v[k] + 0.f;
+        }
+        if (accumulate) {
+            ldn<N>(o + p, t);
+#pragma unroll
+            for (int k = 0; k < N; ++k) v[k] = t[k] + v[k];
+        }
+        stn<N>(o + p, v);
+    };
+    URNN_PLANE_WALK(P, body);
 }
 
 // Zero-fill as a kernel.  hipMemsetAsync captured into a hipGraph did not execute on replay (ROCm 7.0: the classification
@@ -810,17 +902,25 @@ __global__ __launch_bounds__(256) void lrelu_pool_bwd_kernel(float *u, const flo
     const int bc = blockIdx.y;
     float *up = u + (size_t)bc * P;
     const float *dp = dy + (size_t)bc * (pool ? P2 : P);
-    for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += gridDim.x * 256) {
-        float d;
+    auto body = [&](auto n_tag, int p) {
+        constexpr int N = decltype(n_tag)::value;
+        float uv[N], d[N];
+        ldn<N>(up + p, uv);
         if (pool) {
-            const int y = p / W, x = p - y * W;
-            const int y2 = y >> 1, x2 = x >> 1;
-            d = (y2 * W2 + x2 < P2 && x2 < W2) ? 0.25f * dp[y2 * W2 + x2] : 0.f;   // odd last row / column: dropped by the floor pooling
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const int y = (p + k) / W, x = (p + k) - y * W;
+                const int y2 = y >> 1, x2 = x >> 1;
+                d[k] = (y2 * W2 + x2 < P2 && x2 < W2) ? 0.25f * dp[y2 * W2 + x2] : 0.f;   // odd last row / column: dropped by the floor pooling
+            }
         } else {
-            d = dp[p];
+            ldn<N>(dp + p, d);
         }
-        up[p] = up[p] >= 0.f ? d : d * slope;
-    }
+#pragma unroll
+        for (int k = 0; k < N; ++k) uv[k] = uv[k] >= 0.f ? d[k] : d[k] * slope;
+        stn<N>(up + p, uv);
+    };
+    URNN_PLANE_WALK(P, body);
 }
 
 // Deconv: D4[b][(a*2+bb)*Cout + co][i*W + j] = dy[b][co][2i+a][2j+bb] * lrelu'(y[...])   (y = forward output, sign-preserving)
@@ -833,6 +933,25 @@ __global__ __launch_bounds__(256) void deconv_unshuffle_bwd_kernel(const float *
     const float *dp = dy + ((size_t)b * Cout + co) * 4 * P, *yp = y + ((size_t)b * Cout + co) * 4 * P;
     float *o = d4 + (size_t)bn * P;
     const int W2 = 2 * W;
+    if (W % 4 == 0) {
+        // four consecutive input pixels lie in one row: their outputs are every second float of eight consecutive ones
+        for (int p = (blockIdx.x * 256 + threadIdx.x) * 4; p < P; p += gridDim.x * 1024) {
+            const int i = p / W, j = p - i * W;
+            const size_t q = (size_t)(2 * i + a) * W2 + 2 * j;
+            float y8[8], d8[8], ov[4];
+            ldn<4>(yp + q, *reinterpret_cast<float(*)[4]>(y8));
+            ldn<4>(yp + q + 4, *reinterpret_cast<float(*)[4]>(y8 + 4));
+            ldn<4>(dp + q, *reinterpret_cast<float(*)[4]>(d8));
+            ldn<4>(dp + q + 4, *reinterpret_cast<float(*)[4]>(d8 + 4));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float yv = bb ? y8[2 * k + 1] : y8[2 * k], dv = bb ? d8[2 * k + 1] : d8[2 * k];
+                ov[k] = yv >= 0.f ? dv : dv * slope;
+            }
+            stn<4>(o + p, ov);
+        }
+        return;
+    }
     for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += gridDim.x * 256) {
         const int i = p / W, j = p - i * W;
         const size_t q = (size_t)(2 * i + a) * W2 + 2 * j + bb;
@@ -953,53 +1072,88 @@ __global__ __launch_bounds__(256) void head_train_save_kernel(const float *__res
     }
 }
 
-// prediction layer: draw = dout * mask * lrelu'(reg);  ds[c] = w_r[c] * draw
+// prediction layer: draw = dout * mask * lrelu'(reg);  ds[c] = w_r[c] * draw.  grid (chunks, B), pixels in quads (URNN_PLANE_WALK)
 __global__ __launch_bounds__(256) void head_pred_bwd_kernel(const float *__restrict__ dout, const float *__restrict__ cls,
                                                             const float *__restrict__ reg, const float *__restrict__ reg_w, float thr,
                                                             float slope, int P, float *__restrict__ draw, float *__restrict__ ds)
 {
-    const int p = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    if (p >= P) return;
-    const size_t i = (size_t)b * P + p;
-    const float d = (cls[i] >= thr ? dout[i] : 0.f) * (reg[i] >= 0.f ? 1.f : slope);
-    draw[i] = d;
+    const int b = blockIdx.y;
+    const size_t base = (size_t)b * P;
+    float w[HC];
 #pragma unroll
-    for (int c = 0; c < HC; ++c) ds[((size_t)b * HC + c) * P + p] = reg_w[c] * d;
+    for (int c = 0; c < HC; ++c) w[c] = reg_w[c];
+    auto body = [&](auto n_tag, int p) {
+        constexpr int N = decltype(n_tag)::value;
+        float cv[N], dv[N], rv[N], d[N], o[N];
+        ldn<N>(cls + base + p, cv);
+        ldn<N>(dout + base + p, dv);
+        ldn<N>(reg + base + p, rv);
+#pragma unroll
+        for (int k = 0; k < N; ++k) d[k] = (cv[k] >= thr ? dv[k] : 0.f) * (rv[k] >= 0.f ? 1.f : slope);
+        stn<N>(draw + base + p, d);
+#pragma unroll
+        for (int c = 0; c < HC; ++c) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) o[k] = w[c] * d[k];
+            stn<N>(ds + ((size_t)b * HC + c) * P + p, o);
+        }
+    };
+    URNN_PLANE_WALK(P, body);
 }
 
 // LayerNorm + SiLU backward, first half: dy = ds * SiLU'(y); dgamma/dbeta (element-wise, summed over samples);
-// dxhat = dy * gamma -> ds (in place); per-sample partial sums of dxhat and dxhat * xhat.  grid (chunks); loops over samples.
+// dxhat = dy * gamma -> ds (in place); per-sample partial sums of dxhat and dxhat * xhat.  grid (chunks of 1024 pixels, 16 channels):
+// a thread owns one quad of four pixels of one channel plane (16-byte accesses) and loops over the samples;
+// partial[b][channel * chunks + chunk][2].
 __global__ __launch_bounds__(256) void head_ln_bwd_a_kernel(float *ds, const float *__restrict__ u, const float *__restrict__ g,
                                                             const float *__restrict__ bt, const float *__restrict__ stats, int B, int P,
                                                             float *dg, float *dbt, int accumulate, float *__restrict__ partial)
 {
     __shared__ float sh[2][4];
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    const bool in = p < P;
-    const size_t CP = (size_t)HC * P;
-    float ag[HC], ab[HC];
-#pragma unroll
-    for (int c = 0; c < HC; ++c) ag[c] = ab[c] = 0.f;
+    const int c = blockIdx.y;
+    const int p = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int n = P - p >= 4 ? 4 : (P - p > 0 ? P - p : 0);          // pixels of this thread's quad inside the plane
+    const size_t CP = (size_t)HC * P, row = (size_t)c * P + p;
+    float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f}, gm[4] = {0.f, 0.f, 0.f, 0.f}, bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (n == 4) {
+        ldn<4>(g + row, gm);
+        ldn<4>(bt + row, bv);
+    } else {
+        for (int k = 0; k < n; ++k) {
+            gm[k] = g[row + k];
+            bv[k] = bt[row + k];
+        }
+    }
     for (int b = 0; b < B; ++b) {
         const float mean = stats[b * 2], rstd = stats[b * 2 + 1];
         float s1 = 0.f, s2 = 0.f;
-        if (in) {
-#pragma unroll
-            for (int c = 0; c < HC; ++c) {
-                const size_t i = b * CP + (size_t)c * P + p;
-                const float xh = (u[i] - mean) * rstd;
-                const float gm = g[(size_t)c * P + p];
-                const float y = xh * gm + bt[(size_t)c * P + p];
-                const float sg = 1.0f / (1.0f + expf(-y));
-                const float dy = ds[i] * sg * (1.0f + y * (1.0f - sg));
-                ag[c] += dy * xh;
-                ab[c] += dy;
-                const float dxh = dy * gm;
-                ds[i] = dxh;
-                s1 += dxh;
-                s2 += dxh * xh;
+        float uv[4] = {0.f, 0.f, 0.f, 0.f}, dv[4] = {0.f, 0.f, 0.f, 0.f};
+        const size_t i = b * CP + row;
+        if (n == 4) {
+            ldn<4>(u + i, uv);
+            ldn<4>(ds + i, dv);
+        } else {
+            for (int k = 0; k < n; ++k) {
+                uv[k] = u[i + k];
+                dv[k] = ds[i + k];
             }
         }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xh = (uv[k] - mean) * rstd;
+            const float y = xh * gm[k] + bv[k];
+            const float sg = 1.0f / (1.0f + expf(-y));
+            const float dy = k < n ? dv[k] * sg * (1.0f + y * (1.0f - sg)) : 0.f;
+            ag[k] += dy * xh;
+            ab[k] += dy;
+            const float dxh = dy * gm[k];
+            dv[k] = dxh;
+            s1 += dxh;
+            s2 += dxh * xh;
+        }
+        if (n == 4) stn<4>(ds + i, dv);
+        else
+            for (int k = 0; k < n; ++k) ds[i + k] = dv[k];
         s1 = wave_sum(s1);
         s2 = wave_sum(s2);
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1007,17 +1161,28 @@ __global__ __launch_bounds__(256) void head_ln_bwd_a_kernel(float *ds, const flo
         if (lane == 0) { sh[0][wave] = s1; sh[1][wave] = s2; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            float *pp = partial + ((size_t)b * gridDim.x + blockIdx.x) * 2;
+            float *pp = partial + ((size_t)b * (gridDim.x * gridDim.y) + (size_t)c * gridDim.x + blockIdx.x) * 2;
             pp[0] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
             pp[1] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
         }
     }
-    if (in) {
+    float og[4], ob[4];
+    if (n == 4) {
+        if (accumulate) {
+            ldn<4>(dg + row, og);
+            ldn<4>(dbt + row, ob);
+        }
 #pragma unroll
-        for (int c = 0; c < HC; ++c) {
-            const size_t i = (size_t)c * P + p;
-            dg[i] = (accumulate ? dg[i] : 0.f) + ag[c];
-            dbt[i] = (accumulate ? dbt[i] : 0.f) + ab[c];
+        for (int k = 0; k < 4; ++k) {
+            og[k] = (accumulate ? og[k] : 0.f) + ag[k];
+            ob[k] = (accumulate ? ob[k] : 0.f) + ab[k];
+        }
+        stn<4>(dg + row, og);
+        stn<4>(dbt + row, ob);
+    } else {
+        for (int k = 0; k < n; ++k) {
+            dg[row + k] = (accumulate ? dg[row + k] : 0.f) + ag[k];
+            dbt[row + k] = (accumulate ? dbt[row + k] : 0.f) + ab[k];
         }
     }
 }
@@ -1047,15 +1212,23 @@ __global__ __launch_bounds__(64) void head_ln_coef_kernel(const float *__restric
 __global__ __launch_bounds__(256) void head_ln_bwd_b_kernel(float *ds, const float *__restrict__ u, const float *__restrict__ stats,
                                                             const float *__restrict__ coef, int P)
 {
-    const int p = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    if (p >= P) return;
+    const int bc = blockIdx.y, b = bc / HC;                  // grid (chunks, B * 16): one channel plane per blockIdx.y, pixels in quads
     const float mean = stats[b * 2], rstd = stats[b * 2 + 1], m1 = coef[b * 2], m2 = coef[b * 2 + 1];
+    const float *up = u + (size_t)bc * P;
+    float *dp = ds + (size_t)bc * P;
+    auto body = [&](auto n_tag, int p) {
+        constexpr int N = decltype(n_tag)::value;
+        float uv[N], dv[N];
+        ldn<N>(up + p, uv);
+        ldn<N>(dp + p, dv);
 #pragma unroll
-    for (int c = 0; c < HC; ++c) {
-        const size_t i = ((size_t)b * HC + c) * P + p;
-        const float xh = (u[i] - mean) * rstd;
-        ds[i] = rstd * (ds[i] - m1 - xh * m2);
-    }
+        for (int k = 0; k < N; ++k) {
+            const float xh = (uv[k] - mean) * rstd;
+            dv[k] = rstd * (dv[k] - m1 - xh * m2);
+        }
+        stn<N>(dp + p, dv);
+    };
+    URNN_PLANE_WALK(P, body);
 }
 
 hipError_t urnn_train_head_save(const float *feat, const float *conv_w, const float *ln_w, const float *ln_b, const float *stats, int B,
@@ -1068,17 +1241,20 @@ hipError_t urnn_train_head_save(const float *feat, const float *conv_w, const fl
 hipError_t urnn_train_head_pred_bwd(const float *dout, const float *cls, const float *reg, const float *reg_w, float thr, float slope,
                                     int B, int P, float *draw, float *ds, hipStream_t st)
 {
-    hipLaunchKernelGGL(head_pred_bwd_kernel, dim3((P + 255) / 256, B), dim3(256), 0, st, dout, cls, reg, reg_w, thr, slope, P, draw, ds);
+    hipLaunchKernelGGL(head_pred_bwd_kernel, plane_grid(P, B), dim3(256), 0, st, dout, cls, reg, reg_w, thr, slope, P, draw, ds);
     return hipGetLastError();
 }
+
+// blocks per channel plane of head_ln_bwd_a_kernel (1024 pixels each); its partial buffer holds B x 16 x chunks pairs
+int urnn_train_head_ln_chunks(int P) { return (P + 1023) / 1024; }
 
 hipError_t urnn_train_head_ln_bwd(float *ds, const float *u, const float *g, const float *bt, const float *stats, int B, int P, float *dg,
                                   float *dbt, int accumulate, float *partial, float *coef, hipStream_t st)
 {
-    const int nblk = (P + 255) / 256;
-    hipLaunchKernelGGL(head_ln_bwd_a_kernel, dim3(nblk), dim3(256), 0, st, ds, u, g, bt, stats, B, P, dg, dbt, accumulate, partial);
-    hipLaunchKernelGGL(head_ln_coef_kernel, dim3(B), dim3(64), 0, st, partial, nblk, (double)HC * (double)P, coef);
-    hipLaunchKernelGGL(head_ln_bwd_b_kernel, dim3(nblk, B), dim3(256), 0, st, ds, u, stats, coef, P);
+    const int nchunk = urnn_train_head_ln_chunks(P);
+    hipLaunchKernelGGL(head_ln_bwd_a_kernel, dim3(nchunk, HC), dim3(256), 0, st, ds, u, g, bt, stats, B, P, dg, dbt, accumulate, partial);
+    hipLaunchKernelGGL(head_ln_coef_kernel, dim3(B), dim3(64), 0, st, partial, nchunk * HC, (double)HC * (double)P, coef);
+    hipLaunchKernelGGL(head_ln_bwd_b_kernel, plane_grid(P, B * HC), dim3(256), 0, st, ds, u, stats, coef, P);
     return hipGetLastError();
 }
 
