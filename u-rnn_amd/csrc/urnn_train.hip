@@ -1187,24 +1187,40 @@ __global__ __launch_bounds__(256) void head_ln_bwd_a_kernel(float *ds, const flo
     }
 }
 
-// per sample: m1 = sum(dxhat) / (16 P), m2 = sum(dxhat * xhat) / (16 P); one wave per sample
-__global__ __launch_bounds__(64) void head_ln_coef_kernel(const float *__restrict__ partial, int nblk, double count, float *__restrict__ coef)
+// per sample: m1 = sum(dxhat) / (16 P), m2 = sum(dxhat * xhat) / (16 P); one block of 256 threads per sample: thread t adds partials
+// t, t + 256, ... in double (eight loads in flight), xor butterfly per wave, waves 0..3 in order -- a fixed order
+__global__ __launch_bounds__(256) void head_ln_coef_kernel(const float *__restrict__ partial, int nblk, double count, float *__restrict__ coef)
 {
-    const int b = blockIdx.x, lane = threadIdx.x;
+    __shared__ double red[2][4];
+    const int b = blockIdx.x, tid = threadIdx.x;
     const float *pp = partial + (size_t)b * nblk * 2;
     double s1 = 0.0, s2 = 0.0;
-    for (int t = lane; t < nblk; t += 64) {
-        s1 += (double)pp[2 * t];
-        s2 += (double)pp[2 * t + 1];
+    for (int t0 = 0; t0 < nblk; t0 += 256 * 8) {
+        f32x2 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int t = t0 + q * 256 + tid;
+            v[q] = t < nblk ? *reinterpret_cast<const f32x2 *>(pp + 2 * t) : f32x2{0.f, 0.f};
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            s1 += (double)v[q].x;
+            s2 += (double)v[q].y;
+        }
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         s1 += __shfl_xor(s1, m, 64);
         s2 += __shfl_xor(s2, m, 64);
     }
-    if (lane == 0) {
-        coef[b * 2] = (float)(s1 / count);
-        coef[b * 2 + 1] = (float)(s2 / count);
+    if ((tid & 63) == 0) {
+        red[0][tid >> 6] = s1;
+        red[1][tid >> 6] = s2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        coef[b * 2] = (float)(((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / count);
+        coef[b * 2 + 1] = (float)(((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / count);
     }
 }
 
@@ -1253,7 +1269,7 @@ hipError_t urnn_train_head_ln_bwd(float *ds, const float *u, const float *g, con
 {
     const int nchunk = urnn_train_head_ln_chunks(P);
     hipLaunchKernelGGL(head_ln_bwd_a_kernel, dim3(nchunk, HC), dim3(256), 0, st, ds, u, g, bt, stats, B, P, dg, dbt, accumulate, partial);
-    hipLaunchKernelGGL(head_ln_coef_kernel, dim3(B), dim3(64), 0, st, partial, nchunk * HC, (double)HC * (double)P, coef);
+    hipLaunchKernelGGL(head_ln_coef_kernel, dim3(B), dim3(256), 0, st, partial, nchunk * HC, (double)HC * (double)P, coef);
     hipLaunchKernelGGL(head_ln_bwd_b_kernel, plane_grid(P, B * HC), dim3(256), 0, st, ds, u, stats, coef, P);
     return hipGetLastError();
 }
