@@ -16,7 +16,7 @@ sys.path.insert(0, REPO)
 import bench  # noqa: E402  (kernel_source_hash: the same function bench.py checks the record with)
 FAMILIES = {   # bench.py's roofline families -> kernel-name pattern (template arguments: NB, PB, MAP, EPI, ...)
     "gates": re.compile(r"conv_gemm_kernel<\s*\d+,\s*\d+,\s*\d+,\s*3,"),                 # EPI_GRU1 = 3, the >= 24 000-pixel planes
-    "candidate": re.compile(r"cand_fused_kernel<|conv_gemm_kernel<\s*\d+,\s*\d+,\s*\d+,\s*4,"),   # fused / EPI_CAND = 4
+    "candidate": re.compile(r"cand_fused_kernel<|cand_gated_kernel<|conv_gemm_kernel<\s*\d+,\s*\d+,\s*\d+,\s*4,"),   # fused / EPI_CAND = 4
     "blend": re.compile(r"gru_blend_kernel<\s*4,"),                                     # the 16-byte form: full and half resolution at 500x500
     "head": re.compile(r"head_k[1-4]<"),
     "small_cells": re.compile(r"small_cell_gemm_kernel<|coop_cell_kernel<"),

@@ -391,6 +391,10 @@ class RolloutEngine:
                 set_counters()
                 for key in seq:
                     graphs[key].replay()
+                    # (one graph at a time here: a freshly instantiated graph uploads itself on its first launch, and a host-side
+                    # segmentation fault inside hipGraphLaunch was seen once in ~10 runs of the GPU suite at exactly this replay,
+                    # with several first launches in flight.  Untimed warm-up: the synchronisations cost nothing that is measured.)
+                    torch.cuda.synchronize(self.device)
         torch.cuda.synchronize(self.device)
         self._graphs2 = graphs
         for s, v in zip(self.states + self.enc_alt, saved):
