@@ -375,6 +375,42 @@ int urnn_stage1_scalar_rain_rollout_f32(const float *S, const float *rain, const
                                         const float *bias, float *out, const int *t_dev, int *t_next, int B, int T, int nums,
                                         int Cout, int H, int W, float rain_max, float cumsum_max, float slope, void *stream);
 
+/* One whole inference timestep behind one call -- ED.forward, model.py:65-121 inside test.py:326-377's loop -- for a host that is not
+ * Python: the launches the per-module entries above make for a frame, in their order, on ONE stream (enqueue-only: capture the call in a
+ * hipGraph and replay it per frame -- what u-rnn_amd/rollout.py's one-chain engine does with the same launches; its three-chain schedule,
+ * DESIGN.md 4.3, adds ~17 % on top and stays host-side).
+ *   urnn_net_f32: the network as the slabs of urnn_pack_conv_f32 / urnn_pack_deconv_f32 / urnn_pack_gru_f32 and the norms' affines, plus its
+ *     channel counts (net_params.py:80-116: in 2n+3 -> 16 | 64 | 64(pool) | 96 | 96(pool) | 96 ; decoder 96 (x = 0, dec_zero_input_channels
+ *     = 96) -> 96 | 96 -> 96 | 64 -> 16; head width 16).  Index 0 of every decoder array is the DEEPEST stage (Decoder.stage3 / rnn3).
+ *   x_t (B, in_channels, H, W): the frame's input (urnn_preprocess_f32); states: e1 e2 e3 d1 d2 d3 as model.py returns them (d1 the
+ *     deepest), (B, F, H / s, W / s), updated IN PLACE; outputs and frame_index as urnn_head_f32.  H and W multiples of four.
+ *   The cells run with URNN_PHASE_FUSED_R | URNN_PHASE_COOP and the head as urnn_head_coop_f32 wherever the shapes qualify (an inference
+ *   step; the training forward needs the raw planes and uses the per-module entries).  Operand-range rules as for those entries.
+ *   workspace: urnn_step_workspace_bytes; urnn_step_workspace_init zeroes its two status areas (once per workspace) and returns their
+ *   addresses (word 0 of each: URNN_STATUS_* bits). */
+typedef struct urnn_net_f32 {
+    int in_channels;                       /* 2 * nums + 3                                                            */
+    int enc_stage_out[3];                  /* Encoder.stage1..3 output channels (16, 64, 96); stages 2 and 3 pool 2x2 */
+    int enc_features[3];                   /* Encoder.rnn1..3 hidden channels (64, 96, 96)                            */
+    int dec_zero_input_channels;           /* Decoder.rnn3's declared (all-zero) input channels (96)                  */
+    int dec_features[3];                   /* Decoder.rnn3, rnn2, rnn1 hidden channels (96, 96, 64)                   */
+    int dec_stage_out[2];                  /* Decoder.stage3, stage2 (transposed convs) output channels (96, 96)      */
+    int feat_channels;                     /* Decoder.stage1 output = head width (16)                                 */
+    const float *enc_stage[3];             /* urnn_pack_conv_f32 slabs                                                */
+    const float *enc_cell[3];              /* urnn_pack_gru_f32 slabs (skip = 0)                                      */
+    const float *enc_gn1_w[3], *enc_gn1_b[3], *enc_gn2_w[3], *enc_gn2_b[3];
+    const float *dec_cell[3];              /* urnn_pack_gru_f32 slabs (skip = 1), deepest first                       */
+    const float *dec_gn1_w[3], *dec_gn1_b[3], *dec_gn2_w[3], *dec_gn2_b[3];
+    const float *dec_stage[3];             /* [0], [1]: urnn_pack_deconv_f32 slabs of stage3, stage2; [2]: urnn_pack_conv_f32 slab of stage1 */
+    const float *head_conv_w, *head_ln_w, *head_ln_b, *cls_w, *cls_b, *reg_w, *reg_b;   /* as urnn_head_f32          */
+} urnn_net_f32;
+size_t urnn_step_workspace_bytes(const urnn_net_f32 *net, int B, int H, int W);
+int urnn_step_workspace_init(const urnn_net_f32 *net, void *workspace, size_t workspace_bytes, int B, int H, int W, int **cell_status,
+                             int **head_status, void *stream);
+int urnn_step_f32(const urnn_net_f32 *net, const float *x_t, float *const states[6], float *out_masked, float *out_cls, float *out_raw,
+                  const int *frame_index, void *workspace, size_t workspace_bytes, int B, int H, int W, float cls_thred, float eps,
+                  float slope, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

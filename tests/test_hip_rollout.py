@@ -904,3 +904,34 @@ def test_fused_tails_rollout_matches_the_default_schedule(dev):
         assert torch.equal(a, b), f"state {k} differs with fused tails"
     assert_close(tails.out_raw[:T].cpu().numpy(), base.out_raw[:T].cpu().numpy(), 1e-5, "pre-mask reg with fused tails")
     assert_close(tails.out_cls[:T].cpu().numpy(), base.out_cls[:T].cpu().numpy(), 1e-5, "cls with fused tails")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W,B", [(64, 64, 1), (52, 120, 2), (256, 256, 1)])
+def test_c_abi_step_equals_the_one_chain_engine(dev, H, W, B):
+    """urnn_step_f32 (include/urnn_hip.h: ED.forward, model.py:65-121, as ONE call for a host that is not Python) against the one-chain
+    rollout engine, which enqueues the same launches through the per-module entries: frames and the six states bit-identical over a few
+    steps -- on a plane whose cells and head take their cooperative forms, with two events per GPU, and on one whose full-resolution
+    cells recompute the reset gate (URNN_PHASE_FUSED_R)."""
+    import urnn_amd.weights as uw
+    from urnn_amd import ops
+    from urnn_amd.rollout import RolloutEngine
+    from urnn_amd.step import StepNet
+    nums, T = 3, 4
+    C = 2 * nums + 3
+    net, _ = make_net(H, W, C, 11, dev)
+    ev = uw.make_event(T, H, W, 60.0, seed=5, spatial_rain=True, batch=B)
+    eng = RolloutEngine(net, H, W, nums, 60.0, 250.0, batch=B, max_frames=T, spatial_rain=True, use_graph=False, keep_raw=True)
+    want = eng.rollout(ev).clone()
+    want_states = [s.clone() for s in eng.final_states()]
+    sn = StepNet(net, B, H, W, C)
+    states = [torch.zeros_like(s) for s in want_states]
+    masked, cls, raw = (torch.zeros((T, B, H, W), dtype=torch.float32, device=dev) for _ in range(3))
+    for t in range(T):
+        x_t = ops.preprocess(eng.rain, eng.cumsum, eng.dem, eng.imperv, eng.manhole, eng.dem_min, eng.dem_max, t, nums, 60.0, 250.0)
+        sn.step(x_t, states, masked, cls, raw, frame_index=torch.tensor([t], dtype=torch.int32, device=dev))
+    assert sn.status() == (0, 0)
+    assert torch.equal(masked, want), f"frames differ: max {float((masked - want).abs().max()):.3e}"
+    assert torch.equal(raw, eng.out_raw[:T])
+    for k, (a, b) in enumerate(zip(states, want_states)):
+        assert torch.equal(a, b), f"state {k} differs"

@@ -1354,3 +1354,127 @@ extern "C" int urnn_advance_counter(int *counter, int delta, void *stream)
     CHECK_HIP(urnn_launch_advance(counter, delta, (hipStream_t)stream), "advance_counter");
     return URNN_OK;
 }
+
+// ---- one whole timestep behind one call ---------------------------------------------------------------------------------------
+// ED.forward (model.py:65-121): encoder (stage conv -> cell) x 3, decoder (cell -> transposed conv) x 2 + cell + conv, head -- the
+// launches a Python host makes through the per-module entries, in their order, on ONE stream: enqueue-only like them, so the caller can
+// capture the call in a hipGraph and replay it per frame (what RolloutEngine(overlap=False) does with the same launches).  An INFERENCE
+// step: the cells take URNN_PHASE_FUSED_R | URNN_PHASE_COOP and the head its cooperative form wherever the shapes qualify (one stream:
+// a cooperative launch's blocks are all resident once its predecessor drains), so the workspaces' raw planes are undefined afterwards.
+struct StepWs {
+    float *a1, *a2, *a3, *u3, *u2, *feat;
+    void *cell, *head;
+    size_t cell_bytes, head_bytes, bytes;
+};
+
+static StepWs carve_step(void *base, const urnn_net_f32 *n, int B, int H, int W)
+{
+    size_t off = 0;
+    auto take = [&](size_t nbytes) {
+        void *p = base ? reinterpret_cast<char *>(base) + off : nullptr;
+        off += align_up(nbytes, 256);
+        return p;
+    };
+    const int H2 = H / 2, W2 = W / 2, H4 = H2 / 2, W4 = W2 / 2;
+    const size_t P1 = (size_t)H * W, P2 = (size_t)H2 * W2, P4 = (size_t)H4 * W4;
+    StepWs w;
+    w.cell_bytes = 0;
+    const int F[6] = {n->enc_features[0], n->enc_features[1], n->enc_features[2], n->dec_features[0], n->dec_features[1], n->dec_features[2]};
+    const int hh[6] = {H, H2, H4, H4, H2, H}, ww[6] = {W, W2, W4, W4, W2, W};
+    for (int k = 0; k < 6; ++k) {
+        const size_t b = urnn_gru_cell_workspace_bytes(B, F[k], hh[k], ww[k]);
+        w.cell_bytes = b > w.cell_bytes ? b : w.cell_bytes;
+    }
+    w.head_bytes = urnn_head_workspace_bytes(B, n->feat_channels, H, W);
+    w.cell = take(w.cell_bytes);           // (first: its status words are the call's status words)
+    w.head = take(w.head_bytes);
+    w.a1 = reinterpret_cast<float *>(take((size_t)B * n->enc_stage_out[0] * P1 * 4));
+    w.a2 = reinterpret_cast<float *>(take((size_t)B * n->enc_stage_out[1] * P2 * 4));
+    w.a3 = reinterpret_cast<float *>(take((size_t)B * n->enc_stage_out[2] * P4 * 4));
+    w.u3 = reinterpret_cast<float *>(take((size_t)B * n->dec_stage_out[0] * P2 * 4));
+    w.u2 = reinterpret_cast<float *>(take((size_t)B * n->dec_stage_out[1] * P1 * 4));
+    w.feat = reinterpret_cast<float *>(take((size_t)B * n->feat_channels * P1 * 4));
+    w.bytes = off;
+    return w;
+}
+
+static int step_net_ok(const urnn_net_f32 *n)
+{
+    if (!n) return 0;
+    for (int k = 0; k < 3; ++k)
+        if (!n->enc_stage[k] || !n->enc_cell[k] || !n->dec_cell[k] || !n->enc_gn1_w[k] || !n->enc_gn1_b[k] || !n->enc_gn2_w[k] || !n->enc_gn2_b[k] ||
+            !n->dec_gn1_w[k] || !n->dec_gn1_b[k] || !n->dec_gn2_w[k] || !n->dec_gn2_b[k] || n->enc_stage_out[k] < 1 || n->enc_features[k] < 32 || n->dec_features[k] < 32)
+            return 0;
+    return n->dec_stage[0] && n->dec_stage[1] && n->dec_stage[2] && n->head_conv_w && n->head_ln_w && n->head_ln_b && n->cls_w && n->cls_b && n->reg_w &&
+           n->reg_b && n->in_channels >= 1 && n->dec_stage_out[0] >= 1 && n->dec_stage_out[1] >= 1 && n->feat_channels == 16;
+}
+
+extern "C" size_t urnn_step_workspace_bytes(const urnn_net_f32 *net, int B, int H, int W)
+{
+    if (!step_net_ok(net) || B < 1 || H < 4 || W < 4) return 0;
+    return carve_step(nullptr, net, B, H, W).bytes;
+}
+
+extern "C" int urnn_step_f32(const urnn_net_f32 *net, const float *x_t, float *const states[6], float *out_masked, float *out_cls, float *out_raw,
+                             const int *frame_index, void *workspace, size_t workspace_bytes, int B, int H, int W, float cls_thred,
+                             float eps, float slope, void *stream)
+{
+    if (!step_net_ok(net)) return fail(URNN_EINVAL, "urnn_step_f32: incomplete network description (NULL slab or bad channel count)");
+    if (!x_t || !states || !out_masked || !out_cls || !workspace) return fail(URNN_ENULL, "urnn_step_f32: NULL argument");
+    for (int k = 0; k < 6; ++k)
+        if (!states[k]) return fail(URNN_ENULL, "urnn_step_f32: NULL state %d", k);
+    if (B < 1 || H < 4 || W < 4 || (H & 3) || (W & 3)) return fail(URNN_EINVAL, "urnn_step_f32: H = %d, W = %d must be multiples of four (two 2x2 poolings, two 2x2 transposed convolutions)", H, W);
+    const StepWs ws = carve_step(workspace, net, B, H, W);
+    if (workspace_bytes < ws.bytes) return fail(URNN_EWORKSPACE, "urnn_step_f32: workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
+    const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4;
+    float *e1 = states[0], *e2 = states[1], *e3 = states[2], *d1 = states[3], *d2 = states[4], *d3 = states[5];
+    const int *so = net->enc_stage_out, *ef = net->enc_features, *df = net->dec_features, *uo = net->dec_stage_out;
+    int rc;
+    const int CELL_MASK = URNN_PHASE_ALL | URNN_PHASE_FUSED_R | URNN_PHASE_COOP;
+#define URNN_STEP(call) do { rc = (call); if (rc) return rc; } while (0)
+    // encoder (encoder.py:140-185): stage conv (+ pool) -> ConvGRU cell, three scales; states updated in place
+    URNN_STEP(urnn_stage_conv_f32(x_t, net->enc_stage[0], ws.a1, B, net->in_channels, so[0], H, W, 0, slope, stream));
+    URNN_STEP(urnn_gru_cell_phases_f32(ws.a1, nullptr, e1, net->enc_cell[0], net->enc_gn1_w[0], net->enc_gn1_b[0], net->enc_gn2_w[0], net->enc_gn2_b[0], e1,
+                                ws.cell, ws.cell_bytes, B, so[0], ef[0], H, W, eps, CELL_MASK, stream));
+    URNN_STEP(urnn_stage_conv_f32(e1, net->enc_stage[1], ws.a2, B, ef[0], so[1], H, W, 1, slope, stream));
+    URNN_STEP(urnn_gru_cell_phases_f32(ws.a2, nullptr, e2, net->enc_cell[1], net->enc_gn1_w[1], net->enc_gn1_b[1], net->enc_gn2_w[1], net->enc_gn2_b[1], e2,
+                                ws.cell, ws.cell_bytes, B, so[1], ef[1], H2, W2, eps, CELL_MASK, stream));
+    URNN_STEP(urnn_stage_conv_f32(e2, net->enc_stage[2], ws.a3, B, ef[1], so[2], H2, W2, 1, slope, stream));
+    URNN_STEP(urnn_gru_cell_phases_f32(ws.a3, nullptr, e3, net->enc_cell[2], net->enc_gn1_w[2], net->enc_gn1_b[2], net->enc_gn2_w[2], net->enc_gn2_b[2], e3,
+                                ws.cell, ws.cell_bytes, B, so[2], ef[2], H4, W4, eps, CELL_MASK, stream));
+    // decoder (decoder.py:130-203): Skip-ConvGRU cell -> transposed conv, deepest scale first (its x is zero: ConvRNN.py:143-146)
+    URNN_STEP(urnn_gru_cell_phases_f32(nullptr, e3, d1, net->dec_cell[0], net->dec_gn1_w[0], net->dec_gn1_b[0], net->dec_gn2_w[0], net->dec_gn2_b[0], d1,
+                                ws.cell, ws.cell_bytes, B, net->dec_zero_input_channels, df[0], H4, W4, eps, CELL_MASK, stream));
+    URNN_STEP(urnn_deconv2x2_f32(d1, net->dec_stage[0], ws.u3, B, df[0], uo[0], H4, W4, slope, stream));
+    URNN_STEP(urnn_gru_cell_phases_f32(ws.u3, e2, d2, net->dec_cell[1], net->dec_gn1_w[1], net->dec_gn1_b[1], net->dec_gn2_w[1], net->dec_gn2_b[1], d2,
+                                ws.cell, ws.cell_bytes, B, uo[0], df[1], H2, W2, eps, CELL_MASK, stream));
+    URNN_STEP(urnn_deconv2x2_f32(d2, net->dec_stage[1], ws.u2, B, df[1], uo[1], H2, W2, slope, stream));
+    URNN_STEP(urnn_gru_cell_phases_f32(ws.u2, e1, d3, net->dec_cell[2], net->dec_gn1_w[2], net->dec_gn1_b[2], net->dec_gn2_w[2], net->dec_gn2_b[2], d3,
+                                ws.cell, ws.cell_bytes, B, uo[1], df[2], H, W, eps, CELL_MASK, stream));
+    URNN_STEP(urnn_stage_conv_f32(d3, net->dec_stage[2], ws.feat, B, df[2], net->feat_channels, H, W, 0, slope, stream));
+    // head + wet / dry mask (flood_head.py:131-202)
+    if (urnn_head_coop_blocks_f32(B, H, W) > 0)
+        URNN_STEP(urnn_head_coop_f32(ws.feat, net->head_conv_w, net->head_ln_w, net->head_ln_b, net->cls_w, net->cls_b, net->reg_w, net->reg_b, out_masked,
+                                     out_cls, out_raw, frame_index, ws.head, ws.head_bytes, B, net->feat_channels, H, W, cls_thred, eps, slope, stream));
+    else
+        URNN_STEP(urnn_head_f32(ws.feat, net->head_conv_w, net->head_ln_w, net->head_ln_b, net->cls_w, net->cls_b, net->reg_w, net->reg_b, out_masked,
+                                out_cls, out_raw, frame_index, ws.head, ws.head_bytes, B, net->feat_channels, H, W, cls_thred, eps, slope, stream));
+#undef URNN_STEP
+    return URNN_OK;
+}
+
+// The status / barrier words of the step's cell and head scratch (include/urnn_hip.h "status words"): zero them once per workspace,
+// read them at a synchronisation point of the caller's choice.
+extern "C" int urnn_step_workspace_init(const urnn_net_f32 *net, void *workspace, size_t workspace_bytes, int B, int H, int W, int **cell_status,
+                                        int **head_status, void *stream)
+{
+    if (!step_net_ok(net) || !workspace) return fail(URNN_ENULL, "urnn_step_workspace_init: NULL argument or incomplete network description");
+    if (B < 1 || H < 4 || W < 4) return fail(URNN_EINVAL, "urnn_step_workspace_init: bad dims");
+    const StepWs ws = carve_step(workspace, net, B, H, W);
+    if (workspace_bytes < ws.bytes) return fail(URNN_EWORKSPACE, "urnn_step_workspace_init: workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
+    CHECK_HIP(urnn_train_zero(reinterpret_cast<float *>(ws.cell), URNN_STATUS_BYTES / sizeof(float), (hipStream_t)stream), "zero the cell status words");
+    CHECK_HIP(urnn_train_zero(reinterpret_cast<float *>(ws.head), URNN_STATUS_BYTES / sizeof(float), (hipStream_t)stream), "zero the head status words");
+    if (cell_status) *cell_status = reinterpret_cast<int *>(ws.cell);
+    if (head_status) *head_status = reinterpret_cast<int *>(ws.head);
+    return URNN_OK;
+}
