@@ -116,6 +116,15 @@ int urnn_max_abs_f32(const float *values, long n, float *max_abs_out, void *stre
 int urnn_stage_conv_f32(const float *in, const float *packed, float *out, int B, int Cin, int Cout, int H, int W, int pool,
                         float slope, void *stream);
 
+/* The decoder's last stage (Decoder.stage1: Conv1x1 F -> 16 + LeakyReLU, decoder.py:150-164) with the FIRST pass of the head done in its
+ * epilogue: out as urnn_stage_conv_f32(pool = 0), plus the partial statistics of the head's first LayerNorm (u0 = stems.conv . out,
+ * flood_head.py:131-140) in head_partial0 (urnn_head_tail_partial_floats floats) -- urnn_head_after_tail_f32 then runs the head without
+ * reading the feature map for them.  head_conv_w: the head's conv_w (its first 16 x 16 block is used).  Applies (urnn_stage_conv_stem_applies)
+ * where the conv takes its 128-pixel-tile form: Cout = 16, P % 4 == 0, >= 131 072 pixels per launch, f16-piece matrix modes; URNN_EINVAL elsewhere. */
+int urnn_stage_conv_stem_applies(int B, int Cin, int Cout, int H, int W);
+int urnn_stage_conv_stem_f32(const float *in, const float *packed, float *out, int B, int Cin, int Cout, int H, int W, float slope,
+                             const float *head_conv_w, float *head_partial0, void *stream);
+
 /* ConvGRU (e == NULL) / Skip-ConvGRU cell, one timestep.
  * Replaces CGRU_cell.forward(inputs, hidden_state, seq_len=1) -- ConvRNN.py:111-194 -- including the
  * torch.cat of decoder.py:130-135.  x (B,I,H,W) may be NULL: x == 0 (decoder stage 3, ConvRNN.py:143-146).

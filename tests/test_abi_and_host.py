@@ -19,6 +19,17 @@ def built():
     return _lib
 
 
+def test_header_is_plain_c():
+    """include/urnn_hip.h is the boundary a C / cgo / JNI consumer compiles against: it must be valid C99 on its own."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    header = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "urnn_hip.h")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", header], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_library_exports_every_declared_symbol(built):
     header = open(os.path.join(REPO, "include", "urnn_hip.h")).read()
     declared = set(re.findall(r"\b(urnn_[a-z0-9_]+)\s*\(", header))

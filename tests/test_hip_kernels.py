@@ -418,3 +418,35 @@ def test_frame_loop_forms_store_the_next_frame_index(dev, H, W, B):
         ops.head(feat, conv_w, ln_w, ln_b, cw, cb_, rw, rb, 0.5, out_masked=bufs[0], out_cls=bufs[1], out_raw=bufs[2], frame_index=own,
                  ws=ws, frame_next=own)
     assert ops.workspace_status(ws) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W,B", [(256, 512, 1), (200, 336, 2)])
+def test_last_conv_takes_the_heads_first_statistics(dev, H, W, B):
+    """urnn_stage_conv_stem_f32 (decoder.py:150-164 + flood_head.py:131-140): the decoder's 64 -> 16 conv with the head's first LayerNorm
+    partials taken in its epilogue -- the feature map bit-identical to urnn_stage_conv_f32, the head run from those partials
+    (three passes over the plane instead of four) within 1e-5 of the four-pass head (the sums are grouped differently: 128-pixel
+    tiles of the conv against 256-pixel blocks of head_k1) and both within 1e-4 of the oracle."""
+    from oracle import oracle as orc
+    from urnn_amd import ops
+    rs = np.random.RandomState(77 + H)
+    assert ops.stage_conv_stem_applies(B, 64, 16, H, W) and not ops.stage_conv_stem_applies(1, 64, 16, 64, 64)
+    x = rs.normal(0, 1, (B, 64, H, W)).astype(np.float32)
+    wc = rs.normal(0, 1 / 8.0, (16, 64, 1, 1)).astype(np.float32)
+    bc = rs.normal(0, 0.1, 16).astype(np.float32)
+    cpk = ops.pack_conv(T(wc, dev), T(bc, dev))
+    conv_w = T(rs.normal(0, 0.25, (5, 16, 16)).astype(np.float32), dev)
+    ln_w = T(rs.uniform(0.5, 1.5, (5, 16, H, W)).astype(np.float32), dev)
+    ln_b = T(rs.normal(0, 0.1, (5, 16, H, W)).astype(np.float32), dev)
+    cw, cb_, rw, rb = (T(rs.normal(0, 0.3, 16).astype(np.float32), dev), T(np.zeros(1, np.float32), dev),
+                       T(rs.normal(0, 0.3, 16).astype(np.float32), dev), T(np.full(1, 0.1, np.float32), dev))
+    want = ops.stage_conv(T(x, dev), cpk, 16, False)
+    part0 = ops.head_tail_partial(B, H, W, dev)
+    got = ops.stage_conv(T(x, dev), cpk, 16, False, head_w=conv_w, head_partial0=part0)
+    assert torch.equal(got, want), f"feature map differs: max {float((got - want).abs().max()):.3e}"
+    four = ops.head(want, conv_w, ln_w, ln_b, cw, cb_, rw, rb, 0.5, want_raw=True)
+    three = ops.head(got, conv_w, ln_w, ln_b, cw, cb_, rw, rb, 0.5, want_raw=True, partial0=part0)
+    for a_, b_, what in ((three[1], four[1], "cls"), (three[2], four[2], "pre-mask reg")):
+        assert_close(a_.cpu().numpy(), b_.cpu().numpy(), 1e-5, f"three-pass head vs four-pass head, {what}")
+    ref_f = orc.stage_conv(x, wc.reshape(16, 64), bc, False)
+    assert_close(got.cpu().numpy(), ref_f, TOL, "feature map vs oracle")

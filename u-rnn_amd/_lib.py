@@ -70,6 +70,8 @@ SIGNATURES = {
     "urnn_gru_cell_strip_stats_f32": (_i, [_p, _sz, _i, _i, _i, _i, _i, _i, _p, _p]),
     "urnn_head_strip_f32": (_i, [_p] * 13 + [_sz, _i, _i, _i, _i, _f, _f, _f, _i, ctypes.c_long, _p]),
     "urnn_head_strip_stats_f32": (_i, [_p, _sz, _i, _i, _i, _i, _i, _i, _p, _p]),
+    "urnn_stage_conv_stem_applies": (_i, [_i, _i, _i, _i, _i]),
+    "urnn_stage_conv_stem_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _p, _p]),
     "urnn_step_workspace_bytes": (_sz, [_p, _i, _i, _i]),
     "urnn_step_workspace_init": (_i, [_p, _p, _sz, _i, _i, _i, _p, _p, _p]),
     "urnn_step_f32": (_i, [_p] * 8 + [_sz, _i, _i, _i, _f, _f, _f, _p]),

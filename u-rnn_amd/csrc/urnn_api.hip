@@ -121,7 +121,7 @@ extern "C" int urnn_pack_deconv_f32(const float *weight, const float *bias, floa
 
 // ---- stage conv ------------------------------------------------------------------------------------------------------
 static int stage_conv_impl(const float *in, const float *packed, float *out, int B, int Cin, int Cout, int H, int W, int pool, float slope,
-                           int wide, void *stream);
+                           int wide, void *stream, const float *stem_w = nullptr, float *stem_partial = nullptr);
 
 extern "C" int urnn_stage_conv_f32(const float *in, const float *packed, float *out, int B, int Cin, int Cout, int H, int W,
                                    int pool, float slope, void *stream)
@@ -130,8 +130,31 @@ extern "C" int urnn_stage_conv_f32(const float *in, const float *packed, float *
 }
 
 // wide = 1: `in` holds gradients (the input-gradient GEMMs of the backward pass): bf16 x 6 split instead of f16 x 3
+// The flat conv to the head's 16 channels with the head's first LayerNorm statistics taken in its epilogue (conv_gemm_kernel, stemW): the
+// 128-pixel-tile form of the kernel only -- planes of >= 131 072 pixels per launch with P % 4 == 0, the f16-piece matrix modes
+static bool stage_conv_stem_ok(int B, int Cin, int Cout, int H, int W)
+{
+    if (B < 1 || Cin < 1 || Cout != 16 || H < 1 || W < 1) return false;
+    const int mm = urnn_get_matrix_mode();
+    if (mm != URNN_MATRIX_FP32 && mm != URNN_MATRIX_FP32_CAND) return false;
+    int pb, map;
+    pick_tile((long)B * H * W, urnn_conv_ng(Cout), (long)H * W, &pb, &map, "URNN_TUNE_PB_CONV", 1024);
+    return pb == 4 && map == MAP_VEC && urnn_conv_nb(Cout) == 1;
+}
+
+extern "C" int urnn_stage_conv_stem_applies(int B, int Cin, int Cout, int H, int W) { return stage_conv_stem_ok(B, Cin, Cout, H, W) ? 1 : 0; }
+
+extern "C" int urnn_stage_conv_stem_f32(const float *in, const float *packed, float *out, int B, int Cin, int Cout, int H, int W, float slope,
+                                        const float *head_conv_w, float *head_partial0, void *stream)
+{
+    if (!head_conv_w || !head_partial0) return fail(URNN_ENULL, "urnn_stage_conv_stem_f32: NULL head_conv_w / head_partial0");
+    if (!stage_conv_stem_ok(B, Cin, Cout, H, W))
+        return fail(URNN_EINVAL, "urnn_stage_conv_stem_f32: this conv does not take the 128-pixel-tile form to 16 channels (urnn_stage_conv_stem_applies)");
+    return stage_conv_impl(in, packed, out, B, Cin, Cout, H, W, 0, slope, 0, stream, head_conv_w, head_partial0);
+}
+
 static int stage_conv_impl(const float *in, const float *packed, float *out, int B, int Cin, int Cout, int H, int W, int pool, float slope,
-                           int wide, void *stream)
+                           int wide, void *stream, const float *stem_w, float *stem_partial)
 {
     if (!in || !packed || !out) return fail(URNN_ENULL, "urnn_stage_conv_f32: NULL argument");
     if (B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return fail(URNN_EINVAL, "urnn_stage_conv_f32: bad dims");
@@ -163,6 +186,8 @@ static int stage_conv_impl(const float *in, const float *packed, float *out, int
     p.slope = slope;
     p.out0 = out;
     p.wide = wide;
+    p.stemW = stem_w;
+    p.stemPart = stem_partial;
     hipStream_t st = (hipStream_t)stream;
     if (pool) {
         p.W2 = W / 2;
@@ -1362,7 +1387,7 @@ extern "C" int urnn_advance_counter(int *counter, int delta, void *stream)
 // step: the cells take URNN_PHASE_FUSED_R | URNN_PHASE_COOP and the head its cooperative form wherever the shapes qualify (one stream:
 // a cooperative launch's blocks are all resident once its predecessor drains), so the workspaces' raw planes are undefined afterwards.
 struct StepWs {
-    float *a1, *a2, *a3, *u3, *u2, *feat;
+    float *a1, *a2, *a3, *u3, *u2, *feat, *part0;
     void *cell, *head;
     size_t cell_bytes, head_bytes, bytes;
 };
@@ -1394,6 +1419,7 @@ static StepWs carve_step(void *base, const urnn_net_f32 *n, int B, int H, int W)
     w.u3 = reinterpret_cast<float *>(take((size_t)B * n->dec_stage_out[0] * P2 * 4));
     w.u2 = reinterpret_cast<float *>(take((size_t)B * n->dec_stage_out[1] * P1 * 4));
     w.feat = reinterpret_cast<float *>(take((size_t)B * n->feat_channels * P1 * 4));
+    w.part0 = reinterpret_cast<float *>(take(urnn_head_tail_partial_floats(B, H, W) * 4));
     w.bytes = off;
     return w;
 }
@@ -1451,9 +1477,15 @@ extern "C" int urnn_step_f32(const urnn_net_f32 *net, const float *x_t, float *c
     URNN_STEP(urnn_deconv2x2_f32(d2, net->dec_stage[1], ws.u2, B, df[1], uo[1], H2, W2, slope, stream));
     URNN_STEP(urnn_gru_cell_phases_f32(ws.u2, e1, d3, net->dec_cell[2], net->dec_gn1_w[2], net->dec_gn1_b[2], net->dec_gn2_w[2], net->dec_gn2_b[2], d3,
                                 ws.cell, ws.cell_bytes, B, uo[1], df[2], H, W, eps, CELL_MASK, stream));
-    URNN_STEP(urnn_stage_conv_f32(d3, net->dec_stage[2], ws.feat, B, df[2], net->feat_channels, H, W, 0, slope, stream));
+    const bool stem = stage_conv_stem_ok(B, df[2], net->feat_channels, H, W);   // the head's first statistics in the last conv's epilogue
+    if (stem) URNN_STEP(urnn_stage_conv_stem_f32(d3, net->dec_stage[2], ws.feat, B, df[2], net->feat_channels, H, W, slope, net->head_conv_w, ws.part0, stream));
+    else URNN_STEP(urnn_stage_conv_f32(d3, net->dec_stage[2], ws.feat, B, df[2], net->feat_channels, H, W, 0, slope, stream));
     // head + wet / dry mask (flood_head.py:131-202)
-    if (urnn_head_coop_blocks_f32(B, H, W) > 0)
+    if (stem)
+        URNN_STEP(urnn_head_after_tail_f32(ws.feat, net->head_conv_w, net->head_ln_w, net->head_ln_b, net->cls_w, net->cls_b, net->reg_w, net->reg_b,
+                                           out_masked, out_cls, out_raw, frame_index, ws.head, ws.head_bytes, B, net->feat_channels, H, W, cls_thred, eps,
+                                           slope, ws.part0, stream));
+    else if (urnn_head_coop_blocks_f32(B, H, W) > 0)
         URNN_STEP(urnn_head_coop_f32(ws.feat, net->head_conv_w, net->head_ln_w, net->head_ln_b, net->cls_w, net->cls_b, net->reg_w, net->reg_b, out_masked,
                                      out_cls, out_raw, frame_index, ws.head, ws.head_bytes, B, net->feat_channels, H, W, cls_thred, eps, slope, stream));
     else

@@ -439,8 +439,8 @@ __device__ __forceinline__ float *head_partial(const HeadParams &p, int which, i
 // own loads -- ~1 000 blocks x 4 waves x 8 KB of L2 reads, a dependent round trip and ~60 registers per tile: head_k4 32 -> 20 us
 // without it, the three finalize launches cost 3 x 3-5 us.  (Also tried: the producer's last block to finish folds -- one
 // agent-scope counter and a release fence per block: 17-40 ns per block SERIALISED, head_k3 31 -> 110 us.)
-// The cooperative head folds across its grid barriers (small planes), and a feature map whose producer took the first norm's
-// partials (urnn_tail.hip) is folded by head_k2's waves as before.
+// The cooperative head folds across its grid barriers (small planes); a feature map whose producer took the first norm's partials
+// (the decoder's last conv, conv_gemm_kernel's stemW epilogue, or urnn_tail.hip) is finalized from there (prm.partial0).
 __device__ __forceinline__ void head_fold_stats(const HeadParams &prm, int which, int b, bool publish, float &mean_f, float &rstd_f)
 {
     const int lane = threadIdx.x & 63;
@@ -549,22 +549,20 @@ __global__ __launch_bounds__(256) void head_k1(const HeadParams prm)
                       nullptr);
 }
 
-// TAIL: the producer of feat took the first norm's partials (urnn_tail.hip, prm.partial0) and head_k1 did not run: every wave folds them
-template <bool AL, bool TAIL>
+template <bool AL>
 __global__ __launch_bounds__(256) void head_k2(const HeadParams prm)
 {
     const int b = blockIdx.y;
     const HeadLane L = head_lane(blockIdx.x, prm.P);
     const size_t CP = (size_t)HEAD_C * prm.P;
-    if (TAIL && prm.bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *prm.bump = *prm.frame_index + 1;   // (head_k1 did not run)
+    if (prm.partial0 && prm.bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *prm.bump = *prm.frame_index + 1;   // (head_k1 did not run)
     f32x4 f[4], t[4], g[4], bt[4], u[4];
     head_load<AL>(prm.feat + b * CP, prm.P, L, f);               // the tile's rows travel while the statistics are folded
     head_load<AL>(prm.ln_w, prm.P, L, g);
     head_load<AL>(prm.ln_b, prm.P, L, bt);
     const f32x4 a0 = head_weights(prm.conv_w), a1 = head_weights(prm.conv_w + 1 * HEAD_C * HEAD_C), a3 = head_weights(prm.conv_w + 3 * HEAD_C * HEAD_C);
     float m0, r0;
-    if constexpr (TAIL) head_fold_stats(prm, 0, b, blockIdx.x == 0 && threadIdx.x < 64, m0, r0);
-    else head_stats(prm, 0, b, m0, r0);
+    head_stats(prm, 0, b, m0, r0);
     head_conv(a0, f, t);
     head_ln_silu(t, g, bt, m0, r0);
     float sc, qc, sq, qq;
@@ -717,6 +715,11 @@ __global__ __launch_bounds__(64) void ln_finalize_kernel(const HeadParams prm, i
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
     const float *pp = prm.partial + (((size_t)which * prm.B + b) * prm.nblk) * 2;
+    if (which == 0 && prm.partial0) {                  // statistics of u0 taken by the producer of feat: its own block size
+        pp = prm.partial0 + (size_t)b * prm.nblk0 * 2;
+        nblk_used = prm.nblk0;
+        block_pix = prm.bpix0;
+    }
     double s1, s2;
     fold_lane_chain<16>(pp, nblk_used, block_pix, HEAD_C, prm.P, lane, s1, s2);      // (urnn_common.h: the order every finalizer shares)
 #pragma unroll
@@ -746,13 +749,10 @@ static hipError_t launch_head_v(const HeadParams &p, int mask, hipStream_t st)
     const int fin = p.Pglobal > 0 ? 2 : nb;                  // strip mode: the partials hold the all-reduced totals as two pseudo-blocks
     const int bpix = p.Pglobal > 0 ? 0 : HEAD_BLOCK_PIX;     //             ... which are raw (sum, sum of squares)
     dim3 grid(nb, p.B), grid3(nb, p.B, 2), blk(256);
-    const bool tail = p.partial0 != nullptr;                 // the producer of feat took norm 0's partials: no head_k1, head_k2 folds them
+    const bool tail = p.partial0 != nullptr;                 // the producer of feat took norm 0's partials (the decoder's last conv, or the fused cell tail): no head_k1
     if ((mask & URNN_HEAD_K1) && !tail) hipLaunchKernelGGL(head_k1<AL>, grid, blk, 0, st, p);
-    if ((mask & URNN_HEAD_F1) && !tail) hipLaunchKernelGGL(ln_finalize_kernel, dim3(p.B, 1), dim3(64), 0, st, p, 0, 1, fin, bpix);
-    if (mask & URNN_HEAD_K2) {
-        if (tail) hipLaunchKernelGGL((head_k2<AL, true>), grid, blk, 0, st, p);
-        else hipLaunchKernelGGL((head_k2<AL, false>), grid, blk, 0, st, p);
-    }
+    if (mask & URNN_HEAD_F1) hipLaunchKernelGGL(ln_finalize_kernel, dim3(p.B, 1), dim3(64), 0, st, p, 0, 1, fin, bpix);   // (folds p.partial0 when set)
+    if (mask & URNN_HEAD_K2) hipLaunchKernelGGL(head_k2<AL>, grid, blk, 0, st, p);
     if (mask & URNN_HEAD_F2) hipLaunchKernelGGL(ln_finalize_kernel, dim3(p.B, 2), dim3(64), 0, st, p, 1, 2, fin, bpix);
     if (mask & URNN_HEAD_K3) hipLaunchKernelGGL(head_k3<AL>, grid3, blk, 0, st, p);
     if (mask & URNN_HEAD_F3) hipLaunchKernelGGL(ln_finalize_kernel, dim3(p.B, 2), dim3(64), 0, st, p, 2, 2, fin, bpix);

@@ -309,6 +309,9 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
     else if constexpr (SPLIT) stage_weights(reinterpret_cast<const float *>(prm.wsplit) + (size_t)g * prm.sDwords, urnn_smem, prm.sDwords, wave, WPB, lane);
     else stage_weights(prm.wt + (size_t)g * prm.aFloats, urnn_smem, prm.aFloats, wave, WPB, lane);
     if (threadIdx.x < NB * 32) bias[threadIdx.x] = (EPI == EPI_GRU1 && SPLIT == 3 && prm.biasf ? prm.biasf : prm.bias)[n0 + threadIdx.x];
+    if constexpr (EPI == EPI_LRELU && NB == 1 && PB == 4 && MAP == MAP_VEC) {
+        if (prm.stemW && threadIdx.x < 256) ssm[threadIdx.x] = prm.stemW[threadIdx.x];      // the head's stem conv, for the epilogue's statistics
+    }
     if constexpr (GATED) {
         // GroupNorm of the gates is finalised HERE instead of in a launch of its own: one wave per (sample, 32-channel
         // group) folds the gate GEMM's per-tile (sum, sumsq) partials in double, in a fixed order (lane-strided, then an xor
@@ -714,6 +717,55 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
                         store_row<MAP, PB>(prm.out0 + ((size_t)b * prm.Cout + n) * prm.P, pm, v);
                     }
                 }
+            if constexpr (NB == 1 && PB == 4 && MAP == MAP_VEC) {
+                if (prm.stemW) {
+                    // u0 = Ws . f for the tile's 128 pixels and its LayerNorm partials (sum, squares about the tile mean): rows 0..7 of a
+                    // lane are channels {0-3, 8-11} + 4 half of ONE pixel per pixel block; the partner lane (lane ^ 32) holds the other
+                    // eight.  Lane (j, half) computes outputs {0-3, 8-11} + 4 half of its four pixels.  Whole waves (shuffles).
+                    // On the matrix pipe: accumulator row r of a pixel block IS the B operand of v_mfma_f32_32x32x2_f32 for the k-pair
+                    // (channel row_c(r), channel row_c(r) + 4) -- lanes 0-31 hold the first, lanes 32-63 the second --, and the result's
+                    // rows 0..7 of a lane are the outputs {0-3, 8-11} + 4 half of its pixel: eight MFMAs per pixel block, no shuffles.
+                    const float *hw = ssm;
+                    float a8[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) a8[r] = j < 16 ? hw[j * 16 + row_c(r) + 4 * half] : 0.f;     // A[m = j][k = half]: Ws[m][channel]
+                    float u8[PB][8];
+                    float s = 0.f;
+#pragma unroll
+                    for (int pb = 0; pb < PB; ++pb) {
+                        f32x16 ua;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) ua[r] = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            const float f = lrelu(fin(acc[0][pb][r], bias_h[row_c(r)]), prm.slope);
+                            ua = __builtin_amdgcn_mfma_f32_32x32x2f32(a8[r], f, ua, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            u8[pb][r] = ua[r];
+                            if (pm.valid[pb]) s += ua[r];
+                        }
+                    }
+                    s = wave_sum(s);
+                    const int nvalid = tile_valid(tile, 32 * PB, prm.P);
+                    const float m = s / (16.f * (float)nvalid);
+                    float q = 0.f;
+#pragma unroll
+                    for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            const float d = u8[pb][r] - m;
+                            if (pm.valid[pb]) q = fmaf(d, d, q);
+                        }
+                    q = wave_sum(q);
+                    if (lane == 0) {
+                        float *pp = prm.stemPart + ((size_t)b * prm.tilesPerSample + tile) * 2;
+                        pp[0] = s;
+                        pp[1] = q;
+                    }
+                }
+            }
         } else if constexpr (EPI == EPI_POOL) {
             // out[b][n][q] = 0.25 * sum_{2x2} lrelu(acc + bias)
 #pragma unroll
@@ -943,7 +995,7 @@ static size_t conv_lds_bytes(const ConvGemmParams &p, int D, int WPB)
     using R = Ring<PB, MAP>;
     const int sm = split_mode<NB, PB, EPI>(p);
     const size_t slab = sm == 3 ? (size_t)p.fDwords * 4 : (sm ? (size_t)p.sDwords * 4 : (size_t)p.aFloats * 4);
-    return slab + (size_t)WPB * ((D + 1) * R::SLOT) + NB * 128 + (EPI == EPI_CAND ? (size_t)p.B * p.F * 8 : 0);
+    return slab + (size_t)WPB * ((D + 1) * R::SLOT) + NB * 128 + (EPI == EPI_CAND ? (size_t)p.B * p.F * 8 : 0) + (EPI == EPI_LRELU && p.stemW ? 1024 : 0);
 }
 
 template <int NB, int PB, int MAP, int EPI, int D, int WPB, int SPLIT>

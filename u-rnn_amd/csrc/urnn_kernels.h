@@ -83,6 +83,11 @@ struct ConvGemmParams {
     int fu1Dwords, fu2Dwords;
     const float *biasfu;
     int *status;          // the workspace's status word (urnn_common.h flag_nonfinite); may be NULL
+    // EPI_LRELU to 16 channels on 128-pixel tiles (the decoder's last conv): the head's stem conv (16 x 16, row-major) applied to the
+    // tile in the epilogue and the partial statistics of the head's first LayerNorm [B][tilesPerSample][2] -- head_k1's pass over the
+    // feature map done where the map is made (flood_head.py:131-140); NULL: off
+    const float *stemW;
+    float *stemPart;
     int abl;              // tuning builds (-DURNN_TUNING): ablation mask URNN_TUNE_ABL -- phases of cand_fused_kernel skipped for timing (wrong results)
 };
 

@@ -57,12 +57,13 @@ class StageLayers(nn.Module):
         return self._cache.get((L.weight, L.bias), lambda: fn(L.weight.detach(), L.bias.detach()), weights=(L.weight,))
 
     @torch.no_grad()
-    def forward(self, x, out=None):
+    def forward(self, x, out=None, head_w=None, head_partial0=None):
+        """``head_w`` / ``head_partial0``: ops.stage_conv (the decoder's last conv taking the head's first statistics)."""
         x = x.contiguous()
         packed = self._packed()
         with ops.exact_matrix_if(self._cache.wide):       # a weight beyond the f16 pieces' range: exact fp32 MFMA for this layer
             if self.kind == "conv":
-                return ops.stage_conv(x, packed, self.out_channels, self.pool, out=out)
+                return ops.stage_conv(x, packed, self.out_channels, self.pool, out=out, head_w=head_w, head_partial0=head_partial0)
             return ops.deconv2x2(x, packed, self.out_channels, out=out)
 
 

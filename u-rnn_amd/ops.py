@@ -191,12 +191,24 @@ def pack_deconv(weight, bias):
 
 
 # ---- forwards ----------------------------------------------------------------------------------------
-def stage_conv(x, packed, Cout, pool, out=None, slope=LRELU_SLOPE):
-    """[AvgPool2](LeakyReLU(conv1x1(x))): x (B,Cin,H,W) -> (B,Cout,H[/2],W[/2])."""
+def stage_conv_stem_applies(B, Cin, Cout, H, W):
+    """Can the flat conv to the head's 16 channels take the head's first LayerNorm statistics in its epilogue (urnn_stage_conv_stem_f32)?"""
+    return bool(lib().urnn_stage_conv_stem_applies(B, Cin, Cout, H, W))
+
+
+def stage_conv(x, packed, Cout, pool, out=None, slope=LRELU_SLOPE, head_w=None, head_partial0=None):
+    """[AvgPool2](LeakyReLU(conv1x1(x))): x (B,Cin,H,W) -> (B,Cout,H[/2],W[/2]).  ``head_w`` (the head's conv_w) + ``head_partial0``
+    (``head_tail_partial``): the decoder's last conv also leaves the head's first LayerNorm partials there (``stage_conv_stem_applies``)."""
     _dev_check(x, packed, out)
     B, Cin, H, W = x.shape
     if out is None:
         out = torch.empty((B, Cout, H // 2, W // 2) if pool else (B, Cout, H, W), dtype=torch.float32, device=x.device)
+    if head_w is not None:
+        if pool or head_partial0 is None:
+            raise ValueError("the head's statistics go with the flat conv and need their partial buffer")
+        check(lib().urnn_stage_conv_stem_f32(_ptr(x), _ptr(packed), _ptr(out), B, Cin, Cout, H, W, slope, _ptr(head_w), _ptr(head_partial0),
+                                             _stream()), "urnn_stage_conv_stem_f32")
+        return out
     check(lib().urnn_stage_conv_f32(_ptr(x), _ptr(packed), _ptr(out), B, Cin, Cout, H, W, 1 if pool else 0, slope,
                                     _stream()), "urnn_stage_conv_f32")
     return out

@@ -90,6 +90,7 @@ class RolloutEngine:
         # 4.10: the fused kernel reads 256-byte runs per plane where the blend reads 4 KB ones), hence off by default
         self._fused_tails = bool(fused_tails)
         self._tails = None          # decided at the first step (the layers' weight ranges are known once they are packed)
+        self._stem = None           # likewise: the decoder's last conv takes the head's first statistics (_stem_stats)
         self._k1part = [ops.head_tail_partial(B, H, W, dev) for _ in range(2 if self.overlap else 1)]
         self._param_stamp = None    # what the captured graphs' packed weights were made from (see _check_params)
         self._probe = None          # {"enc1": [(start, stop), ...], "dec1": [...]} while probing
@@ -142,8 +143,8 @@ class RolloutEngine:
         self._cell("dec2", dec.rnn2, self.u3, e2, d2, d2, ws)
         dec.stage2(d2, out=self.u2)
         if not self._cell("dec1", dec.rnn1, self.u2, e1, d3, d3, ws, conv_out=self.feat, k1part=self._k1part[0]):
-            dec.stage1(d3, out=self.feat)
-        tail = self._tail_of("dec1") is not None
+            self._last_conv(d3, self.feat, self._k1part[0])
+        tail = self._tail_of("dec1") is not None or self._stem_stats()
         net.head.run(self.feat, out_masked=self.out_masked, out_cls=self.out_cls, out_raw=self.out_raw,
                      frame_index=self.t_dev, ws=ws, partial0=self._k1part[0] if tail else None, coop=self._head_coop and not tail)
         ops.advance_counter(self.t_dev, 1)
@@ -158,6 +159,23 @@ class RolloutEngine:
             ops.preprocess(self.rain, self.cumsum, self.dem, self.imperv, self.manhole, self.dem_min, self.dem_max, 0,
                            self.nums, self.rain_max, self.cumsum_max, out=self.x_in, t_dev=t_dev, t_next=t_next)
             self.net.encoder.stage1(self.x_in, out=self.a1)
+
+    def _stem_stats(self):
+        """Does the decoder's last conv take the head's first LayerNorm statistics in its epilogue (ops.stage_conv_stem_applies: the big
+        planes)?  Decided once per set of weights; never together with the fused cell tail or with a layer on the exact instruction."""
+        if self._stem is None:
+            st = self.net.decoder.stage1
+            st._packed()                                              # (sets the layer's `wide` flag)
+            self._stem = (self._tail_of("dec1") is None and not st._cache.wide and not self._head_coop and
+                          ops.stage_conv_stem_applies(self.B, st.layer.in_channels, st.out_channels, self.H, self.W))
+        return self._stem
+
+    def _last_conv(self, d3, feat, k1part):
+        """Decoder.stage1 (64 -> 16 + LeakyReLU) into ``feat``; with ``_stem_stats`` also the head's first pass (its partials -> k1part)."""
+        if self._stem_stats():
+            self.net.decoder.stage1(d3, out=feat, head_w=self.net.head.flat_params()["conv_w"], head_partial0=k1part)
+        else:
+            self.net.decoder.stage1(d3, out=feat)
 
     def _tail_of(self, name):
         """The stage conv fused into the named cell's last kernel, or None (decided once per set of weights)."""
@@ -270,7 +288,7 @@ class RolloutEngine:
         def s1():
             feat = self.feat if parity == 0 else self.feat_alt
             if not self._cell("dec1", dec.rnn1, self.u2, e1, d3, d3, ws, conv_out=feat, k1part=self._k1part[parity]):
-                dec.stage1(d3, out=feat)
+                self._last_conv(d3, feat, self._k1part[parity])
         return [s3, s2, s1]
 
     def _enc_chain(self, parity):
@@ -284,7 +302,7 @@ class RolloutEngine:
     def _head_chain(self, parity):
         """head(t) for t % 2 == parity (reads feat[parity], frame index t2[parity]).  On a chain of its own (stream, scratch) when
         ``_head_own_chain``, else in front of the encoder pass on chain 1."""
-        tail = self._tail_of("dec1") is not None
+        tail = self._tail_of("dec1") is not None or self._stem_stats()
         self.net.head.run(self.feat if parity == 0 else self.feat_alt, out_masked=self.out_masked, out_cls=self.out_cls,
                           out_raw=self.out_raw, frame_index=self.t2[parity:parity + 1], ws=self._ws[2 if self._head_own_chain else 0],
                           partial0=self._k1part[parity] if tail else None, coop=self._head_coop and not tail,
@@ -499,6 +517,7 @@ class RolloutEngine:
         stamp = (getattr(self.net, "_urnn_generation", 0), lib().urnn_get_matrix_mode()) + tuple((p.data_ptr(), p._version) for p in self.net.parameters())
         if stamp != self._param_stamp:
             self._tails = None                  # (a layer's `wide` flag may have changed with its weights)
+            self._stem = None
             if self._param_stamp is not None:
                 self._graph = None
                 self._graphs2 = None
