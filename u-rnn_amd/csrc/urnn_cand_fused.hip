@@ -396,7 +396,7 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void cand_fused_kernel(const Con
                             const float dd = v[pb] - mt;
                             if (FULLT || pm.valid[pb]) s2[nb] = fmaf(dd, dd, s2[nb]);
                         }
-                        if (!(abl & 4)) store_row<MAP, PB>(orow, pm, v);
+                        if (!(abl & 4)) store_row_nt<MAP, PB>(orow, pm, v);      // (non-temporal: urnn_gemm.h)
                     }
                 }
                 wave_sum_n<NBF>(s2);

@@ -170,6 +170,23 @@ __device__ __forceinline__ void store_row(float *row, const PixelMap<MAP, PB> &p
     }
 }
 
+// store_row with non-temporal stores on the pair maps: for the fused candidate kernel, whose 64 output planes would otherwise push the
+// rows it is about to re-read (the tile's hidden state for phase 2, the next tile's inputs) out of the XCD's L2 -- same-box A/B of
+// the two libraries: cand_fused_kernel enc1 57.5 -> 55.4 us, dec1 88.8 -> 81.3 us.  Not for the gate GEMMs (full resolution: no
+// change; half resolution: 32.7 -> 35.5, 38.3 -> 41.2 us) nor the half-resolution candidate (no change): they keep store_row.
+template <int MAP, int PB>
+__device__ __forceinline__ void store_row_nt(float *row, const PixelMap<MAP, PB> &pm, const float (&v)[PB])
+{
+    if constexpr (is_pair(MAP)) {
+#if (URNN_ABL & 4)
+        if (pm.off[0] != -12345) { asm volatile("" ::"v"(v[0])); return; }
+#endif
+        if (pm.valid[0]) __builtin_nontemporal_store(f32x2{v[0], v[1]}, reinterpret_cast<f32x2 *>(row + pm.off[0]));
+    } else {
+        store_row<MAP, PB>(row, pm, v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Per-wave activation ring.  One slot = one k-pair = PB*256 B; lane l's own bytes sit at  quad*1024 + l*16  (16-B DMA) or
 // pb*256 + l*4  (dword DMA).
