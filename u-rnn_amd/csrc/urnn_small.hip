@@ -18,6 +18,9 @@
 
 #include <limits.h>
 #include <stdlib.h>
+#ifndef URNN_SMALL_PF
+#define URNN_SMALL_PF 8     // 16-k groups of weight pieces requested ahead of the MFMAs (the L2-resident slab): 4 -> 8 is +0.5 % frames/s on both schedules (profiles/r05_ab_small_pf.txt)
+#endif
 
 extern __shared__ __attribute__((aligned(16))) char urnn_small_smem[];
 
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(1024) void small_cell_gemm_kernel(const ConvGemmPar
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    constexpr int PF = 4;                                                 // weight pieces prefetched PF groups ahead
+    constexpr int PF = URNN_SMALL_PF;                                     // weight pieces prefetched PF groups ahead
     u32x4 ah[PF], am[PF], al[PF];
 #pragma unroll
     for (int q = 0; q < PF; ++q) {
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(768) void coop_cell_kernel(const CoopCellParams cp,
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    constexpr int PF = 4;
+    constexpr int PF = URNN_SMALL_PF;
     u32x4 ah[PF], am[PF];
 #pragma unroll
     for (int q = 0; q < PF; ++q) {
