@@ -373,14 +373,14 @@ __global__ __launch_bounds__(64 * WPB, WPB / 4) void conv_gemm_kernel(const Conv
     __syncthreads();
 
     if constexpr (WPB > 4) {
-        // Waves w and w + 4 share a SIMD.  Optional start offset for the later waves (prm.stagger eighths of an even split of
-        // one tile's MFMA time), meant to put the pair in anti-phase so that one wave's store epilogue hides behind the
-        // other's MFMAs.  Measured after the cell re-split: with one or two tiles per wave the offset costs more as tail than
-        // it hides (whole rollout 1070 frames/s at 0, 1047 at half a tile, 1020 at a full tile) -- the launcher passes 0.
+        // Waves w and w + 4 share a SIMD.  Start offset for the later waves: prm.stagger naps of s_sleep 64 (~4 096 cycles each).  Every
+        // wave of the chip starts its first tile at the same time, so all first epilogues -- 2 048 waves x 16 KB of stores -- fall
+        // together, and a wave's next loads queue behind its own stores (one in-order counter): DESIGN 4.16.  A nap or two take the two
+        // waves of a SIMD far enough apart where a wave has two tiles (enc1 gates, same box: 49.8 us without, 46.5 with one nap, 44.4 with
+        // two; dec1 unchanged); any offset where a wave has a single tile only adds a tail (dec2 37.5 -> 41.6 us at two naps).  The
+        // launcher decides (profiles/r05_ab_gate_stagger.txt).
         if (wave >= 4 && prm.stagger) {
-            const int mf = (KT - kp_begin) * NB * PB;
-            const int naps = (mf * 64 * (wave >> 2) / (WPB / 4)) * prm.stagger / 8 / (64 * 64);   // s_sleep 64 ~ 64*64 cycles; stagger/8 of the even split
-            for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(64);
+            for (int i = 0; i < prm.stagger; ++i) __builtin_amdgcn_s_sleep(64);
         }
     }
 
@@ -974,7 +974,7 @@ static int tune_stagger()
 {
     static int v = -1;
     if (v < 0) {
-        v = (int)urnn_tune("URNN_TUNE_STAGGER", 0);   // development knob: start offset of the second wave per SIMD   // in eighths of the even split (8 = half a tile for two waves per SIMD)
+        v = (int)urnn_tune("URNN_TUNE_STAGGER", -1);   // development knob: start offset of the second wave per SIMD in naps (-1: the launcher's rule)
     }
     return v;
 }
@@ -1031,7 +1031,8 @@ static hipError_t launch_conv_split(const ConvGemmParams &p, hipStream_t st, int
     }
     const int grid = persistent_grid(lds, p.NG, p.totalTiles, WPB, max_bpc);
     ConvGemmParams q = p;
-    q.stagger = tune_stagger();
+    // second wave of each SIMD two naps behind the first where the waves have two tiles each (gate GEMMs of the full-resolution cells)
+    q.stagger = tune_stagger() >= 0 ? tune_stagger() : ((EPI == EPI_GRU1 && WPB == 8 && 2L * p.totalTiles >= 3L * grid * WPB) ? 2 : 0);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WPB), lds, st, q);
     return hipGetLastError();
 }

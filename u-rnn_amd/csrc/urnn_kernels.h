@@ -72,7 +72,7 @@ struct ConvGemmParams {
     int Cout, F;
     float slope;
     float *out0;
-    int stagger;          // 8-wave blocks: start offset of the second wave of each SIMD, in eighths of half a tile (launcher: 0)
+    int stagger;          // 8-wave blocks: start offset of the second wave of each SIMD in naps of s_sleep 64 (conv_gemm_kernel; the launcher's rule) / in 16-k groups (cand_fused_kernel)
     float *partial;       // EPI_GRU1: [B][2F/32][tiles][2]; EPI_CAND: [B][F/32][tiles][2]
     // fused-reset-gate cell (URNN_PHASE_FUSED_R): the gate GEMM keeps the reset gate's statistics but does not store its planes
     // (zOnly), cand_fused_kernel recomputes it from its own slab: phase-1 [W1 r rows | W2 x,e columns], phase-2 W2[:, h] in the
