@@ -26,8 +26,11 @@ extern "C" {
 #endif
 
 /* ABI history.  1: rounds 1-3.  2: the first 256 bytes of every cell / head workspace are status / barrier words (zero them once:
- * "Operand range of the default matrix mode" and URNN_PHASE_COOP below), the cooperative and frame-loop entry points, the cell tail. */
-#define URNN_ABI_VERSION 2
+ * "Operand range of the default matrix mode" and URNN_PHASE_COOP below), the cooperative and frame-loop entry points, the cell tail.
+ * 3: the status area is URNN_STATUS_AREA_BYTES = 16 KB (zero once): the cooperative launches' grid barrier moved from two words of the
+ * first 256 bytes to 33 words, 256 bytes apart, from byte 1024 on (sharded arrivals, no fences: 2.7 instead of 7.7 us per barrier). */
+#define URNN_ABI_VERSION 3
+#define URNN_STATUS_AREA_BYTES 16384
 
 #define URNN_OK 0
 #define URNN_EINVAL (-1)   /* bad dimension / unsupported shape                     */
@@ -97,7 +100,7 @@ int urnn_pack_deconv_f32(const float *weight, const float *bias, float *packed, 
  *     weights reach 64 must be launched under URNN_MATRIX_FP32_MFMA (exact fp32 matrix instruction, no range limit); the Python
  *     host does exactly that per layer (u-rnn_amd/networks/_packing.py, ops.exact_matrix_if) -- reference checkpoint path:
  *     test.py:380-408.
- *   - activations: the FIRST 256 BYTES of every cell / head workspace are status words.  Kernels only ever atomically OR into
+ *   - activations: the FIRST URNN_STATUS_AREA_BYTES (16 KB) of every cell / head workspace are status / barrier words.  Kernels only ever atomically OR into
  *     word 0: URNN_STATUS_GATES / _CAND when the GroupNorm sums of a cell's gates / candidate are not finite, URNN_STATUS_HEAD
  *     for a LayerNorm of the head -- which is where an overflowed operand (inf out of the matrix pipe) surfaces, one norm later
  *     at most.  The owner zeroes the workspace once and reads the word wherever it synchronises anyway (RolloutEngine: once per
@@ -157,7 +160,7 @@ int urnn_gru_cell_f32(const float *x, const float *e, const float *h, const floa
  * blend, with the raw gates and the candidate kept in registers; only the partial GroupNorm statistics leave the CU between the
  * phases (ConvRNN.py:111-194).  Same arithmetic and summation orders as the three kernels: h_out is bit-identical.  Needs every
  * phase in the mask; ignored where the shape does not qualify.  The workspace's raw gate / candidate planes are then undefined.
- * Word 16 and 32 of the workspace's status area are the launch's barrier state (zero once, never touch).  A grid barrier that does
+ * Bytes 1024 .. 9727 of the workspace's status area are the launch's barrier state (zero once, never touch).  A grid barrier that does
  * not complete within ~1 s gives up and sets URNN_STATUS_BARRIER in the status word instead of hanging the GPU.
  * urnn_gru_cell_coop_blocks: how many blocks that launch would take for a cell of this shape (0: the flag would be ignored).  Every
  * block must be resident at once (one per CU): a caller that keeps SEVERAL kernel chains in flight passes the flag only for cells

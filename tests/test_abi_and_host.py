@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol(built):
     for name in sorted(declared):
         assert hasattr(lib, name), f"liburnn_hip.so does not export {name}"
     assert declared == set(built.SIGNATURES), "ctypes signature table and header disagree"
-    assert lib.urnn_abi_version() == 2
+    assert lib.urnn_abi_version() == 3
 
 
 def test_packed_sizes_and_argument_errors_without_gpu(built):

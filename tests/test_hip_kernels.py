@@ -270,11 +270,61 @@ def test_cooperative_cell_equals_three_kernels(dev, I, F, skip, H, W, B, with_x)
     assert ops.workspace_status(ws) == 0
 
 
+@pytest.mark.parametrize("I,F,skip,H,W,B", [
+    (64, 96, 0, 250, 250, 1),     # encoder stage 2 at 500x500: 977 tiles, 245 blocks of four (the last one holds a single, partial tile)
+    (96, 96, 1, 250, 250, 1),     # decoder stage 2: K = 288, eighteen 16-k groups
+    (96, 96, 1, 200, 280, 1),     # Futian's half resolution: 875 tiles
+    (96, 64, 1, 150, 152, 1),     # F = 64: two channel blocks per role, 357 tiles
+    (64, 96, 0, 110, 110, 2),     # two samples of 190 tiles: a block straddles the samples; the samples' last tile has 4 valid pixels
+])
+def test_cooperative_tiles_cell_vs_three_kernels_and_oracle(dev, I, F, skip, H, W, B):
+    """URNN_PHASE_COOP on a half-resolution plane (ConvRNN.py:111-194; urnn_coop_tiles.hip): the whole cell as one cooperative launch of
+    persistent blocks with four 64-pixel tiles each -- raw gates and candidate stay in the accumulators between the phases, two grid
+    barriers for the two GroupNorms.  Same f16-piece arithmetic and MFMA order as the three-kernel cell; the GroupNorm partials are
+    summed in another order inside a tile, so h' agrees with the three kernels to rounding (<= 2e-6 of max |h'|) rather than to the bit;
+    within 1e-4 of the oracle; in place, bit-stable over repeated launches (the barrier words are reused); status word clean."""
+    from oracle import oracle as orc
+    from urnn_amd import ops
+    from urnn_amd._lib import lib
+    rs = np.random.RandomState(91 + I + F + H)
+    K = I + (2 * F if skip else F)
+    p = {"W1": rs.normal(0, 1 / np.sqrt(K), (2 * F, K)).astype(np.float32), "b1": rs.normal(0, 0.1, 2 * F).astype(np.float32),
+         "g1": rs.uniform(0.5, 1.5, 2 * F).astype(np.float32), "be1": rs.normal(0, 0.1, 2 * F).astype(np.float32),
+         "W2": rs.normal(0, 1 / np.sqrt(K), (F, K)).astype(np.float32), "b2": rs.normal(0, 0.1, F).astype(np.float32),
+         "g2": rs.uniform(0.5, 1.5, F).astype(np.float32), "be2": rs.normal(0, 0.1, F).astype(np.float32)}
+    x = rs.normal(0, 1, (B, I, H, W)).astype(np.float32)
+    e = rs.normal(0, 1, (B, F, H, W)).astype(np.float32) if skip else None
+    h = rs.normal(0, 1, (B, F, H, W)).astype(np.float32)
+    tiles = B * ((H * W + 63) // 64)
+    blocks = lib().urnn_gru_cell_coop_blocks(B, I, F, H, W, int(skip), 1)
+    assert blocks == (tiles + 3) // 4, f"expected the four-tiles-per-block cooperative launch ({(tiles + 3) // 4} blocks), the library plans {blocks}"
+    packed = ops.pack_gru(T(p["W1"].reshape(2 * F, K, 1, 1), dev), T(p["b1"], dev), T(p["W2"].reshape(F, K, 1, 1), dev),
+                          T(p["b2"], dev), I, F, bool(skip))
+    args = (T(x, dev), None if e is None else T(e, dev))
+    aff = (T(p["g1"], dev), T(p["be1"], dev), T(p["g2"], dev), T(p["be2"], dev))
+    ws = ops.workspace(ops.gru_cell_workspace_bytes(B, F, H, W), dev)
+    three = ops.gru_cell(*args, T(h, dev), packed, *aff, I, phases=ops.PHASE_ALL, ws=ws)
+    one = ops.gru_cell(*args, T(h, dev), packed, *aff, I, phases=ops.PHASE_ALL | ops.PHASE_COOP, ws=ws)
+    torch.cuda.synchronize()
+    assert ops.workspace_status(ws) == 0
+    d = float((one - three).abs().max()) / float(three.abs().max())
+    print(f"cooperative tiles vs three kernels: max |dh'| / max |h'| = {d:.2e}; bit-identical: {torch.equal(one, three)}")
+    assert d <= 2e-6
+    ref = orc.gru_cell(x, e, h, p)
+    assert_close(one.cpu().numpy(), ref, TOL, "cooperative tiles cell vs oracle")
+    hh = T(h, dev)
+    for _ in range(10):                                   # in place, barrier state reused launch after launch
+        hh.copy_(T(h, dev))
+        ops.gru_cell(*args, hh, packed, *aff, I, out=hh, phases=ops.PHASE_ALL | ops.PHASE_COOP, ws=ws)
+        assert torch.equal(hh, one)
+    assert ops.workspace_status(ws) == 0
+
+
 def test_cooperative_cell_is_not_planned_for_large_planes_or_other_modes(dev):
     from urnn_amd import ops
     from urnn_amd._lib import lib
     L = lib()
-    assert L.urnn_gru_cell_coop_blocks(1, 64, 96, 250, 250, 0, 1) == 0          # 977 blocks: not co-resident
+    assert L.urnn_gru_cell_coop_blocks(1, 64, 96, 250, 250, 0, 1) == 245        # 977 tiles: four per block (urnn_coop_tiles.hip)
     assert L.urnn_gru_cell_coop_blocks(1, 16, 64, 500, 500, 0, 1) == 0
     assert L.urnn_gru_cell_coop_blocks(1, 16, 128, 64, 64, 0, 1) == 0           # F = 128: sixteen waves of gates
     assert L.urnn_gru_cell_coop_blocks(1, 96, 96, 125, 125, 0, 1) == 245

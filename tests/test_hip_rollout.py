@@ -577,6 +577,81 @@ def test_whole_event_vs_committed_oracle_trace(dev, trace):
     assert wstrict <= 1.0
 
 
+def _subset_err(got, want, plane_max, floor_frac):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    return float((np.abs(got - want) / np.maximum(np.abs(want), floor_frac * max(float(plane_max), 1e-30))).max())
+
+
+@pytest.mark.parametrize("trace", ["reference_trace_500x500_T360.npz", "reference_trace_400x560_T72.npz"])
+def test_whole_event_vs_reference_trace(dev, trace):
+    """The headline config pinned to the REFERENCE ITSELF over the whole event (reference loop test.py:352-371,
+    model.py:65-121).  tests/golden/make_reference_trace.py ran the reference's own ED in the build container -- as shipped (float32,
+    "ref32") and as a float64 copy of the same modules ("ref64") -- for location1 (500x500, C = 63, T = 360) and Futian (400x560,
+    C = 15, T = 72, spatial rain) and kept, per sampled frame, 4096 random pixels + the 1024 where ref32 and ref64 differ most + the
+    1024 nearest the wet/dry threshold, plus subsets of the final states.  The benchmarked schedule (hipGraph, three kernel chains)
+    must stay, on every sampled frame and final state, within
+        max(1e-4, 1.5 x |ref32 - ref64| on the same values)   of ref64
+    under the tests' floor (0.1 x the plane's max) AND under SURVEY 8c's strict floor (1e-3 x the plane's max); HIP against ref32
+    is printed beside it (two float32 evaluations of the same graph: each carries its own roundoff)."""
+    import urnn_amd.weights as uw
+    from urnn_amd.rollout import RolloutEngine
+    path = os.path.join(os.path.dirname(__file__), "golden", trace)
+    if not os.path.isfile(path):
+        pytest.fail(f"{trace} missing: generate it in the build container with tests/golden/make_reference_trace.py")
+    g = np.load(path)
+    H, W, nums, T = int(g["H"]), int(g["W"]), int(g["nums"]), int(g["T"])
+    rain_max, cum_max, spatial = float(g["rain_max"]), float(g["cumsum_max"]), bool(int(g["spatial"]))
+    net, sd = make_net(H, W, 2 * nums + 3, int(g["weights_seed"]), dev)
+    ev = uw.make_event(T, H, W, rain_max, seed=int(g["event_seed"]), spatial_rain=spatial)
+    eng = RolloutEngine(net, H, W, nums, rain_max, cum_max, max_frames=T, spatial_rain=spatial, keep_raw=True, overlap=True, use_graph=True)
+    eng.rollout(ev)
+    fr = g["frames"]
+    fr_d = torch.from_numpy(fr.astype(np.int64)).to(dev)
+    idx = np.concatenate([np.broadcast_to(g["pixels"].astype(np.int64), (len(fr), g["pixels"].size)), g["adv_idx"].astype(np.int64)], axis=1)
+    idx_d = torch.from_numpy(np.ascontiguousarray(idx)).to(dev)
+    raw = torch.gather(eng.out_raw[:T, 0].reshape(T, -1)[fr_d], 1, idx_d).cpu().numpy()
+    cls = torch.gather(eng.out_cls[:T, 0].reshape(T, -1)[fr_d], 1, idx_d).cpu().numpy()
+    r64 = np.concatenate([g["r64_raw"], g["a64_raw"]], axis=1)
+    c64 = np.concatenate([g["r64_cls"], g["a64_cls"]], axis=1)
+    r32 = np.concatenate([g["r32_raw"], g["a32_raw"]], axis=1)
+    c32 = np.concatenate([g["r32_cls"], g["a32_cls"]], axis=1)
+    worst = {0.1: 0.0, 1e-3: 0.0}
+    peak = {}
+    lines = []
+    for i, t in enumerate(fr):
+        rmax, cmax = g["ref64_raw_plane_max"][i], g["ref64_cls_plane_max"][i]
+        row = [int(t)]
+        for floor in (0.1, 1e-3):
+            eh_r, eh_c = _subset_err(raw[i], r64[i], rmax, floor), _subset_err(cls[i], c64[i], cmax, floor)
+            e32_r, e32_c = _subset_err(r32[i], r64[i], rmax, floor), _subset_err(c32[i], c64[i], cmax, floor)
+            hr_r, hr_c = _subset_err(raw[i], r32[i], rmax, floor), _subset_err(cls[i], c32[i], cmax, floor)
+            worst[floor] = max(worst[floor], eh_r / max(1e-4, 1.5 * e32_r), eh_c / max(1e-4, 1.5 * e32_c))
+            for k, v in (("hip_reg", eh_r), ("hip_cls", eh_c), ("ref32_reg", e32_r), ("ref32_cls", e32_c), ("hip_vs_ref32_reg", hr_r), ("hip_vs_ref32_cls", hr_c)):
+                peak[(floor, k)] = max(peak.get((floor, k), 0.0), v)
+            row += [eh_r, e32_r, hr_r, eh_c, e32_c, hr_c]
+        lines.append(row)
+    for row in lines[::12] + [lines[-1]]:
+        print("frame %4d | floor 0.1 max: reg HIP-ref64 %.2e ref32-ref64 %.2e HIP-ref32 %.2e, cls %.2e %.2e %.2e | strict floor 1e-3 max: reg %.2e %.2e %.2e, cls %.2e %.2e %.2e" % tuple(row))
+    srep = []
+    for k, st in enumerate(eng.final_states()):
+        got = st.reshape(-1)[torch.from_numpy(g[f"state{k}_idx"]).to(dev)].cpu().numpy()
+        smax = g["state_plane_max"][k]
+        for floor in (0.1, 1e-3):
+            eh = _subset_err(got, g[f"state{k}_ref64"], smax, floor)
+            e32 = _subset_err(g[f"state{k}_ref32"], g[f"state{k}_ref64"], smax, floor)
+            worst[floor] = max(worst[floor], eh / max(1e-4, 1.5 * e32))
+            srep.append((k, floor, f"{eh:.2e}", f"{e32:.2e}"))
+    for floor, nm in ((0.1, "floor 0.1 x plane max"), (1e-3, "STRICT floor 1e-3 x plane max (SURVEY 8c)")):
+        print(f"{trace} [{nm}] {len(fr)} of {T} frames x {idx.shape[1]} pixels, worst frame: pre-mask reg HIP vs ref64 {peak[(floor, 'hip_reg')]:.2e} "
+              f"(reference fp32 vs its own fp64 {peak[(floor, 'ref32_reg')]:.2e}; HIP vs ref32 {peak[(floor, 'hip_vs_ref32_reg')]:.2e}), cls {peak[(floor, 'hip_cls')]:.2e} "
+              f"({peak[(floor, 'ref32_cls')]:.2e}; {peak[(floor, 'hip_vs_ref32_cls')]:.2e}); worst error / bar = {worst[floor]:.2f}")
+    print(f"{trace} final states (state, floor, HIP vs ref64, ref32 vs ref64): {srep}")
+    print(f"{trace}: the reference's own full-plane fp32-vs-fp64 error, worst frame: reg {float(g['ref32_reg_err_full'].max()):.2e} (strict {float(g['ref32_reg_err_full_strict'].max()):.2e}), "
+          f"cls {float(g['ref32_cls_err_full'].max()):.2e} (strict {float(g['ref32_cls_err_full_strict'].max()):.2e}); wet/dry flips ref32 vs ref64 per frame: max {int(g['ref32_flips'].max())}")
+    assert worst[0.1] <= 1.0, f"HIP further from the reference's exact result than max(1e-4, 1.5 x the reference's own fp32 roundoff): {worst[0.1]:.2f} x the bar"
+    assert worst[1e-3] <= 1.0, f"strict floor: {worst[1e-3]:.2f} x the bar"
+
+
 @pytest.mark.parametrize("name,H,W,nums,T,B,rain_max,cum_max,spatial", [
     ("futian", 400, 560, 6, 72, 1, 5.0, 100.0, True),      # BASELINE configs[4] at its own T (futian_scratch.yaml:41-51,66-68: duration 72)
     ("ukea", 52, 120, 6, 36, 1, 10.0, 150.0, True),        # BASELINE configs[4], ukea_scratch.yaml:43-53,68-70

@@ -95,7 +95,7 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if handle.urnn_abi_version() != 2:
+        if handle.urnn_abi_version() != 3:
             raise UrnnError("liburnn_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -5,7 +5,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "liburnn_hip.so")
-SOURCES = ["urnn_gemm.hip", "urnn_gemm_gates.hip", "urnn_gemm_cand.hip", "urnn_gemm_deconv.hip", "urnn_cand_fused.hip", "urnn_cand_gated.hip", "urnn_small.hip",
+SOURCES = ["urnn_gemm.hip", "urnn_gemm_gates.hip", "urnn_gemm_cand.hip", "urnn_gemm_deconv.hip", "urnn_cand_fused.hip", "urnn_cand_gated.hip", "urnn_small.hip", "urnn_coop_tiles.hip",
            "urnn_tail.hip", "urnn_elem.hip", "urnn_train.hip", "urnn_api.hip"]
 HEADERS = ["urnn_common.h", "urnn_kernels.h", "urnn_gemm.h", os.path.join("..", "..", "include", "urnn_hip.h")]
 

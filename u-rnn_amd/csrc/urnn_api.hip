@@ -454,6 +454,20 @@ static int gru_cell_impl(const float *x, const float *e, const float *h, const f
         pb2 = 2;
         tiles2 = (int)((P + 63) / 64);
     }
+    // URNN_PHASE_COOP on a half-resolution plane (more 64-pixel tiles than CUs, at most four per CU): ONE cooperative launch with the gates
+    // and the candidate resident in the accumulators of persistent blocks (urnn_coop_tiles.hip)
+    if ((phase_mask & URNN_PHASE_COOP) && !tail && (phase_mask & URNN_PHASE_ALL) == URNN_PHASE_ALL && global_pixels <= 0 && !fused_r) {
+        const int nb = urnn_coop_tiles_blocks(p, c, B);
+        if (nb > 0) {
+            if (coop_blocks) {                                      // plan only (urnn_gru_cell_coop_blocks)
+                *coop_blocks = nb;
+                return URNN_OK;
+            }
+            CHECK_HIP(urnn_launch_coop_tiles(p, c, gn2_w, gn2_b, ws.ss2, ws.st2, h, h_out, reinterpret_cast<unsigned *>(ws.status) + 256, B, st),
+                      "gru cell (one cooperative launch, four tiles per block)");
+            return URNN_OK;
+        }
+    }
     // URNN_PHASE_COOP: the whole cell of a small plane as ONE cooperative launch (urnn_small.hip coop_cell_kernel) -- when the caller
     // asked for every phase and the shape qualifies; otherwise the flag is ignored and the three kernels run
     if ((phase_mask & URNN_PHASE_COOP) && !tail && (phase_mask & URNN_PHASE_ALL) == URNN_PHASE_ALL && global_pixels <= 0 && !fused_r && small_gates &&
@@ -462,7 +476,7 @@ static int gru_cell_impl(const float *x, const float *e, const float *h, const f
             *coop_blocks = B * (int)((P + 63) / 64);
             return URNN_OK;
         }
-        CHECK_HIP(urnn_launch_coop_cell(p, c, gn2_w, gn2_b, ws.ss2, h_out, reinterpret_cast<unsigned *>(ws.status) + 16, B, st), "gru cell (one cooperative launch)");
+        CHECK_HIP(urnn_launch_coop_cell(p, c, gn2_w, gn2_b, ws.ss2, h_out, reinterpret_cast<unsigned *>(ws.status) + 256, B, st), "gru cell (one cooperative launch)");
         return URNN_OK;
     }
     if (coop_blocks) return URNN_OK;                                // plan only: not a cooperative launch (*coop_blocks stays 0)
@@ -1068,7 +1082,7 @@ static int head_impl(const float *feat, const float *conv_w, const float *ln_w, 
         return fail(URNN_EINVAL, "urnn_head_rollout_f32: frame_next must not be the head's own frame_index");
     if (coop) {
         if (urnn_head_coop_blocks(B, (int)P) <= 0) return fail(URNN_EINVAL, "urnn_head_coop_f32: the launch's blocks cannot all be resident on this device (urnn_head_coop_blocks_f32 returned 0)");
-        CHECK_HIP(urnn_launch_head_coop(p, reinterpret_cast<unsigned *>(ws.status) + 16, (hipStream_t)stream), "head (one cooperative launch)");
+        CHECK_HIP(urnn_launch_head_coop(p, reinterpret_cast<unsigned *>(ws.status) + 256, (hipStream_t)stream), "head (one cooperative launch)");
         return URNN_OK;
     }
     CHECK_HIP(urnn_launch_head(p, phase_mask, (hipStream_t)stream), "head");

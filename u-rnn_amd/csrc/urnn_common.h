@@ -16,6 +16,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// 8-byte agent-scope (write-through / L1-bypassing) store and load of a float pair: the only accesses coop_grid_barrier_nf orders
+__device__ __forceinline__ void publish8(float *p, float a, float b)
+{
+    const f32x2 v = {a, b};
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ f32x2 consume8(const float *p)
+{
+    return __builtin_bit_cast(f32x2, __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
 // A value the compiler may not fold into a neighbouring operation: hipcc contracts a * b + c into an fma wherever it likes (and
 // __fmul_rn / __dmul_rn are plain multiplications to it), so the SAME source line can round once in one kernel and twice in another --
 // one ulp in a tile's centred sum of squares was enough to move a GroupNorm scale by a float ulp between the cooperative cell and
@@ -104,7 +115,14 @@ __device__ __forceinline__ double tile_x2(float s1, float y, int n)
 // spent by every block before its first byte moved.
 // FAST = false: the plain loop only (the head's kernels fold ~8 elements per lane in every wave of ~500 short-lived blocks: there the
 // two-path version measured slower -- head_k3 36 -> 54 us -- although it executes fewer instructions).
-template <int U, bool FAST = true>
+// COH: the partials were published by other blocks of THIS launch across coop_grid_barrier_nf: 8-byte agent-scope loads (consume8).
+template <bool COH>
+__device__ __forceinline__ f32x2 load_partial(const float *p)
+{
+    if constexpr (COH) return consume8(p);
+    else return *reinterpret_cast<const f32x2 *>(p);
+}
+template <int U, bool FAST = true, bool COH = false>
 __device__ __forceinline__ void fold_lane_chain(const float *pp, int ntiles, int tile_pix, int chans, int P, int lane, double &s1, double &s2)
 {
     s1 = 0.0;
@@ -116,13 +134,13 @@ __device__ __forceinline__ void fold_lane_chain(const float *pp, int ntiles, int
         const int tpart = (P % tile_pix) != 0 && P / tile_pix < ntiles ? P / tile_pix : -1;   // the partial tile, if any
         const int nclean = tpart >= 0 ? tpart : ntiles;                    // tiles [0, nclean) are full
         const bool mine = tpart >= 0 && (tpart & 63) == lane;              // (requested with the loop's first loads, used after them)
-        const f32x2 ldp = *reinterpret_cast<const f32x2 *>(pp + 2 * (mine ? tpart : 0));
+        const f32x2 ldp = load_partial<COH>(pp + 2 * (mine ? tpart : 0));
         for (int t0 = 0; t0 < nclean; t0 += 64 * U) {
             f32x2 v[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int t = t0 + u * 64 + lane;
-                const f32x2 ld = *reinterpret_cast<const f32x2 *>(pp + 2 * (t < nclean ? t : 0));   // (clamped: no branch around the load)
+                const f32x2 ld = load_partial<COH>(pp + 2 * (t < nclean ? t : 0));   // (clamped: no branch around the load)
                 v[u] = t < nclean ? ld : f32x2{0.f, 0.f};
             }
 #pragma unroll
@@ -143,7 +161,7 @@ __device__ __forceinline__ void fold_lane_chain(const float *pp, int ntiles, int
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int t = t0 + u * 64 + lane;
-            v[u] = t < ntiles ? *reinterpret_cast<const f32x2 *>(pp + 2 * t) : f32x2{0.f, 0.f};
+            v[u] = t < ntiles ? load_partial<COH>(pp + 2 * t) : f32x2{0.f, 0.f};
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -158,7 +176,7 @@ __device__ __forceinline__ void fold_lane_chain(const float *pp, int ntiles, int
 // (|activation| >= 2047 or |weight| >= 64 in the default matrix mode) turns into inf in the matrix pipe and surfaces here, one
 // norm later at most.  The owner of the workspace zeroes it once and reads the word at a synchronisation point of its choice.
 // (bits URNN_STATUS_GATES / _CAND / _HEAD: include/urnn_hip.h)
-#define URNN_STATUS_BYTES 256
+#define URNN_STATUS_BYTES 16384   // bytes 0-255: status word + the round-5 barrier words; 1024-9727: coop_grid_barrier_nf's words (include/urnn_hip.h)
 #ifndef URNN_STATUS_BARRIER
 #define URNN_STATUS_BARRIER 8     // a grid barrier gave up (include/urnn_hip.h)
 #endif
@@ -304,10 +322,58 @@ __device__ __forceinline__ void fold_thread_chain(const float *pp, int ntiles, i
     }
 }
 
-// ---- grid barrier of the cooperative launches (urnn_small.hip coop_cell_kernel, urnn_elem.hip head_coop_kernel) -------------------------
-// One monotonic generation word + an arrival counter the last arriver resets (MI355X_MICROARCH.md "barrier-counter" with the
-// hand-off protocol of cdna_hip_programming.md section 6 G16: every wave drains its stores, one lane releases at agent scope, polls
-// relaxed, acquires once).  <= 256 arrivals.
+// ---- grid barriers of the cooperative launches (urnn_small.hip coop_cell_kernel, urnn_elem.hip head_coop_kernel) ------------------------
+// Round 6 (tools/ubench/grid_barrier.hip, profiles/r06_grid_barrier.txt): the round-5 barrier below -- one arrival counter, one
+// generation word, an agent-scope release fence before the arrival and an acquire fence after the release -- costs 7.7 us for 245
+// blocks (1.1 us + ~25 ns per arrival on the one word, ~1.7 us per fence), and the quarter-resolution cell spent 17 of its 37 us in
+// two of them.  coop_grid_barrier_nf: arrivals sharded 16 ways (blockIdx % 16; <= 16 arrivals per word, the last arriver of a shard
+// bumps a top counter, the last of those writes 16 generation words, a block polls its shard's) and NO fences: 2.7 us for 245 blocks.
+// Its contract: everything a block publishes across the barrier travels as 8-byte agent-scope atomic stores (write-through) and is
+// read back with 8-byte agent-scope atomic loads (publish8 / consume8 below; MI355X_MICROARCH.md "valid forms": 8-B agent atomics on
+// both sides) -- the cooperative kernels publish nothing but per-tile partial statistics, one (sum, centred second moment) pair per
+// wave.  Plain stores / loads across this barrier are NOT ordered by it.
+// Barrier words (dwords from `bar`, 64 apart = 256 B so that no two share a channel's line): [64 s] shard arrivals, [1024] top counter,
+// [1088 + 64 s] shard generation words, s < 16: the workspace's status area holds them from byte 1024 on (URNN_STATUS_BYTES).
+#define URNN_BARRIER_SHARDS 16
+__device__ __forceinline__ void coop_grid_barrier_nf(unsigned *bar, unsigned block, unsigned nblocks, int *status)
+{
+    constexpr unsigned NS = URNN_BARRIER_SHARDS;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave: its published granules have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned s = block % NS;
+        unsigned *genw = bar + 1088 + 64 * s;
+        const unsigned gen = __hip_atomic_load(genw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned mine = nblocks / NS + (s < nblocks % NS ? 1u : 0u);     // blocks of this shard
+        const unsigned used = nblocks < NS ? nblocks : NS;                      // shards with blocks
+        bool last = false;
+        if (__hip_atomic_fetch_add(&bar[64 * s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mine - 1) {
+            __hip_atomic_store(&bar[64 * s], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__hip_atomic_fetch_add(&bar[1024], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == used - 1) {
+                __hip_atomic_store(&bar[1024], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = true;
+            }
+        }
+        if (last) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the counter resets have landed before anybody is released
+            for (unsigned k = 0; k < NS; ++k) __hip_atomic_store(bar + 1088 + 64 * k, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            int spins = 0;
+            while (__hip_atomic_load(genw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 22)) {               // ~1 s: something else holds the chip; give up loudly instead of hanging it
+                    if (status) atomicOr(status, URNN_STATUS_BARRIER);
+                    break;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// The round-5 barrier: one monotonic generation word + an arrival counter the last arriver resets (MI355X_MICROARCH.md "barrier-counter"
+// with the hand-off protocol of cdna_hip_programming.md section 6 G16: every wave drains its stores, one lane releases at agent scope,
+// polls relaxed, acquires once): orders PLAIN stores / loads across it.  <= 256 arrivals.
 __device__ __forceinline__ void coop_grid_barrier(unsigned *bar, unsigned nblocks, int *status)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

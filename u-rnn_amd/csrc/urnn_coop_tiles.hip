@@ -1,0 +1,590 @@
+// urnn_coop_tiles.hip -- a WHOLE ConvGRU / Skip-ConvGRU cell of a HALF-RESOLUTION plane (ConvRNN.py:111-194; 62 500 pixels at
+// 500x500, 56 000 at Futian's 400x560) in ONE cooperative launch whose raw gates and candidate never leave the chip.
+//
+// The three-kernel cell moves the raw gates (2F planes) and the raw candidate (F planes) out to HBM and back and reads its inputs
+// twice: 608 MB per frame for the two half-resolution cells against 160 MB of algorithmic traffic, 166 us.  Here a block is one CU
+// and owns up to FOUR 64-pixel tiles (977 tiles over 256 CUs); its output -- 3F channels (z | r | c) x 256 pixels -- stays in the
+// accumulators of its twelve waves from the first k-step to the blend:
+//   wave = (role wr in {z, r, c}, tile slot wc): all F channels of its role for the 64 pixels of tile wc = F/32 x 2 MFMA tiles of
+//   32 x 32 (96 accumulator registers at F = 96); waves wc sit on SIMD wc (a z-, an r- and a c-wave per SIMD).
+// Phase A (output-stationary GEMM, K streamed in 16-k groups):
+//   * activations: the group's 16 input rows x 4 tiles arrive as fp32 through LDS-DMA (4 rows x 256 B per instruction, issued five
+//     groups ahead by the z- and r-waves) into a SIX-slot ring; a wave reads its tile's B fragments straight from the ring and splits
+//     them into f16 pieces in registers (the three waves of a tile redo the split: VALU is idle next to the matrix pipe here);
+//   * weights: the group's 3F/32 blocks x two f16 pieces (the packed slabs of the three-kernel cell, L2-resident) arrive by LDS-DMA
+//     from the c-waves two groups ahead (three buffers) -- ONE copy per CU and k-group for all four tiles (the activation-stationary
+//     kernels of urnn_small.hip re-stream them per 64-pixel tile, which is what made them lose at this size);
+//   * z / r accumulate all K groups, c the x | e groups; one __syncthreads per group.
+//   The gates' centred tile statistics go out as 8-byte agent-scope granules.                                     | grid barrier 1
+// Phase B: a wave per norm group folds the statistics (the order every finalizer shares) -> (scale, shift) table in LDS.  The ring's
+//   last F/16 slots still hold the tiles' hidden state: the r-waves turn it IN PLACE into r (.) h (one dword = the value's two f16
+//   pieces), the c-waves finish the candidate with W2[:, h] (staged once per CU) and publish its statistics, the z-waves apply
+//   their sigmoid meanwhile.                                                                                      | grid barrier 2
+// Phase C: z goes through LDS to the c-waves, which fold the candidate's statistics, re-read h from global memory (L2 / MALL) and
+//   blend.  HBM traffic: K input planes + F planes of h a second time + F planes out.
+// Arithmetic: the f16 x 3 pieces, MFMA order and activation functions of every other forward kernel; GroupNorm partials per 64-pixel
+// tile, folded in the shared order.  Every block must be resident (one per CU); barriers: urnn_common.h coop_grid_barrier_nf.
+#include "urnn_common.h"
+#include "urnn_kernels.h"
+
+#include <limits.h>
+
+typedef __attribute__((address_space(3))) void *ct_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *ct_gbl_ptr_t;
+typedef __amdgpu_buffer_rsrc_t ct_rsrc_t;
+
+extern __shared__ __attribute__((aligned(16))) char urnn_ct_smem[];
+
+#ifdef URNN_TRACE
+static __device__ unsigned long long *urnn_ct_trace_buf = nullptr;
+extern "C" int urnn_debug_set_trace_urnn_coop_tiles(unsigned long long *p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(urnn_ct_trace_buf), &p, sizeof(p)); }
+#define CT_STAMP(k) do { if (urnn_ct_trace_buf && lane == 0) urnn_ct_trace_buf[((size_t)blockIdx.x * 16 + wave) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CT_STAMP(k) do { } while (0)
+#endif
+
+static constexpr int CT_D = 6;                    // ring slots (16-k groups of activations in LDS): >= F/16, the hidden state stays resident
+static constexpr int CT_NT = 4;                   // tiles per block
+static constexpr int CT_SLOT = CT_NT * 4096;      // one group's 16 rows x 64 pixels x fp32 of every tile
+static constexpr int CT_WBUF = 20 * 1024;         // one group's weight blocks (9 x 2 KB at F = 96) + the DMA padding
+static constexpr int CT_NW = 3;                   // weight buffers
+
+struct CoopTilesParams {
+    const float *seg[3];      // x | e | h (encoder: x | h)
+    int segC[3];
+    int segG0[3];             // first absolute 16-k group of each segment (INT_MAX: unused)
+    unsigned segBytes[3];     // bytes of each segment's tensor (the DMA descriptors' bounds)
+    int kg0, KG, KGxe;        // first absolute group, groups of the gate GEMM, the first KGxe of them are the candidate's plain (x | e) rows
+    const unsigned *wblk[9];  // per canonical block [z_0 .. | r_0 .. | c_0 ..]: its f16 pieces at absolute group 0 ...
+    int wstride[9];           // ... and the dwords from one group to the next
+    const float *gbias;       // gate bias in packed order; block cb's 32 values start at gbiasOff[cb]
+    int gbiasOff[6];
+    const float *cbias;       // [F]
+    const float *gn1_w, *gn1_b, *gn2_w, *gn2_b;
+    float eps;
+    const float *h;
+    float *h_out;
+    float *partial1, *partial2;   // [B][2F/32][tiles][2], [B][F/32][tiles][2]: 64-pixel tiles
+    float *ss1_out, *ss2_out;     // [B][2F][2], [B][F][2]: what the three-kernel cell leaves in the workspace
+    float *st1_out, *st2_out;     // [B][2F/32][2], [B][F/32][2] (mean, rstd)
+    unsigned *bar;
+    int *status;
+    int B, P, F, tilesPerSample, totalTiles, nblocks;
+};
+
+__device__ __forceinline__ void ct_bdma16(ct_rsrc_t r, unsigned voff, unsigned soff, char *l) { __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (ct_lds_ptr_t)l, 16, voff, soff, 0, 0); }
+__device__ __forceinline__ void ct_dma16(const unsigned *g, char *l) { __builtin_amdgcn_global_load_lds((ct_gbl_ptr_t)g, (ct_lds_ptr_t)l, 16, 0, 0); }
+template <int N>
+__device__ __forceinline__ void ct_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void ct_wait_vm_groups(int groups, int per)       // at most `groups` x `per` VMEM operations still in flight
+{
+    const int n = groups * per;
+    if (n >= 10) ct_wait_vmcnt<10>();
+    else if (n >= 8) ct_wait_vmcnt<8>();
+    else if (n >= 6) ct_wait_vmcnt<6>();
+    else if (n >= 5) ct_wait_vmcnt<5>();
+    else if (n >= 4) ct_wait_vmcnt<4>();
+    else if (n >= 3) ct_wait_vmcnt<3>();
+    else if (n >= 2) ct_wait_vmcnt<2>();
+    else ct_wait_vmcnt<0>();
+}
+
+// Block barrier WITHOUT the compiler's fence: __syncthreads() makes hipcc drain vmcnt to 0 first (it must assume the LDS-DMA in flight is
+// covered by the fence), which would wait for the rows requested five groups ahead at every k-step.  The waits that matter are explicit:
+// counted vmcnt waits for the DMA a wave issued itself, lgkmcnt(0) for its LDS traffic.
+__device__ __forceinline__ void ct_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// arrive at / leave the sharded grid barrier of urnn_common.h from ONE thread; the caller brackets it with its own __syncthreads
+__device__ __forceinline__ void ct_barrier_lane(unsigned *bar, unsigned block, unsigned nblocks, int *status)
+{
+    constexpr unsigned NS = URNN_BARRIER_SHARDS;
+    const unsigned s = block % NS;
+    unsigned *genw = bar + 1088 + 64 * s;
+    const unsigned gen = __hip_atomic_load(genw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned mine = nblocks / NS + (s < nblocks % NS ? 1u : 0u);
+    const unsigned used = nblocks < NS ? nblocks : NS;
+    bool last = false;
+    if (__hip_atomic_fetch_add(&bar[64 * s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mine - 1) {
+        __hip_atomic_store(&bar[64 * s], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_fetch_add(&bar[1024], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == used - 1) {
+            __hip_atomic_store(&bar[1024], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = true;
+        }
+    }
+    if (last) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (unsigned k = 0; k < NS; ++k) __hip_atomic_store(bar + 1088 + 64 * k, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        int spins = 0;
+        while (__hip_atomic_load(genw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 22)) {
+                if (status) atomicOr(status, URNN_STATUS_BARRIER);
+                break;
+            }
+        }
+    }
+}
+
+// G = F / 32 channel blocks per role
+template <int G>
+__global__ __launch_bounds__(768) void coop_tiles_kernel(const CoopTilesParams cp)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3;                      // role: 0 z, 1 r, 2 c; tile slot
+    const int j = lane & 31, half = lane >> 5;
+    const int P = cp.P, F = cp.F;
+    const int KG = cp.KG, KGxe = cp.KGxe, NH = F / 16;            // NH hidden-state groups = the last groups of the k-loop
+    char *ring = urnn_ct_smem;
+    char *wbuf = ring + CT_D * CT_SLOT;
+    float *biasl = reinterpret_cast<float *>(wbuf + CT_NW * CT_WBUF);   // [3 G 32] z | r | c channels
+    // from phase B on (the weight buffers are free past the 12 G^2 KB of W2[:, h]): (scale, shift) tables, one per tile slot
+    float *sstab = reinterpret_cast<float *>(wbuf + 48 * 1024);           // [4 slots][3 G 32][2]
+    CT_STAMP(0);
+
+    // ---- tiles of this block: slot ti holds global tile blockIdx * CT_NT + ti (sample b, 64-pixel tile t): consecutive tiles, so a block
+    // straddles two samples only at a sample's end -----------------------------------------------------------------------------------------
+    auto slot_tile = [&](int ti, int &b_, int &t_) -> bool {
+        const int T = (int)blockIdx.x * CT_NT + ti;
+        const bool on = T < cp.totalTiles;
+        b_ = on ? T / cp.tilesPerSample : 0;
+        t_ = on ? T - b_ * cp.tilesPerSample : 0;
+        return on;
+    };
+    int tb, tt;
+    const bool tile_on = slot_tile(wc, tb, tt);                   // (whole wave)
+    const int nvalid = tile_on ? tile_valid(tt, 64, P) : 0;
+
+    for (int i = threadIdx.x; i < 3 * G * 32; i += blockDim.x) {
+        const int cb = i >> 5;
+        biasl[i] = cb < 2 * G ? cp.gbias[cp.gbiasOff[cb] + (i & 31)] : cp.cbias[i - 2 * G * 32];
+    }
+
+    // ---- DMA duties ---------------------------------------------------------------------------------------------------------------------
+    // waves 0-7: activations.  Wave w moves rows 4 qd .. 4 qd + 3 (qd = w & 3) of tile slots w >> 2 and (w >> 2) + 2: lane l = row l >> 4,
+    // pixels 4 (l & 15) .. + 3.  A slot without a tile re-reads tile 0 of sample 0 (nobody looks at it; the issue count stays uniform).
+    const ct_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(cp.seg[0]), 0, (int)cp.segBytes[0], 0x00020000);
+    const ct_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(cp.seg[1]), 0, (int)cp.segBytes[1], 0x00020000);
+    const ct_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(cp.seg[2]), 0, (int)cp.segBytes[2], 0x00020000);
+    const int qd = wave & 3, ts0 = (wave >> 2) & 1;
+    unsigned voff[2][3];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        int bk, tk;
+        slot_tile(ts0 + 2 * k, bk, tk);
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            voff[k][s] = (unsigned)((((size_t)bk * cp.segC[s] + (lane >> 4)) * P + (size_t)tk * 64 + 4 * (lane & 15)) * 4);
+    }
+    auto issue_acts = [&](int gn) __attribute__((always_inline)) {           // the 16 rows of relative group gn -> ring slot gn % D
+        const int Ga = cp.kg0 + gn;
+        const int s = Ga >= cp.segG0[2] ? 2 : (Ga >= cp.segG0[1] ? 1 : 0);
+        const unsigned soff = (unsigned)((16 * (Ga - cp.segG0[s]) + 4 * qd) * P) * 4u;
+        char *dst = ring + (gn % CT_D) * CT_SLOT + qd * 1024;
+        if (s == 0) {
+            ct_bdma16(rs0, voff[0][0], soff, dst + ts0 * 4096);
+            ct_bdma16(rs0, voff[1][0], soff, dst + (ts0 + 2) * 4096);
+        } else if (s == 1) {
+            ct_bdma16(rs1, voff[0][1], soff, dst + ts0 * 4096);
+            ct_bdma16(rs1, voff[1][1], soff, dst + (ts0 + 2) * 4096);
+        } else {
+            ct_bdma16(rs2, voff[0][2], soff, dst + ts0 * 4096);
+            ct_bdma16(rs2, voff[1][2], soff, dst + (ts0 + 2) * 4096);
+        }
+    };
+    // waves 8-11: weights.  2 x 3 G pieces of 1 KB per group, NQ per wave; indices past the end re-copy the first pieces into the buffer's padding
+    constexpr int NPCS = 2 * 3 * G, NQ = (NPCS + 3) / 4;
+    auto issue_weights = [&](int gn) __attribute__((always_inline)) {
+        const int Ga = cp.kg0 + gn;
+        char *dst = wbuf + (gn % CT_NW) * CT_WBUF;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int n = wc + 4 * q, nn = n < NPCS ? n : n - NPCS;
+            const int blk = nn >> 1;
+            ct_dma16(cp.wblk[blk] + (size_t)Ga * cp.wstride[blk] + (nn & 1) * 256 + lane * 4, dst + n * 1024);
+        }
+    };
+    if (wr < 2) {
+        for (int gn = 0; gn < CT_D - 1 && gn < KG; ++gn) issue_acts(gn);
+    } else {
+        issue_weights(0);
+        if (KG > 1) issue_weights(1);
+    }
+
+    f32x16 acc[G][2];
+#pragma unroll
+    for (int blk = 0; blk < G; ++blk)
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[blk][pb][r] = 0.f;
+
+    // one group's matrix work of this wave: B fragments of its tile from ring slot `slot` (fp32 rows or, packed = true, one dword of two
+    // f16 pieces per value), A fragments of its G blocks from `wsrc` ([block][hi | lo][64 lanes][16 B]); f16 x 3, small terms first
+    const int boff = wc * 4096 + half * 256 + j * 4;
+    auto group_mfma = [&](const char *slot, const char *wsrc, bool packed) __attribute__((always_inline)) {
+        unsigned bh[2][4], bl[2][4];
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+            float v[8];
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)          // row 4 d + 2 q + half of the group, pixel 32 pb + j
+                    v[2 * d + q] = *reinterpret_cast<const float *>(slot + boff + (4 * d + 2 * q) * 256 + pb * 128);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                if (packed) {
+                    const unsigned a = __float_as_uint(v[2 * d]), b = __float_as_uint(v[2 * d + 1]);
+                    bh[pb][d] = __builtin_amdgcn_perm(b, a, 0x05040100u);      // {b.lo16, a.lo16}: the hi pieces
+                    bl[pb][d] = __builtin_amdgcn_perm(b, a, 0x07060302u);      // {b.hi16, a.hi16}: the lo pieces
+                } else {
+                    split2_pair(v[2 * d], v[2 * d + 1], URNN_F16_ASCALE, bh[pb][d], bl[pb][d]);
+                }
+            }
+        }
+#pragma unroll
+        for (int blk = 0; blk < G; ++blk) {
+            const f16x8 ah = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4 *>(wsrc + blk * 2048 + lane * 16));
+            const f16x8 al = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4 *>(wsrc + blk * 2048 + 1024 + lane * 16));
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                acc[blk][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, as_f16x8(bh[pb]), acc[blk][pb], 0, 0, 0);
+                acc[blk][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, as_f16x8(bl[pb]), acc[blk][pb], 0, 0, 0);
+                acc[blk][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, as_f16x8(bh[pb]), acc[blk][pb], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- phase A: the k-loop ---------------------------------------------------------------------------------------------------------------
+    CT_STAMP(1);
+    for (int g = 0; g < KG; ++g) {
+        if (wr < 2) {                                   // group g's rows have landed: at most the D - 2 groups after it are still in flight
+            const int ahead = KG - 1 - g < CT_D - 2 ? KG - 1 - g : CT_D - 2;
+            ct_wait_vm_groups(ahead, 2);
+        } else {                                        // group g's weights: at most group g + 1's in flight
+            ct_wait_vm_groups(g + 1 < KG ? 1 : 0, NQ);
+        }
+        ct_sync();                                      // ... for every wave's share; and everybody is done with group g - 1's slot and weights
+        if (wr < 2) {
+            if (g + CT_D - 1 < KG) issue_acts(g + CT_D - 1);        // -> the slot of group g - 1
+        } else {
+            if (g + 2 < KG) issue_weights(g + 2);                   // -> the buffer of group g - 1
+        }
+        if (tile_on && (wr < 2 || g < KGxe))
+            group_mfma(ring + (g % CT_D) * CT_SLOT, wbuf + (g % CT_NW) * CT_WBUF + wr * G * 2048, false);
+    }
+    CT_STAMP(2);
+
+    // ---- raw gates (bias added) stay in the accumulators; centred statistics of every (64-pixel tile, 32-channel group) -> partial1 ---------
+    auto row_c = [](int r) { return (r & 3) + 8 * (r >> 2); };
+    const float inv_n = nvalid == 64 ? 1.0f / 2048.0f : 1.0f / (32.0f * (float)(nvalid > 0 ? nvalid : 1));
+    const bool okp[2] = {tt * 64 + j < P && tile_on, tt * 64 + 32 + j < P && tile_on};
+    auto finish_and_stats = [&](int role, float *partial, int ngroups) __attribute__((always_inline)) {
+#pragma unroll
+        for (int blk = 0; blk < G; ++blk) {
+            const float *bias_h = biasl + (role * G + blk) * 32 + 4 * half;
+            float s1 = 0.f;
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc[blk][pb][r] = fmaf(acc[blk][pb][r], URNN_F16_DESCALE, bias_h[row_c(r)]);
+                    if (okp[pb]) s1 += acc[blk][pb][r];
+                }
+            s1 = wave_sum(s1);
+            const float mt = nofma(s1 * inv_n);
+            float s2 = 0.f;
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float d = acc[blk][pb][r] - mt;
+                    if (okp[pb]) s2 = fmaf(d, d, s2);
+                }
+            s2 = wave_sum(s2);
+            if (lane == 0 && nvalid > 0)
+                publish8(partial + (((size_t)tb * ngroups + (role == 2 ? blk : role * G + blk)) * cp.tilesPerSample + tt) * 2, s1, s2);
+        }
+    };
+    if (wr < 2) finish_and_stats(wr, cp.partial1, 2 * G);
+
+    // the candidate's hidden-state weights W2[:, h] (NH groups x G blocks x two pieces), once per CU, into the weight buffers: everybody is
+    // past the k-loop's last weight read after this barrier
+    __syncthreads();
+    if (wr == 2) {
+        constexpr int NH_MAX = 2 * G;                    // F / 16
+        const int total = NH_MAX * G * 2;                // 1-KB pieces: [group][block][piece]
+        for (int n = wc; n < total; n += 4) {
+            const int gi = n / (2 * G), rem = n - gi * 2 * G, blk = rem >> 1;
+            ct_dma16(cp.wblk[2 * G + blk] + (size_t)(cp.kg0 + KGxe + gi) * cp.wstride[2 * G + blk] + (rem & 1) * 256 + lane * 4, wbuf + n * 1024);
+        }
+    }
+    CT_STAMP(3);
+
+    // ---- grid barrier 1 ----------------------------------------------------------------------------------------------------------------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) ct_barrier_lane(cp.bar, blockIdx.x, (unsigned)cp.nblocks, cp.status);
+    __syncthreads();
+    CT_STAMP(4);
+
+
+    // ---- phase B: GroupNorm of the gates.  Wave (role z / r, wc < G) folds norm group role G + wc for the sample of tile slot 0 and, where
+    // a later slot belongs to another sample (B > 1, a sample's end inside this block), again for that one: table [slot][channel] ----------
+    int sb[CT_NT];                                        // sample of every slot (block-uniform)
+    bool son[CT_NT];
+#pragma unroll
+    for (int ti = 0; ti < CT_NT; ++ti) {
+        int t_;
+        son[ti] = slot_tile(ti, sb[ti], t_);
+    }
+    auto fold_group = [&](const float *partial, int ngroups, int grp, const float *gam, const float *bet, int ch0, float *ss_out, float *st_out,
+                          int status_bit) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ti = 0; ti < CT_NT; ++ti) {
+            if (!son[ti]) continue;
+            float *tab = sstab + (size_t)ti * 3 * G * 64;
+            if (ti > 0 && sb[ti] == sb[ti - 1]) {                       // same sample as the slot before: copy its table entries
+                if (lane < 32) {
+                    const float *prev = sstab + (size_t)(ti - 1) * 3 * G * 64;
+                    tab[2 * (ch0 + lane)] = prev[2 * (ch0 + lane)];
+                    tab[2 * (ch0 + lane) + 1] = prev[2 * (ch0 + lane) + 1];
+                }
+                continue;
+            }
+            const int bs = sb[ti];
+            const float *pp = partial + ((size_t)bs * ngroups + grp) * cp.tilesPerSample * 2;
+            double s1, s2;
+            fold_lane_chain<8, true, true>(pp, cp.tilesPerSample, 64, 32, P, lane, s1, s2);      // (urnn_common.h: the order every finalizer shares)
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                s1 += __shfl_xor(s1, m, 64);
+                s2 += __shfl_xor(s2, m, 64);
+            }
+            const double count = 32.0 * (double)P;
+            const double mean = s1 / count;
+            double var = s2 / count - nofma(mean * mean);   // (no contraction: every finalizer gives the same bits)
+            var = var > 0.0 ? var : 0.0;
+            const double rstd = 1.0 / sqrt(var + (double)cp.eps);
+            // the block that holds the sample's first tile leaves the tables the three-kernel cell leaves in the workspace
+            int t0, b0;
+            slot_tile(ti, b0, t0);
+            if (lane < 32) {
+                const int c = grp * 32 + lane;
+                const double sc = (double)gam[c] * rstd;
+                const float fsc = (float)sc, fsh = (float)((double)bet[c] - nofma(mean * sc));
+                tab[2 * (ch0 + lane)] = fsc;
+                tab[2 * (ch0 + lane) + 1] = fsh;
+                if (t0 == 0 && ss_out) {
+                    ss_out[((size_t)bs * ngroups * 32 + c) * 2] = fsc;
+                    ss_out[((size_t)bs * ngroups * 32 + c) * 2 + 1] = fsh;
+                }
+            }
+            if (t0 == 0 && lane == 0) {
+                flag_nonfinite(cp.status, status_bit, s1, s2);
+                if (st_out) {
+                    st_out[((size_t)bs * ngroups + grp) * 2] = (float)mean;
+                    st_out[((size_t)bs * ngroups + grp) * 2 + 1] = (float)rstd;
+                }
+            }
+        }
+    };
+    if (wr < 2 && wc < G) fold_group(cp.partial1, 2 * G, wr * G + wc, cp.gn1_w, cp.gn1_b, (wr * G + wc) * 32, cp.ss1_out, cp.st1_out, URNN_STATUS_GATES);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (wr == 2: the W2[:, h] pieces have landed)
+    __syncthreads();
+    CT_STAMP(5);
+
+    // ---- r-waves: r (.) h in place over the hidden-state rows the ring still holds (its last NH groups) --------------------------------
+    const float *mytab = sstab + (size_t)wc * 3 * G * 64;
+    if (wr == 1 && tile_on) {
+#pragma unroll
+        for (int blk = 0; blk < G; ++blk)
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    // accumulator rows 4 q + i, i < 4: hidden channels 32 blk + 8 q + 4 half + i: group (2 blk + (q >> 1)), rows 8 (q & 1) + 4 half + i
+                    const int gi = 2 * blk + (q >> 1);
+                    char *base = ring + ((KG - NH + gi) % CT_D) * CT_SLOT + wc * 4096 + (8 * (q & 1) + 4 * half) * 256 + (pb * 32 + j) * 4;
+                    float hv[4], rv[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) hv[i] = *reinterpret_cast<const float *>(base + i * 256);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const f32x2 st = *reinterpret_cast<const f32x2 *>(mytab + 2 * ((G + blk) * 32 + 8 * q + 4 * half + i));
+                        rv[i] = hv[i] * gate_sigmoid(acc[blk][pb][4 * q + i], st.x, st.y);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; i += 2) {
+                        unsigned ph, pl;
+                        split2_pair(rv[i], rv[i + 1], URNN_F16_ASCALE, ph, pl);       // ph = {hi(i+1), hi(i)}, pl = {lo(i+1), lo(i)}
+                        *reinterpret_cast<unsigned *>(base + i * 256) = __builtin_amdgcn_perm(pl, ph, 0x05040100u);          // {lo(i), hi(i)}
+                        *reinterpret_cast<unsigned *>(base + (i + 1) * 256) = __builtin_amdgcn_perm(pl, ph, 0x07060302u);    // {lo(i+1), hi(i+1)}
+                    }
+                }
+    }
+    __syncthreads();
+    CT_STAMP(6);
+
+    // ---- c-waves: the candidate's hidden-state groups; z-waves: their sigmoid meanwhile -------------------------------------------------------
+    if (wr == 2) {
+        if (tile_on) {
+            for (int gi = 0; gi < NH; ++gi) group_mfma(ring + ((KG - NH + gi) % CT_D) * CT_SLOT, wbuf + gi * G * 2048, true);
+        }
+        finish_and_stats(2, cp.partial2, G);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the statistics have left before the loads below join the queue
+    } else if (wr == 0 && tile_on) {
+#pragma unroll
+        for (int blk = 0; blk < G; ++blk)
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const f32x2 st = *reinterpret_cast<const f32x2 *>(mytab + 2 * (blk * 32 + row_c(r) + 4 * half));
+                    acc[blk][pb][r] = gate_sigmoid(acc[blk][pb][r], st.x, st.y);
+                }
+    }
+    // the c-waves' first hidden-state values for the blend travel across the barrier
+    const float *hbase = cp.h + ((size_t)tb * F + 4 * half) * P + (size_t)tt * 64 + j;
+    float hn[16];
+    auto load_h = [&](int blk, int pb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hn[r] = okp[pb] ? hbase[(size_t)(blk * 32 + row_c(r)) * P + pb * 32] : 0.f;
+    };
+    if (wr == 2 && tile_on) load_h(0, 0);
+    CT_STAMP(7);
+
+    // ---- grid barrier 2; the z-waves hand z to the c-waves through LDS (over the ring, which is dead now) while lane 0 waits ------------------
+    // (the c-waves' h loads stay in flight: their statistics were drained before the loads were issued)
+    if (wr != 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ct_sync();
+    float *zbuf = reinterpret_cast<float *>(ring) + (size_t)wc * (G * 2 * 1024);    // [slot][blk][pb][16][64]
+    if (wr == 0 && tile_on) {
+#pragma unroll
+        for (int blk = 0; blk < G; ++blk)
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zbuf[((blk * 2 + pb) * 16 + r) * 64 + lane] = acc[blk][pb][r];
+    }
+    if (threadIdx.x == 64 * 4) ct_barrier_lane(cp.bar, blockIdx.x, (unsigned)cp.nblocks, cp.status);     // (an r-wave's lane: it has nothing else to do)
+    ct_sync();
+    CT_STAMP(8);
+
+    // ---- phase C: GroupNorm of the candidate (c-waves wc < G fold group wc), blend ------------------------------------------------------------------
+    if (wr == 2 && wc < G) fold_group(cp.partial2, G, wc, cp.gn2_w, cp.gn2_b, (2 * G + wc) * 32, cp.ss2_out, cp.st2_out, URNN_STATUS_CAND);
+    ct_sync();
+    CT_STAMP(9);
+    if (wr == 2 && tile_on) {
+        float *obase = cp.h_out + ((size_t)tb * F + 4 * half) * P + (size_t)tt * 64 + j;
+#pragma unroll
+        for (int blk = 0; blk < G; ++blk)
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                float hc[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hc[r] = hn[r];
+                if (pb == 0) load_h(blk, 1);                        // the next unit's rows travel while this one is blended
+                else if (blk + 1 < G) load_h(blk + 1, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const f32x2 st = *reinterpret_cast<const f32x2 *>(mytab + 2 * ((2 * G + blk) * 32 + row_c(r) + 4 * half));
+                    const float z = zbuf[((blk * 2 + pb) * 16 + r) * 64 + lane];
+                    const float n = tanhf_fast(fmaf(acc[blk][pb][r], st.x, st.y));
+                    if (okp[pb]) obase[(size_t)(blk * 32 + row_c(r)) * P + pb * 32] = gru_blend(z, n, hc[r]);
+                }
+            }
+    }
+#ifdef URNN_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CT_STAMP(10);
+#endif
+}
+
+// ---- host side -----------------------------------------------------------------------------------------------------------------------------
+static size_t ct_lds_bytes(int G) { return (size_t)CT_D * CT_SLOT + (size_t)CT_NW * CT_WBUF + (size_t)3 * G * 32 * 4; }
+
+// Does a cell of this shape take the multi-tile cooperative launch?  p / c: the gate / candidate parameter blocks as gru_cell_impl builds them.
+// Returns the number of blocks (0: no).
+int urnn_coop_tiles_blocks(const ConvGemmParams &p, const ConvGemmParams &c, int B)
+{
+    static const int on = (int)urnn_tune("URNN_TUNE_COOP_TILES", 1);   // development knob (A/B)
+    if (!on) return 0;
+    const int mm = urnn_get_matrix_mode();
+    if (mm != URNN_MATRIX_FP32 && mm != URNN_MATRIX_FP32_CAND) return 0;              // the f16-piece arithmetic only
+    const int F = p.F, G = F / 32;
+    if (G != 2 && G != 3) return 0;
+    if (!p.wf16 || p.fDwords <= 0 || !p.biasf || !c.wf16 || c.fDwords <= 0) return 0;
+    if (p.P % 4 != 0 || p.KT % 8 != 0 || p.kpBegin % 8 != 0) return 0;
+    for (int s = 0; s < 3; ++s)
+        if (p.segKp0[s] != INT_MAX && (p.segKp0[s] % 8 != 0 || p.segC[s] % 16 != 0)) return 0;
+    if (c.hKp0 % 8 != 0 || (p.KT - c.hKp0) * 2 != F || c.hKp0 <= p.kpBegin) return 0;   // x | e first, at least one plain group
+    const int KG = (p.KT - p.kpBegin) / 8;
+    if (KG < CT_D) return 0;                                                         // (the ring's prologue assumes K >= 96)
+    if (2 * G > CT_D) return 0;                                                      // the hidden state must fit the ring
+    const long tiles = (long)B * ((p.P + 63) / 64);
+    const int cus = urnn_device_cus();
+    const long blocks = (tiles + CT_NT - 1) / CT_NT;
+    if (tiles <= cus) return 0;                                                      // small planes: one tile per block (urnn_small.hip)
+    if (blocks > cus) return 0;                                                      // every block must be resident, one per CU
+    if (ct_lds_bytes(G) > 160 * 1024) return 0;
+    return (int)blocks;
+}
+
+hipError_t urnn_launch_coop_tiles(const ConvGemmParams &p, const ConvGemmParams &c, const float *gn2_w, const float *gn2_b, float *ss2_out, float *st2_out,
+                                  const float *h, float *h_out, unsigned *bar, int B, hipStream_t st)
+{
+    const int F = p.F, G = F / 32;
+    CoopTilesParams cp = {};
+    const int nseg = p.segKp0[2] != INT_MAX ? 3 : 2;
+    for (int s = 0; s < 3; ++s) {
+        const bool used = s < nseg;
+        cp.seg[s] = used ? p.seg[s] : p.seg[0];
+        cp.segC[s] = used ? p.segC[s] : 0;
+        cp.segG0[s] = used ? p.segKp0[s] / 8 : INT_MAX;
+        const double bytes = used ? (double)B * p.segC[s] * p.P * 4.0 : 0.0;
+        cp.segBytes[s] = bytes > 4294967295.0 ? 0xffffffffu : (unsigned)bytes;
+    }
+    cp.kg0 = p.kpBegin / 8;
+    cp.KG = (p.KT - p.kpBegin) / 8;
+    cp.KGxe = c.hKp0 / 8 - cp.kg0;
+    // canonical gate block cb of [z_0 .. | r_0 ..] -> its place (g, nb) in the grouped f16 slab
+    for (int g = 0; g < p.NGf; ++g)
+        for (int nb = 0; nb < p.NBf; ++nb) {
+            const int cb = urnn_gate_cb(p.gHalves, p.gGS, G, g, nb);
+            cp.wblk[cb] = p.wf16 + (size_t)g * p.fDwords + (size_t)nb * 512;
+            cp.wstride[cb] = p.NBf * 512;
+            cp.gbiasOff[cb] = (g * p.NBf + nb) * 32;
+        }
+    const int cNB = urnn_cand_nb(F);
+    for (int ci = 0; ci < G; ++ci) {
+        cp.wblk[2 * G + ci] = c.wf16 + (size_t)(ci / cNB) * c.fDwords + (size_t)(ci % cNB) * 512;
+        cp.wstride[2 * G + ci] = cNB * 512;
+    }
+    cp.gbias = p.biasf;
+    cp.cbias = c.bias;
+    cp.gn1_w = c.gn_w; cp.gn1_b = c.gn_b; cp.gn2_w = gn2_w; cp.gn2_b = gn2_b;
+    cp.eps = c.eps;
+    cp.h = h; cp.h_out = h_out;
+    cp.partial1 = p.partial; cp.partial2 = c.partial;
+    cp.ss1_out = c.ss_out; cp.ss2_out = ss2_out;
+    cp.st1_out = c.stat_out; cp.st2_out = st2_out;
+    cp.bar = bar;
+    cp.status = p.status;
+    cp.B = B; cp.P = p.P; cp.F = F;
+    cp.tilesPerSample = (p.P + 63) / 64;
+    cp.totalTiles = B * cp.tilesPerSample;
+    cp.nblocks = (cp.totalTiles + CT_NT - 1) / CT_NT;
+    const size_t lds = ct_lds_bytes(G);
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(coop_tiles_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(coop_tiles_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
+    if (G == 2) hipLaunchKernelGGL(coop_tiles_kernel<2>, dim3(cp.nblocks), dim3(768), lds, st, cp);
+    else hipLaunchKernelGGL(coop_tiles_kernel<3>, dim3(cp.nblocks), dim3(768), lds, st, cp);
+    return hipGetLastError();
+}

@@ -405,6 +405,8 @@ __device__ __forceinline__ void head_lane_stats(const f32x4 (&u)[4], int npx, fl
     }
 }
 
+// COH: the partials cross a coop_grid_barrier_nf of this launch (head_coop_kernel): 8-byte agent-scope stores (urnn_common.h publish8)
+template <bool COH = false>
 __device__ __forceinline__ void head_block_stats2(float sa, float qa, float sb, float qb, int n_lane, bool two, int nvalid, float *dst_a,
                                                   float *dst_b)
 {
@@ -417,11 +419,16 @@ __device__ __forceinline__ void head_block_stats2(float sa, float qa, float sb, 
     float Qa = n_lane > 0 ? fmaf(fn * da, da, qa) : 0.f, Qb = n_lane > 0 ? fmaf(fn * db, db, qb) : 0.f;
     head_block_sum2(Qa, Qb);
     if (threadIdx.x == 0) {
-        dst_a[0] = Sa;
-        dst_a[1] = Qa;
-        if (two) {
-            dst_b[0] = Sb;
-            dst_b[1] = Qb;
+        if constexpr (COH) {
+            publish8(dst_a, Sa, Qa);
+            if (two) publish8(dst_b, Sb, Qb);
+        } else {
+            dst_a[0] = Sa;
+            dst_a[1] = Qa;
+            if (two) {
+                dst_b[0] = Sb;
+                dst_b[1] = Qb;
+            }
         }
     }
 }
@@ -441,6 +448,7 @@ __device__ __forceinline__ float *head_partial(const HeadParams &p, int which, i
 // agent-scope counter and a release fence per block: 17-40 ns per block SERIALISED, head_k3 31 -> 110 us.)
 // The cooperative head folds across its grid barriers (small planes); a feature map whose producer took the first norm's partials
 // (the decoder's last conv, conv_gemm_kernel's stemW epilogue, or urnn_tail.hip) is finalized from there (prm.partial0).
+template <bool COH = false>
 __device__ __forceinline__ void head_fold_stats(const HeadParams &prm, int which, int b, bool publish, float &mean_f, float &rstd_f)
 {
     const int lane = threadIdx.x & 63;
@@ -452,7 +460,7 @@ __device__ __forceinline__ void head_fold_stats(const HeadParams &prm, int which
         block_pix = prm.bpix0;
     }
     double s1, s2;
-    fold_lane_chain<8>(pp, nblk_used, block_pix, HEAD_C, prm.P, lane, s1, s2);      // (urnn_common.h: the order every finalizer shares)
+    fold_lane_chain<8, true, COH>(pp, nblk_used, block_pix, HEAD_C, prm.P, lane, s1, s2);      // (urnn_common.h: the order every finalizer shares)
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         s1 += __shfl_xor(s1, m, 64);
@@ -646,15 +654,15 @@ __global__ __launch_bounds__(256) void head_coop_kernel(const HeadParams prm, un
         head_conv(head_weights(prm.conv_w), f, u1);
         float s, q;
         head_lane_stats<AL>(u1, L.npx, s, q);
-        head_block_stats2(s, q, 0.f, 0.f, 4 * L.npx, false, nvalid, head_partial(prm, 0, b, blockIdx.x), nullptr);
+        head_block_stats2<true>(s, q, 0.f, 0.f, 4 * L.npx, false, nvalid, head_partial(prm, 0, b, blockIdx.x), nullptr);
     }
     head_load<AL>(prm.ln_w, prm.P, L, g);                          // (the next pass's affine rows travel across the barrier)
     head_load<AL>(prm.ln_b, prm.P, L, bt);
-    coop_grid_barrier(bar, (unsigned)nblocks, prm.status);
+    coop_grid_barrier_nf(bar, blockIdx.y * gridDim.x + blockIdx.x, (unsigned)nblocks, prm.status);
     // ---- pass 2 (head_k2): t = SiLU(LN0(u0)); u1 = Wc1 . t, u2 = Wq1 . t
     {
         float m0, r0;
-        head_fold_stats(prm, 0, b, pub, m0, r0);
+        head_fold_stats<true>(prm, 0, b, pub, m0, r0);
         float sc, qc, sq, qq;
         f32x4 t[4];
 #pragma unroll
@@ -664,16 +672,16 @@ __global__ __launch_bounds__(256) void head_coop_kernel(const HeadParams prm, un
         head_lane_stats<AL>(u1, L.npx, sc, qc);
         head_conv(head_weights(prm.conv_w + 3 * HEAD_C * HEAD_C), t, u2);
         head_lane_stats<AL>(u2, L.npx, sq, qq);
-        head_block_stats2(sc, qc, sq, qq, 4 * L.npx, true, nvalid, head_partial(prm, 1, b, blockIdx.x), head_partial(prm, 3, b, blockIdx.x));
+        head_block_stats2<true>(sc, qc, sq, qq, 4 * L.npx, true, nvalid, head_partial(prm, 1, b, blockIdx.x), head_partial(prm, 3, b, blockIdx.x));
     }
     head_load<AL>(prm.ln_w + 1 * CP, prm.P, L, g);
     head_load<AL>(prm.ln_b + 1 * CP, prm.P, L, bt);
-    coop_grid_barrier(bar, (unsigned)nblocks, prm.status);
+    coop_grid_barrier_nf(bar, blockIdx.y * gridDim.x + blockIdx.x, (unsigned)nblocks, prm.status);
     // ---- pass 3 (head_k3): u1 <- Wc2 . SiLU(LN1(u1)), u2 <- Wq2 . SiLU(LN3(u2))
     {
         float m1, r1, m3, r3;
-        head_fold_stats(prm, 1, b, pub, m1, r1);
-        head_fold_stats(prm, 3, b, pub, m3, r3);
+        head_fold_stats<true>(prm, 1, b, pub, m1, r1);
+        head_fold_stats<true>(prm, 3, b, pub, m3, r3);
         float sc, qc, sq, qq;
         f32x4 x[4];
 #pragma unroll
@@ -688,16 +696,16 @@ __global__ __launch_bounds__(256) void head_coop_kernel(const HeadParams prm, un
         head_ln_silu(x, g, bt, m3, r3);
         head_conv(head_weights(prm.conv_w + 4 * HEAD_C * HEAD_C), x, u2);
         head_lane_stats<AL>(u2, L.npx, sq, qq);
-        head_block_stats2(sc, qc, sq, qq, 4 * L.npx, true, nvalid, head_partial(prm, 2, b, blockIdx.x), head_partial(prm, 4, b, blockIdx.x));
+        head_block_stats2<true>(sc, qc, sq, qq, 4 * L.npx, true, nvalid, head_partial(prm, 2, b, blockIdx.x), head_partial(prm, 4, b, blockIdx.x));
     }
     head_load<AL>(prm.ln_w + 2 * CP, prm.P, L, g);
     head_load<AL>(prm.ln_b + 2 * CP, prm.P, L, bt);
-    coop_grid_barrier(bar, (unsigned)nblocks, prm.status);
+    coop_grid_barrier_nf(bar, blockIdx.y * gridDim.x + blockIdx.x, (unsigned)nblocks, prm.status);
     // ---- pass 4 (head_k4): predictions + wet / dry mask
     {
         float m2, r2, m4, r4;
-        head_fold_stats(prm, 2, b, pub, m2, r2);
-        head_fold_stats(prm, 4, b, pub, m4, r4);
+        head_fold_stats<true>(prm, 2, b, pub, m2, r2);
+        head_fold_stats<true>(prm, 4, b, pub, m4, r4);
         head_ln_silu(u1, g, bt, m2, r2);
         head_load<AL>(prm.ln_w + 4 * CP, prm.P, L, g);
         head_load<AL>(prm.ln_b + 4 * CP, prm.P, L, bt);

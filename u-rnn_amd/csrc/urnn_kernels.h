@@ -138,6 +138,11 @@ hipError_t urnn_launch_small_cand(ConvGemmParams p, int B, hipStream_t st);
 bool urnn_coop_cell_ok(const ConvGemmParams &p, const ConvGemmParams &c, int B);
 hipError_t urnn_launch_coop_cell(ConvGemmParams p, const ConvGemmParams &c, const float *gn2_w, const float *gn2_b, float *ss2_out, float *h_out,
                                  unsigned *bar, int B, hipStream_t st);
+// the whole cell of a HALF-RESOLUTION plane as one cooperative launch, four 64-pixel tiles per block, gates and candidate resident in the
+// accumulators (urnn_coop_tiles.hip); blocks: how many blocks that launch takes (0: the shape does not qualify)
+int urnn_coop_tiles_blocks(const ConvGemmParams &p, const ConvGemmParams &c, int B);
+hipError_t urnn_launch_coop_tiles(const ConvGemmParams &p, const ConvGemmParams &c, const float *gn2_w, const float *gn2_b, float *ss2_out, float *st2_out,
+                                  const float *h, float *h_out, unsigned *bar, int B, hipStream_t st);
 int urnn_cand_nb(int F);      // n-blocks per group of the candidate GEMM
 // the two-stream candidate of a half-resolution plane on 64-pixel tiles and a group-wise ring (urnn_cand_gated.hip); plan: 1 when it
 // takes the launch -- the candidate's GroupNorm partials are then per 64-pixel tile

@@ -24,6 +24,15 @@
 
 extern __shared__ __attribute__((aligned(16))) char urnn_small_smem[];
 
+#ifdef URNN_TRACE
+// tuning builds: [block][wave (16)][16] s_memtime stamps of the cooperative cell's phases (tools/trace_coop.py)
+static __device__ unsigned long long *urnn_small_trace_buf = nullptr;
+extern "C" int urnn_debug_set_trace_urnn_small(unsigned long long *p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(urnn_small_trace_buf), &p, sizeof(p)); }
+#define COOP_STAMP(k) do { if (urnn_small_trace_buf && lane == 0) urnn_small_trace_buf[((size_t)blockIdx.x * 16 + wave) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define COOP_STAMP(k) do { } while (0)
+#endif
+
 // GATED = 0: gate GEMM (EPI_GRU1 semantics).  GATED = 1: candidate GEMM (EPI_CAND): rows >= hKp0 are sigmoid(GN(r)) * h; the
 // gates' GroupNorm is finalised in the prologue (block 0 of each sample publishes the tables, as conv_gemm_kernel does).
 template <int GATED, int MODE>
@@ -382,6 +391,7 @@ __global__ __launch_bounds__(768) void coop_cell_kernel(const CoopCellParams cp,
     const int kg0 = prm.kpBegin >> 3, KG = (prm.KT - prm.kpBegin) >> 3;
     constexpr int NPC = 2;
 
+    COOP_STAMP(0);
     unsigned *Bp = reinterpret_cast<unsigned *>(urnn_small_smem);       // [KG][2][2][64][4] dwords
     const int panelDw = KG * 2 * NPC * 256;
     float *zbuf = reinterpret_cast<float *>(Bp + panelDw);               // [F/32][2][16][64]: z from the update-gate waves to their partners
@@ -449,7 +459,9 @@ __global__ __launch_bounds__(768) void coop_cell_kernel(const CoopCellParams cp,
             }
         }
     }
+    COOP_STAMP(1);
     __syncthreads();
+    COOP_STAMP(2);
 
     const u32x4 *Bw = reinterpret_cast<const u32x4 *>(Bp) + (size_t)pbw * NPC * 64 + lane;
     auto mfma3 = [&](const u32x4 &wh, const u32x4 &wl, int gq) {
@@ -473,6 +485,7 @@ __global__ __launch_bounds__(768) void coop_cell_kernel(const CoopCellParams cp,
         }
     }
 
+    COOP_STAMP(3);
     // ---- phase A epilogue: raw gates stay in registers, centred statistics of the 32 x 32 tile -> partial1 ---------------------------
     const int tile = blk * 2 + pbw;
     const int px = tile * 32 + j;
@@ -498,11 +511,8 @@ __global__ __launch_bounds__(768) void coop_cell_kernel(const CoopCellParams cp,
             if (ok) s2 = fmaf(d, d, s2);
         }
         s2 = wave_sum(s2);
-        if (lane == 0 && nvalid > 0) {
-            float *pp = prm.partial + (((size_t)b * 2 * G + cb) * prm.tilesPerSample + tile) * 2;
-            pp[0] = s1;
-            pp[1] = s2;
-        }
+        if (lane == 0 && nvalid > 0)            // published across the grid barrier: one 8-byte agent-scope store (urnn_common.h coop_grid_barrier_nf)
+            publish8(prm.partial + (((size_t)b * 2 * G + cb) * prm.tilesPerSample + tile) * 2, s1, s2);
     }
     const int cg = ci / cp.cNB, cnb = ci - cg * cp.cNB;
     const u32x4 *Cw = reinterpret_cast<const u32x4 *>(cp.cwf16 + (size_t)cg * cp.cfDwords) + lane;
@@ -515,7 +525,9 @@ __global__ __launch_bounds__(768) void coop_cell_kernel(const CoopCellParams cp,
         for (int r = 0; r < 16; ++r) hv[r] = ok ? hrow[(size_t)row_c(r) * P] : 0.f;
     }
 
-    coop_grid_barrier(cp.bar, (unsigned)cp.nblocks, prm.status);
+    COOP_STAMP(4);
+    coop_grid_barrier_nf(cp.bar, blockIdx.x, (unsigned)cp.nblocks, prm.status);
+    COOP_STAMP(5);
 
     // ---- phase B: GroupNorm of this wave's gate block (the GATED prologue's fold: 8 loads in flight, lane-strided, xor butterfly) --
     float *sst = sstab + wave * 64;
@@ -523,7 +535,7 @@ __global__ __launch_bounds__(768) void coop_cell_kernel(const CoopCellParams cp,
         const float *pp = prm.partial + ((size_t)b * 2 * G + cb) * prm.tilesPerSample * 2;
         const int gtiles = prm.tilesPerSample;
         double s1, s2;
-        fold_lane_chain<8>(pp, gtiles, 32, 32, P, lane, s1, s2);      // (urnn_common.h: the order every finalizer shares)
+        fold_lane_chain<8, true, true>(pp, gtiles, 32, 32, P, lane, s1, s2);      // (urnn_common.h: the order every finalizer shares; agent-scope loads)
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {
             s1 += __shfl_xor(s1, m, 64);
@@ -546,6 +558,7 @@ __global__ __launch_bounds__(768) void coop_cell_kernel(const CoopCellParams cp,
         }
         if (blk == 0 && pbw == 0 && lane == 0) flag_nonfinite(prm.status, URNN_STATUS_GATES, s1, s2);
     }
+    COOP_STAMP(6);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the table is this wave's own: no block barrier)
     if (is_r) {                                              // the candidate's first weight pieces (L2) travel during the gating
 #pragma unroll
@@ -583,7 +596,9 @@ __global__ __launch_bounds__(768) void coop_cell_kernel(const CoopCellParams cp,
 #pragma unroll
         for (int r = 0; r < 16; ++r) zb[r * 64] = acc[r];
     }
+    COOP_STAMP(7);
     __syncthreads();
+    COOP_STAMP(8);
     if (is_r) {
         // candidate GEMM (small_cell_gemm_kernel<1, 3>'s main loop on the panel whose hidden rows now hold r (.) h)
 #pragma unroll
@@ -616,14 +631,12 @@ __global__ __launch_bounds__(768) void coop_cell_kernel(const CoopCellParams cp,
             if (ok) s2 = fmaf(d, d, s2);
         }
         s2 = wave_sum(s2);
-        if (lane == 0 && nvalid > 0) {
-            float *pp = cp.partial2 + (((size_t)b * G + ci) * prm.tilesPerSample + tile) * 2;
-            pp[0] = s1;
-            pp[1] = s2;
-        }
+        if (lane == 0 && nvalid > 0) publish8(cp.partial2 + (((size_t)b * G + ci) * prm.tilesPerSample + tile) * 2, s1, s2);
     }
 
-    coop_grid_barrier(cp.bar, (unsigned)cp.nblocks, prm.status);
+    COOP_STAMP(9);
+    coop_grid_barrier_nf(cp.bar, blockIdx.x, (unsigned)cp.nblocks, prm.status);
+    COOP_STAMP(10);
 
     // ---- phase C: candidate GroupNorm (gru_blend_kernel<FIN>'s order), z from the partner wave's hand-over, blend ----------------------
     if (is_r) {
@@ -632,7 +645,7 @@ __global__ __launch_bounds__(768) void coop_cell_kernel(const CoopCellParams cp,
         auto sub = [&](int w, double &o1, double &o2) {
             double a1 = 0.0, a2 = 0.0;
             for (int t = w * 64 + lane; t < prm.tilesPerSample; t += 256) {
-                const f32x2 v = *reinterpret_cast<const f32x2 *>(pp + 2 * t);
+                const f32x2 v = consume8(pp + 2 * t);
                 a1 += (double)v.x;
                 a2 += tile_x2(v.x, v.y, 32 * tile_valid(t, 32, P));
             }
@@ -669,6 +682,7 @@ __global__ __launch_bounds__(768) void coop_cell_kernel(const CoopCellParams cp,
         if (blk == 0 && pbw == 0 && lane == 0) flag_nonfinite(prm.status, URNN_STATUS_CAND, S1, S2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    COOP_STAMP(11);
     if (is_r && ok) {
         float *orow = cp.h_out + ((size_t)b * F + ci * 32 + 4 * half) * P + px;
 #pragma unroll
@@ -679,6 +693,10 @@ __global__ __launch_bounds__(768) void coop_cell_kernel(const CoopCellParams cp,
             orow[(size_t)row_c(r) * P] = gru_blend(z, n, hv[r]);
         }
     }
+#ifdef URNN_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    COOP_STAMP(12);
+#endif
 }
 
 // LDS of a cooperative cell launch: panel (or the z hand-over, whichever is larger) + gate bias + candidate bias + per-wave tables

@@ -86,10 +86,11 @@ def _ptr(t):
 
 def workspace(nbytes, device):
     """A scratch buffer of ``nbytes`` bytes (caller-owned, as the C ABI requires)."""
-    # the first 256 bytes of a cell / head workspace are STATUS words that kernels only ever OR into (include/urnn_hip.h): only
-    # those need to start at zero -- the rest is scratch every kernel writes before it reads (tens of MB per full-resolution cell)
+    # the first 16 KB of a cell / head workspace are STATUS words that kernels only ever OR into and the cooperative launches' barrier
+    # words (include/urnn_hip.h URNN_STATUS_AREA_BYTES): only those need to start at zero -- the rest is scratch every kernel writes
+    # before it reads (tens of MB per full-resolution cell)
     buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-    buf[:min(256, int(nbytes))].zero_()
+    buf[:min(STATUS_AREA_BYTES, int(nbytes))].zero_()
     return buf
 
 
@@ -140,6 +141,7 @@ def head_workspace_bytes(B, C, H, W):
     return lib().urnn_head_workspace_bytes(B, C, H, W)
 
 
+STATUS_AREA_BYTES = 16384                                               # include/urnn_hip.h URNN_STATUS_AREA_BYTES
 STATUS_GATES, STATUS_CAND, STATUS_HEAD, STATUS_BARRIER = 1, 2, 4, 8     # include/urnn_hip.h: word 0 of a cell / head workspace
 STATUS_NAMES = {STATUS_GATES: "GroupNorm sums of a cell's gates", STATUS_CAND: "GroupNorm sums of a cell's candidate",
                 STATUS_HEAD: "LayerNorm sums of the head",
