@@ -15,7 +15,7 @@ three (candidate GEMMs / gate GEMMs / blend; the candidate GEMMs since round 3),
 stream: `avg_launch_us` on ONE kernel chain, where an event pair spans the kernel alone (the figure profiles/r05_kernel_stats_
 overlap0.txt -- rocprofv3 --kernel-trace --stats of `bench.py --overlap 0` -- must agree with), `live_overlapped` in the
 benchmarked schedule of concurrent chains (kernel + what it queued behind: profiles/r05_kernel_stats.txt holds the kernels' own
-durations there); every family under "roofline.kernels" -- and "cpu_baseline" (the C oracle on the host cores, bounded sample,
+durations there); every family under "roofline.kernels" -- and "cpu_baseline" (float32 torch ops on CPU tensors at the best of a few thread counts, the C oracle nested under it; bounded sample,
 rank 0 at N=1 only).  `python bench.py --gpus N` without a launcher re-runs itself as N ranks (torch.distributed.run).
 """
 import argparse
@@ -140,7 +140,7 @@ def cpu_model():
     return platform.processor() or platform.machine()
 
 
-def cpu_baseline(sd, cfgname, budget_s=15.0, max_frames=8):
+def c_oracle_baseline(sd, cfgname, budget_s=8.0, max_frames=6):
     """The C oracle (oracle/urnn_oracle.c, OpenMP) on the host cores: same synthetic event, first frames of the
     rollout, input assembly included -- frames/s like the reference's Inference timer."""
     from oracle import oracle as orc
@@ -194,6 +194,29 @@ def torch_cpu_baseline(sd, cfgname, threads, budget_s=10.0, max_frames=4):
     return {"value": n / dt, "unit": "frames/s", "cores": int(threads),
             "arith": "plain float32 torch ops on CPU tensors (tests/torch_ref.py: conv2d / group_norm / layer_norm ...), the reference's own arithmetic",
             "sample": f"{n} frames of the {H}x{W} C={2*nums+3} rollout after 1 warm-up frame ({dt:.1f} s), torch {torch.__version__} with {int(threads)} threads"}
+
+
+def cpu_baseline(sd, cfgname):
+    """the CPU path beside the GPU number is the reference's arithmetic -- plain float32 torch ops on CPU tensors
+    (tests/torch_ref.py, pinned to the reference's goldens) -- on the box's host cores, at the BEST of a few thread counts (a 128-thread
+    EPYC runs this memory-bound step fastest well below its thread count: VERDICT r5 weak item 10); the C oracle's figure is nested
+    under it.  About 25 s of CPU work in total."""
+    ncpu = os.cpu_count() or 1
+    counts = [t for t in (8, 16, 32, 64, 128) if t <= ncpu] or [ncpu]
+    runs = []
+    for t in counts:
+        try:
+            runs.append(torch_cpu_baseline(sd, cfgname, t, budget_s=3.5, max_frames=2))
+        except Exception as exc:
+            runs.append({"value": 0.0, "cores": t, "error": repr(exc)})
+    best = max(runs, key=lambda r: r["value"])
+    out = dict(best, kind="port", cpu_model=cpu_model(), logical_cpus=ncpu,
+               thread_sweep={str(r["cores"]): round(r["value"], 3) for r in runs})
+    try:
+        out["c_oracle"] = c_oracle_baseline(sd, cfgname)
+    except Exception as exc:
+        out["c_oracle"] = {"error": repr(exc)}
+    return out
 
 
 def train_roofline(dev, H, W, B, dtype):
@@ -379,6 +402,25 @@ def self_launch(n):
     sys.exit(subprocess.call(cmd, env=env))
 
 
+def bind_rank_to_cores(local_rank, world, mode):
+    """CPU placement of one rank: N graph-replaying processes on a 128-core two-socket host should not migrate across
+    each other's cores or NUMA nodes.  ``--bind auto`` (default): bind when the node runs >= 4 ranks; ``on`` / ``off``: force.  Rank r gets
+    the r-th of ``world`` equal, contiguous slices of the logical CPUs this process may use (Linux numbers a socket's cores contiguously
+    and the GPUs of an MI355X node are split evenly over the sockets, so contiguous slices keep a rank on one node) and sizes torch's
+    intra-op pool to it.  Returns the slice (first, last) or None."""
+    if mode == "off" or (mode == "auto" and world < 4) or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        per = max(1, len(cpus) // max(world, 1))
+        mine = cpus[local_rank * per:(local_rank + 1) * per] or cpus
+        os.sched_setaffinity(0, mine)
+        torch.set_num_threads(max(1, min(len(mine), 16)))
+        return (mine[0], mine[-1])
+    except OSError:
+        return None
+
+
 def kernel_source_hash():
     """sha256 over the HIP sources + headers the library is built from (u-rnn_amd/build_ext.py): identifies the kernels whatever
     machine compiled them (the .so bytes may differ between two builds of the same sources; its own hash is recorded beside)."""
@@ -425,6 +467,8 @@ def main():
     ap.add_argument("--no-long-run", action="store_true", help="skip the additional 360-step figure of short runs (counter-collection passes)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="control-plane backend for N>1 (nccl = RCCL over xGMI; gloo only for single-GPU dry runs of the N>1 path)")
+    ap.add_argument("--bind", default="auto", choices=["auto", "on", "off"],
+                    help="bind every rank to its own contiguous slice of the host's CPUs (auto: when >= 4 ranks run on the node)")
     ap.add_argument("--share-gpu", action="store_true", help="dry run: every rank uses cuda:0 (needs --dist-backend gloo)")
     ap.add_argument("--overlap", type=int, default=1,
                     help="1 (default): encoder(t+1) || decoder+head(t) as two concurrent kernel chains; 0: one chain")
@@ -459,6 +503,7 @@ def main():
                  "(one process per GPU; --share-gpu --dist-backend gloo is the single-GPU dry run)")
     dev = torch.device("cuda", 0 if args.share_gpu else local_rank)
     torch.cuda.set_device(dev)
+    bound = bind_rank_to_cores(local_rank, world, args.bind)
     dist = None
     if "WORLD_SIZE" in os.environ:                         # launched by torchrun (also with one rank: RCCL is exercised either way)
         import torch.distributed as dist
@@ -570,7 +615,7 @@ def main():
                                 f"{B} event(s) per GPU, inference rollout incl. per-frame input assembly") if len(names) == 1 else
                                ("mixed: " + " + ".join(f"{n} {CONFIGS[n][0]}x{CONFIGS[n][1]} T={CONFIGS[n][3]}" for n in names) +
                                 f" events alternating, {B} event(s) per GPU, one hipGraph per shape"),
-                   "events_per_gpu": B, "parallelism": f"event-parallel x{world} (no collective)",
+                   "events_per_gpu": B, "parallelism": f"event-parallel x{world} (no collective)", "cpu_binding": (f"cpus {bound[0]}-{bound[1]} per rank" if bound else "none"),
                    "graph": not args.no_graph, "overlap_chains": bool(args.overlap),
                    "kernel_chains": (3 if eng._head_own_chain else 2) if args.overlap else 1, "matrix_mode": args.matrix_mode,
                    "fused_tails": bool(args.fused_tails)},
@@ -641,10 +686,6 @@ def main():
         if world == 1 and not args.no_cpu_baseline and len(names) == 1:
             try:
                 result["cpu_baseline"] = cpu_baseline(sd, args.config)
-                try:    # the torch-CPU restatement beside it; the C oracle stays the headline CPU figure
-                    result["cpu_baseline"]["torch_cpu"] = torch_cpu_baseline(sd, args.config, result["cpu_baseline"]["cores"])
-                except Exception as exc:
-                    result["cpu_baseline"]["torch_cpu"] = {"error": repr(exc)}
             except Exception as exc:
                 result["cpu_baseline"] = {"error": repr(exc)}
         print(json.dumps(result))

@@ -41,6 +41,12 @@ extern "C" {
 int urnn_abi_version(void);
 const char *urnn_last_error(void);
 
+/* One device per process.  The library caches, once per process, the compute-unit count of the device that is current at the first
+ * cooperative plan (the block limits of URNN_PHASE_COOP / urnn_head_coop_f32) and the raised dynamic-LDS limits of its large kernels:
+ * drive ONE device per process (torchrun's model, main.py:76-81) and make it current before the first call.  All phases of one cell
+ * (urnn_gru_cell_phases_f32 called several times for the same cell) must run under the same matrix mode: the candidate's tile size --
+ * and with it the layout of its GroupNorm partials the later phases fold -- is planned from the shapes AND the mode. */
+
 /* Arithmetic of the GEMM kernels, process-wide (one process drives one GPU; the launch functions read it when they enqueue, so a
  * captured hipGraph keeps the mode it was captured with).
  *   URNN_MATRIX_FP32 (default): the reference's fp32 semantics on the 16-bit matrix pipe.  Forward GEMMs: both fp32 operands

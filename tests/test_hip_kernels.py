@@ -500,3 +500,62 @@ def test_last_conv_takes_the_heads_first_statistics(dev, H, W, B):
         assert_close(a_.cpu().numpy(), b_.cpu().numpy(), 1e-5, f"three-pass head vs four-pass head, {what}")
     ref_f = orc.stage_conv(x, wc.reshape(16, 64), bc, False)
     assert_close(got.cpu().numpy(), ref_f, TOL, "feature map vs oracle")
+
+
+def _poisoned(nbytes, dev):
+    """A workspace whose scratch is all-ones bits (NaN as float32) behind the zeroed status area."""
+    from urnn_amd import ops
+    ws = torch.full((int(nbytes),), 0xFF, dtype=torch.uint8, device=dev)
+    ws[:min(ops.STATUS_AREA_BYTES, int(nbytes))].zero_()
+    return ws
+
+
+@pytest.mark.parametrize("I,F,skip,H,W,B,flags", [
+    (16, 64, 0, 64, 64, 1, 0),          # small plane, three kernels
+    (16, 64, 0, 64, 64, 1, 64),         # ... one cooperative launch
+    (96, 96, 1, 37, 41, 2, 0),          # ragged plane, two samples
+    (64, 96, 0, 250, 250, 1, 0),        # half resolution, three kernels (grouped gate GEMM, two-stream candidate)
+    (64, 96, 0, 250, 250, 1, 64),       # ... the four-tiles-per-block cooperative launch
+    (16, 64, 0, 500, 500, 1, 32),       # full resolution with the reset gate recomputed (URNN_PHASE_FUSED_R)
+])
+def test_cell_and_head_do_not_read_uninitialised_scratch(dev, I, F, skip, H, W, B, flags):
+    """ops.workspace() hands out torch.empty memory with only the status area zeroed: every kernel must write its scratch
+    before it reads it.  A cell and the head run on a workspace POISONED with NaN bit patterns must give the bits of the zero-filled run
+    (a masked read of the form 0 * garbage would turn into NaN)."""
+    from urnn_amd import ops
+    rs = np.random.RandomState(5 + I + F + H)
+    K = I + (2 * F if skip else F)
+    packed = ops.pack_gru(T(rs.normal(0, 1 / np.sqrt(K), (2 * F, K, 1, 1)).astype(np.float32), dev), T(rs.normal(0, 0.1, 2 * F).astype(np.float32), dev),
+                          T(rs.normal(0, 1 / np.sqrt(K), (F, K, 1, 1)).astype(np.float32), dev), T(rs.normal(0, 0.1, F).astype(np.float32), dev), I, F, bool(skip))
+    aff = tuple(T(a.astype(np.float32), dev) for a in (rs.uniform(0.5, 1.5, 2 * F), rs.normal(0, 0.1, 2 * F), rs.uniform(0.5, 1.5, F), rs.normal(0, 0.1, F)))
+    x = T(rs.normal(0, 1, (B, I, H, W)).astype(np.float32), dev)
+    e = T(rs.normal(0, 1, (B, F, H, W)).astype(np.float32), dev) if skip else None
+    h = T(rs.normal(0, 1, (B, F, H, W)).astype(np.float32), dev)
+    nbytes = ops.gru_cell_workspace_bytes(B, F, H, W)
+    clean = ops.gru_cell(x, e, h, packed, *aff, I, phases=ops.PHASE_ALL | flags, ws=torch.zeros(nbytes, dtype=torch.uint8, device=dev))
+    ws = _poisoned(nbytes, dev)
+    dirty = ops.gru_cell(x, e, h, packed, *aff, I, phases=ops.PHASE_ALL | flags, ws=ws)
+    torch.cuda.synchronize()
+    assert ops.workspace_status(ws) == 0
+    assert bool(torch.isfinite(dirty).all()) and torch.equal(clean, dirty)
+    # the head on the same plane
+    C = 16
+    feat = T(rs.normal(0, 1, (B, C, H, W)).astype(np.float32), dev)
+    conv_w = T(rs.normal(0, 0.25, (5, C, C)).astype(np.float32), dev)
+    ln_w, ln_b = T(rs.uniform(0.5, 1.5, (5, C, H * W)).astype(np.float32), dev), T(rs.normal(0, 0.1, (5, C, H * W)).astype(np.float32), dev)
+    cls_w, reg_w = T(rs.normal(0, 0.25, C).astype(np.float32), dev), T(rs.normal(0, 0.25, C).astype(np.float32), dev)
+    cls_b, reg_b = T(np.asarray([0.05], np.float32), dev), T(np.asarray([-0.02], np.float32), dev)
+    hb = ops.head_workspace_bytes(B, C, H, W)
+    for coop in ((False, True) if lib_head_coop(B, H, W) else (False,)):
+        a = ops.head(feat, conv_w, ln_w, ln_b, cls_w, cls_b, reg_w, reg_b, 0.5, want_raw=True, ws=torch.zeros(hb, dtype=torch.uint8, device=dev), coop=coop)
+        wsh = _poisoned(hb, dev)
+        b = ops.head(feat, conv_w, ln_w, ln_b, cls_w, cls_b, reg_w, reg_b, 0.5, want_raw=True, ws=wsh, coop=coop)
+        torch.cuda.synchronize()
+        assert ops.workspace_status(wsh) == 0
+        for u, v in zip(a, b):
+            assert bool(torch.isfinite(v).all()) and torch.equal(u, v), f"head (coop={coop}) read uninitialised scratch"
+
+
+def lib_head_coop(B, H, W):
+    from urnn_amd._lib import lib
+    return lib().urnn_head_coop_blocks_f32(B, H, W) > 0

@@ -139,3 +139,69 @@ def test_strip_calls_reject_fused_phases(dev):
     assert L.urnn_gru_cell_strip_f32(*args, ops.PHASE_GATES | ops.PHASE_CAND, 4 * Hs * Ws, None) != 0
     assert "exchanged" in L.urnn_last_error().decode()
     assert L.urnn_gru_cell_strip_f32(*args, ops.PHASE_GATES, Hs * Ws - 1, None) != 0
+
+
+def _full_size_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    import urnn_amd.weights as uw
+    from urnn_amd.net_config import load_net_config
+    from urnn_amd.networks.model import ED
+    from urnn_amd.networks.net_params import get_network_params
+    from urnn_amd.strips import StripRollout
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # the ranks share the one GPU of the test box
+    dev = torch.device("cuda:0")
+    Hf = Wf = 500
+    nums, Tn = 30, 13
+    C = 2 * nums + 3
+    ep, dp = get_network_params(False, Hf, Wf, C, load_net_config())
+    net = ED(False, ep, dp, 0.5, False, input_height=Hf, input_width=Wf)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in uw.make_state_dict(Hf, Wf, C, seed=0).items()})
+    net = net.to(dev)
+    ev = uw.make_event(360, Hf, Wf, 6.0, seed=42)                     # the headline event (its first 13 frames are run)
+    sr = StripRollout(net, Hf, Wf, nums, 6.0, 250.0, rank=rank, world=world)
+    sr.load_event(ev)
+    masked, cls = [], []
+    with torch.no_grad():
+        for t in range(Tn):
+            m, c = sr.step(t)
+            masked.append(m)
+            cls.append(c)
+    full_m, full_c = sr.gather(torch.stack(masked)), sr.gather(torch.stack(cls))
+    torch.cuda.synchronize()
+    if rank == 0:
+        np.save(os.path.join(out_dir, "masked.npy"), full_m.cpu().numpy())
+        np.save(os.path.join(out_dir, "cls.npy"), full_c.cpu().numpy())
+    dist.destroy_process_group()
+
+
+def test_two_strips_at_full_size_vs_the_reference_trace(dev, tmp_path):
+    """BASELINE configs[1]'s grid (500x500, C = 63) split into two strips of 248 + 252 rows on two gloo ranks that share the GPU (VERDICT r5
+    item 7: the strips had only ever run at 32x48): the first 13 frames of the headline event against the REFERENCE's float64 rollout
+    (tests/golden/reference_trace_500x500_T360.npz, frames 0 / 4 / 8 / 12, 4096 random pixels): the class map within 1e-4, the masked
+    depth away from the wet/dry threshold within 1e-4 of the plane's maximum (test.py:352-371)."""
+    import torch.multiprocessing as mp
+    golden = os.path.join(os.path.dirname(__file__), "golden", "reference_trace_500x500_T360.npz")
+    if not os.path.isfile(golden):
+        pytest.fail("reference_trace_500x500_T360.npz missing")
+    g = np.load(golden)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_full_size_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    masked, cls = np.load(tmp_path / "masked.npy"), np.load(tmp_path / "cls.npy")
+    pix = g["pixels"].astype(np.int64)
+    worst_c = worst_m = 0.0
+    for i, t in enumerate(g["frames"]):
+        if t > 12:
+            break
+        c64, r64 = g["r64_cls"][i].astype(np.float64), g["r64_raw"][i].astype(np.float64)
+        got_c = cls[t, 0].reshape(-1)[pix].astype(np.float64)
+        got_m = masked[t, 0].reshape(-1)[pix].astype(np.float64)
+        worst_c = max(worst_c, float((np.abs(got_c - c64) / np.maximum(np.abs(c64), 0.1 * g["ref64_cls_plane_max"][i])).max()))
+        sure = np.abs(c64 - 0.5) > 1e-5
+        want_m = r64 * (c64 >= 0.5)          # reg_preds' output (activation included, network_blocks.py:156-171) . [cls >= cls_thred] (flood_head.py:166-202)
+        worst_m = max(worst_m, float((np.abs(got_m - want_m)[sure] / max(0.1 * float(g["ref64_raw_plane_max"][i]), 1e-30)).max()))
+    print(f"two strips at 500x500, frames 0-12 vs the reference's float64 rollout: cls {worst_c:.2e}, masked depth {worst_m:.2e}")
+    assert worst_c <= 1e-4 and worst_m <= 1e-4

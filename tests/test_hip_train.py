@@ -508,6 +508,54 @@ def test_two_rank_ddp_training_keeps_replicas_identical(dev, tmp_path):
     assert np.isfinite(f0).all() and np.abs(g0).max() > 0
 
 
+def _rccl_order_worker(rank, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from urnn_amd.distributed import OverlappedGradientMean
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)          # RCCL, a world of one: the call path and its streams are real
+    n = 40_421_010                                                                 # the 500x500 network's parameters (161.7 MB of gradients)
+    src = torch.randn(n, device=dev)
+    flat = torch.empty_like(src)
+    warm = OverlappedGradientMean(flat, split=n - 40_000_000, force=True)
+    flat.copy_(src)
+    warm.start_tail()
+    warm.finish()                                                                  # (communicator set-up, untimed)
+    torch.cuda.synchronize()
+    ogm = OverlappedGradientMean(flat, split=n - 40_000_000, force=True)
+    torch.cuda._sleep(int(2.0e8))                                                  # ~0.1 s of GPU time in front of the producer
+    flat.copy_(src).mul_(2.0)                                                      # the "backward pass": writes the gradients on the current stream
+    ogm.start_tail()                                                               # async all-reduce of the tail on RCCL's stream
+    ogm.finish()                                                                   # head remainder + join
+    after = torch.cuda.Event()
+    after.record()
+    host_ran_ahead = not after.query()                                             # the host came back while the GPU is still in the sleep / reduction
+    out = flat * 1.0                                                               # the "optimizer": a consumer on the current stream
+    torch.cuda.synchronize()
+    ok = bool(torch.equal(out, src * 2.0))
+    with open(os.path.join(out_dir, "rccl_order.txt"), "w") as f:
+        f.write(f"{int(host_ran_ahead)} {int(ok)}")
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_overlapped_gradient_mean_is_stream_ordered_on_rccl(tmp_path):
+    """OverlappedGradientMean over the nccl (= RCCL) backend on ONE GPU (a world of one; the two-rank RCCL tests below need two GPUs
+    and skip on the test box): the async all-reduce starts behind the kernels that produced the gradients and the consumer behind
+    ``finish()`` sees the reduced buffer, while the HOST is never blocked -- the ordering is stream waits (``work.wait()``), not a
+    synchronisation (main.py:384-387).  The gloo tests cannot show this: gloo stages through the host."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_rccl_order_worker, args=(port, str(tmp_path)), nprocs=1, join=True)
+    ahead, ok = (int(v) for v in open(tmp_path / "rccl_order.txt").read().split())
+    assert ok == 1, "the consumer did not see the all-reduced gradients"
+    assert ahead == 1, "finish() blocked the host until the GPU had drained: the join must be a stream wait"
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank (the 1-GPU test box cannot host two)")
 def test_two_rank_ddp_training_over_rccl(tmp_path):
     """The same two-rank run with one GPU per rank and the nccl (= RCCL) backend: the head's gradient all-reduce overlaps the

@@ -162,3 +162,44 @@ def test_torch_ref_window_gradients_vs_reference_autograd(golden):
             assert np.abs(got).max() == 0.0, name
         else:
             assert np.abs(got - ref).max() / scale <= 1e-3, name
+
+
+# ---- the oracle pinned to the REFERENCE ITSELF at the headline size and horizon -------------------------------------
+def _sub_err(a, b, plane_max, floor_frac):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float((np.abs(a - b) / np.maximum(np.abs(b), floor_frac * max(float(plane_max), 1e-30))).max())
+
+
+def test_oracle_trace_vs_reference_trace_whole_event(golden):
+    """500x500, C = 63, all 360 frames (test.py:352-371, model.py:65-121).  Two committed traces of the SAME seeded event on the SAME
+    pixels: tests/golden/whole_event_500x500_T360.npz -- the C oracle (oracle/urnn_oracle.c), generated by make_whole_event_trace.py --
+    and tests/golden/reference_trace_500x500_T360.npz -- the reference's own modules in float32 and as a float64 copy, generated in the
+    build container by make_reference_trace.py.  Before round 6 the oracle was pinned to the reference by fixtures of <= 30 steps and
+    <= 64x64 only.  On every sampled frame (4096 random pixels + the oracle trace's 2048 adversarial ones) and on the final-state
+    subsets the oracle must sit within 1e-4 of the reference's float64 result under the tests' floor (0.1 x plane max; measured
+    4.0e-5), and under SURVEY 8c's strict floor (1e-3 x plane max) within 3 x what the reference's own float32 evaluation is away from
+    its float64 one on that frame's full plane (measured: 1.9 x at worst; the float32 reference itself reaches 3.6e-3 there)."""
+    ref, orc_t = golden("reference_trace_500x500_T360.npz"), golden("whole_event_500x500_T360.npz")
+    for k in ("H", "W", "nums", "T", "weights_seed", "event_seed"):
+        assert int(ref[k]) == int(orc_t[k]), k
+    assert np.array_equal(ref["frames"], orc_t["frames"]) and np.array_equal(ref["pixels"], orc_t["pixels"])
+    worst, worst_strict, w32 = 0.0, 0.0, 0.0
+    for i, t in enumerate(ref["frames"]):
+        rmax, cmax = ref["ref64_raw_plane_max"][i], ref["ref64_cls_plane_max"][i]
+        pairs = [(orc_t["oracle_raw"][i], ref["r64_raw"][i], rmax), (orc_t["adv_oracle_raw"][i], ref["oracle_adv_ref64_raw"][i], rmax),
+                 (orc_t["oracle_cls"][i], ref["r64_cls"][i], cmax), (orc_t["adv_oracle_cls"][i], ref["oracle_adv_ref64_cls"][i], cmax)]
+        e = max(_sub_err(a, b, m, 0.1) for a, b, m in pairs)
+        es_reg = max(_sub_err(a, b, m, 1e-3) for a, b, m in pairs[:2])
+        es_cls = max(_sub_err(a, b, m, 1e-3) for a, b, m in pairs[2:])
+        worst = max(worst, e)
+        worst_strict = max(worst_strict, es_reg / max(1e-4, 3.0 * float(ref["ref32_reg_err_full_strict"][i])), es_cls / max(1e-4, 3.0 * float(ref["ref32_cls_err_full_strict"][i])))
+        w32 = max(w32, _sub_err(ref["r32_raw"][i], ref["r64_raw"][i], rmax, 0.1))
+        assert e <= 1e-4, f"frame {int(t)}: oracle vs reference fp64 {e:.2e}"
+    for k in range(6):
+        assert np.array_equal(ref[f"state{k}_idx"], orc_t[f"state{k}_idx"])
+        es = _sub_err(orc_t[f"state{k}_oracle"], ref[f"state{k}_ref64"], ref["state_plane_max"][k], 0.1)
+        assert es <= 1e-4, f"final state {k}: {es:.2e}"
+        worst = max(worst, es)
+    print(f"C oracle vs the reference's float64 rollout, 121 of 360 frames at 500x500: worst {worst:.2e} (floor 0.1 x max; the reference's own float32 on the "
+          f"random pixels: {w32:.2e}); strict floor: worst error / (3 x the reference's float32 full-plane error) = {worst_strict:.2f}")
+    assert worst_strict <= 1.0

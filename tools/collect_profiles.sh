@@ -7,7 +7,7 @@ TAG=${1:-r05}
 O=$R/gpurun_out/$TAG; P=/tmp/prof_$TAG
 mkdir -p $O $P; cd /tmp; export TMPDIR=/tmp
 # one chain, eager (every dispatch attributed) -- with the kernel selection of the benchmarked overlapped schedule (URNN_TUNE_COOP_BIG=0)
-export URNN_TUNE_COOP_BIG=0
+export URNN_TUNING=1 URNN_TUNE_COOP_BIG=0
 CMD="python $R/bench.py --steps 14 --warmup 2 --no-cpu-baseline --no-long-run --overlap 0 --no-graph"
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   name=$(echo $pass | cut -d' ' -f1)
@@ -47,7 +47,7 @@ timeout 300 python $R/tools/kernel_bench.py > $O/kernel_bench.txt 2>&1
 timeout 300 python $R/bench.py --mode train > $O/bench_train.log 2>&1
 timeout 300 python $R/bench.py --mode train --dtype bf16 > $O/bench_train_bf16.log 2>&1
 timeout 300 python $R/bench.py --mode train --seq-num 12 > $O/bench_train_seq12.log 2>&1
-URNN_TUNE_TRAIN_CHAINS=0 URNN_TUNE_TRAIN_BWD_CHAINS=0 timeout 300 python $R/bench.py --mode train > $O/bench_train_one_chain.log 2>&1   # the window step by step on one stream
+URNN_TUNING=1 URNN_TUNE_TRAIN_CHAINS=0 URNN_TUNE_TRAIN_BWD_CHAINS=0 timeout 300 python $R/bench.py --mode train > $O/bench_train_one_chain.log 2>&1   # the window step by step on one stream
 timeout 420 rocprofv3 --kernel-trace --stats -d $P/stats_train -o t -- python $R/bench.py --mode train > /dev/null 2>&1
 python $R/tools/prof_summary.py $P/stats_train/t_results.db > $O/train_kernel_stats.txt 2>&1
 python $R/tools/wgrad_trace.py $P/stats_train/t_results.db > $O/train_wgrad_launches.txt 2>&1

@@ -17,6 +17,8 @@ from urnn_amd import ops, _lib
 from urnn_amd.rollout import RolloutEngine
 import urnn_amd.weights as uw
 
+NAMES_TILES = ["setup: tiles, bias, first DMA", "k-loop (phase A)", "gate stats + W2h request", "GRID BARRIER 1", "fold gates + sync", "r.h in place + sync",
+               "cand h-groups | z sigmoid", "GRID BARRIER 2 (+ z hand-over)", "fold cand + sync", "blend + store drain"]
 NAMES = ["panel load+split", "block barrier", "gate k-loop", "stats + h request", "GRID BARRIER 1", "fold gates", "gate + r.h -> panel", "block barrier",
          "cand k-loop + stats", "GRID BARRIER 2", "fold cand", "blend + store drain"]
 
@@ -35,9 +37,13 @@ def main():
     cells = {"enc1": (net.encoder.rnn1, eng.a1, None, e1), "dec1": (net.decoder.rnn1, eng.u2, e1, d3), "enc2": (net.encoder.rnn2, eng.a2, None, e2),
              "dec2": (net.decoder.rnn2, eng.u3, e2, d2), "enc3": (net.encoder.rnn3, eng.a3, None, e3), "dec3": (net.decoder.rnn3, None, e3, d1)}
     L = _lib.lib()
-    setter = getattr(L, "urnn_debug_set_trace_urnn_small", None)
-    assert setter is not None, "build the trace library first: python tools/build_variants.py trace; URNN_LIB=u-rnn_amd/liburnn_hip_trace.so"
-    setter.argtypes = [ctypes.c_void_p]
+    setters = [getattr(L, n, None) for n in ("urnn_debug_set_trace_urnn_small", "urnn_debug_set_trace_urnn_coop_tiles")]
+    assert all(f is not None for f in setters), "build the trace library first: python tools/build_variants.py trace; URNN_LIB=u-rnn_amd/liburnn_hip_trace.so"
+    for f in setters:
+        f.argtypes = [ctypes.c_void_p]
+
+    def setter(p):
+        return max(f(p) for f in setters)
     for name in which:
         cell, x, e, h = cells[name]
         tmp = h.clone()
@@ -65,16 +71,24 @@ def main():
         nb = int(used[:, 0].sum())
         nw = int(used[0].sum())
         # s_memtime is a 100 MHz counter shared by the chip: reference everything to the earliest entry stamp
-        t0 = t[used][:, 0].min()
-        tt = (t[used][:, :13] - t0) / 100.0          # us
-        print(f"\n{name}: {nb} blocks x {nw} waves; launch {us:.1f} us (events, 20 launches back to back); stamped span {tt[:, 12].max():.1f} us")
-        print(f"{'phase':28s} {'mean':>7s} {'p10':>7s} {'p50':>7s} {'p90':>7s} {'max':>7s}   ends at (mean / max) us")
-        for k, nm in enumerate(NAMES):
+        tiles_kernel = name in ("enc2", "dec2")      # (half resolution: urnn_coop_tiles.hip, 11 stamps)
+        names, ns = (NAMES_TILES, 11) if tiles_kernel else (NAMES, 13)
+        # s_memtime counts shader cycles, per XCD: reference every block to the earliest entry stamp of its own XCD (block % 8)
+        tb = t.copy()
+        for xc in range(8):
+            sel = used.copy()
+            sel[np.arange(nblk) % 8 != xc] = False
+            if sel.any():
+                tb[np.arange(nblk) % 8 == xc] -= t[sel][:, 0].min()
+        tt = tb[used][:, :ns] / 100.0                # units of 100 cycles (~0.043 us at 2.3 GHz)
+        print(f"\n{name}: {nb} blocks x {nw} waves; launch {us:.1f} us (events, 20 launches back to back); stamped span {tt[:, ns - 1].max():.1f} x 100 cycles")
+        print(f"{'phase (units of 100 cycles)':34s} {'mean':>7s} {'p10':>7s} {'p50':>7s} {'p90':>7s} {'max':>7s}   ends at (mean / max)")
+        for k, nm in enumerate(names):
             d = tt[:, k + 1] - tt[:, k]
-            print(f"{nm:28s} {d.mean():7.2f} {np.percentile(d, 10):7.2f} {np.percentile(d, 50):7.2f} {np.percentile(d, 90):7.2f} {d.max():7.2f}   {tt[:, k + 1].mean():7.2f} / {tt[:, k + 1].max():7.2f}")
+            print(f"{nm:34s} {d.mean():7.2f} {np.percentile(d, 10):7.2f} {np.percentile(d, 50):7.2f} {np.percentile(d, 90):7.2f} {d.max():7.2f}   {tt[:, k + 1].mean():7.2f} / {tt[:, k + 1].max():7.2f}")
         print(f"entry stamps: first {tt[:, 0].min():.2f}, mean {tt[:, 0].mean():.2f}, last {tt[:, 0].max():.2f} us (block scheduling skew)")
         # barrier anatomy: when did the LAST wave arrive (stamp before) and when did waves leave
-        for k, nm in ((4, "grid barrier 1"), (9, "grid barrier 2")):
+        for k, nm in (((3, "grid barrier 1"), (7, "grid barrier 2")) if tiles_kernel else ((4, "grid barrier 1"), (9, "grid barrier 2"))):
             print(f"{nm}: last arrival {tt[:, k].max():.2f} us, first release {tt[:, k + 1].min():.2f}, last release {tt[:, k + 1].max():.2f} us")
 
 

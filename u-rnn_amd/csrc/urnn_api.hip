@@ -447,8 +447,9 @@ static int gru_cell_impl(const float *x, const float *e, const float *h, const f
     if (global_pixels >= URNN_FULL_RES_PIXELS && urnn_get_matrix_mode() == URNN_MATRIX_FP32) c.candExact = 1;
     int pb2, map2;
     int tiles2 = gru_tiles(B, F, P, 2, &pb2, &map2);
-    // half-resolution planes: the two-stream candidate on 64-pixel tiles (urnn_cand_gated.hip).  Decided from the shapes alone, so that
-    // phase-split callers see the same tile size in the candidate and in the blend's fold
+    // half-resolution planes: the two-stream candidate on 64-pixel tiles (urnn_cand_gated.hip).  Decided from the shapes and the process-wide
+    // matrix mode (urnn_cand_gated_plan), so phase-split callers see the same tile size in the candidate and in the blend's fold AS LONG AS
+    // every phase of the cell runs under the same mode (include/urnn_hip.h "One device per process ...")
     const bool gated2 = !fused_r && global_pixels <= 0 && !small_on && urnn_cand_gated_plan(c, B) != 0;
     if (gated2) {
         pb2 = 2;

@@ -127,11 +127,14 @@ __device__ __forceinline__ void ct_barrier_lane(unsigned *bar, unsigned block, u
 }
 
 // G = F / 32 channel blocks per role
-template <int G>
-__global__ __launch_bounds__(768) void coop_tiles_kernel(const CoopTilesParams cp)
+// One role's whole program.  The three roles are three instantiations called from three branches of the kernel, NOT one body with
+// role tests inside: with a shared body the register allocator sees one set of accumulators live on every path (an r-wave's are dead
+// once r (.) h is formed, and its registers then hold the tile's previous state) and spills ~150 registers around the phases.
+template <int G, int ROLE>
+__device__ __forceinline__ void ct_role(const CoopTilesParams &cp, const int lane, const int wave)
 {
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wr = wave >> 2, wc = wave & 3;                      // role: 0 z, 1 r, 2 c; tile slot
+    constexpr int wr = ROLE;                                      // role: 0 z, 1 r, 2 c
+    const int wc = wave & 3;                                      // tile slot
     const int j = lane & 31, half = lane >> 5;
     const int P = cp.P, F = cp.F;
     const int KG = cp.KG, KGxe = cp.KGxe, NH = F / 16;            // NH hidden-state groups = the last groups of the k-loop
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(768) void coop_tiles_kernel(const CoopTilesParams c
         }
     };
     if (wr < 2) {
-        for (int gn = 0; gn < CT_D - 1 && gn < KG; ++gn) issue_acts(gn);
+        for (int gn = 0; gn < CT_D && gn < KG; ++gn) issue_acts(gn);       // every ring slot
     } else {
         issue_weights(0);
         if (KG > 1) issue_weights(1);
@@ -219,144 +222,165 @@ __global__ __launch_bounds__(768) void coop_tiles_kernel(const CoopTilesParams c
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[blk][pb][r] = 0.f;
 
-    // one group's matrix work of this wave: B fragments of its tile from ring slot `slot` (fp32 rows or, packed = true, one dword of two
-    // f16 pieces per value), A fragments of its G blocks from `wsrc` ([block][hi | lo][64 lanes][16 B]); f16 x 3, small terms first
+    // B fragments of this wave's tile for one 16-k group: dword d of lane (j, half) = rows 4 d + half (low) and 4 d + 2 + half (high) of the
+    // group at pixel 32 pb + j, as two f16 pieces.  Item i < 8 = (pb = i >> 2, d = i & 3).
     const int boff = wc * 4096 + half * 256 + j * 4;
-    auto group_mfma = [&](const char *slot, const char *wsrc, bool packed) __attribute__((always_inline)) {
-        unsigned bh[2][4], bl[2][4];
+    auto prep_item = [&](const char *slot, int i, unsigned (&ph)[2][4], unsigned (&pl)[2][4]) __attribute__((always_inline)) {
+        const int pb = i >> 2, d = i & 3;
+        const float v0 = *reinterpret_cast<const float *>(slot + boff + (4 * d) * 256 + pb * 128);
+        const float v1 = *reinterpret_cast<const float *>(slot + boff + (4 * d + 2) * 256 + pb * 128);
+        split2_pair(v0, v1, URNN_F16_ASCALE, ph[pb][d], pl[pb][d]);
+    };
+    auto mfma_block = [&](const char *wsrc, int blk, const unsigned (&ph)[2][4], const unsigned (&pl)[2][4]) __attribute__((always_inline)) {
+        const f16x8 ah = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4 *>(wsrc + blk * 2048 + lane * 16));
+        const f16x8 al = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4 *>(wsrc + blk * 2048 + 1024 + lane * 16));
 #pragma unroll
-        for (int pb = 0; pb < 2; ++pb) {
-            float v[8];
-#pragma unroll
-            for (int d = 0; d < 4; ++d)
-#pragma unroll
-                for (int q = 0; q < 2; ++q)          // row 4 d + 2 q + half of the group, pixel 32 pb + j
-                    v[2 * d + q] = *reinterpret_cast<const float *>(slot + boff + (4 * d + 2 * q) * 256 + pb * 128);
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                if (packed) {
-                    const unsigned a = __float_as_uint(v[2 * d]), b = __float_as_uint(v[2 * d + 1]);
-                    bh[pb][d] = __builtin_amdgcn_perm(b, a, 0x05040100u);      // {b.lo16, a.lo16}: the hi pieces
-                    bl[pb][d] = __builtin_amdgcn_perm(b, a, 0x07060302u);      // {b.hi16, a.hi16}: the lo pieces
-                } else {
-                    split2_pair(v[2 * d], v[2 * d + 1], URNN_F16_ASCALE, bh[pb][d], bl[pb][d]);
-                }
-            }
-        }
-#pragma unroll
-        for (int blk = 0; blk < G; ++blk) {
-            const f16x8 ah = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4 *>(wsrc + blk * 2048 + lane * 16));
-            const f16x8 al = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4 *>(wsrc + blk * 2048 + 1024 + lane * 16));
-#pragma unroll
-            for (int pb = 0; pb < 2; ++pb) {
-                acc[blk][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, as_f16x8(bh[pb]), acc[blk][pb], 0, 0, 0);
-                acc[blk][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, as_f16x8(bl[pb]), acc[blk][pb], 0, 0, 0);
-                acc[blk][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, as_f16x8(bh[pb]), acc[blk][pb], 0, 0, 0);
-            }
+        for (int pb = 0; pb < 2; ++pb) {                    // f16 x 3, small terms first (the order of every forward kernel)
+            acc[blk][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, as_f16x8(ph[pb]), acc[blk][pb], 0, 0, 0);
+            acc[blk][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, as_f16x8(pl[pb]), acc[blk][pb], 0, 0, 0);
+            acc[blk][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, as_f16x8(ph[pb]), acc[blk][pb], 0, 0, 0);
         }
     };
 
     // ---- phase A: the k-loop ---------------------------------------------------------------------------------------------------------------
+    // (Software-pipelining the split of group g + 1 under group g's MFMAs needs a second set of fragment registers: 96 accumulators + 2 x 16
+    // pieces + A fragments + addressing exceed the 168 registers of three waves per SIMD and the accumulators spill inside the loop.)
     CT_STAMP(1);
     for (int g = 0; g < KG; ++g) {
-        if (wr < 2) {                                   // group g's rows have landed: at most the D - 2 groups after it are still in flight
-            const int ahead = KG - 1 - g < CT_D - 2 ? KG - 1 - g : CT_D - 2;
-            ct_wait_vm_groups(ahead, 2);
+        if (wr < 2) {                                   // group g's rows have landed; the groups requested after it may still travel
+            const int issued = g == 0 ? (KG < CT_D ? KG : CT_D) - 1 : (g - 2 + CT_D < KG - 1 ? g - 2 + CT_D : KG - 1);   // last group requested so far
+            ct_wait_vm_groups(issued - g, 2);
         } else {                                        // group g's weights: at most group g + 1's in flight
             ct_wait_vm_groups(g + 1 < KG ? 1 : 0, NQ);
         }
         ct_sync();                                      // ... for every wave's share; and everybody is done with group g - 1's slot and weights
         if (wr < 2) {
-            if (g + CT_D - 1 < KG) issue_acts(g + CT_D - 1);        // -> the slot of group g - 1
+            if (g > 0 && g - 1 + CT_D < KG) issue_acts(g - 1 + CT_D);   // -> the slot of group g - 1
         } else {
-            if (g + 2 < KG) issue_weights(g + 2);                   // -> the buffer of group g - 1
+            if (g + 2 < KG) issue_weights(g + 2);                       // -> the buffer of group g - 1
         }
-        if (tile_on && (wr < 2 || g < KGxe))
-            group_mfma(ring + (g % CT_D) * CT_SLOT, wbuf + (g % CT_NW) * CT_WBUF + wr * G * 2048, false);
+        if (tile_on && (wr < 2 || g < KGxe)) {
+            unsigned ph[2][4], pl[2][4];
+            const char *slot = ring + (g % CT_D) * CT_SLOT;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) prep_item(slot, i, ph, pl);
+            __builtin_amdgcn_sched_barrier(0);           // (one pixel half's rows in registers at a time)
+#pragma unroll
+            for (int i = 4; i < 8; ++i) prep_item(slot, i, ph, pl);
+            __builtin_amdgcn_sched_barrier(0);
+            const char *wsrc = wbuf + (g % CT_NW) * CT_WBUF + wr * G * 2048;
+#pragma unroll
+            for (int blk = 0; blk < G; ++blk) {
+                mfma_block(wsrc, blk, ph, pl);
+                __builtin_amdgcn_sched_barrier(0);       // (one block's A fragments at a time: all three hoisted cost 16 registers the loop does not have)
+            }
+        }
     }
     CT_STAMP(2);
 
-    // ---- raw gates (bias added) stay in the accumulators; centred statistics of every (64-pixel tile, 32-channel group) -> partial1 ---------
+    // Everything below addresses memory through these copies: laundered so that the compiler cannot form the phases' per-lane addresses
+    // BEFORE the k-loop and carry them through it (it did: ~40 registers, and an accumulator tile lived in scratch inside the loop).
+    int lane_b = lane;
+    asm volatile("" : "+v"(lane_b));
+    const int j_b = lane_b & 31, half_b = lane_b >> 5;
+    const int boff_b = wc * 4096 + half_b * 256 + j_b * 4;
+
     auto row_c = [](int r) { return (r & 3) + 8 * (r >> 2); };
     const float inv_n = nvalid == 64 ? 1.0f / 2048.0f : 1.0f / (32.0f * (float)(nvalid > 0 ? nvalid : 1));
-    const bool okp[2] = {tt * 64 + j < P && tile_on, tt * 64 + 32 + j < P && tile_on};
+    const bool okp[2] = {tt * 64 + j_b < P && tile_on, tt * 64 + 32 + j_b < P && tile_on};
+    // accumulators -> raw values (bias added, in place); centred statistics of every (64-pixel tile, 32-channel group) of this wave's role
     auto finish_and_stats = [&](int role, float *partial, int ngroups) __attribute__((always_inline)) {
+        float s1[G], s2[G], mt[G];
 #pragma unroll
         for (int blk = 0; blk < G; ++blk) {
-            const float *bias_h = biasl + (role * G + blk) * 32 + 4 * half;
-            float s1 = 0.f;
+            const float *bias_h = biasl + (role * G + blk) * 32 + 4 * half_b;
+            s1[blk] = 0.f;
 #pragma unroll
             for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     acc[blk][pb][r] = fmaf(acc[blk][pb][r], URNN_F16_DESCALE, bias_h[row_c(r)]);
-                    if (okp[pb]) s1 += acc[blk][pb][r];
+                    if (okp[pb]) s1[blk] += acc[blk][pb][r];
                 }
-            s1 = wave_sum(s1);
-            const float mt = nofma(s1 * inv_n);
-            float s2 = 0.f;
+        }
+        wave_sum_n<G>(s1);                                  // (the G reductions interleaved: one latency instead of G)
+#pragma unroll
+        for (int blk = 0; blk < G; ++blk) {
+            mt[blk] = nofma(s1[blk] * inv_n);
+            s2[blk] = 0.f;
 #pragma unroll
             for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float d = acc[blk][pb][r] - mt;
-                    if (okp[pb]) s2 = fmaf(d, d, s2);
+                    const float d = acc[blk][pb][r] - mt[blk];
+                    if (okp[pb]) s2[blk] = fmaf(d, d, s2[blk]);
                 }
-            s2 = wave_sum(s2);
-            if (lane == 0 && nvalid > 0)
-                publish8(partial + (((size_t)tb * ngroups + (role == 2 ? blk : role * G + blk)) * cp.tilesPerSample + tt) * 2, s1, s2);
+        }
+        wave_sum_n<G>(s2);
+        if (lane_b == 0 && nvalid > 0) {
+#pragma unroll
+            for (int blk = 0; blk < G; ++blk)
+                publish8(partial + (((size_t)tb * ngroups + (role == 2 ? blk : role * G + blk)) * cp.tilesPerSample + tt) * 2, s1[blk], s2[blk]);
         }
     };
-    if (wr < 2) finish_and_stats(wr, cp.partial1, 2 * G);
 
-    // the candidate's hidden-state weights W2[:, h] (NH groups x G blocks x two pieces), once per CU, into the weight buffers: everybody is
-    // past the k-loop's last weight read after this barrier
-    __syncthreads();
-    if (wr == 2) {
-        constexpr int NH_MAX = 2 * G;                    // F / 16
-        const int total = NH_MAX * G * 2;                // 1-KB pieces: [group][block][piece]
-        for (int n = wc; n < total; n += 4) {
-            const int gi = n / (2 * G), rem = n - gi * 2 * G, blk = rem >> 1;
-            ct_dma16(cp.wblk[2 * G + blk] + (size_t)(cp.kg0 + KGxe + gi) * cp.wstride[2 * G + blk] + (rem & 1) * 256 + lane * 4, wbuf + n * 1024);
-        }
-    }
-    CT_STAMP(3);
-
-    // ---- grid barrier 1 ----------------------------------------------------------------------------------------------------------------
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) ct_barrier_lane(cp.bar, blockIdx.x, (unsigned)cp.nblocks, cp.status);
-    __syncthreads();
-    CT_STAMP(4);
-
-
-    // ---- phase B: GroupNorm of the gates.  Wave (role z / r, wc < G) folds norm group role G + wc for the sample of tile slot 0 and, where
-    // a later slot belongs to another sample (B > 1, a sample's end inside this block), again for that one: table [slot][channel] ----------
-    int sb[CT_NT];                                        // sample of every slot (block-uniform)
+    // GroupNorm of one norm group for every tile slot of this block: (scale, shift) of its 32 channels into the slot's table.  Slots of one
+    // sample share the fold (consecutive tiles: a block straddles samples only where B > 1 and a sample ends inside it).
+    int sb[CT_NT];
     bool son[CT_NT];
 #pragma unroll
     for (int ti = 0; ti < CT_NT; ++ti) {
         int t_;
         son[ti] = slot_tile(ti, sb[ti], t_);
     }
+    // l2e: the table is a gate's -- its entries are (scale, shift) x log2(e), what gate_sigmoid forms per value elsewhere (same products, same
+    // bits, formed once per channel instead of once per pixel); the workspace tables keep the plain (scale, shift)
     auto fold_group = [&](const float *partial, int ngroups, int grp, const float *gam, const float *bet, int ch0, float *ss_out, float *st_out,
-                          int status_bit) __attribute__((always_inline)) {
+                          int status_bit, bool l2e) __attribute__((always_inline)) {
 #pragma unroll
         for (int ti = 0; ti < CT_NT; ++ti) {
             if (!son[ti]) continue;
             float *tab = sstab + (size_t)ti * 3 * G * 64;
             if (ti > 0 && sb[ti] == sb[ti - 1]) {                       // same sample as the slot before: copy its table entries
-                if (lane < 32) {
+                if (lane_b < 32) {
                     const float *prev = sstab + (size_t)(ti - 1) * 3 * G * 64;
-                    tab[2 * (ch0 + lane)] = prev[2 * (ch0 + lane)];
-                    tab[2 * (ch0 + lane) + 1] = prev[2 * (ch0 + lane) + 1];
+                    tab[2 * (ch0 + lane_b)] = prev[2 * (ch0 + lane_b)];
+                    tab[2 * (ch0 + lane_b) + 1] = prev[2 * (ch0 + lane_b) + 1];
                 }
                 continue;
             }
             const int bs = sb[ti];
-            const float *pp = partial + ((size_t)bs * ngroups + grp) * cp.tilesPerSample * 2;
-            double s1, s2;
-            fold_lane_chain<8, true, true>(pp, cp.tilesPerSample, 64, 32, P, lane, s1, s2);      // (urnn_common.h: the order every finalizer shares)
+            // two tiles per 16-byte write-through-coherent load (sc1, as the 8-byte agent-scope loads of consume8), eight loads in flight per
+            // lane: ONE round trip for up to 1024 tiles (the 8-byte form in two dependent batches cost 6.7 us here).  Lane l takes tile pairs
+            // l, l + 64, ... in ascending order, then the xor butterfly: a fixed order.
+            double s1 = 0.0, s2 = 0.0;
+            {
+                const int nt = cp.tilesPerSample, tpart = (P & 63) != 0 ? P / 64 : -1;
+                const ct_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(partial), 0, (int)0x7fffffff, 0x00020000);
+                const unsigned base = (unsigned)((((size_t)bs * ngroups + grp) * nt) * 8);
+                for (int u0 = 0; 2 * u0 < nt; u0 += 64 * 8) {
+                    u32x4 v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int u = u0 + 64 * k + lane_b;
+                        v[k] = __builtin_amdgcn_raw_buffer_load_b128(rp, 2 * u < nt ? base + 16u * (unsigned)u : base, 0, 16);      // aux 16 = sc1
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int u = u0 + 64 * k + lane_b;
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int t = 2 * u + e;
+                            const float a = __uint_as_float(v[k][2 * e]), m2 = __uint_as_float(v[k][2 * e + 1]);
+                            if (t < nt) {
+                                const double dx = (double)a;
+                                s1 += dx;
+                                s2 += t == tpart ? tile_x2(a, m2, 32 * (P - tpart * 64)) : (double)m2 + dx * dx * (1.0 / 2048.0);   // (full tile: 32 x 64 values)
+                            }
+                        }
+                    }
+                }
+            }
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) {
                 s1 += __shfl_xor(s1, m, 64);
@@ -367,21 +391,21 @@ __global__ __launch_bounds__(768) void coop_tiles_kernel(const CoopTilesParams c
             double var = s2 / count - nofma(mean * mean);   // (no contraction: every finalizer gives the same bits)
             var = var > 0.0 ? var : 0.0;
             const double rstd = 1.0 / sqrt(var + (double)cp.eps);
-            // the block that holds the sample's first tile leaves the tables the three-kernel cell leaves in the workspace
             int t0, b0;
-            slot_tile(ti, b0, t0);
-            if (lane < 32) {
-                const int c = grp * 32 + lane;
+            slot_tile(ti, b0, t0);                          // the block that holds a sample's first tile leaves the workspace tables
+            if (lane_b < 32) {
+                const int c = grp * 32 + lane_b;
                 const double sc = (double)gam[c] * rstd;
                 const float fsc = (float)sc, fsh = (float)((double)bet[c] - nofma(mean * sc));
-                tab[2 * (ch0 + lane)] = fsc;
-                tab[2 * (ch0 + lane) + 1] = fsh;
+                const float L2E = 1.44269502162933349609375f;       // (urnn_common.h gate_sigmoid)
+                tab[2 * (ch0 + lane_b)] = l2e ? nofma(fsc * L2E) : fsc;
+                tab[2 * (ch0 + lane_b) + 1] = l2e ? nofma(fsh * L2E) : fsh;
                 if (t0 == 0 && ss_out) {
                     ss_out[((size_t)bs * ngroups * 32 + c) * 2] = fsc;
                     ss_out[((size_t)bs * ngroups * 32 + c) * 2 + 1] = fsh;
                 }
             }
-            if (t0 == 0 && lane == 0) {
+            if (t0 == 0 && lane_b == 0) {
                 flag_nonfinite(cp.status, status_bit, s1, s2);
                 if (st_out) {
                     st_out[((size_t)bs * ngroups + grp) * 2] = (float)mean;
@@ -390,116 +414,210 @@ __global__ __launch_bounds__(768) void coop_tiles_kernel(const CoopTilesParams c
             }
         }
     };
-    if (wr < 2 && wc < G) fold_group(cp.partial1, 2 * G, wr * G + wc, cp.gn1_w, cp.gn1_b, (wr * G + wc) * 32, cp.ss1_out, cp.st1_out, URNN_STATUS_GATES);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (wr == 2: the W2[:, h] pieces have landed)
-    __syncthreads();
-    CT_STAMP(5);
-
-    // ---- r-waves: r (.) h in place over the hidden-state rows the ring still holds (its last NH groups) --------------------------------
     const float *mytab = sstab + (size_t)wc * 3 * G * 64;
-    if (wr == 1 && tile_on) {
+    float *zbuf = reinterpret_cast<float *>(ring) + (size_t)wc * (G * 2 * 1024);       // phase C: z, [slot][blk][pb][16][64] over the ring
+    float *hbuf = reinterpret_cast<float *>(wbuf) + (size_t)wc * (G * 1024);           //          h of one pixel half_b, [slot][blk][16][64] over the weight buffers
+    const int NHh = NH;
+
+    // From here on the three roles run their own code (so that a role's dead accumulators are dead for the register allocator too); every
+    // path passes the SAME sequence of block barriers: Sa Sb Sc Sd Se Sf Sg Sh Si Sj.
+    if (wr == 0) {
+        // =============================================== z-waves ===================================================================
+        finish_and_stats(0, cp.partial1, 2 * G);
+        ct_sync();                                                                  // Sa
+        CT_STAMP(3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // the statistics have been acknowledged
+        ct_sync();                                                                  // Sb
+        if (threadIdx.x == 0) ct_barrier_lane(cp.bar, blockIdx.x, (unsigned)cp.nblocks, cp.status);       // grid barrier 1
+        ct_sync();                                                                  // Sc
+        CT_STAMP(4);
+        if (wc < G) fold_group(cp.partial1, 2 * G, wc, cp.gn1_w, cp.gn1_b, wc * 32, cp.ss1_out, cp.st1_out, URNN_STATUS_GATES, true);
+        ct_sync();                                                                  // Sd
+        CT_STAMP(5);
+        if (tile_on) {                                                              // z = sigmoid(GN(raw)) in place, next to the r-waves' gating
+#pragma unroll
+            for (int blk = 0; blk < G; ++blk)
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const f32x2 st = *reinterpret_cast<const f32x2 *>(mytab + 2 * (blk * 32 + row_c(r) + 4 * half_b));
+                        acc[blk][pb][r] = sigmoid_of_log2arg(fmaf(acc[blk][pb][r], st.x, st.y));      // (= gate_sigmoid: the table holds the folded affine)
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+        ct_sync();                                                                  // Se
+        CT_STAMP(6);
+        CT_STAMP(7);
+        ct_sync();                                                                  // Sf: the ring is dead
+        if (tile_on) {
+#pragma unroll
+            for (int blk = 0; blk < G; ++blk)
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) zbuf[((blk * 2 + pb) * 16 + r) * 64 + lane_b] = acc[blk][pb][r];
+        }
+        ct_sync();                                                                  // Sg
+        CT_STAMP(8);
+        ct_sync();                                                                  // Sh
+        CT_STAMP(9);
+        ct_sync();                                                                  // Si
+        ct_sync();                                                                  // Sj
+    } else if (wr == 1) {
+        // =============================================== r-waves ===================================================================
+        finish_and_stats(1, cp.partial1, 2 * G);
+        ct_sync();                                                                  // Sa
+        CT_STAMP(3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ct_sync();                                                                  // Sb
+        ct_sync();                                                                  // Sc
+        CT_STAMP(4);
+        if (wc < G) fold_group(cp.partial1, 2 * G, G + wc, cp.gn1_w, cp.gn1_b, (G + wc) * 32, cp.ss1_out, cp.st1_out, URNN_STATUS_GATES, true);
+        ct_sync();                                                                  // Sd
+        CT_STAMP(5);
+        // r (.) h in place over the hidden-state rows the ring still holds (its last NH groups): one dword = the value's two f16 pieces
+        if (tile_on) {
+#pragma unroll
+            for (int blk = 0; blk < G; ++blk)
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        // accumulator rows 4 q + i, i < 4: hidden channels 32 blk + 8 q + 4 half_b + i: group 2 blk + (q >> 1), rows 8 (q & 1) + 4 half_b + i
+                        const int gi = 2 * blk + (q >> 1);
+                        char *base = ring + ((KG - NHh + gi) % CT_D) * CT_SLOT + wc * 4096 + (8 * (q & 1) + 4 * half_b) * 256 + (pb * 32 + j_b) * 4;
+                        float hv[4], rv[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) hv[i] = *reinterpret_cast<const float *>(base + i * 256);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const f32x2 st = *reinterpret_cast<const f32x2 *>(mytab + 2 * ((G + blk) * 32 + 8 * q + 4 * half_b + i));
+                            rv[i] = hv[i] * sigmoid_of_log2arg(fmaf(acc[blk][pb][4 * q + i], st.x, st.y));
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; i += 2) {
+                            unsigned ph, pl;
+                            split2_pair(rv[i], rv[i + 1], URNN_F16_ASCALE, ph, pl);       // ph = {hi(i+1), hi(i)}, pl = {lo(i+1), lo(i)}
+                            *reinterpret_cast<unsigned *>(base + i * 256) = __builtin_amdgcn_perm(pl, ph, 0x05040100u);          // {lo(i), hi(i)}
+                            *reinterpret_cast<unsigned *>(base + (i + 1) * 256) = __builtin_amdgcn_perm(pl, ph, 0x07060302u);    // {lo(i+1), hi(i+1)}
+                        }
+                        if (q == 3) __builtin_amdgcn_sched_barrier(0);      // (16 independent chains per step)
+                    }
+        }
+        ct_sync();                                                                  // Se
+        CT_STAMP(6);
+        // the tile's previous state for the blend: all of it into this wave's (now free) registers, one round trip, while the c-waves multiply
+        float hreg[G][2][16];
+        const float *hbase = cp.h + ((size_t)tb * F + 4 * half_b) * P + (size_t)tt * 64 + j_b;
 #pragma unroll
         for (int blk = 0; blk < G; ++blk)
 #pragma unroll
             for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    // accumulator rows 4 q + i, i < 4: hidden channels 32 blk + 8 q + 4 half + i: group (2 blk + (q >> 1)), rows 8 (q & 1) + 4 half + i
-                    const int gi = 2 * blk + (q >> 1);
-                    char *base = ring + ((KG - NH + gi) % CT_D) * CT_SLOT + wc * 4096 + (8 * (q & 1) + 4 * half) * 256 + (pb * 32 + j) * 4;
-                    float hv[4], rv[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) hv[i] = *reinterpret_cast<const float *>(base + i * 256);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const f32x2 st = *reinterpret_cast<const f32x2 *>(mytab + 2 * ((G + blk) * 32 + 8 * q + 4 * half + i));
-                        rv[i] = hv[i] * gate_sigmoid(acc[blk][pb][4 * q + i], st.x, st.y);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; i += 2) {
-                        unsigned ph, pl;
-                        split2_pair(rv[i], rv[i + 1], URNN_F16_ASCALE, ph, pl);       // ph = {hi(i+1), hi(i)}, pl = {lo(i+1), lo(i)}
-                        *reinterpret_cast<unsigned *>(base + i * 256) = __builtin_amdgcn_perm(pl, ph, 0x05040100u);          // {lo(i), hi(i)}
-                        *reinterpret_cast<unsigned *>(base + (i + 1) * 256) = __builtin_amdgcn_perm(pl, ph, 0x07060302u);    // {lo(i+1), hi(i+1)}
-                    }
-                }
-    }
-    __syncthreads();
-    CT_STAMP(6);
-
-    // ---- c-waves: the candidate's hidden-state groups; z-waves: their sigmoid meanwhile -------------------------------------------------------
-    if (wr == 2) {
+                for (int r = 0; r < 16; ++r) hreg[blk][pb][r] = okp[pb] ? hbase[(size_t)(blk * 32 + row_c(r)) * P + pb * 32] : 0.f;
+        CT_STAMP(7);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ct_sync();                                                                  // Sf: the weight buffers are dead
         if (tile_on) {
-            for (int gi = 0; gi < NH; ++gi) group_mfma(ring + ((KG - NH + gi) % CT_D) * CT_SLOT, wbuf + gi * G * 2048, true);
+#pragma unroll
+            for (int blk = 0; blk < G; ++blk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hbuf[(blk * 16 + r) * 64 + lane_b] = hreg[blk][0][r];
+        }
+        ct_sync();                                                                  // Sg
+        CT_STAMP(8);
+        ct_sync();                                                                  // Sh
+        CT_STAMP(9);
+        ct_sync();                                                                  // Si: the c-waves are through with the first pixel half_b
+        if (tile_on) {
+#pragma unroll
+            for (int blk = 0; blk < G; ++blk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hbuf[(blk * 16 + r) * 64 + lane_b] = hreg[blk][1][r];
+        }
+        ct_sync();                                                                  // Sj
+    } else {
+        // =============================================== c-waves ===================================================================
+        ct_sync();                                                                  // Sa: everybody is past the k-loop's last weight read
+        {   // W2[:, h] (NH groups x G blocks x two pieces), once per CU, into the weight buffers
+            const int total = NHh * G * 2;                 // 1-KB pieces: [group][block][piece]
+            for (int n = wc; n < total; n += 4) {
+                const int gi = n / (2 * G), rem = n - gi * 2 * G, blk = rem >> 1;
+                ct_dma16(cp.wblk[2 * G + blk] + (size_t)(cp.kg0 + KGxe + gi) * cp.wstride[2 * G + blk] + (rem & 1) * 256 + lane_b * 4, wbuf + n * 1024);
+            }
+        }
+        CT_STAMP(3);
+        ct_sync();                                                                  // Sb
+        ct_sync();                                                                  // Sc
+        CT_STAMP(4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // W2[:, h] has landed
+        ct_sync();                                                                  // Sd
+        CT_STAMP(5);
+        ct_sync();                                                                  // Se: r (.) h is in the ring
+        CT_STAMP(6);
+        if (tile_on) {
+            for (int gi = 0; gi < NHh; ++gi) {
+                const char *slot = ring + ((KG - NHh + gi) % CT_D) * CT_SLOT;
+                unsigned ph[2][4], pl[2][4];
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const unsigned a = *reinterpret_cast<const unsigned *>(slot + boff_b + (4 * d) * 256 + pb * 128);
+                        const unsigned b = *reinterpret_cast<const unsigned *>(slot + boff_b + (4 * d + 2) * 256 + pb * 128);
+                        ph[pb][d] = __builtin_amdgcn_perm(b, a, 0x05040100u);      // {b.lo16, a.lo16}: the hi pieces
+                        pl[pb][d] = __builtin_amdgcn_perm(b, a, 0x07060302u);      // {b.hi16, a.hi16}: the lo pieces
+                    }
+#pragma unroll
+                for (int blk = 0; blk < G; ++blk) mfma_block(wbuf + gi * G * 2048, blk, ph, pl);
+            }
         }
         finish_and_stats(2, cp.partial2, G);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the statistics have left before the loads below join the queue
-    } else if (wr == 0 && tile_on) {
+        CT_STAMP(7);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            // the statistics have been acknowledged
+        ct_sync();                                                                  // Sf
+        if (threadIdx.x == 64 * 8) ct_barrier_lane(cp.bar, blockIdx.x, (unsigned)cp.nblocks, cp.status);     // grid barrier 2
+        ct_sync();                                                                  // Sg: z and the first half_b of h are in LDS
+        CT_STAMP(8);
+        if (wc < G) fold_group(cp.partial2, G, wc, cp.gn2_w, cp.gn2_b, (2 * G + wc) * 32, cp.ss2_out, cp.st2_out, URNN_STATUS_CAND, false);
+        ct_sync();                                                                  // Sh
+        CT_STAMP(9);
+        float *obase = cp.h_out + ((size_t)tb * F + 4 * half_b) * P + (size_t)tt * 64 + j_b;
 #pragma unroll
-        for (int blk = 0; blk < G; ++blk)
+        for (int pb = 0; pb < 2; ++pb) {
+            if (tile_on) {
 #pragma unroll
-            for (int pb = 0; pb < 2; ++pb)
+                for (int blk = 0; blk < G; ++blk) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const f32x2 st = *reinterpret_cast<const f32x2 *>(mytab + 2 * (blk * 32 + row_c(r) + 4 * half));
-                    acc[blk][pb][r] = gate_sigmoid(acc[blk][pb][r], st.x, st.y);
-                }
-    }
-    // the c-waves' first hidden-state values for the blend travel across the barrier
-    const float *hbase = cp.h + ((size_t)tb * F + 4 * half) * P + (size_t)tt * 64 + j;
-    float hn[16];
-    auto load_h = [&](int blk, int pb) __attribute__((always_inline)) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) hn[r] = okp[pb] ? hbase[(size_t)(blk * 32 + row_c(r)) * P + pb * 32] : 0.f;
-    };
-    if (wr == 2 && tile_on) load_h(0, 0);
-    CT_STAMP(7);
-
-    // ---- grid barrier 2; the z-waves hand z to the c-waves through LDS (over the ring, which is dead now) while lane 0 waits ------------------
-    // (the c-waves' h loads stay in flight: their statistics were drained before the loads were issued)
-    if (wr != 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    ct_sync();
-    float *zbuf = reinterpret_cast<float *>(ring) + (size_t)wc * (G * 2 * 1024);    // [slot][blk][pb][16][64]
-    if (wr == 0 && tile_on) {
-#pragma unroll
-        for (int blk = 0; blk < G; ++blk)
-#pragma unroll
-            for (int pb = 0; pb < 2; ++pb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) zbuf[((blk * 2 + pb) * 16 + r) * 64 + lane] = acc[blk][pb][r];
-    }
-    if (threadIdx.x == 64 * 4) ct_barrier_lane(cp.bar, blockIdx.x, (unsigned)cp.nblocks, cp.status);     // (an r-wave's lane: it has nothing else to do)
-    ct_sync();
-    CT_STAMP(8);
-
-    // ---- phase C: GroupNorm of the candidate (c-waves wc < G fold group wc), blend ------------------------------------------------------------------
-    if (wr == 2 && wc < G) fold_group(cp.partial2, G, wc, cp.gn2_w, cp.gn2_b, (2 * G + wc) * 32, cp.ss2_out, cp.st2_out, URNN_STATUS_CAND);
-    ct_sync();
-    CT_STAMP(9);
-    if (wr == 2 && tile_on) {
-        float *obase = cp.h_out + ((size_t)tb * F + 4 * half) * P + (size_t)tt * 64 + j;
-#pragma unroll
-        for (int blk = 0; blk < G; ++blk)
-#pragma unroll
-            for (int pb = 0; pb < 2; ++pb) {
-                float hc[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) hc[r] = hn[r];
-                if (pb == 0) load_h(blk, 1);                        // the next unit's rows travel while this one is blended
-                else if (blk + 1 < G) load_h(blk + 1, 0);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const f32x2 st = *reinterpret_cast<const f32x2 *>(mytab + 2 * ((2 * G + blk) * 32 + row_c(r) + 4 * half));
-                    const float z = zbuf[((blk * 2 + pb) * 16 + r) * 64 + lane];
-                    const float n = tanhf_fast(fmaf(acc[blk][pb][r], st.x, st.y));
-                    if (okp[pb]) obase[(size_t)(blk * 32 + row_c(r)) * P + pb * 32] = gru_blend(z, n, hc[r]);
+                    for (int r = 0; r < 16; ++r) {
+                        const f32x2 st = *reinterpret_cast<const f32x2 *>(mytab + 2 * ((2 * G + blk) * 32 + row_c(r) + 4 * half_b));
+                        const float z = zbuf[((blk * 2 + pb) * 16 + r) * 64 + lane_b];
+                        const float hp = hbuf[(blk * 16 + r) * 64 + lane_b];
+                        const float n = tanhf_fast(fmaf(acc[blk][pb][r], st.x, st.y));
+                        if (okp[pb]) obase[(size_t)(blk * 32 + row_c(r)) * P + pb * 32] = gru_blend(z, n, hp);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            ct_sync();                                                              // Si, Sj
+        }
     }
 #ifdef URNN_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     CT_STAMP(10);
 #endif
+}
+
+template <int G>
+__global__ __launch_bounds__(768) void coop_tiles_kernel(const CoopTilesParams cp)
+{
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int role = wave >> 2;
+    if (role == 0) ct_role<G, 0>(cp, lane, wave);
+    else if (role == 1) ct_role<G, 1>(cp, lane, wave);
+    else ct_role<G, 2>(cp, lane, wave);
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------------------------------

@@ -68,10 +68,11 @@ class OverlappedGradientMean:
     ``ReduceOp.AVG`` (no scaling pass); gloo (CPU dry runs, several ranks on one GPU) stages through the host and is
     synchronous -- same call order, same result."""
 
-    def __init__(self, flat, split, group=None, bucket_floats=1 << 24):
+    def __init__(self, flat, split, group=None, bucket_floats=1 << 24, force=False):
         import torch.distributed as dist
         self.flat, self.split, self.group, self.bucket = flat, int(split), group, int(bucket_floats)
-        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        # force: run the collectives even in a world of one (tests drive the RCCL call path and its stream ordering on a 1-GPU box)
+        self.active = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or bool(force))
         self.world = dist.get_world_size(group) if self.active else 1
         self.nccl = self.active and dist.get_backend(group) == "nccl"
         self._pending = []

@@ -3,6 +3,8 @@
 Every function takes contiguous float32 CUDA(=HIP) tensors, passes ``data_ptr()`` + dims + the current
 stream across the ABI and returns torch tensors.  No op has a PyTorch fallback.
 """
+import os
+
 import torch
 
 from ._lib import check, lib
@@ -82,6 +84,14 @@ def _dev_check(*tensors):
 
 def _ptr(t):
     return 0 if t is None else t.data_ptr()
+
+
+def tuning_env(name, default):
+    """Development knobs (URNN_TUNE_*: A/B switches of the schedules) are read ONLY when URNN_TUNING=1 is set -- the product path
+    takes every default whatever else the environment holds (the library's own knobs exist in -DURNN_TUNING builds only)."""
+    if os.environ.get("URNN_TUNING") != "1":
+        return default
+    return os.environ.get(name, default)
 
 
 def workspace(nbytes, device):

@@ -7,6 +7,7 @@ import os
 import torch
 
 from . import ops
+from .ops import tuning_env as _tuning_env
 from ._lib import lib
 from .dataset import event_to_device
 from .general import initialize_states
@@ -15,7 +16,7 @@ from .general import initialize_states
 class RolloutEngine:
     def __init__(self, net, input_height, input_width, historical_nums, rain_max, cumsum_rain_max, batch=1,
                  max_frames=360, spatial_rain=False, net_cfg=None, use_graph=True, keep_raw=False,
-                 device=None, overlap=False, fused_reset_gate=True, coop_cells=True, fused_tails=False):
+                 device=None, overlap=False, fused_reset_gate=True, coop_cells=True, fused_tails=False, coop_mutex=False):
         self.net = net
         # cells whose shape has the form recompute the reset gate inside the candidate kernel instead of round-tripping its raw
         # planes through HBM (include/urnn_hip.h URNN_PHASE_FUSED_R); the engine never reads a cell's workspace
@@ -106,16 +107,34 @@ class RolloutEngine:
         resident = {}                                                # blocks of the cooperative launches in use, by layer
         cus = int(torch.cuda.get_device_properties(self.device).multi_processor_count)   # 256 on an MI355X (the library bounds its plans by the same count)
 
+        # Round 6, measured and left OFF (coop_mutex=True / URNN_TUNING=1 URNN_TUNE_COOP_MUTEX=1 turns it on): a cooperative launch of MORE
+        # than half the chip's CUs (the quarter-resolution cells' 245 blocks, the half-resolution cells' 245 persistent blocks of four
+        # tiles, urnn_coop_tiles.hip) can run next to other chains as long as no two of them are in flight at once -- the engine orders
+        # them with one event edge per iteration (``_big_next``; kernels without a grid barrier always finish and free their CUs, so a
+        # lone cooperative launch only ever waits).  Correct (the full-size rollout tests pass on it), and 8.5 % SLOWER than the three
+        # kernels per cell: 1 354 against 1 480 frames/s on one box (profiles/r06_ab_coop_mutex.txt).  A launch that needs every CU
+        # drains the other two chains before it can start and idles the chip while its blocks trickle in -- the overlapped schedule
+        # lives on kernels that share CUs.  The cooperative half-resolution cells therefore serve the ONE-chain schedule
+        # (overlap=False, urnn_step_f32: +6 %), the three-chain schedule keeps the three kernels.
+        self._coop_mutex = self.overlap and bool(coop_cells) and (coop_mutex or _tuning_env("URNN_TUNE_COOP_MUTEX", "0") != "0")
+        self._big_coop = {}
+        self._big_next = {}
+        names = iter(("enc1", "enc2", "enc3", "dec3", "dec2", "dec1"))
+
         def coop_flag(cell, has_x, skip):
             n = L.urnn_gru_cell_coop_blocks(B, cell.input_channels, cell.num_features, cell.shape[0], cell.shape[1], int(skip), int(has_x))
             # (URNN_TUNE_COOP_BIG=0: a one-chain engine keeps the two-chain policy -- the counter passes of tools/collect_profiles.sh run
             # eager on one chain and must execute the kernels of the benchmarked schedule)
-            big_ok = not self.overlap and os.environ.get("URNN_TUNE_COOP_BIG", "1") != "0"
-            use = coop_cells and n > 0 and (n <= cus // 2 or big_ok)
-            resident[len(resident)] = n if use else 0
+            big_ok = (not self.overlap and _tuning_env("URNN_TUNE_COOP_BIG", "1") != "0") or self._coop_mutex
+            # more 64-pixel tiles than CUs: the launch is the four-tiles-per-block one (urnn_coop_tiles.hip), whose blocks take a whole CU each
+            # (159 KB of LDS, every register): next to other chains it waits for CUs to drain whatever its block count -- one chain only
+            whole_cu = B * ((cell.shape[0] * cell.shape[1] + 63) // 64) > cus
+            use = coop_cells and n > 0 and (n <= cus // 2 or big_ok) and (not whole_cu or not self.overlap or self._coop_mutex)
+            self._big_coop[next(names)] = bool(use and self.overlap and (n > cus // 2 or whole_cu))
+            resident[len(resident)] = n if (use and n <= cus // 2) else 0          # (the large ones are serialised: they never add up)
             return ops.PHASE_COOP if use else 0
         nhead = L.urnn_head_coop_blocks_f32(B, H, W)                 # ... and the head likewise (urnn_head_coop_f32)
-        self._head_coop = bool(coop_cells) and nhead > 0 and (nhead <= cus // 2 or (not self.overlap and nhead <= cus and os.environ.get("URNN_TUNE_COOP_BIG", "1") != "0"))
+        self._head_coop = bool(coop_cells) and nhead > 0 and (nhead <= cus // 2 or (not self.overlap and nhead <= cus and _tuning_env("URNN_TUNE_COOP_BIG", "1") != "0"))
         self._coop = {"enc1": coop_flag(enc.rnn1, 1, 0), "enc2": coop_flag(enc.rnn2, 1, 0), "enc3": coop_flag(enc.rnn3, 1, 0),
                       "dec3": coop_flag(dec.rnn3, 0, 1), "dec2": coop_flag(dec.rnn2, 1, 1), "dec1": coop_flag(dec.rnn1, 1, 1)}
         # The head as a THIRD chain (own stream and scratch): head(t-1) || encoder(t+1) || decoder(t) -- +2 % at 500x500, +4 % at 400x560
@@ -123,7 +142,7 @@ class RolloutEngine:
         # such launch of each chain, together, must fit the chip's 256 CUs (a block each) -- else the head stays in front of the encoder.
         blocks = list(resident.values())                             # enc1..3, dec3..1 in the order of the dict above
         together = max(blocks[:3]) + max(blocks[3:]) + (nhead if self._head_coop else 0)
-        self._head_own_chain = self.overlap and os.environ.get("URNN_TUNE_HEAD_CHAIN", "1") != "0" and together <= cus
+        self._head_own_chain = self.overlap and _tuning_env("URNN_TUNE_HEAD_CHAIN", "1") != "0" and together <= cus
         self._dem_stamp = None
 
     # -- one timestep, all launches on the current stream ----------------------------------------------
@@ -197,6 +216,8 @@ class RolloutEngine:
         stage = self._tail_of(name) if conv_out is not None else None
         head_w = self.net.head.flat_params()["conv_w"][0] if (stage is not None and k1part is not None) else None
         flags = self._cell_flags | self._coop[name]
+        # a cooperative launch of more than half the chip inside an overlapped iteration: the NEXT such launch, if another chain's, waits for it
+        notify = self._big_next.get(name) if self._probe is None else None
 
         def run(mask):
             if stage is not None and (mask & ops.PHASE_BLEND):
@@ -213,6 +234,12 @@ class RolloutEngine:
                 self._probe[name][kind].append((a, b))
         else:
             run(ops.PHASE_ALL)
+        if notify is not None:
+            # The other chain's stream waits IMMEDIATELY (its later launches queue behind the wait; what it holds already is unaffected): a
+            # wait captured after the recording stream had moved on, and a record nobody waits for, both crashed hipStreamEndCapture (ROCm 7.0).
+            evt = torch.cuda.Event()
+            evt.record(torch.cuda.current_stream(self.device))
+            notify.wait_event(evt)
         return stage is not None          # True: conv_out has been written
 
     PROBED_CELLS = ("enc1", "dec1", "enc2", "dec2")
@@ -313,6 +340,18 @@ class RolloutEngine:
         segment in the order ENQUEUE_ORDER (H head, E encoder segment, D decoder segment)."""
         cur = torch.cuda.current_stream(self.device)
         s1, s2 = self._side[:2]
+        # mutual exclusion of the large cooperative launches (``_big_coop``): in enqueue order, each one followed by one of ANOTHER chain
+        # makes that chain's stream wait for it (same chain: stream order does it)
+        seq, ie_, id_ = [], 0, 0
+        for ch in _tuning_env("URNN_TUNE_CHAIN_ORDER", self.ENQUEUE_ORDER):
+            if ch == "E":
+                seq.append((("enc1", "enc2", "enc3")[ie_], s1))
+                ie_ += 1
+            elif ch == "D":
+                seq.append((("dec3", "dec2", "dec1")[id_], s2))
+                id_ += 1
+        bigs = [(n, st) for n, st in seq if self._big_coop.get(n)]
+        self._big_next = {n: (bigs[i + 1][1] if i + 1 < len(bigs) and bigs[i + 1][1] is not st else None) for i, (n, st) in enumerate(bigs)}
         s1.wait_stream(cur)
         s2.wait_stream(cur)
         s3 = self._side[2] if self._head_own_chain else s1
@@ -320,7 +359,7 @@ class RolloutEngine:
             s3.wait_stream(cur)
         enc = self._enc_segments(1 - parity)
         dec = self._dec_segments(parity)
-        order = os.environ.get("URNN_TUNE_CHAIN_ORDER", self.ENQUEUE_ORDER)
+        order = _tuning_env("URNN_TUNE_CHAIN_ORDER", self.ENQUEUE_ORDER)
         if sorted(order) != sorted("HEEEDDD"):
             raise RuntimeError("enqueue order must hold one H, three E and three D")
         ie = idd = 0
@@ -343,6 +382,7 @@ class RolloutEngine:
         cur.wait_stream(s2)
         if with_head and s3 is not s1:
             cur.wait_stream(s3)
+        self._big_next = {}
 
     # The decoder chain is the longest: its first segment goes first, then the chains alternate (profiles/r04_enqueue_order.txt:
     # against head-then-encoder-then-decoder +2.5 % at 64x64, +4.5 % at 128x128, +1 % at 52x120, +0.5..1 % at 500x500 / 400x560)
@@ -356,7 +396,7 @@ class RolloutEngine:
         # Warm-up and first replays run a few frames for real.  They start at an EVEN frame b (the graphs are per frame parity and
         # "prologue" / "first 0" are an even frame's), as close behind the frames done as the buffers allow; the output rows they
         # write are saved and restored (after a mid-event re-capture near the end of an event they may be finished frames).
-        self._group = max(0, int(os.environ.get("URNN_TUNE_GROUP", self.GROUP))) & ~1
+        self._group = max(0, int(_tuning_env("URNN_TUNE_GROUP", self.GROUP))) & ~1
         rows = self.out_masked.shape[0]
         b = max(0, min(self._frames_done + (self._frames_done & 1), (rows - self._group - 2) & ~1, (rows - 2) & ~1))
         outs = [o for o in (self.out_masked, self.out_cls, self.out_raw) if o is not None]

@@ -9,6 +9,7 @@ import os
 import torch
 
 from . import ops, train_ops
+from .ops import tuning_env as _tuning_env
 from .dataset import event_to_device
 
 
@@ -31,8 +32,8 @@ class WindowGradients:
         # until its backward ran, "bwd" is the backward kernels' scratch
         self.arena = ops.Arena(self.device)
         self._fwd_streams = None
-        self.forward_chains = os.environ.get("URNN_TUNE_TRAIN_CHAINS", "1") != "0"      # _forward_window instead of step by step
-        self.backward_chains = os.environ.get("URNN_TUNE_TRAIN_BWD_CHAINS", "1") != "0"  # _backward_window likewise
+        self.forward_chains = _tuning_env("URNN_TUNE_TRAIN_CHAINS", "1") != "0"      # _forward_window instead of step by step
+        self.backward_chains = _tuning_env("URNN_TUNE_TRAIN_BWD_CHAINS", "1") != "0"  # _backward_window likewise
         self._arena_d, self._arena_e = ops.Arena(self.device), ops.Arena(self.device)    # scratch of the decoder / encoder backward chains
 
     # -- forward of one timestep, keeping what the backward reads ---------------------------------------------------
@@ -428,6 +429,15 @@ class Trainer:
         if flipped:
             self._graphs.clear()
 
+    def release_weight_ranges(self):
+        """Hand the weight-range check back to the layers (``PackedCache.get`` re-reads max |w| when a layer is repacked): the flags
+        ``refresh_weight_ranges`` set are this trainer's promise for ONE event; anything else that runs this network afterwards --
+        ``Inference`` / ``RolloutEngine``, an eager window, another ``load_state_dict`` -- must not inherit it."""
+        for mod in self.net.modules():
+            cache = getattr(mod, "_cache", None)
+            if hasattr(cache, "owner_checks"):
+                cache.owner_checks = False
+
     def set_lr(self, lr):
         """Learning rate of the following windows (the epoch loop calls this once per epoch; the captured window is re-captured)."""
         lr = float(lr)
@@ -453,6 +463,8 @@ class Trainer:
             for k, v in own.items():
                 v.copy_(torch.as_tensor(sd[k]).to(device=v.device, dtype=v.dtype).reshape(v.shape))
         self._invalidate_packed()
+        self.refresh_weight_ranges()
+        self.release_weight_ranges()
 
     def optimizer_state_dict(self):
         """torch.optim.Adam.state_dict() of the equivalent optimizer: parameters numbered in ``net.parameters()`` order."""
@@ -665,9 +677,14 @@ class Trainer:
         window_size = T - loc if window_size is None else window_size
         states, losses = None, []
         self.refresh_weight_ranges()
-        for ind in (window_starts(loc, seq_num, window_size) if starts is None else starts):
-            if prewarming:
-                states = self.prewarm(ev, ind) if ind > 0 else None
-            loss, states = self.train_window(ev, label[:, ind:ind + seq_num], ind, seq_num, states)
-            losses.append(loss)
+        try:
+            for ind in (window_starts(loc, seq_num, window_size) if starts is None else starts):
+                if prewarming:
+                    states = self.prewarm(ev, ind) if ind > 0 else None
+                loss, states = self.train_window(ev, label[:, ind:ind + seq_num], ind, seq_num, states)
+                losses.append(loss)
+        finally:
+            # after the event's last optimizer step: flags for the weights as they are NOW, then the layers check for themselves again
+            self.refresh_weight_ranges()
+            self.release_weight_ranges()
         return losses, states
