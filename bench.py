@@ -202,11 +202,11 @@ def cpu_baseline(sd, cfgname):
     EPYC runs this memory-bound step fastest well below its thread count: VERDICT r5 weak item 10); the C oracle's figure is nested
     under it.  About 25 s of CPU work in total."""
     ncpu = os.cpu_count() or 1
-    counts = [t for t in (8, 16, 32, 64, 128) if t <= ncpu] or [ncpu]
+    counts = [t for t in (16, 32, 64, 128) if t <= ncpu] or [ncpu]
     runs = []
     for t in counts:
         try:
-            runs.append(torch_cpu_baseline(sd, cfgname, t, budget_s=3.5, max_frames=2))
+            runs.append(torch_cpu_baseline(sd, cfgname, t, budget_s=2.5, max_frames=2))
         except Exception as exc:
             runs.append({"value": 0.0, "cores": t, "error": repr(exc)})
     best = max(runs, key=lambda r: r["value"])

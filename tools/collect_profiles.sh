@@ -1,9 +1,9 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence on the GPU box: raw databases stay in /tmp, text summaries go to gpurun_out/$1.
-# usage (through gpurun): bash tools/collect_profiles.sh r05   (then copy gpurun_out/r05/* to profiles/r05_*, pmc_kernels.json + pmc_train.json to profiles/)
+# usage (through gpurun): bash tools/collect_profiles.sh r06   (then copy gpurun_out/r06/* to profiles/r06_*, pmc_kernels.json + pmc_train.json to profiles/)
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=${1:-r05}
+TAG=${1:-r06}
 O=$R/gpurun_out/$TAG; P=/tmp/prof_$TAG
 mkdir -p $O $P; cd /tmp; export TMPDIR=/tmp
 # one chain, eager (every dispatch attributed) -- with the kernel selection of the benchmarked overlapped schedule (URNN_TUNE_COOP_BIG=0)
@@ -51,5 +51,8 @@ URNN_TUNING=1 URNN_TUNE_TRAIN_CHAINS=0 URNN_TUNE_TRAIN_BWD_CHAINS=0 timeout 300 
 timeout 420 rocprofv3 --kernel-trace --stats -d $P/stats_train -o t -- python $R/bench.py --mode train > /dev/null 2>&1
 python $R/tools/prof_summary.py $P/stats_train/t_results.db > $O/train_kernel_stats.txt 2>&1
 python $R/tools/wgrad_trace.py $P/stats_train/t_results.db > $O/train_wgrad_launches.txt 2>&1
+# the bf16 arm's kernels beside the fp32 arm's (why bf16 mode is only ~7 % faster)
+timeout 420 rocprofv3 --kernel-trace --stats -d $P/stats_train_bf16 -o t -- python $R/bench.py --mode train --dtype bf16 > /dev/null 2>&1
+python $R/tools/prof_summary.py $P/stats_train_bf16/t_results.db > $O/train_kernel_stats_bf16.txt 2>&1
 for f in $O/*.log; do grep -v "amdgpu.ids\|^W2026\|^E2026\|simple_timer" $f > $f.tmp; mv $f.tmp $f; done
 ls -la $O

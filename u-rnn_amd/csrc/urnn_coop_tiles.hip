@@ -242,10 +242,67 @@ __device__ __forceinline__ void ct_role(const CoopTilesParams &cp, const int lan
         }
     };
 
-    // ---- phase A: the k-loop ---------------------------------------------------------------------------------------------------------------
+    // ---- phase A: the k-loop.  CT_PIPELINE = 1 (built, measured, off): group g + 1's fragments read and split under group g's MFMAs.  It fits
+    // the registers since the roles are separate instantiations (166, no spill) and is SLOWER: 30.2 / 31.8 instead of 28.0 / 28.5 hundred
+    // cycles per group at K = 160 / 288 (profiles/r06_trace_coop_tiles.txt).  The loop takes the same ~2 800 cycles per 16-row group whether
+    // the c-waves multiply (4 of 10 groups at K = 160, 12 of 18 at K = 288) or not: it is bound by the arrival of the group's 16 KB of rows
+    // (5.9 B per clock and CU = 3.4 TB/s chip-wide, the rate every row-streaming GEMM of this library reaches), not by the matrix pipe.
+    CT_STAMP(1);
+#ifndef CT_PIPELINE
+#define CT_PIPELINE 0
+#endif
+#if CT_PIPELINE
+    unsigned curh[2][4], curl[2][4], nxth[2][4], nxtl[2][4];
+    {   // group 0's fragments
+        if (wr < 2) ct_wait_vm_groups((KG < CT_D ? KG : CT_D) - 1, 2);
+        else ct_wait_vm_groups(KG > 1 ? 1 : 0, NQ);
+        ct_sync();
+        if (tile_on) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) prep_item(ring, i, curh, curl);
+        }
+    }
+    for (int g = 0; g < KG; ++g) {
+        const bool more = g + 1 < KG;
+        if (wr < 2) {                                   // group g + 1's rows have landed; the groups requested after it may still travel
+            const int issued = g == 0 ? (KG < CT_D ? KG : CT_D) - 1 : (g - 1 + CT_D < KG - 1 ? g - 1 + CT_D : KG - 1);   // last group requested so far
+            ct_wait_vm_groups(more ? issued - (g + 1) : 0, 2);
+        } else {                                        // group g's weights: at most group g + 1's in flight
+            ct_wait_vm_groups(more ? 1 : 0, NQ);
+        }
+        ct_sync();                                      // ... for every wave's share; everybody has taken group g's fragments and is done with group g - 1's weights
+        if (wr < 2) {
+            if (g + CT_D < KG) issue_acts(g + CT_D);                    // -> the slot of group g
+        } else {
+            if (g + 2 < KG) issue_weights(g + 2);                       // -> the buffer of group g - 1
+        }
+        const bool mul = tile_on && (wr < 2 || g < KGxe);
+        const bool prep = tile_on && more && (wr < 2 || g + 1 < KGxe);
+        const char *wsrc = wbuf + (g % CT_NW) * CT_WBUF + wr * G * 2048;
+        const char *nslot = ring + ((g + 1) % CT_D) * CT_SLOT;
+        constexpr int PER = (8 + G - 1) / G;            // fragment items per block step: 3, 3, 2 at G = 3
+#pragma unroll
+        for (int blk = 0; blk < G; ++blk) {
+            if (mul) mfma_block(wsrc, blk, curh, curl);
+            if (prep) {
+#pragma unroll
+                for (int i = blk * PER; i < (blk + 1) * PER && i < 8; ++i) prep_item(nslot, i, nxth, nxtl);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (prep) {
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    curh[pb][d] = nxth[pb][d];
+                    curl[pb][d] = nxtl[pb][d];
+                }
+        }
+    }
+#else
     // (Software-pipelining the split of group g + 1 under group g's MFMAs needs a second set of fragment registers: 96 accumulators + 2 x 16
     // pieces + A fragments + addressing exceed the 168 registers of three waves per SIMD and the accumulators spill inside the loop.)
-    CT_STAMP(1);
     for (int g = 0; g < KG; ++g) {
         if (wr < 2) {                                   // group g's rows have landed; the groups requested after it may still travel
             const int issued = g == 0 ? (KG < CT_D ? KG : CT_D) - 1 : (g - 2 + CT_D < KG - 1 ? g - 2 + CT_D : KG - 1);   // last group requested so far
@@ -276,6 +333,7 @@ __device__ __forceinline__ void ct_role(const CoopTilesParams &cp, const int lan
             }
         }
     }
+#endif
     CT_STAMP(2);
 
     // Everything below addresses memory through these copies: laundered so that the compiler cannot form the phases' per-lane addresses
