@@ -210,3 +210,44 @@ def test_bench_cell_kernel_work_matches_the_stage_accounting():
     assert w["candidate"]["dec2"][0] == 4.0 * 62500 * (288 + 192)
     assert w["blend"]["dec1"][0] == 256 * MB and w["blend"]["enc2"][0] == 4.0 * 62500 * 384
     assert w["gates"]["dec1"][1] == 2.0 * 250000 * 128 * 224
+
+
+def test_python_host_reads_tuning_knobs_only_under_the_switch(monkeypatch):
+    """The product path takes every default whatever URNN_TUNE_* the environment holds; URNN_TUNING=1 turns the development knobs on
+    (rollout.py / training.py used to read them unconditionally)."""
+    from urnn_amd.ops import tuning_env
+    monkeypatch.delenv("URNN_TUNING", raising=False)
+    monkeypatch.setenv("URNN_TUNE_GROUP", "2")
+    assert tuning_env("URNN_TUNE_GROUP", 4) == 4
+    monkeypatch.setenv("URNN_TUNING", "1")
+    assert tuning_env("URNN_TUNE_GROUP", 4) == "2"
+    assert tuning_env("URNN_TUNE_NOT_SET", "x") == "x"
+    import re
+    for mod in ("rollout.py", "training.py"):
+        src = open(os.path.join(REPO, "u-rnn_amd", mod)).read()
+        assert not re.search(r'os\.environ\.get\("URNN_TUNE_', src), f"{mod} reads a tuning knob without the switch"
+
+
+def test_bench_binds_ranks_to_disjoint_cpu_slices():
+    """bench.py --bind: N ranks get N disjoint contiguous slices of the CPUs the process may use; auto = from four ranks."""
+    import importlib.util
+    if not hasattr(os, "sched_setaffinity"):
+        pytest.skip("no sched_setaffinity on this platform")
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    before = os.sched_getaffinity(0)
+    try:
+        assert bench.bind_rank_to_cores(0, 2, "auto") is None and bench.bind_rank_to_cores(0, 8, "off") is None
+        if len(before) >= 4:
+            world = 4
+            slices = []
+            for r in range(world):
+                os.sched_setaffinity(0, before)
+                lo_hi = bench.bind_rank_to_cores(r, world, "auto")
+                assert lo_hi is not None
+                slices.append(os.sched_getaffinity(0))
+            assert all(len(s) == len(before) // world for s in slices)
+            assert all(slices[a].isdisjoint(slices[b]) for a in range(world) for b in range(a + 1, world))
+    finally:
+        os.sched_setaffinity(0, before)

@@ -18,8 +18,8 @@ python $R/tools/make_pmc_json.py $O/pmc_FETCH_SIZE.txt $O/pmc_WRITE_SIZE.txt $O/
 unset URNN_TUNE_COOP_BIG
 # the ONE-chain schedule as it runs by default (cooperative cells wherever planned: urnn_coop_tiles.hip at half resolution): its byte counters
 for name in FETCH_SIZE WRITE_SIZE; do
-  timeout 420 rocprofv3 --kernel-trace --pmc $name -d $P/pmc1_$name -o p -- $CMD > $P/pmc1_$name.log 2>&1
-  { echo "# rocprofv3 --kernel-trace --pmc $name -- $CMD   (one chain, default kernel selection: cooperative cells)"; python $R/tools/pmc_summary.py $P/pmc1_$name/p_results.db "" --frames=-1; } > $O/pmc_one_chain_$name.txt 2>&1
+  timeout 420 rocprofv3 --kernel-trace --pmc $name -d $P/pmc1_$name -o p -- python $R/tools/one_chain_frames.py 12 > $P/pmc1_$name.log 2>&1
+  { echo "# rocprofv3 --kernel-trace --pmc $name -- python tools/one_chain_frames.py 12   (one chain, eager, default kernel selection: cooperative cells; 12 frames)"; python $R/tools/pmc_summary.py $P/pmc1_$name/p_results.db "" --frames=12; } > $O/pmc_one_chain_$name.txt 2>&1
 done
 # the training step's byte counters (two windows of 4 timesteps, eager so that every dispatch is attributed)
 TCMD="python $R/bench.py --mode train --steps 4 --warmup 4 --no-graph"
