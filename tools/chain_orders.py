@@ -12,7 +12,7 @@ for pos in itertools.combinations(range(6),3):
 res=[]
 for o in sorted(orders):
     env=dict(os.environ, URNN_TUNING="1", URNN_TUNE_CHAIN_ORDER=o)
-    out=subprocess.run([sys.executable,'bench.py','--no-cpu-baseline','--steps','360','--warmup','36'],env=env,capture_output=True,text=True).stdout
+    out=subprocess.run([sys.executable,'bench.py','--no-cpu-baseline','--no-long-run','--steps','360','--warmup','36'],env=env,capture_output=True,text=True).stdout
     m=re.search(r'"value": ([0-9.]+)',out)
     v=float(m.group(1)) if m else 0
     res.append((v,o)); print(o,v,flush=True)

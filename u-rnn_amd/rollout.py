@@ -344,7 +344,7 @@ class RolloutEngine:
         # mutual exclusion of the large cooperative launches (``_big_coop``): in enqueue order, each one followed by one of ANOTHER chain
         # makes that chain's stream wait for it (same chain: stream order does it)
         seq, ie_, id_ = [], 0, 0
-        for ch in _tuning_env("URNN_TUNE_CHAIN_ORDER", self.ENQUEUE_ORDER):
+        for ch in _tuning_env("URNN_TUNE_CHAIN_ORDER", self._enqueue_order()):
             if ch == "E":
                 seq.append((("enc1", "enc2", "enc3")[ie_], s1))
                 ie_ += 1
@@ -360,7 +360,7 @@ class RolloutEngine:
             s3.wait_stream(cur)
         enc = self._enc_segments(1 - parity)
         dec = self._dec_segments(parity)
-        order = _tuning_env("URNN_TUNE_CHAIN_ORDER", self.ENQUEUE_ORDER)
+        order = _tuning_env("URNN_TUNE_CHAIN_ORDER", self._enqueue_order())
         if sorted(order) != sorted("HEEEDDD"):
             raise RuntimeError("enqueue order must hold one H, three E and three D")
         ie = idd = 0
@@ -387,7 +387,14 @@ class RolloutEngine:
 
     # The decoder chain is the longest: its first segment goes first, then the chains alternate (profiles/r04_enqueue_order.txt:
     # against head-then-encoder-then-decoder +2.5 % at 64x64, +4.5 % at 128x128, +1 % at 52x120, +0.5..1 % at 500x500 / 400x560)
+    # Round 6 (profiles/r06_ab_enqueue_order.txt, same-box alternations): on the big planes the head first and the decoder's two deep segments
+    # before the encoder's first -- "HDDEDEE" -- is +0.9 % at 500x500 (1 490 -> 1 504, 1 477 -> 1 490 on two boxes) and +0.3 % at 400x560; on the
+    # small grids it loses 2-3.5 % (64x64 6 741 -> 6 536, 128x128 5 753 -> 5 631): the order follows the plane size.
     ENQUEUE_ORDER = "DEHDEDE"
+    ENQUEUE_ORDER_LARGE = "HDDEDEE"
+
+    def _enqueue_order(self):
+        return self.ENQUEUE_ORDER_LARGE if self.H * self.W >= 100000 else self.ENQUEUE_ORDER
     GROUP = 4
 
     def _capture_overlap(self):
