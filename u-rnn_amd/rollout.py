@@ -118,6 +118,7 @@ class RolloutEngine:
         # (overlap=False, urnn_step_f32: +6 %), the three-chain schedule keeps the three kernels.
         self._coop_mutex = self.overlap and bool(coop_cells) and (coop_mutex or _tuning_env("URNN_TUNE_COOP_MUTEX", "0") != "0")
         self._mutex_small_only = _tuning_env("URNN_TUNE_COOP_MUTEX", "0") == "2"      # (A/B: only the one-tile-per-block cells join the order)
+        self._mutex_tiles_only = _tuning_env("URNN_TUNE_COOP_MUTEX", "0") == "3"      # (A/B: only the four-tiles-per-block cells)
         self._big_coop = {}
         self._big_next = {}
         names = iter(("enc1", "enc2", "enc3", "dec3", "dec2", "dec1"))
@@ -131,6 +132,8 @@ class RolloutEngine:
             # (159 KB of LDS, every register): next to other chains it waits for CUs to drain whatever its block count -- one chain only
             whole_cu = B * ((cell.shape[0] * cell.shape[1] + 63) // 64) > cus
             use = coop_cells and n > 0 and (n <= cus // 2 or big_ok) and (not whole_cu or not self.overlap or (self._coop_mutex and not self._mutex_small_only))
+            if self.overlap and self._mutex_tiles_only and not whole_cu and n > cus // 2:
+                use = False
             self._big_coop[next(names)] = bool(use and self.overlap and (n > cus // 2 or whole_cu))
             resident[len(resident)] = n if (use and n <= cus // 2) else 0          # (the large ones are serialised: they never add up)
             return ops.PHASE_COOP if use else 0
