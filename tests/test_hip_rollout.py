@@ -106,8 +106,9 @@ def test_overlapped_chains_match_sequential(dev):
     ev = uw.make_event(T, H, W, 60.0, seed=1)
     seq = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T)
     a = seq.rollout(ev).clone()
-    for use_graph in (False, True):
-        ovl = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T, overlap=True, use_graph=use_graph)
+    for use_graph, levels in ((False, False), (True, False), (False, True), (True, True)):      # three chains | the level pipeline (four, a frame apart)
+        ovl = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T, overlap=True, use_graph=use_graph, levels=levels)
+        assert ovl.levels == levels
         b = ovl.rollout(ev)
         torch.cuda.synchronize()
         assert torch.equal(a, b)
@@ -133,7 +134,7 @@ def test_grouped_iterations_and_piecewise_runs_match_sequential(dev, monkeypatch
     ev = uw.make_event(T, H, W, 60.0, seed=2)
     seq = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T)
     a = seq.rollout(ev).clone()
-    ovl = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T, overlap=True)
+    ovl = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T, overlap=True, levels=False)      # (the three-chain schedule on a small plane)
     for pieces in ((23,), (3, 7, 1, 12), (1, 1, 2, 5, 6, 8), (10, 13)):
         ovl.load_event(ev)
         ovl.reset()
@@ -158,8 +159,50 @@ def test_grouped_iterations_and_piecewise_runs_match_sequential(dev, monkeypatch
         assert torch.equal(a, ovl.out_masked[:T]), f"re-capture after {cut} frames"
 
 
+@pytest.mark.parametrize("shape", [(32, 48, 1), (64, 64, 1), (24, 40, 2)])
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_level_pipeline_and_piecewise_runs_match_sequential(dev, shape, use_graph):
+    """The level pipeline (RolloutEngine(levels=True), the default on small planes with overlap=True): five units on four streams, cut by level of the
+    network, each a frame behind the one that feeds it, the encoder states in rings of six buffers.  A re-scheduling only -- frames and
+    final states equal the one-chain engine's bit for bit however an event is cut into run() calls (each call fills and drains the pipeline;
+    calls shorter than four frames run eagerly), through the captured graphs of every frame % 6, and across a re-capture in mid-event."""
+    import urnn_amd.weights as uw
+    from urnn_amd.rollout import RolloutEngine
+    H, W, B = shape
+    nums, T = 3, 23
+    net, _ = make_net(H, W, 9, 3, dev)
+    ev = uw.make_event(T, H, W, 60.0, seed=2, batch=B)
+    seq = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T, batch=B)
+    a = seq.rollout(ev).clone()
+    ovl = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T, batch=B, overlap=True, use_graph=use_graph)
+    assert ovl.levels and len(ovl._ws) == 5 and len(ovl._side) == 4
+    for pieces in ((23,), (3, 7, 1, 12), (6, 6, 11), (1, 1, 2, 5, 6, 8), (10, 13), (7, 8, 8)):
+        ovl.load_event(ev)
+        ovl.reset()
+        ovl.out_masked.zero_()
+        for n in pieces:
+            ovl.run(n)
+        ovl.check_status()
+        assert int(ovl.t2[T % 2]) == T and int(ovl.te2[T % 2]) == T                 # the words the next head / input assembly would read
+        assert torch.equal(a, ovl.out_masked[:T]), f"run() calls of {pieces} frames"
+        for x, y in zip(seq.final_states(), ovl.final_states()):
+            assert torch.equal(x, y)
+    if use_graph:
+        assert sorted({k[0] for k in ovl._graphs2}) == ["drain", "fill", "group", "steady"] and len(ovl._graphs2) == 24
+        for cut in (6, 9, 16):
+            ovl.load_event(ev)
+            ovl.reset()
+            ovl.run(cut)
+            ovl._graphs2 = None
+            ovl.run(T - cut)
+            ovl.check_status()
+            assert torch.equal(a, ovl.out_masked[:T]), f"re-capture after {cut} frames"
+    assert torch.equal(a, ovl.rollout(ev))
+
+
+@pytest.mark.parametrize("levels", [False, True])
 @pytest.mark.parametrize("T", [1, 2, 3, 5])
-def test_very_short_events_on_the_overlapped_schedule(dev, T):
+def test_very_short_events_on_the_overlapped_schedule(dev, T, levels):
     """Events shorter than a group of iterations (and than the capture warm-up's frames): prologue + first iteration + trailing head
     only, output buffers of one to five rows -- same frames and states as the one-chain engine, twice through the same graphs."""
     import urnn_amd.weights as uw
@@ -169,7 +212,7 @@ def test_very_short_events_on_the_overlapped_schedule(dev, T):
     ev = uw.make_event(T, H, W, 60.0, seed=4)
     seq = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T)
     a = seq.rollout(ev).clone()
-    ovl = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T, overlap=True)
+    ovl = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T, overlap=True, levels=levels)
     for _ in range(2):
         b = ovl.rollout(ev)
         assert b.shape == a.shape and torch.equal(a, b)

@@ -16,7 +16,7 @@ from .general import initialize_states
 class RolloutEngine:
     def __init__(self, net, input_height, input_width, historical_nums, rain_max, cumsum_rain_max, batch=1,
                  max_frames=360, spatial_rain=False, net_cfg=None, use_graph=True, keep_raw=False,
-                 device=None, overlap=False, fused_reset_gate=True, coop_cells=True, fused_tails=False, coop_mutex=False):
+                 device=None, overlap=False, fused_reset_gate=True, coop_cells=True, fused_tails=False, coop_mutex=False, levels=None):
         self.net = net
         # cells whose shape has the form recompute the reset gate inside the candidate kernel instead of round-tripping its raw
         # planes through HBM (include/urnn_hip.h URNN_PHASE_FUSED_R); the engine never reads a cell's workspace
@@ -35,6 +35,13 @@ class RolloutEngine:
         # captured graph: three, or two with the head in front of the encoder -- _head_own_chain); needs ping-pong encoder
         # states and feature maps.  Same arithmetic, same results.
         self.overlap = bool(overlap)
+        # levels=True (default on small planes with overlap=True): the LEVEL PIPELINE -- four concurrent kernel chains cut by level of the
+        # network, each a frame behind the one that feeds it (see "level pipeline" below).  Same launches, same results.
+        if levels is None:
+            levels = self.overlap and not fused_tails and not coop_mutex and int(batch) * int(input_height) * int(input_width) <= self.LEVELS_MAX_PIXELS
+            if _tuning_env("URNN_TUNE_LEVELS", "") in ("0", "1"):
+                levels = self.overlap and _tuning_env("URNN_TUNE_LEVELS", "") == "1"
+        self.levels = bool(levels) and self.overlap
         self.device = torch.device(device) if device is not None else next(net.parameters()).device
         if self.device.type != "cuda":
             raise RuntimeError("RolloutEngine needs the model on a GPU (HIP) device")
@@ -42,7 +49,9 @@ class RolloutEngine:
         B, H, W, dev = self.B, self.H, self.W, self.device
         f32 = dict(dtype=torch.float32, device=dev)
         # static event buffers (filled per event by load_event)
-        rshape = (B, self.Tcap + 1, H, W) if self.spatial else (B, self.Tcap + 1)
+        # rows of the per-frame buffers: the capture warm-up of the overlapped schedules runs a few frames for real (two; the level pipeline eight)
+        self._rows = max(self.Tcap, 8 if self.levels else 2)
+        rshape = (B, self._rows + 1, H, W) if self.spatial else (B, self._rows + 1)
         self.rain = torch.zeros(rshape, **f32)
         self.cumsum = torch.zeros(rshape, **f32)
         self.dem = torch.zeros((B, H, W), **f32)
@@ -51,7 +60,7 @@ class RolloutEngine:
         self.dem_min, self.dem_max = 0.0, 1.0
         # recurrent state, updated in place
         self.states = list(initialize_states(dev, H, W, net_cfg, batch=B))
-        self.enc_alt = [torch.zeros_like(s) for s in self.states[:3]] if self.overlap else None
+        self.enc_alt = [torch.zeros_like(s) for s in self.states[:3]] if (self.overlap and not self.levels) else None
         self._frames_done = 0
         # activations between kernels
         enc, dec = net.encoder, net.decoder
@@ -61,14 +70,14 @@ class RolloutEngine:
         self.S1 = None if self.spatial else torch.zeros((B, enc.stage1.out_channels, H, W), **f32)
         c1 = enc.stage1.layer
         self._w1 = c1.weight.detach().reshape(c1.out_channels, -1).clone()    # pointer-stable copy (captured in the graph)
-        self.a2 = torch.empty((B, enc.stage2.out_channels, H // 2, W // 2), **f32)
-        self.a3 = torch.empty((B, enc.stage3.out_channels, H // 4, W // 4), **f32)
-        self.u3 = torch.empty((B, dec.stage3.out_channels, H // 2, W // 2), **f32)
-        self.u2 = torch.empty((B, dec.stage2.out_channels, H, W), **f32)
-        self.feat = torch.empty((B, dec.stage1.out_channels, H, W), **f32)
+        self.a2 = torch.zeros((B, enc.stage2.out_channels, H // 2, W // 2), **f32)
+        self.a3 = torch.zeros((B, enc.stage3.out_channels, H // 4, W // 4), **f32)
+        self.u3 = torch.zeros((B, dec.stage3.out_channels, H // 2, W // 2), **f32)
+        self.u2 = torch.zeros((B, dec.stage2.out_channels, H, W), **f32)
+        self.feat = torch.zeros((B, dec.stage1.out_channels, H, W), **f32)
         self.feat_alt = torch.empty_like(self.feat) if self.overlap else None   # overlap mode: head(t-1) || decoder(t)
         # outputs for every frame
-        rows = max(self.Tcap, 2)                                     # (the capture warm-up of the overlapped schedule writes two frames)
+        rows = self._rows
         self.out_masked = torch.zeros((rows, B, H, W), **f32)
         self.out_cls = torch.zeros((rows, B, H, W), **f32)
         self.out_raw = torch.zeros((rows, B, H, W), **f32) if keep_raw else None
@@ -84,7 +93,7 @@ class RolloutEngine:
         need = max([L.urnn_head_workspace_bytes(B, 16, H, W)] +
                    [L.urnn_gru_cell_workspace_bytes(B, c.num_features, c.shape[0], c.shape[1])
                     for c in (enc.rnn1, enc.rnn2, enc.rnn3, dec.rnn3, dec.rnn2, dec.rnn1)])
-        self._ws = [ops.workspace(need, dev) for _ in range(3 if self.overlap else 1)]      # (third: the head as a chain of its own)
+        self._ws = [ops.workspace(need, dev) for _ in range(5 if self.levels else 3 if self.overlap else 1)]   # (third: the head as a chain of its own; level pipeline: one per unit)
         # fused_tails=True: the END of a cell runs together with the stage conv that consumes the new state (ops.gru_cell_tail: blend +
         # 1x1 conv [+ pool], for the decoder's last cell + the head's first LayerNorm statistics): enc1 -> stage2, enc2 -> stage3,
         # dec1 -> stage1.  190 MB per frame less through HBM at 500x500, identical bits -- and 3-4 % FEWER frames/s (DESIGN.md section
@@ -92,13 +101,13 @@ class RolloutEngine:
         self._fused_tails = bool(fused_tails)
         self._tails = None          # decided at the first step (the layers' weight ranges are known once they are packed)
         self._stem = None           # likewise: the decoder's last conv takes the head's first statistics (_stem_stats)
-        self._k1part = [ops.head_tail_partial(B, H, W, dev) for _ in range(2 if self.overlap else 1)]
+        self._k1part = [ops.head_tail_partial(B, H, W, dev) for _ in range(self.LEVEL_PERIOD if self.levels else 2 if self.overlap else 1)]
         self._param_stamp = None    # what the captured graphs' packed weights were made from (see _check_params)
         self._probe = None          # {"enc1": [(start, stop), ...], "dec1": [...]} while probing
         self._graph = None
         self._graphs2 = None
         # (equal stream priorities: a high-priority chain starves the other -- 900 instead of 1 250 frames/s either way round)
-        self._side = tuple(torch.cuda.Stream(device=dev) for _ in range(3)) if self.overlap else None
+        self._side = tuple(torch.cuda.Stream(device=dev) for _ in range(self.LEVEL_STREAMS if self.levels else 3)) if self.overlap else None
         # A cooperative cell launch needs ALL its blocks resident (one per CU).  With the encoder and decoder chains in flight, two such
         # launches of at most 128 blocks each always fit side by side (the head's: further below); a larger one could wait at its grid barrier for CUs the other chain's
         # cooperative launch holds while that one waits for CUs of ours.  So with overlap=True only cells of <= 128 blocks take the
@@ -147,6 +156,27 @@ class RolloutEngine:
         blocks = list(resident.values())                             # enc1..3, dec3..1 in the order of the dict above
         together = max(blocks[:3]) + max(blocks[3:]) + (nhead if self._head_coop else 0)
         self._head_own_chain = self.overlap and _tuning_env("URNN_TUNE_HEAD_CHAIN", "1") != "0" and together <= cus
+        if self.levels:
+            # Level pipeline: four streams are in flight at once, so the largest cooperative launch of each, together, must fit the chip (a
+            # block per CU); the largest ones give the flag back until they do.  Rings of LEVEL_PERIOD buffers carry what one unit hands to a later one.
+            nb = dict(zip(("enc1", "enc2", "enc3", "dec3", "dec2", "dec1"), blocks))
+            nb["head"] = nhead if self._head_coop else 0
+            self._plan = self.LEVEL_PLANS[_tuning_env("URNN_TUNE_LEVEL_PLAN", "B" if self._coop["enc1"] else "A")]
+            per_stream = [[n for st, _, names_ in self._plan if st == q for n in names_ if n in nb] for q in range(self.LEVEL_STREAMS)]   # (one launch per stream at a time)
+            while sum(max([nb[n] for n in names_] or [0]) for names_ in per_stream) > cus:
+                big = max(nb, key=nb.get)
+                nb[big] = 0
+                if big == "head":
+                    self._head_coop = False
+                else:
+                    self._coop[big] = 0
+            self._head_own_chain = True
+            P = self.LEVEL_PERIOD
+            self._ring_e = [[torch.zeros_like(st) for _ in range(P)] for st in self.states[:3]]
+            self._ring_d1 = [torch.zeros_like(self.states[3]) for _ in range(P)]
+            self._ring_d2 = [torch.zeros_like(self.states[4]) for _ in range(P)]
+            self._ring = {k: [t] + [torch.zeros_like(t) for _ in range(P - 1)]      # (zeros: the capture warm-up reads slots no frame has written yet)
+                          for k, t in (("a2", self.a2), ("a3", self.a3), ("u3", self.u3), ("u2", self.u2), ("feat", self.feat))}
         self._dem_stamp = None
 
     # -- one timestep, all launches on the current stream ----------------------------------------------
@@ -505,9 +535,169 @@ class RolloutEngine:
         else:
             self._head_chain((self._frames_done - 1) % 2)
 
+    # -- level pipeline: four concurrent chains on small planes, a frame apart ------------------------------------
+    # A small plane (64x64: 64 + 16 + 4 tiles of 64 pixels over the three resolutions) cannot fill the chip from one kernel chain, nor from
+    # three: its launches are latency -- 18-27 us per cooperative cell, 13 us per 1x1 conv, whatever the size -- and a frame of the
+    # three-chain schedule costs the LONGEST chain (the encoder pass: three cells + three convs, ~125-147 us at 64x64).  But only the
+    # cells' own states recur from frame to frame: enc1(t+1) needs enc1(t) and nothing deeper, enc2(t+1) needs enc1(t+1) and enc2(t), ...
+    # (encoder.py:119-215, decoder.py:102-217).  So the timestep is cut by LEVEL into five units on four streams (the runtime multiplexes
+    # streams onto FOUR hardware queues; seven streams measured 100 us per frame with two units sharing a queue, and GPU_MAX_HW_QUEUES=8
+    # three times slower), balanced at 64x64 to 57-66 us of kernels each (LEVEL_PLANS "B"; "A" moves dec3 next to dec2 and dec2's deconv to stream 0):
+    #     input assembly + stage-1 conv + enc1 + stage-2 conv   (stream 0, lag 0)      dec3                        (stream 0, lag 2)
+    #     enc2 + stage-3 conv + enc3                            (stream 1, lag 1)      deconv + dec2 + deconv      (stream 2, lag 3)
+    #                                                                                  dec1 + last conv + head     (stream 3, lag 4)
+    # Iteration i runs unit u on frame i - lag(u); the four streams meet in a barrier between iterations, so a unit only ever reads what
+    # an EARLIER iteration wrote and a frame costs the longest unit (+ 10-25 us of cross-queue dependency latency) instead of the longest chain.  What a unit hands to a later one travels through rings of LEVEL_PERIOD = 6 buffers indexed by frame % 6 -- the encoder
+    # states (enc1(t) is read by dec1(t) four iterations after it was written, while enc1 has moved on to t + 4), dec3's and dec2's states
+    # (read by their deconvs, possibly an iteration later), the stage outputs; dec1's state stays in place.  The captured graphs exist per frame % 6 (6 is
+    # even: the frame-counter words alternate by frame parity): a pipeline fill (four iterations, units joining by lag), one steady
+    # iteration, six steady iterations in one replay, and a drain.  run(n) leaves nothing in flight: n frames cost n + 4 iterations.
+    LEVEL_PERIOD = 6
+    # (stream, lag, launches) per unit; a launch that reads what an earlier one of the SAME frame wrote sits behind it in the same unit or in a
+    # unit of larger lag.  "B" where enc1 is one cooperative launch (64x64: 20 us), "A" where it is three kernels (52x120, 128x128: ~45 us)
+    LEVEL_PLANS = {
+        "A": ((0, 0, ("stage1", "enc1", "conv2")), (1, 1, ("enc2", "conv3", "enc3")), (2, 2, ("dec3", "deconv3", "dec2")),
+              (0, 3, ("deconv2",)), (3, 4, ("dec1", "lastconv", "head"))),
+        "B": ((0, 0, ("stage1", "enc1", "conv2")), (1, 1, ("enc2", "conv3", "enc3")), (0, 2, ("dec3",)),
+              (2, 3, ("deconv3", "dec2", "deconv2")), (3, 4, ("dec1", "lastconv", "head"))),
+    }
+    LEVEL_DEPTH = 4                                                    # the largest lag
+    LEVEL_STREAMS = 4
+    LEVEL_ORDER = (1, 2, 4, 0, 3)                                      # enqueue order of the units' launches within an iteration
+    LEVELS_MAX_PIXELS = 256 * 256                                      # batch x plane: beyond this the kernels fill the chip and three chains do as well (320x320: even)
+
+    def _lv_segments(self, u, tau):
+        """The launches of unit ``u`` (of this engine's plan) for frame ``tau`` as closures (one ABI call each), buffers by tau % LEVEL_PERIOD."""
+        P = self.LEVEL_PERIOD
+        k, km, par = tau % P, (tau - 1) % P, tau % 2
+        enc, dec = self.net.encoder, self.net.decoder
+        E, R, D1, D2, ws = self._ring_e, self._ring, self._ring_d1, self._ring_d2, self._ws[u]
+        d3 = self.states[5]
+
+        def head():
+            tail = self._stem_stats()
+            self.net.head.run(R["feat"][k], out_masked=self.out_masked, out_cls=self.out_cls, out_raw=self.out_raw,
+                              frame_index=self.t2[par:par + 1], ws=ws, partial0=self._k1part[k] if tail else None,
+                              coop=self._head_coop and not tail, frame_next=self.t2[1 - par:2 - par])
+        launch = {
+            "stage1": lambda: self._stage1(self.te2[par:par + 1], t_next=self.te2[1 - par:2 - par]),
+            "enc1": lambda: self._cell("enc1", enc.rnn1, self.a1, None, E[0][km], E[0][k], ws),
+            "conv2": lambda: enc.stage2(E[0][k], out=R["a2"][k]),
+            "enc2": lambda: self._cell("enc2", enc.rnn2, R["a2"][k], None, E[1][km], E[1][k], ws),
+            "conv3": lambda: enc.stage3(E[1][k], out=R["a3"][k]),
+            "enc3": lambda: self._cell("enc3", enc.rnn3, R["a3"][k], None, E[2][km], E[2][k], ws),
+            "dec3": lambda: self._cell("dec3", dec.rnn3, None, E[2][k], D1[km], D1[k], ws),
+            "deconv3": lambda: dec.stage3(D1[k], out=R["u3"][k]),
+            "dec2": lambda: self._cell("dec2", dec.rnn2, R["u3"][k], E[1][k], D2[km], D2[k], ws),
+            "deconv2": lambda: dec.stage2(D2[k], out=R["u2"][k]),
+            "dec1": lambda: self._cell("dec1", dec.rnn1, R["u2"][k], E[0][k], d3, d3, ws),
+            "lastconv": lambda: self._last_conv(d3, R["feat"][k], self._k1part[k]),
+            "head": head,
+        }
+        return [launch[name] for name in self._plan[u][2]]
+
+    def _run_iterations(self, its):
+        """Iterations (i, lo, hi) of the level pipeline over the frames lo <= t < hi, back to back: unit u runs frame i - lag(u) if that
+        is one of them.  The streams fork from the current one, meet in a barrier between iterations and join at the end; within
+        an iteration the units' launches are enqueued round-robin (a graph replay hands its nodes to the queues in creation order)."""
+        cur = torch.cuda.current_stream(self.device)
+        S = self._side[:self.LEVEL_STREAMS]
+        order = [int(c) for c in _tuning_env("URNN_TUNE_LEVEL_ORDER", "")] or self.LEVEL_ORDER
+        for st in S:
+            st.wait_stream(cur)
+        for n, (i, lo, hi) in enumerate(its):
+            if n:
+                # barrier through the current stream (join, fork): in the captured graph every first launch of the new iteration depends
+                # directly on the four last launches of the old one.  (Side streams waiting for each other directly -- all-to-all, or only the
+                # producer -> consumer edges -- end in a segmentation fault inside hipStreamEndCapture on ROCm 7.0, as in _cell.)
+                for st in S:
+                    cur.wait_stream(st)
+                for st in S:
+                    st.wait_stream(cur)
+            act = [(self._side[self._plan[u][0]], self._lv_segments(u, i - self._plan[u][1]))
+                   for u in order if lo <= i - self._plan[u][1] < hi]
+            for j in range(max(len(segs) for _, segs in act)):
+                for st, segs in act:
+                    if j < len(segs):
+                        with torch.cuda.stream(st):
+                            segs[j]()
+        for st in S:
+            cur.wait_stream(st)
+
+    def _capture_levels(self):
+        """Graphs of the level pipeline, per frame % LEVEL_PERIOD: ("fill", p), ("steady", p), ("group", p) = LEVEL_PERIOD steady iterations,
+        ("drain", p).  As in _capture_overlap the warm-up and the first replay of every graph run for real -- on whatever the buffers hold,
+        into output rows b .. b + 8 -- and states, rings, counters and those rows are put back afterwards."""
+        P, NL = self.LEVEL_PERIOD, self.LEVEL_DEPTH
+        self.net.head.flat_params()
+        keep = [self.states[5]] + [t for ring in self._ring_e + [self._ring_d1, self._ring_d2] for t in ring] + [self.t2, self.te2]
+        keep += [ws[:4] for ws in self._ws]         # (the status words: what the warm-up computes on stale buffers is not this event's)
+        saved = [t.clone() for t in keep]
+        rows = self.out_masked.shape[0]
+        b = max(0, min(self._frames_done + (self._frames_done & 1), (rows - 8) & ~1))
+        outs = [o for o in (self.out_masked, self.out_cls, self.out_raw) if o is not None]
+        kept = [o[b:b + 8].clone() for o in outs]
+        pair = torch.tensor([b, b + 1], dtype=torch.int32)
+
+        def set_counters():
+            self.t2.copy_(pair)
+            self.te2.copy_(pair)
+        set_counters()
+        self._run_iterations([(i, 0, 2) for i in range(2 + NL)])     # warm-up (packs weights), eager: two frames through the whole pipeline
+        torch.cuda.synchronize(self.device)
+        big = 1 << 30
+        plans = {}
+        for p in range(P):
+            f = 2 * P + p                           # (frame numbers only matter modulo P: any window away from zero will do)
+            plans[("fill", p)] = [(f + k, f, big) for k in range(NL)]
+            plans[("steady", p)] = [(f, 0, big)]
+            plans[("group", p)] = [(f + k, 0, big) for k in range(P)]
+            plans[("drain", p)] = [(f + k, 0, f) for k in range(NL)]
+        graphs = {}
+        for key, its in plans.items():
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._run_iterations(its)
+            graphs[key] = g
+        for key in plans:                           # first launch = upload; one graph at a time (see _capture_overlap)
+            set_counters()
+            graphs[key].replay()
+            torch.cuda.synchronize(self.device)
+        self._graphs2 = graphs
+        for t, v in zip(keep, saved):
+            t.copy_(v)
+        for o, v in zip(outs, kept):
+            o[b:b + 8].copy_(v)
+        torch.cuda.synchronize(self.device)
+
+    def _run_levels(self, frames):
+        if frames <= 0:
+            return
+        P, NL = self.LEVEL_PERIOD, self.LEVEL_DEPTH
+        f, end = self._frames_done, self._frames_done + frames
+        if self.use_graph and frames >= NL:
+            if self._graphs2 is None:
+                self._capture_levels()
+            g = self._graphs2
+            g[("fill", f % P)].replay()             # iterations f .. f + NL - 1
+            i = f + NL
+            while i + P <= end:
+                g[("group", i % P)].replay()
+                i += P
+            while i < end:
+                g[("steady", i % P)].replay()
+                i += 1
+            g[("drain", end % P)].replay()          # iterations end .. end + NL - 1
+        else:                                       # eager, or a run shorter than the pipeline is deep (its fill and drain overlap)
+            self._run_iterations([(i, f, end) for i in range(f, end + NL)])
+        self._frames_done = end
+
     def final_states(self):
         """The six states after the frames run so far (overlap mode keeps the newest encoder states in the buffer
         of the last frame's parity)."""
+        if self.levels:
+            k = (self._frames_done - 1) % self.LEVEL_PERIOD          # (before the first frame: a slot reset() has zeroed)
+            return [ring[k] for ring in self._ring_e] + [self._ring_d1[k], self._ring_d2[k], self.states[5]]
         if not self.overlap or self._frames_done == 0:
             return list(self.states)
         enc = self._enc_bufs((self._frames_done - 1) % 2)[1]
@@ -581,6 +771,10 @@ class RolloutEngine:
         if self.enc_alt is not None:
             for s in self.enc_alt:
                 s.zero_()
+        if self.levels:
+            for ring in self._ring_e + [self._ring_d1, self._ring_d2]:
+                for s in ring:
+                    s.zero_()
         self.t_dev.zero_()
         if self.overlap:
             self.t2.zero_()
@@ -590,6 +784,8 @@ class RolloutEngine:
     def run(self, frames):
         """Roll ``frames`` timesteps from the current states / frame counter.  Asynchronous."""
         self._check_params()        # a Trainer may have updated / re-homed the weights since the graphs were captured (mid-event run)
+        if self.levels:
+            return self._run_levels(frames)
         if self.overlap:
             return self._run_overlap(frames)
         self._frames_done += frames
