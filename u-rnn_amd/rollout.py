@@ -161,7 +161,8 @@ class RolloutEngine:
             # block per CU); the largest ones give the flag back until they do.  Rings of LEVEL_PERIOD buffers carry what one unit hands to a later one.
             nb = dict(zip(("enc1", "enc2", "enc3", "dec3", "dec2", "dec1"), blocks))
             nb["head"] = nhead if self._head_coop else 0
-            self._plan = self.LEVEL_PLANS[_tuning_env("URNN_TUNE_LEVEL_PLAN", "B" if self._coop["enc1"] else "A")]
+            # (measured, iteration time in us, A / B: 64x64 91 / 83, 52x120 93 / 97, 128x128 110 / 116 -- profiles/r06_level_pipeline.txt)
+            self._plan = self.LEVEL_PLANS[_tuning_env("URNN_TUNE_LEVEL_PLAN", "B" if (self._coop["enc1"] and nb["enc1"] <= 64) else "A")]
             per_stream = [[n for st, _, names_ in self._plan if st == q for n in names_ if n in nb] for q in range(self.LEVEL_STREAMS)]   # (one launch per stream at a time)
             while sum(max([nb[n] for n in names_] or [0]) for names_ in per_stream) > cus:
                 big = max(nb, key=nb.get)
@@ -554,7 +555,7 @@ class RolloutEngine:
     # iteration, six steady iterations in one replay, and a drain.  run(n) leaves nothing in flight: n frames cost n + 4 iterations.
     LEVEL_PERIOD = 6
     # (stream, lag, launches) per unit; a launch that reads what an earlier one of the SAME frame wrote sits behind it in the same unit or in a
-    # unit of larger lag.  "B" where enc1 is one cooperative launch (64x64: 20 us), "A" where it is three kernels (52x120, 128x128: ~45 us)
+    # unit of larger lag.  "B" where enc1 is one cooperative launch of at most 64 blocks (64x64: 20 us), "A" where it takes longer (52x120, 128x128)
     LEVEL_PLANS = {
         "A": ((0, 0, ("stage1", "enc1", "conv2")), (1, 1, ("enc2", "conv3", "enc3")), (2, 2, ("dec3", "deconv3", "dec2")),
               (0, 3, ("deconv2",)), (3, 4, ("dec1", "lastconv", "head"))),
