@@ -159,15 +159,19 @@ def test_grouped_iterations_and_piecewise_runs_match_sequential(dev, monkeypatch
         assert torch.equal(a, ovl.out_masked[:T]), f"re-capture after {cut} frames"
 
 
+@pytest.mark.parametrize("plan", ["default", "F", "A", "B"])
 @pytest.mark.parametrize("shape", [(32, 48, 1), (64, 64, 1), (24, 40, 2)])
 @pytest.mark.parametrize("use_graph", [True, False])
-def test_level_pipeline_and_piecewise_runs_match_sequential(dev, shape, use_graph):
-    """The level pipeline (RolloutEngine(levels=True), the default on small planes with overlap=True): five units on four streams, cut by level of the
-    network, each a frame behind the one that feeds it, the encoder states in rings of six buffers.  A re-scheduling only -- frames and
+def test_level_pipeline_and_piecewise_runs_match_sequential(dev, monkeypatch, shape, use_graph, plan):
+    """The level pipeline (RolloutEngine(levels=True), the default on small planes with overlap=True): four or five units on four streams, cut by
+    level of the network, each a frame behind the one that feeds it, the encoder states in rings of six or ten buffers.  A re-scheduling only -- frames and
     final states equal the one-chain engine's bit for bit however an event is cut into run() calls (each call fills and drains the pipeline;
     calls shorter than four frames run eagerly), through the captured graphs of every frame % 6, and across a re-capture in mid-event."""
     import urnn_amd.weights as uw
     from urnn_amd.rollout import RolloutEngine
+    if plan != "default":                           # (LEVEL_PLANS: F = forward hand-overs, no barrier inside a replay; A / B = a barrier per iteration)
+        monkeypatch.setenv("URNN_TUNING", "1")
+        monkeypatch.setenv("URNN_TUNE_LEVEL_PLAN", plan)
     H, W, B = shape
     nums, T = 3, 23
     net, _ = make_net(H, W, 9, 3, dev)
@@ -175,7 +179,7 @@ def test_level_pipeline_and_piecewise_runs_match_sequential(dev, shape, use_grap
     seq = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T, batch=B)
     a = seq.rollout(ev).clone()
     ovl = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T, batch=B, overlap=True, use_graph=use_graph)
-    assert ovl.levels and len(ovl._ws) == 5 and len(ovl._side) == 4
+    assert ovl.levels and len(ovl._side) == 4
     for pieces in ((23,), (3, 7, 1, 12), (6, 6, 11), (1, 1, 2, 5, 6, 8), (10, 13), (7, 8, 8)):
         ovl.load_event(ev)
         ovl.reset()
@@ -188,7 +192,7 @@ def test_level_pipeline_and_piecewise_runs_match_sequential(dev, shape, use_grap
         for x, y in zip(seq.final_states(), ovl.final_states()):
             assert torch.equal(x, y)
     if use_graph:
-        assert sorted({k[0] for k in ovl._graphs2}) == ["drain", "fill", "group", "steady"] and len(ovl._graphs2) == 24
+        assert sorted({k[0] for k in ovl._graphs2}) == ["drain", "fill", "group", "steady"] and len(ovl._graphs2) == 4 * ovl._lvP
         for cut in (6, 9, 16):
             ovl.load_event(ev)
             ovl.reset()

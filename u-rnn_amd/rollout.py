@@ -101,7 +101,7 @@ class RolloutEngine:
         self._fused_tails = bool(fused_tails)
         self._tails = None          # decided at the first step (the layers' weight ranges are known once they are packed)
         self._stem = None           # likewise: the decoder's last conv takes the head's first statistics (_stem_stats)
-        self._k1part = [ops.head_tail_partial(B, H, W, dev) for _ in range(self.LEVEL_PERIOD if self.levels else 2 if self.overlap else 1)]
+        self._k1part = [ops.head_tail_partial(B, H, W, dev) for _ in range(2 if self.overlap else 1)]      # (level pipeline: a ring, below)
         self._param_stamp = None    # what the captured graphs' packed weights were made from (see _check_params)
         self._probe = None          # {"enc1": [(start, stop), ...], "dec1": [...]} while probing
         self._graph = None
@@ -158,11 +158,21 @@ class RolloutEngine:
         self._head_own_chain = self.overlap and _tuning_env("URNN_TUNE_HEAD_CHAIN", "1") != "0" and together <= cus
         if self.levels:
             # Level pipeline: four streams are in flight at once, so the largest cooperative launch of each, together, must fit the chip (a
-            # block per CU); the largest ones give the flag back until they do.  Rings of LEVEL_PERIOD buffers carry what one unit hands to a later one.
+            # block per CU); the largest ones give the flag back until they do.
             nb = dict(zip(("enc1", "enc2", "enc3", "dec3", "dec2", "dec1"), blocks))
             nb["head"] = nhead if self._head_coop else 0
-            # (measured, iteration time in us, A / B: 64x64 91 / 83, 52x120 93 / 97, 128x128 110 / 116 -- profiles/r06_level_pipeline.txt)
-            self._plan = self.LEVEL_PLANS[_tuning_env("URNN_TUNE_LEVEL_PLAN", "B" if (self._coop["enc1"] and nb["enc1"] <= 64) else "A")]
+            # (measured, iteration time in us, A / B / F: 64x64 91 / 83 / 79-84, 52x120 93 / 97 / 88, 128x128 110 / 116 / 104)
+            # plan F everywhere except the one shape where B's balance wins (64x64, one event: enc1 is a cooperative launch of 64 blocks;
+            # 10 000-10 150 against 9 724 frames/s) -- profiles/r06_level_pipeline.txt
+            pname = _tuning_env("URNN_TUNE_LEVEL_PLAN", "B" if (self._coop["enc1"] and 0 < nb["enc1"] <= 64 and B == 1) else "F")
+            if pname == "AB":
+                pname = "B" if (self._coop["enc1"] and nb["enc1"] <= 64) else "A"
+            plan = self.LEVEL_PLANS[pname]
+            self._plan, self._lv_forward, self._lvP, self._lvG = plan["units"], plan["forward"], plan["period"], plan["group"]
+            if plan["forward"] and _tuning_env("URNN_TUNE_LEVEL_GROUP", ""):                     # (A/B of the replay length: rings follow)
+                self._lvG = int(_tuning_env("URNN_TUNE_LEVEL_GROUP", ""))
+                self._lvP = (self._lvG + 4 + 1) & ~1
+            self._lvD = max(lag for _, lag, _ in self._plan)
             per_stream = [[n for st, _, names_ in self._plan if st == q for n in names_ if n in nb] for q in range(self.LEVEL_STREAMS)]   # (one launch per stream at a time)
             while sum(max([nb[n] for n in names_] or [0]) for names_ in per_stream) > cus:
                 big = max(nb, key=nb.get)
@@ -172,7 +182,8 @@ class RolloutEngine:
                 else:
                     self._coop[big] = 0
             self._head_own_chain = True
-            P = self.LEVEL_PERIOD
+            P = self._lvP
+            self._k1part = [ops.head_tail_partial(B, H, W, dev) for _ in range(P)]
             self._ring_e = [[torch.zeros_like(st) for _ in range(P)] for st in self.states[:3]]
             self._ring_d1 = [torch.zeros_like(self.states[3]) for _ in range(P)]
             self._ring_d2 = [torch.zeros_like(self.states[4]) for _ in range(P)]
@@ -538,38 +549,43 @@ class RolloutEngine:
 
     # -- level pipeline: four concurrent chains on small planes, a frame apart ------------------------------------
     # A small plane (64x64: 64 + 16 + 4 tiles of 64 pixels over the three resolutions) cannot fill the chip from one kernel chain, nor from
-    # three: its launches are latency -- 18-27 us per cooperative cell, 13 us per 1x1 conv, whatever the size -- and a frame of the
+    # three: its launches are latency -- 18-30 us per cooperative cell, 13 us per 1x1 conv, whatever the size -- and a frame of the
     # three-chain schedule costs the LONGEST chain (the encoder pass: three cells + three convs, ~125-147 us at 64x64).  But only the
     # cells' own states recur from frame to frame: enc1(t+1) needs enc1(t) and nothing deeper, enc2(t+1) needs enc1(t+1) and enc2(t), ...
-    # (encoder.py:119-215, decoder.py:102-217).  So the timestep is cut by LEVEL into five units on four streams (the runtime multiplexes
-    # streams onto FOUR hardware queues; seven streams measured 100 us per frame with two units sharing a queue, and GPU_MAX_HW_QUEUES=8
-    # three times slower), balanced at 64x64 to 57-66 us of kernels each (LEVEL_PLANS "B"; "A" moves dec3 next to dec2 and dec2's deconv to stream 0):
-    #     input assembly + stage-1 conv + enc1 + stage-2 conv   (stream 0, lag 0)      dec3                        (stream 0, lag 2)
-    #     enc2 + stage-3 conv + enc3                            (stream 1, lag 1)      deconv + dec2 + deconv      (stream 2, lag 3)
-    #                                                                                  dec1 + last conv + head     (stream 3, lag 4)
-    # Iteration i runs unit u on frame i - lag(u); the four streams meet in a barrier between iterations, so a unit only ever reads what
-    # an EARLIER iteration wrote and a frame costs the longest unit (+ 10-25 us of cross-queue dependency latency) instead of the longest chain.  What a unit hands to a later one travels through rings of LEVEL_PERIOD = 6 buffers indexed by frame % 6 -- the encoder
-    # states (enc1(t) is read by dec1(t) four iterations after it was written, while enc1 has moved on to t + 4), dec3's and dec2's states
-    # (read by their deconvs, possibly an iteration later), the stage outputs; dec1's state stays in place.  The captured graphs exist per frame % 6 (6 is
-    # even: the frame-counter words alternate by frame parity): a pipeline fill (four iterations, units joining by lag), one steady
-    # iteration, six steady iterations in one replay, and a drain.  run(n) leaves nothing in flight: n frames cost n + 4 iterations.
-    LEVEL_PERIOD = 6
-    # (stream, lag, launches) per unit; a launch that reads what an earlier one of the SAME frame wrote sits behind it in the same unit or in a
-    # unit of larger lag.  "B" where enc1 is one cooperative launch of at most 64 blocks (64x64: 20 us), "A" where it takes longer (52x120, 128x128)
+    # (encoder.py:119-215, decoder.py:102-217).  So the timestep is cut by LEVEL into units on FOUR streams (the runtime multiplexes
+    # streams onto four hardware queues: seven streams measured 100 us per frame with two units sharing a queue, GPU_MAX_HW_QUEUES=8 three
+    # times slower), and iteration i runs unit u on frame i - lag(u): a unit only ever reads what an EARLIER iteration wrote, and a frame
+    # costs the longest unit (57-66 us at 64x64) + ~10 us per cross-queue wait instead of the longest chain.  What a unit hands to a later
+    # one travels through rings of ``period`` buffers indexed by frame % period -- the encoder states (enc1(t) is read by dec1(t) three or
+    # four iterations after it was written, when enc1 has moved on), dec3's and dec2's states (their deconvs may run an iteration later), the
+    # stage outputs, the head's feature map; dec1's state stays in place.  The captured graphs exist per frame % period (even: the
+    # frame-counter words alternate by frame parity): a pipeline fill (``depth`` iterations, units joining by lag), one steady iteration,
+    # ``group`` steady iterations in one replay, and a drain.  run(n) leaves nothing in flight: n frames cost n + depth iterations.
+    #
+    # A plan: (stream, lag, launches) per unit; a launch that reads what an earlier one of the SAME frame wrote sits behind it in the same unit
+    # or in a unit of larger lag.  "period" = buffers per ring; "group" = steady iterations per replay.
+    #   F (forward, the default): four units in network order on streams 0..3, so every hand-over goes to a LATER stream -- inside a replay
+    #     stream q + 1 waits for streams 0..q of the previous iteration and nothing waits for a later stream, the replays' ends are the only
+    #     barriers.  Nothing but a replay's length bounds how far stream 0 runs ahead, so the rings hold group + depth + 1 frames.
+    #   A / B: five units, a barrier between iterations (every stream waits for all four); B's balance (63 / 66 / 59 / 57 us at 64x64) wins
+    #     at that one shape, A is B with dec3 next to dec2 for planes whose enc1 is slow.
     LEVEL_PLANS = {
-        "A": ((0, 0, ("stage1", "enc1", "conv2")), (1, 1, ("enc2", "conv3", "enc3")), (2, 2, ("dec3", "deconv3", "dec2")),
-              (0, 3, ("deconv2",)), (3, 4, ("dec1", "lastconv", "head"))),
-        "B": ((0, 0, ("stage1", "enc1", "conv2")), (1, 1, ("enc2", "conv3", "enc3")), (0, 2, ("dec3",)),
-              (2, 3, ("deconv3", "dec2", "deconv2")), (3, 4, ("dec1", "lastconv", "head"))),
+        "A": dict(forward=False, period=6, group=6, units=(
+            (0, 0, ("stage1", "enc1", "conv2")), (1, 1, ("enc2", "conv3", "enc3")), (2, 2, ("dec3", "deconv3", "dec2")),
+            (0, 3, ("deconv2",)), (3, 4, ("dec1", "lastconv", "head")))),
+        "B": dict(forward=False, period=6, group=6, units=(
+            (0, 0, ("stage1", "enc1", "conv2")), (1, 1, ("enc2", "conv3", "enc3")), (0, 2, ("dec3",)),
+            (2, 3, ("deconv3", "dec2", "deconv2")), (3, 4, ("dec1", "lastconv", "head")))),
+        "F": dict(forward=True, period=10, group=6, units=(
+            (0, 0, ("stage1", "enc1", "conv2", "enc2")), (1, 1, ("conv3", "enc3", "dec3")), (2, 2, ("deconv3", "dec2", "deconv2")),
+            (3, 3, ("dec1", "lastconv", "head")))),
     }
-    LEVEL_DEPTH = 4                                                    # the largest lag
     LEVEL_STREAMS = 4
-    LEVEL_ORDER = (1, 2, 4, 0, 3)                                      # enqueue order of the units' launches within an iteration
     LEVELS_MAX_PIXELS = 256 * 256                                      # batch x plane: beyond this the kernels fill the chip and three chains do as well (320x320: even)
 
     def _lv_segments(self, u, tau):
-        """The launches of unit ``u`` (of this engine's plan) for frame ``tau`` as closures (one ABI call each), buffers by tau % LEVEL_PERIOD."""
-        P = self.LEVEL_PERIOD
+        """The launches of unit ``u`` (of this engine's plan) for frame ``tau`` as closures (one ABI call each), buffers by tau % period."""
+        P = self._lvP
         k, km, par = tau % P, (tau - 1) % P, tau % 2
         enc, dec = self.net.encoder, self.net.decoder
         E, R, D1, D2, ws = self._ring_e, self._ring, self._ring_d1, self._ring_d2, self._ws[u]
@@ -599,15 +615,16 @@ class RolloutEngine:
 
     def _run_iterations(self, its):
         """Iterations (i, lo, hi) of the level pipeline over the frames lo <= t < hi, back to back: unit u runs frame i - lag(u) if that
-        is one of them.  The streams fork from the current one, meet in a barrier between iterations and join at the end; within
-        an iteration the units' launches are enqueued round-robin (a graph replay hands its nodes to the queues in creation order)."""
+        is one of them.  The streams fork from the current one and join at the end; between iterations they meet in a barrier (plans A / B)
+        or each waits for the EARLIER streams only (plan F, a barrier every ``group`` iterations); within an iteration the units' launches
+        are enqueued round-robin (a graph replay hands its nodes to the queues in creation order)."""
         cur = torch.cuda.current_stream(self.device)
         S = self._side[:self.LEVEL_STREAMS]
-        order = [int(c) for c in _tuning_env("URNN_TUNE_LEVEL_ORDER", "")] or self.LEVEL_ORDER
+        order = [int(c) for c in _tuning_env("URNN_TUNE_LEVEL_ORDER", "")] or range(len(self._plan))
         for st in S:
             st.wait_stream(cur)
         for n, (i, lo, hi) in enumerate(its):
-            if n:
+            if n and (not self._lv_forward or n % self._lvG == 0):
                 # barrier through the current stream (join, fork): in the captured graph every first launch of the new iteration depends
                 # directly on the four last launches of the old one.  (Side streams waiting for each other directly -- all-to-all, or only the
                 # producer -> consumer edges -- end in a segmentation fault inside hipStreamEndCapture on ROCm 7.0, as in _cell.)
@@ -615,6 +632,12 @@ class RolloutEngine:
                     cur.wait_stream(st)
                 for st in S:
                     st.wait_stream(cur)
+            elif n:
+                # forward plan: stream q + 1 waits for what streams 0 .. q hold NOW -- their launches of the previous iteration -- again
+                # through the current stream, which accumulates (the older entries it drags along are earlier launches of the same streams)
+                for q in range(len(S) - 1):
+                    cur.wait_stream(S[q])
+                    S[q + 1].wait_stream(cur)
             act = [(self._side[self._plan[u][0]], self._lv_segments(u, i - self._plan[u][1]))
                    for u in order if lo <= i - self._plan[u][1] < hi]
             for j in range(max(len(segs) for _, segs in act)):
@@ -626,10 +649,10 @@ class RolloutEngine:
             cur.wait_stream(st)
 
     def _capture_levels(self):
-        """Graphs of the level pipeline, per frame % LEVEL_PERIOD: ("fill", p), ("steady", p), ("group", p) = LEVEL_PERIOD steady iterations,
+        """Graphs of the level pipeline, per frame % period: ("fill", p), ("steady", p), ("group", p) = ``group`` steady iterations,
         ("drain", p).  As in _capture_overlap the warm-up and the first replay of every graph run for real -- on whatever the buffers hold,
         into output rows b .. b + 8 -- and states, rings, counters and those rows are put back afterwards."""
-        P, NL = self.LEVEL_PERIOD, self.LEVEL_DEPTH
+        P, NL, G = self._lvP, self._lvD, self._lvG
         self.net.head.flat_params()
         keep = [self.states[5]] + [t for ring in self._ring_e + [self._ring_d1, self._ring_d2] for t in ring] + [self.t2, self.te2]
         keep += [ws[:4] for ws in self._ws]         # (the status words: what the warm-up computes on stale buffers is not this event's)
@@ -652,7 +675,7 @@ class RolloutEngine:
             f = 2 * P + p                           # (frame numbers only matter modulo P: any window away from zero will do)
             plans[("fill", p)] = [(f + k, f, big) for k in range(NL)]
             plans[("steady", p)] = [(f, 0, big)]
-            plans[("group", p)] = [(f + k, 0, big) for k in range(P)]
+            plans[("group", p)] = [(f + k, 0, big) for k in range(G)]
             plans[("drain", p)] = [(f + k, 0, f) for k in range(NL)]
         graphs = {}
         for key, its in plans.items():
@@ -674,7 +697,7 @@ class RolloutEngine:
     def _run_levels(self, frames):
         if frames <= 0:
             return
-        P, NL = self.LEVEL_PERIOD, self.LEVEL_DEPTH
+        P, NL, G = self._lvP, self._lvD, self._lvG
         f, end = self._frames_done, self._frames_done + frames
         if self.use_graph and frames >= NL:
             if self._graphs2 is None:
@@ -682,9 +705,9 @@ class RolloutEngine:
             g = self._graphs2
             g[("fill", f % P)].replay()             # iterations f .. f + NL - 1
             i = f + NL
-            while i + P <= end:
+            while i + G <= end:
                 g[("group", i % P)].replay()
-                i += P
+                i += G
             while i < end:
                 g[("steady", i % P)].replay()
                 i += 1
@@ -697,7 +720,7 @@ class RolloutEngine:
         """The six states after the frames run so far (overlap mode keeps the newest encoder states in the buffer
         of the last frame's parity)."""
         if self.levels:
-            k = (self._frames_done - 1) % self.LEVEL_PERIOD          # (before the first frame: a slot reset() has zeroed)
+            k = (self._frames_done - 1) % self._lvP                  # (before the first frame: a slot reset() has zeroed)
             return [ring[k] for ring in self._ring_e] + [self._ring_d1[k], self._ring_d2[k], self.states[5]]
         if not self.overlap or self._frames_done == 0:
             return list(self.states)
