@@ -6,7 +6,7 @@ import os
 
 import torch
 
-from . import ops
+from . import level_schedule, ops
 from .ops import tuning_env as _tuning_env
 from ._lib import lib
 from .dataset import event_to_device
@@ -167,12 +167,11 @@ class RolloutEngine:
             pname = _tuning_env("URNN_TUNE_LEVEL_PLAN", "B" if (self._coop["enc1"] and 0 < nb["enc1"] <= 64 and B == 1) else "F")
             if pname == "AB":
                 pname = "B" if (self._coop["enc1"] and nb["enc1"] <= 64) else "A"
-            plan = self.LEVEL_PLANS[pname]
-            self._plan, self._lv_forward, self._lvP, self._lvG = plan["units"], plan["forward"], plan["period"], plan["group"]
+            plan = dict(self.LEVEL_PLANS[pname])
             if plan["forward"] and _tuning_env("URNN_TUNE_LEVEL_GROUP", ""):                     # (A/B of the replay length: rings follow)
-                self._lvG = int(_tuning_env("URNN_TUNE_LEVEL_GROUP", ""))
-                self._lvP = (self._lvG + 4 + 1) & ~1
-            self._lvD = max(lag for _, lag, _ in self._plan)
+                plan["group"] = int(_tuning_env("URNN_TUNE_LEVEL_GROUP", ""))
+                plan["period"] = (plan["group"] + level_schedule.depth(plan) + 2) & ~1
+            self._plan_dict, self._plan, self._lvP = plan, plan["units"], plan["period"]
             per_stream = [[n for st, _, names_ in self._plan if st == q for n in names_ if n in nb] for q in range(self.LEVEL_STREAMS)]   # (one launch per stream at a time)
             while sum(max([nb[n] for n in names_] or [0]) for names_ in per_stream) > cus:
                 big = max(nb, key=nb.get)
@@ -569,18 +568,8 @@ class RolloutEngine:
     #     barriers.  Nothing but a replay's length bounds how far stream 0 runs ahead, so the rings hold group + depth + 1 frames.
     #   A / B: five units, a barrier between iterations (every stream waits for all four); B's balance (63 / 66 / 59 / 57 us at 64x64) wins
     #     at that one shape, A is B with dec3 next to dec2 for planes whose enc1 is slow.
-    LEVEL_PLANS = {
-        "A": dict(forward=False, period=6, group=6, units=(
-            (0, 0, ("stage1", "enc1", "conv2")), (1, 1, ("enc2", "conv3", "enc3")), (2, 2, ("dec3", "deconv3", "dec2")),
-            (0, 3, ("deconv2",)), (3, 4, ("dec1", "lastconv", "head")))),
-        "B": dict(forward=False, period=6, group=6, units=(
-            (0, 0, ("stage1", "enc1", "conv2")), (1, 1, ("enc2", "conv3", "enc3")), (0, 2, ("dec3",)),
-            (2, 3, ("deconv3", "dec2", "deconv2")), (3, 4, ("dec1", "lastconv", "head")))),
-        "F": dict(forward=True, period=10, group=6, units=(
-            (0, 0, ("stage1", "enc1", "conv2", "enc2")), (1, 1, ("conv3", "enc3", "dec3")), (2, 2, ("deconv3", "dec2", "deconv2")),
-            (3, 3, ("dec1", "lastconv", "head")))),
-    }
-    LEVEL_STREAMS = 4
+    LEVEL_PLANS = level_schedule.PLANS          # (the schedule itself is data: level_schedule.py, model-checked by tests/test_level_schedule.py)
+    LEVEL_STREAMS = level_schedule.STREAMS
     LEVELS_MAX_PIXELS = 256 * 256                                      # batch x plane: beyond this the kernels fill the chip and three chains do as well (320x320: even)
 
     def _lv_segments(self, u, tau):
@@ -614,45 +603,28 @@ class RolloutEngine:
         return [launch[name] for name in self._plan[u][2]]
 
     def _run_iterations(self, its):
-        """Iterations (i, lo, hi) of the level pipeline over the frames lo <= t < hi, back to back: unit u runs frame i - lag(u) if that
-        is one of them.  The streams fork from the current one and join at the end; between iterations they meet in a barrier (plans A / B)
-        or each waits for the EARLIER streams only (plan F, a barrier every ``group`` iterations); within an iteration the units' launches
-        are enqueued round-robin (a graph replay hands its nodes to the queues in creation order)."""
+        """Iterations (i, lo, hi) of the level pipeline over the frames lo <= t < hi, back to back in one replay: the stream operations
+        of level_schedule.events -- fork from the current stream, waits between iterations (a barrier, or forward only), the units'
+        launches round-robin, join -- issued on this engine's streams (eagerly, or under capture)."""
         cur = torch.cuda.current_stream(self.device)
-        S = self._side[:self.LEVEL_STREAMS]
-        order = [int(c) for c in _tuning_env("URNN_TUNE_LEVEL_ORDER", "")] or range(len(self._plan))
-        for st in S:
-            st.wait_stream(cur)
-        for n, (i, lo, hi) in enumerate(its):
-            if n and (not self._lv_forward or n % self._lvG == 0):
-                # barrier through the current stream (join, fork): in the captured graph every first launch of the new iteration depends
-                # directly on the four last launches of the old one.  (Side streams waiting for each other directly -- all-to-all, or only the
-                # producer -> consumer edges -- end in a segmentation fault inside hipStreamEndCapture on ROCm 7.0, as in _cell.)
-                for st in S:
-                    cur.wait_stream(st)
-                for st in S:
-                    st.wait_stream(cur)
-            elif n:
-                # forward plan: stream q + 1 waits for what streams 0 .. q hold NOW -- their launches of the previous iteration -- again
-                # through the current stream, which accumulates (the older entries it drags along are earlier launches of the same streams)
-                for q in range(len(S) - 1):
-                    cur.wait_stream(S[q])
-                    S[q + 1].wait_stream(cur)
-            act = [(self._side[self._plan[u][0]], self._lv_segments(u, i - self._plan[u][1]))
-                   for u in order if lo <= i - self._plan[u][1] < hi]
-            for j in range(max(len(segs) for _, segs in act)):
-                for st, segs in act:
-                    if j < len(segs):
-                        with torch.cuda.stream(st):
-                            segs[j]()
-        for st in S:
-            cur.wait_stream(st)
+        stream = lambda q: cur if q == level_schedule.CUR else self._side[q]
+        order = [int(c) for c in _tuning_env("URNN_TUNE_LEVEL_ORDER", "")] or None
+        segs = {}
+        for ev in level_schedule.events(self._plan_dict, its, order):
+            if ev[0] == "wait":
+                stream(ev[1]).wait_stream(stream(ev[2]))
+            else:
+                _, q, u, name, tau = ev
+                if (u, tau) not in segs:
+                    segs[(u, tau)] = dict(zip(self._plan[u][2], self._lv_segments(u, tau)))
+                with torch.cuda.stream(self._side[q]):
+                    segs[(u, tau)][name]()
 
     def _capture_levels(self):
         """Graphs of the level pipeline, per frame % period: ("fill", p), ("steady", p), ("group", p) = ``group`` steady iterations,
         ("drain", p).  As in _capture_overlap the warm-up and the first replay of every graph run for real -- on whatever the buffers hold,
         into output rows b .. b + 8 -- and states, rings, counters and those rows are put back afterwards."""
-        P, NL, G = self._lvP, self._lvD, self._lvG
+        NL = level_schedule.depth(self._plan_dict)
         self.net.head.flat_params()
         keep = [self.states[5]] + [t for ring in self._ring_e + [self._ring_d1, self._ring_d2] for t in ring] + [self.t2, self.te2]
         keep += [ws[:4] for ws in self._ws]         # (the status words: what the warm-up computes on stale buffers is not this event's)
@@ -669,14 +641,7 @@ class RolloutEngine:
         set_counters()
         self._run_iterations([(i, 0, 2) for i in range(2 + NL)])     # warm-up (packs weights), eager: two frames through the whole pipeline
         torch.cuda.synchronize(self.device)
-        big = 1 << 30
-        plans = {}
-        for p in range(P):
-            f = 2 * P + p                           # (frame numbers only matter modulo P: any window away from zero will do)
-            plans[("fill", p)] = [(f + k, f, big) for k in range(NL)]
-            plans[("steady", p)] = [(f, 0, big)]
-            plans[("group", p)] = [(f + k, 0, big) for k in range(G)]
-            plans[("drain", p)] = [(f + k, 0, f) for k in range(NL)]
+        plans = level_schedule.graph_plans(self._plan_dict)      # (frame numbers only matter modulo the period)
         graphs = {}
         for key, its in plans.items():
             g = torch.cuda.CUDAGraph()
@@ -697,24 +662,14 @@ class RolloutEngine:
     def _run_levels(self, frames):
         if frames <= 0:
             return
-        P, NL, G = self._lvP, self._lvD, self._lvG
-        f, end = self._frames_done, self._frames_done + frames
-        if self.use_graph and frames >= NL:
-            if self._graphs2 is None:
-                self._capture_levels()
-            g = self._graphs2
-            g[("fill", f % P)].replay()             # iterations f .. f + NL - 1
-            i = f + NL
-            while i + G <= end:
-                g[("group", i % P)].replay()
-                i += G
-            while i < end:
-                g[("steady", i % P)].replay()
-                i += 1
-            g[("drain", end % P)].replay()          # iterations end .. end + NL - 1
-        else:                                       # eager, or a run shorter than the pipeline is deep (its fill and drain overlap)
-            self._run_iterations([(i, f, end) for i in range(f, end + NL)])
-        self._frames_done = end
+        for key, its in level_schedule.replays(self._plan_dict, self._frames_done, frames, graphs=self.use_graph):
+            if key is None:                         # eager, or a run shorter than the pipeline is deep (its fill and drain overlap)
+                self._run_iterations(its)
+            else:                                   # fill | groups of steady iterations | single steady iterations | drain
+                if self._graphs2 is None:
+                    self._capture_levels()
+                self._graphs2[key].replay()
+        self._frames_done += frames
 
     def final_states(self):
         """The six states after the frames run so far (overlap mode keeps the newest encoder states in the buffer
