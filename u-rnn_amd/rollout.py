@@ -81,11 +81,13 @@ class RolloutEngine:
         self.out_masked = torch.zeros((rows, B, H, W), **f32)
         self.out_cls = torch.zeros((rows, B, H, W), **f32)
         self.out_raw = torch.zeros((rows, B, H, W), **f32) if keep_raw else None
-        self.t_dev = torch.zeros(1, dtype=torch.int32, device=dev)    # one chain: the frame index (urnn_advance_counter per frame)
+        # the frame counters share one buffer (reset() zeroes it in one launch)
+        self._counters = torch.zeros(8, dtype=torch.int32, device=dev)
+        self.t_dev = self._counters[0:1]                              # one chain: the frame index (urnn_advance_counter per frame)
         # overlap mode: a pair of words per kernel family, used alternately by frame parity -- the head of frame t reads t2[t % 2] and
         # stores t + 1 to t2[1 - t % 2], the input assembly of frame t likewise with te2 (urnn_*_rollout_f32): no counter kernels
-        self.t2 = torch.zeros(2, dtype=torch.int32, device=dev)
-        self.te2 = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.t2 = self._counters[2:4]
+        self.te2 = self._counters[4:6]
         self.zero_frame = torch.zeros(1, dtype=torch.int32, device=dev)
         # scratch: OWNED by this engine (a captured graph holds raw pointers into it), one buffer per concurrent kernel chain,
         # sized for the largest consumer before any capture
@@ -189,6 +191,18 @@ class RolloutEngine:
             self._ring = {k: [t] + [torch.zeros_like(t) for _ in range(P - 1)]      # (zeros: the capture warm-up reads slots no frame has written yet)
                           for k, t in (("a2", self.a2), ("a3", self.a3), ("u3", self.u3), ("u2", self.u2), ("feat", self.feat))}
         self._dem_stamp = None
+        # What an event starts from -- the six zero states (general.py:50-95; the overlapped schedules: both copies of the encoder's; the level
+        # pipeline: the ring slot the first frame reads as "previous", period - 1) -- lives in ONE buffer, so that reset() is two launches
+        # (states, counters) instead of one per tensor: 59 fills of ~4 us of host time each were 5 % of a 30-frame event at 64x64.
+        homes = [(self.states, k) for k in range(6)] + ([(self.enc_alt, k) for k in range(3)] if self.enc_alt is not None else [])
+        if self.levels:
+            homes = [(ring, self._lvP - 1) for ring in self._ring_e + [self._ring_d1, self._ring_d2]] + [(self.states, 5)]
+        sizes = [(lst[k].numel() + 63) // 64 * 64 for lst, k in homes]                     # (every view 256-byte aligned)
+        self._zeros = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        off = 0
+        for (lst, k), n in zip(homes, sizes):
+            lst[k] = self._zeros[off:off + lst[k].numel()].view(lst[k].shape)
+            off += n
 
     # -- one timestep, all launches on the current stream ----------------------------------------------
     def _step(self):
@@ -744,20 +758,10 @@ class RolloutEngine:
             self._param_stamp = stamp
 
     def reset(self):
+        """Zero states and frame counter: the start of an event (test.py:352-356)."""
         self._check_params()
-        for s in self.states:
-            s.zero_()
-        if self.enc_alt is not None:
-            for s in self.enc_alt:
-                s.zero_()
-        if self.levels:
-            for ring in self._ring_e + [self._ring_d1, self._ring_d2]:
-                for s in ring:
-                    s.zero_()
-        self.t_dev.zero_()
-        if self.overlap:
-            self.t2.zero_()
-            self.te2.zero_()
+        self._zeros.zero_()
+        self._counters.zero_()
         self._frames_done = 0
 
     def run(self, frames):
