@@ -546,8 +546,9 @@ def main():
         eng_i.reset()
         engines.append((eng_i, T))
     for e_i, T_i in engines:            # every engine captures its graphs (and packs its weights) here: with several shapes the warm-up steps
-        e_i.run(min(T_i, 8))            # below may never reach the second engine, whose capture would then land in the timed region
-        e_i.reset()
+        for _ in range(2 if e_i.levels else 1):      # below may never reach the second engine, whose capture would then land in the timed region
+            e_i.run(T_i if e_i.levels else min(T_i, 8))      # (small planes: two whole events -- the second captures the event-length graph)
+            e_i.reset()
     torch.cuda.synchronize(dev)
     H, W, nums, T, rain_max, cum_max, spatial = CONFIGS[names[0]]
     C = 2 * nums + 3

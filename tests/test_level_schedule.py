@@ -73,11 +73,11 @@ class Model:
                 self.writes.setdefault(key, []).append((frame, s, clock))
 
 
-def check_runs(plan, pieces, graphs):
+def check_runs(plan, pieces, graphs, whole=False):
     m = Model(plan)
     f = 0
     for n in pieces:
-        for key, its in ls.replays(plan, f, n, graphs=graphs):
+        for key, its in ls.replays(plan, f, n, graphs=graphs, whole=whole):
             m.run(ls.events(plan, its))
         f += n
     return m
@@ -87,11 +87,12 @@ PIECES = [(1,), (2,), (3,), (4,), (5,), (7,), (13,), (30,), (36,), (3, 7, 1, 12)
 
 
 @pytest.mark.parametrize("name", sorted(ls.PLANS))
-@pytest.mark.parametrize("graphs", [True, False])
+@pytest.mark.parametrize("graphs", [True, False, "whole"])
 def test_no_launch_can_race_on_a_ring_slot(name, graphs):
+    """graphs: the run cut into fill / group / steady / drain replays | one eager pass | one replay per run() call (the whole-run graphs)"""
     plan = ls.PLANS[name]
     for pieces in PIECES:
-        m = check_runs(plan, pieces, graphs)
+        m = check_runs(plan, pieces, bool(graphs), whole=graphs == "whole")
         assert not m.errors, f"plan {name}, run() calls of {pieces}: " + "; ".join(m.errors[:4])
         done = sum(pieces)
         # every frame went through every launch exactly once
@@ -140,6 +141,10 @@ def test_captured_graphs_are_the_replays_modulo_the_period(name):
         for key, its in ls.replays(plan, f, n):
             if key is not None:
                 assert shape(its) == shape(graphs[key]), f"plan {name}: run({n}) from frame {f}, replay {key}"
+        # a whole-run graph captured at frame f serves every later run of n frames from the same phase
+        (key, its), = ls.replays(plan, f, n, whole=True)
+        (key2, its2), = ls.replays(plan, f + 3 * P, n, whole=True)
+        assert key == key2 == ("run", f % P, n) and shape(its) == shape(its2)
 
 
 def test_the_model_finds_a_ring_that_is_too_short():

@@ -83,13 +83,15 @@ def events(plan, its, order=None):
     return ev
 
 
-def replays(plan, f, n, graphs=True):
+def replays(plan, f, n, graphs=True, whole=False):
     """run(n) from frame f as the engine cuts it into replays: [(key, its), ...] -- fill, groups, single steady iterations, drain
-    (key = (kind, frame phase), the captured graph that is replayed), or one eager pass when the run is shorter than the pipeline is deep."""
+    (key = (kind, frame phase), the captured graph that is replayed), or one eager pass when the run is shorter than the pipeline is deep.
+    whole: the run as ONE replay, key ("run", frame phase, n) -- the graph the engine captures for a run length it has seen before (an
+    event length): its barriers every ``group`` iterations cost less than the ends of eight replays."""
     P, D, G = plan["period"], depth(plan), plan["group"]
     end = f + n
-    if not graphs or n < max(D, 1):
-        return [(None, [(i, f, end) for i in range(f, end + D)])]
+    if not graphs or n < max(D, 1) or whole:
+        return [(("run", f % P, n) if (graphs and whole) else None, [(i, f, end) for i in range(f, end + D)])]
     big = 1 << 30
     out = [(("fill", f % P), [(f + k, f, big) for k in range(D)])]
     i = f + D

@@ -105,6 +105,8 @@ class RolloutEngine:
         self._stem = None           # likewise: the decoder's last conv takes the head's first statistics (_stem_stats)
         self._k1part = [ops.head_tail_partial(B, H, W, dev) for _ in range(2 if self.overlap else 1)]      # (level pipeline: a ring, below)
         self._param_stamp = None    # what the captured graphs' packed weights were made from (see _check_params)
+        self._params = None
+        self._lv_seen = {}          # level pipeline: how often run(n) came from a frame phase (see _run_levels)
         self._probe = None          # {"enc1": [(start, stop), ...], "dec1": [...]} while probing
         self._graph = None
         self._graphs2 = None
@@ -163,10 +165,9 @@ class RolloutEngine:
             # block per CU); the largest ones give the flag back until they do.
             nb = dict(zip(("enc1", "enc2", "enc3", "dec3", "dec2", "dec1"), blocks))
             nb["head"] = nhead if self._head_coop else 0
-            # (measured, iteration time in us, A / B / F: 64x64 91 / 83 / 79-84, 52x120 93 / 97 / 88, 128x128 110 / 116 / 104)
-            # plan F everywhere except the one shape where B's balance wins (64x64, one event: enc1 is a cooperative launch of 64 blocks;
-            # 10 000-10 150 against 9 724 frames/s) -- profiles/r06_level_pipeline.txt
-            pname = _tuning_env("URNN_TUNE_LEVEL_PLAN", "B" if (self._coop["enc1"] and 0 < nb["enc1"] <= 64 and B == 1) else "F")
+            # (measured, iteration time in us, A / B / F: 64x64 91 / 83 / 79-84, 52x120 93 / 97 / 88, 128x128 110 / 116 / 104; whole events with
+            # the event-length graph, frames/s B | F: 64x64 11 505 | 11 721, 52x120 10 051 | 10 942, 128x128 8 528 | 9 143 -- r06_level_pipeline.txt)
+            pname = _tuning_env("URNN_TUNE_LEVEL_PLAN", "F")
             if pname == "AB":
                 pname = "B" if (self._coop["enc1"] and nb["enc1"] <= 64) else "A"
             plan = dict(self.LEVEL_PLANS[pname])
@@ -580,8 +581,9 @@ class RolloutEngine:
     #   F (forward, the default): four units in network order on streams 0..3, so every hand-over goes to a LATER stream -- inside a replay
     #     stream q + 1 waits for streams 0..q of the previous iteration and nothing waits for a later stream, the replays' ends are the only
     #     barriers.  Nothing but a replay's length bounds how far stream 0 runs ahead, so the rings hold group + depth + 1 frames.
-    #   A / B: five units, a barrier between iterations (every stream waits for all four); B's balance (63 / 66 / 59 / 57 us at 64x64) wins
-    #     at that one shape, A is B with dec3 next to dec2 for planes whose enc1 is slow.
+    #   A / B: five units, a barrier between iterations (every stream waits for all four); B's balance (63 / 66 / 59 / 57 us at 64x64) was
+    #     ahead at that one shape until a whole event became one replay; A is B with dec3 next to dec2 for planes whose enc1 is slow.  Kept
+    #     as measured alternatives (URNN_TUNE_LEVEL_PLAN under URNN_TUNING=1) and in the tests.
     LEVEL_PLANS = level_schedule.PLANS          # (the schedule itself is data: level_schedule.py, model-checked by tests/test_level_schedule.py)
     LEVEL_STREAMS = level_schedule.STREAMS
     LEVELS_MAX_PIXELS = 256 * 256                                      # batch x plane: beyond this the kernels fill the chip and three chains do as well (320x320: even)
@@ -673,16 +675,36 @@ class RolloutEngine:
             o[b:b + 8].copy_(v)
         torch.cuda.synchronize(self.device)
 
+    WHOLE_RUN_MIN, WHOLE_RUN_MAX, WHOLE_RUN_GRAPHS = 12, 1024, 4
+
     def _run_levels(self, frames):
         if frames <= 0:
             return
-        for key, its in level_schedule.replays(self._plan_dict, self._frames_done, frames, graphs=self.use_graph):
-            if key is None:                         # eager, or a run shorter than the pipeline is deep (its fill and drain overlap)
+        f = self._frames_done
+        # A run length seen before from the same frame phase (an event length: every event of a data set has the reference's `duration`,
+        # test.py:352) gets a graph of its own, captured the second time it comes and kept for the last few lengths: one replay with a
+        # barrier every ``group`` iterations instead of fill + groups + single iterations + drain, ~18 us per replay end at 64x64.
+        key = ("run", f % self._lvP, frames)
+        whole = False
+        if self.use_graph and self.WHOLE_RUN_MIN <= frames <= self.WHOLE_RUN_MAX:
+            self._lv_seen[key] = self._lv_seen.get(key, 0) + 1
+            whole = self._lv_seen[key] >= 2
+        for k, its in level_schedule.replays(self._plan_dict, f, frames, graphs=self.use_graph, whole=whole):
+            if k is None:                           # eager, or a run shorter than the pipeline is deep (its fill and drain overlap)
                 self._run_iterations(its)
-            else:                                   # fill | groups of steady iterations | single steady iterations | drain
-                if self._graphs2 is None:
-                    self._capture_levels()
-                self._graphs2[key].replay()
+                continue
+            if self._graphs2 is None:               # fill | groups of steady iterations | single steady iterations | drain
+                self._capture_levels()
+            if k not in self._graphs2:              # (a whole run: captured on demand; its first replay uploads it)
+                torch.cuda.synchronize(self.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._run_iterations(its)
+                runs = [q for q in self._graphs2 if q[0] == "run"]
+                if len(runs) >= self.WHOLE_RUN_GRAPHS:
+                    del self._graphs2[runs[0]]      # (dicts keep insertion order: the oldest)
+                self._graphs2[k] = g
+            self._graphs2[k].replay()
         self._frames_done += frames
 
     def final_states(self):
@@ -743,12 +765,17 @@ class RolloutEngine:
                 self._graphs2 = None
         return T
 
-    def _check_params(self):
+    def _check_params(self, walk=True):
         """A captured timestep holds raw pointers to the PACKED copies of the weights (and to the head's stacked affines), so a
         weight change must drop the graphs: ``load_state_dict`` / in-place edits bump the tensors' version counters, an
         optimizer that re-homes or rewrites parameters behind torch's back (``Trainer``) bumps ``net._urnn_generation``."""
         # ... and the launches inside a graph keep the GEMM arithmetic (urnn_set_matrix_mode) they were captured with
-        stamp = (getattr(self.net, "_urnn_generation", 0), lib().urnn_get_matrix_mode()) + tuple((p.data_ptr(), p._version) for p in self.net.parameters())
+        # (the walk over the module tree is two thirds of this check's 60 us: reset() -- once per event -- walks, a run() in mid-event asks the
+        # Parameter objects found then; replacing a Parameter OBJECT between two run() calls of one event goes through net._urnn_generation)
+        gen = getattr(self.net, "_urnn_generation", 0)
+        if walk or self._params is None or self._param_stamp is None or gen != self._param_stamp[0]:
+            self._params = list(self.net.parameters())
+        stamp = (gen, lib().urnn_get_matrix_mode()) + tuple((p.data_ptr(), p._version) for p in self._params)
         if stamp != self._param_stamp:
             self._tails = None                  # (a layer's `wide` flag may have changed with its weights)
             self._stem = None
@@ -766,7 +793,7 @@ class RolloutEngine:
 
     def run(self, frames):
         """Roll ``frames`` timesteps from the current states / frame counter.  Asynchronous."""
-        self._check_params()        # a Trainer may have updated / re-homed the weights since the graphs were captured (mid-event run)
+        self._check_params(walk=False)        # a Trainer may have updated / re-homed the weights since the graphs were captured (mid-event run)
         if self.levels:
             return self._run_levels(frames)
         if self.overlap:
