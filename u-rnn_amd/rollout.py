@@ -95,7 +95,13 @@ class RolloutEngine:
         need = max([L.urnn_head_workspace_bytes(B, 16, H, W)] +
                    [L.urnn_gru_cell_workspace_bytes(B, c.num_features, c.shape[0], c.shape[1])
                     for c in (enc.rnn1, enc.rnn2, enc.rnn3, dec.rnn3, dec.rnn2, dec.rnn1)])
-        self._ws = [ops.workspace(need, dev) for _ in range(5 if self.levels else 3 if self.overlap else 1)]   # (third: the head as a chain of its own; level pipeline: one per unit)
+        # (three chains: the third is the head's; level pipeline: one per unit.)  One allocation, so that check_status() reads every status
+        # word in ONE transfer -- five device reads per event were 4 % of a 30-frame event at 64x64
+        nws = 5 if self.levels else 3 if self.overlap else 1
+        self._ws_stride = (int(need) + 255) // 256 * 256
+        self._ws_all = ops.workspace(self._ws_stride * nws, dev)
+        self._ws_all.view(nws, self._ws_stride)[:, :ops.STATUS_AREA_BYTES].zero_()
+        self._ws = [self._ws_all[k * self._ws_stride:k * self._ws_stride + int(need)] for k in range(nws)]
         # fused_tails=True: the END of a cell runs together with the stage conv that consumes the new state (ops.gru_cell_tail: blend +
         # 1x1 conv [+ pool], for the decoder's last cell + the head's first LayerNorm statistics): enc1 -> stage2, enc2 -> stage3,
         # dec1 -> stage1.  190 MB per frame less through HBM at 500x500, identical bits -- and 3-4 % FEWER frames/s (DESIGN.md section
@@ -829,8 +835,8 @@ class RolloutEngine:
         the word synchronises (the caller is about to fetch the frames anyway).  On a hit: re-run the first frames eagerly with a
         finiteness check behind every layer and raise naming the first one that fails."""
         bits = 0
-        for ws in self._ws:
-            bits |= ops.workspace_status(ws)
+        for word in self._ws_all.view(torch.int32)[::self._ws_stride // 4].cpu().tolist():
+            bits |= int(word)
         if bits == 0:
             return
         for ws in self._ws:
