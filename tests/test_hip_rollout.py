@@ -159,6 +159,40 @@ def test_grouped_iterations_and_piecewise_runs_match_sequential(dev, monkeypatch
         assert torch.equal(a, ovl.out_masked[:T]), f"re-capture after {cut} frames"
 
 
+def test_three_chain_run_lengths_seen_again_replay_as_chunk_graphs(dev, monkeypatch):
+    """The three-chain schedule (the big planes'; here forced on a small one): a run length that comes again from the same frame parity
+    is captured as one graph per <= CHUNK_FRAMES frames (first iteration, steady iterations and trailing head inside) and replayed from
+    then on -- same launches in the same order: frames and states stay bit-identical to the one-chain engine, for one chunk and for
+    several (first / middle / last), from frame zero and in mid-event, and across an eviction of the oldest graphs."""
+    import urnn_amd.weights as uw
+    from urnn_amd.rollout import RolloutEngine
+    H, W, nums, T = 32, 48, 3, 30
+    net, _ = make_net(H, W, 9, 3, dev)
+    ev = uw.make_event(T, H, W, 60.0, seed=6)
+    seq = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T)
+    a = seq.rollout(ev).clone()
+    want = [s.clone() for s in seq.final_states()]
+    for chunk in (120, 8):
+        monkeypatch.setattr(RolloutEngine, "CHUNK_FRAMES", chunk)
+        ovl = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T, overlap=True, levels=False)
+        for rep in range(3):
+            assert torch.equal(a, ovl.rollout(ev)), f"CHUNK_FRAMES={chunk}, rollout {rep}"
+            assert all(torch.equal(x, y) for x, y in zip(want, ovl.final_states()))
+        chunks = [k for k in ovl._graphs2 if isinstance(k, tuple) and k[0] == "chunk"]
+        assert len(chunks) == (1 if chunk == 120 else 4) and all(k[1] == (k[3] is True) for k in chunks)      # (30 frames = 8 + 8 + 7 + 7)
+        for rep in range(3):                            # the same cut into two run() calls, the second from an odd / even frame
+            for cut in (13, 16):
+                ovl.load_event(ev)
+                ovl.reset()
+                ovl.out_masked.zero_()
+                ovl.run(cut)
+                ovl.run(T - cut)
+                ovl.check_status()
+                assert torch.equal(a, ovl.out_masked[:T]), f"CHUNK_FRAMES={chunk}, run({cut}) + run({T - cut}), repetition {rep}"
+        assert len([k for k in ovl._graphs2 if isinstance(k, tuple) and k[0] == "chunk"]) <= ovl.CHUNK_GRAPHS
+        assert torch.equal(a, ovl.rollout(ev))
+
+
 @pytest.mark.parametrize("plan", ["default", "F", "A", "B"])
 @pytest.mark.parametrize("shape", [(32, 48, 1), (64, 64, 1), (24, 40, 2)])
 @pytest.mark.parametrize("use_graph", [True, False])
