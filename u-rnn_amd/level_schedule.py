@@ -50,7 +50,6 @@ ACCESS = {
 }
 RINGS = {"a1": 1, "d3": 1, "e1": "period", "e2": "period", "e3": "period", "d1": "period", "d2": "period", "a2": "period", "a3": "period",
          "u3": "period", "u2": "period", "feat": "period", "k1part": "period"}
-ORDER = tuple(ACCESS)        # network order
 
 
 def depth(plan):

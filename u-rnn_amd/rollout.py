@@ -112,7 +112,7 @@ class RolloutEngine:
         self._k1part = [ops.head_tail_partial(B, H, W, dev) for _ in range(2 if self.overlap else 1)]      # (level pipeline: a ring, below)
         self._param_stamp = None    # what the captured graphs' packed weights were made from (see _check_params)
         self._params = None
-        self._lv_seen = {}          # level pipeline: how often run(n) came from a frame phase (see _run_levels)
+        self._run_seen = {}         # overlapped schedules: how often run(n) came from a frame phase (see _run_overlap / _run_levels)
         self._probe = None          # {"enc1": [(start, stop), ...], "dec1": [...]} while probing
         self._graph = None
         self._graphs2 = None
@@ -545,8 +545,8 @@ class RolloutEngine:
         if self.use_graph and frames >= self.WHOLE_RUN_MIN:
             # a run length that comes again from the same frame parity (an event length; bench.py's --steps): graphs of its own
             key = ("seen", self._frames_done == 0, self._frames_done % 2, frames)
-            self._lv_seen[key] = self._lv_seen.get(key, 0) + 1
-            if self._lv_seen[key] >= 2 and _tuning_env("URNN_TUNE_WHOLE_RUN", "1") != "0":
+            self._run_seen[key] = self._run_seen.get(key, 0) + 1
+            if self._run_seen[key] >= 2 and _tuning_env("URNN_TUNE_WHOLE_RUN", "1") != "0":
                 return self._run_overlap_chunks(frames)
         i = 0
         while i < frames:
@@ -732,8 +732,8 @@ class RolloutEngine:
         key = ("run", f % self._lvP, frames)
         whole = False
         if self.use_graph and self.WHOLE_RUN_MIN <= frames <= self.WHOLE_RUN_MAX:
-            self._lv_seen[key] = self._lv_seen.get(key, 0) + 1
-            whole = self._lv_seen[key] >= 2
+            self._run_seen[key] = self._run_seen.get(key, 0) + 1
+            whole = self._run_seen[key] >= 2
         for k, its in level_schedule.replays(self._plan_dict, f, frames, graphs=self.use_graph, whole=whole):
             if k is None:                           # eager, or a run shorter than the pipeline is deep (its fill and drain overlap)
                 self._run_iterations(its)
