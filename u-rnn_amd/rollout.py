@@ -115,6 +115,7 @@ class RolloutEngine:
         self._run_seen = {}         # overlapped schedules: how often run(n) came from a frame phase (see _run_overlap / _run_levels)
         self._probe = None          # {"enc1": [(start, stop), ...], "dec1": [...]} while probing
         self._graph = None
+        self._graph_group = None
         self._graphs2 = None
         # (equal stream priorities: a high-priority chain starves the other -- 900 instead of 1 250 frames/s either way round)
         self._side = tuple(torch.cuda.Stream(device=dev) for _ in range(self.LEVEL_STREAMS if self.levels else 3)) if self.overlap else None
@@ -776,6 +777,18 @@ class RolloutEngine:
         with torch.cuda.graph(g):
             self._step()
         self._graph = g
+        # ... and ONE_CHAIN_GROUP timesteps in one replay (the frame counter is a device word the step itself advances): a graph launch per
+        # frame leaves the chip idle for a few microseconds every frame
+        self._graph_group = None
+        self._one_group = max(1, int(_tuning_env("URNN_TUNE_ONE_CHAIN_GROUP", self.ONE_CHAIN_GROUP)))
+        if self._one_group > 1:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(self._one_group):
+                    self._step()
+            self._graph_group = g
+
+    ONE_CHAIN_GROUP = 8
 
     # -- public API -----------------------------------------------------------------------------------
     def load_event(self, event):
@@ -852,7 +865,11 @@ class RolloutEngine:
                 for s, v in zip(self.states, saved):
                     s.copy_(v)
                 self.t_dev.copy_(t0)
-            for _ in range(frames):
+            left = frames
+            while self._graph_group is not None and left >= self._one_group:
+                self._graph_group.replay()
+                left -= self._one_group
+            for _ in range(left):
                 self._graph.replay()
         else:
             for _ in range(frames):
