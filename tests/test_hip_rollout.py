@@ -194,7 +194,7 @@ def test_three_chain_run_lengths_seen_again_replay_as_chunk_graphs(dev, monkeypa
 
 
 @pytest.mark.parametrize("plan", ["default", "F", "A", "B"])
-@pytest.mark.parametrize("shape", [(32, 48, 1), (64, 64, 1), (24, 40, 2)])
+@pytest.mark.parametrize("shape", [(32, 48, 1), (64, 64, 1), (24, 40, 2), (320, 384, 1)])
 @pytest.mark.parametrize("use_graph", [True, False])
 def test_level_pipeline_and_piecewise_runs_match_sequential(dev, monkeypatch, shape, use_graph, plan):
     """The level pipeline (RolloutEngine(levels=True), the default on small planes with overlap=True): four or five units on four streams, cut by
@@ -210,7 +210,9 @@ def test_level_pipeline_and_piecewise_runs_match_sequential(dev, monkeypatch, sh
     nums, T = 3, 23
     net, _ = make_net(H, W, 9, 3, dev)
     ev = uw.make_event(T, H, W, 60.0, seed=2, batch=B)
-    seq = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T, batch=B)
+    # (the reference schedule: one chain -- except on the plane where a one-chain engine takes the four-tiles-per-block cooperative cells,
+    # which agree with the three kernels to 2e-6, not bit for bit: there the three-chain schedule, which launches what the pipeline launches)
+    seq = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T, batch=B, overlap=H * W > 65536, levels=False)
     a = seq.rollout(ev).clone()
     ovl = RolloutEngine(net, H, W, nums, 60.0, 250.0, max_frames=T, batch=B, overlap=True, use_graph=use_graph)
     assert ovl.levels and len(ovl._side) == 4

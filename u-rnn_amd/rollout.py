@@ -38,7 +38,8 @@ class RolloutEngine:
         # levels=True (default on small planes with overlap=True): the LEVEL PIPELINE -- four concurrent kernel chains cut by level of the
         # network, each a frame behind the one that feeds it (see "level pipeline" below).  Same launches, same results.
         if levels is None:
-            levels = self.overlap and not fused_tails and not coop_mutex and int(batch) * int(input_height) * int(input_width) <= self.LEVELS_MAX_PIXELS
+            px = int(batch) * int(input_height) * int(input_width)
+            levels = self.overlap and not fused_tails and not coop_mutex and (px <= self.LEVELS_MAX_PIXELS or (int(batch) == 1 and px <= self.LEVELS_MAX_PIXELS_ONE))
             if _tuning_env("URNN_TUNE_LEVELS", "") in ("0", "1"):
                 levels = self.overlap and _tuning_env("URNN_TUNE_LEVELS", "") == "1"
         self.levels = bool(levels) and self.overlap
@@ -632,7 +633,11 @@ class RolloutEngine:
     #     as measured alternatives (URNN_TUNE_LEVEL_PLAN under URNN_TUNING=1) and in the tests.
     LEVEL_PLANS = level_schedule.PLANS          # (the schedule itself is data: level_schedule.py, model-checked by tests/test_level_schedule.py)
     LEVEL_STREAMS = level_schedule.STREAMS
-    LEVELS_MAX_PIXELS = 256 * 256                                      # batch x plane: beyond this the kernels fill the chip and three chains do as well (320x320: even)
+    # batch x plane up to which the level pipeline is the default.  One event: ahead of three chains up to 448x448 (us per frame, three chains |
+    # levels, both with their run-length graphs: 256x256 247 | 224, 288x288 288 | 298, 320x320 337 | 336, 384x384 477 | 417, 400x400 467 | 426,
+    # 448x448 543 | 532; 400x560 585 | 615, 500x500 664 | 671 -- the big planes keep three chains).  Batched events: even at 128x128 x 8.
+    LEVELS_MAX_PIXELS = 256 * 256
+    LEVELS_MAX_PIXELS_ONE = 448 * 448
 
     def _lv_segments(self, u, tau):
         """The launches of unit ``u`` (of this engine's plan) for frame ``tau`` as closures (one ABI call each), buffers by tau % period."""
